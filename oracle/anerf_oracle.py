@@ -1,0 +1,306 @@
+"""CPU oracle for the A-NeRF ray-march hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file restates, in plain PyTorch-CPU fp32 ops, the algorithm of the reference's hot path
+(LemonATsu/A-NeRF: core/raycasters.py + core/encoders.py + core/cutoff_embedder.py +
+core/networks/nerf.py + core/utils/ray_utils.py).  Each function cites the reference file:line it
+follows.  It exists to CHECK the HIP path; it is not a product path and not a fallback:
+only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it.
+
+Parity status: PINNED.  tests/golden/gen_golden.py imports the reference itself (in the build
+container, where /root/reference exists), runs it on seeded synthetic inputs and commits the outputs
+as tests/golden/*.npz; tests/test_oracle_golden.py checks this file against those vectors.
+
+All tensors fp32, differentiable (autograd gives the gradient oracle for the backward kernels).
+"""
+import math
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+N_JOINTS = 24
+
+
+class OracleConfig:
+    """Static configuration of the path (reference: create_raycaster, raycasters.py:17-184)."""
+
+    def __init__(self, multires=7, multires_views=4, framecode_ch=0, density_scale=1.0,
+                 softplus_shift=None, netwidth=256, netdepth=8, skip=4):
+        self.multires = multires
+        self.multires_views = multires_views
+        self.framecode_ch = framecode_ch
+        self.density_scale = density_scale
+        self.softplus_shift = softplus_shift  # None -> relu density (raycasters.py:230-238)
+        self.W, self.D, self.skip = netwidth, netdepth, skip
+        self.dim_v = N_JOINTS * (1 + 2 * multires)
+        self.dim_r = N_JOINTS * 3
+        self.dim_d = N_JOINTS * 3 * (1 + 2 * multires_views)
+        self.dim_x = self.dim_v + self.dim_r
+
+
+# ------------------------------------------------------------------------------------------------
+# A2: ray bounds inside the x-z cylinder           (core/utils/ray_utils.py:292-344)
+# ------------------------------------------------------------------------------------------------
+def ray_bounds(rays_o, rays_d, cyls, near, far):
+    """near/far [N,1] overridden by the ray/circle intersection in the ground plane.
+
+    near/far inputs are the placeholder bounds (0 and 1 from render(), trainer.py:83,131).
+    Rows whose ray misses the circle (Q = NaN) take the nan-mean over this call's rays (:328-342).
+    """
+    g = [0, 2]
+    p_near = (rays_o + rays_d * near)[:, g]
+    p_far = (rays_o + rays_d * far)[:, g]
+    nc = cyls[:, :2] - p_near
+    nf = p_far - p_near
+    nf_len = nf.norm(dim=-1)
+    scale = rays_d[:, g].norm(dim=-1, keepdim=True)
+    cross = nc[:, 0] * nf[:, 1] - nc[:, 1] * nf[:, 0]
+    dist = (cross.abs() / nf_len)[:, None]
+    Q = (cyls[:, 2:3] ** 2 - dist ** 2) ** 0.5
+    K = ((nc * nf).sum(-1) / nf_len)[:, None]
+    inside = (Q < K).float()
+    new_near = near + inside * (K - Q) / scale
+    new_far = near + (K + Q) / scale
+    bad = torch.isnan(Q[:, 0])
+    if bool(torch.isnan(new_near).any()):
+        ok_n = ~torch.isnan(new_near[:, 0])
+        ok_f = ~torch.isnan(new_far[:, 0])
+        new_near = new_near.clone()
+        new_far = new_far.clone()
+        new_near[bad] = new_near[ok_n].mean() if bool(ok_n.any()) else near[bad]
+        new_far[bad] = new_far[ok_f].mean() if bool(ok_f.any()) else far[bad]
+    return new_near, new_far
+
+
+# ------------------------------------------------------------------------------------------------
+# A3: coarse sample depths                          (core/utils/ray_utils.py:204-251)
+# ------------------------------------------------------------------------------------------------
+def coarse_z(near, far, n_samples, t_rand=None, lindisp=False):
+    """z [N,S]; t_rand [N,S] in [0,1) enables stratified jitter (perturb>0)."""
+    t = torch.linspace(0.0, 1.0, n_samples)[None]
+    if lindisp:
+        z = 1.0 / (1.0 / near * (1.0 - t) + 1.0 / far * t)
+    else:
+        z = near * (1.0 - t) + far * t
+    if t_rand is not None:
+        mid = 0.5 * (z[:, 1:] + z[:, :-1])
+        hi = torch.cat([mid, z[:, -1:]], -1)
+        lo = torch.cat([z[:, :1], mid], -1)
+        z = lo + (hi - lo) * t_rand
+    return z
+
+
+# ------------------------------------------------------------------------------------------------
+# A4/A5: world->bone transform and skeleton-relative features   (core/encoders.py:8-37,110-122,181-193)
+# ------------------------------------------------------------------------------------------------
+def bone_features(pts, rays_d, skts):
+    """pts [N,S,3], rays_d [N,3], skts [N or 1,24,4,4] ->
+    v [N,S,24] (distance to each joint in bone space), r [N,S,72] (unit direction, 3j+c),
+    e [N,72] (unit ray direction in bone space, per ray)."""
+    R = skts[:, :, :3, :3]                      # [n,24,3,3]
+    t = skts[:, :, :3, 3]                       # [n,24,3]
+    y = torch.einsum("njab,nsb->nsja", R.expand(pts.shape[0], -1, -1, -1), pts) + t[:, None].expand(pts.shape[0], -1, -1, -1)
+    v = y.norm(dim=-1)
+    r = F.normalize(y, dim=-1, p=2, eps=1e-12).flatten(start_dim=2)
+    dl = torch.einsum("njab,nb->nja", R.expand(rays_d.shape[0], -1, -1, -1), rays_d)
+    e = F.normalize(dl, dim=-1, p=2, eps=1e-12).flatten(start_dim=1)
+    return v, r, e
+
+
+# ------------------------------------------------------------------------------------------------
+# A6: positional encoding with sigmoid cutoff        (core/cutoff_embedder.py:111-174)
+# ------------------------------------------------------------------------------------------------
+def cutoff_pe(x, dist, n_freq, tau, cutoff, per_joint):
+    """x [...,C] with C = 24*per_joint (per_joint=1 for v, 3 for ray dirs); dist [...,24].
+    Returns [..., C*(1+2*n_freq)], channel = k*C + c with k=0 raw, 1+2f sin(2^f x), 2+2f cos(2^f x);
+    every band (raw input included: cutoff_inputs=True) is gated by w_j = 1 - sigmoid(tau*(dist_j - c_j))."""
+    w = 1.0 - torch.sigmoid(tau * (dist - cutoff))
+    w = w.repeat_interleave(per_joint, dim=-1)
+    bands = [x]
+    for f in range(n_freq):
+        bands.append(torch.sin(x * (2.0 ** f)))
+        bands.append(torch.cos(x * (2.0 ** f)))
+    out = torch.stack(bands, dim=-2) * w[..., None, :]
+    return out.flatten(start_dim=-2)
+
+
+def encode(cfg, pts, rays_d, skts, tau_v, tau_d, cut_v, cut_d, cam_idx=None):
+    """MLP input X [N,S,dim_x + dim_d (+1)]  (RayCaster.encode_inputs + run_network cat,
+    raycasters.py:476-577).  embedbones_fn is the identity (multires_bones=0)."""
+    v, r, e = bone_features(pts, rays_d, skts)
+    V = cutoff_pe(v, v, cfg.multires, tau_v, cut_v, 1)
+    eS = e[:, None, :].expand(-1, pts.shape[1], -1)
+    Dv = cutoff_pe(eS, v, cfg.multires_views, tau_d, cut_d, 3)
+    parts = [V, r, Dv]
+    if cam_idx is not None:
+        parts.append(cam_idx.view(-1, 1, 1).expand(-1, pts.shape[1], 1))
+    return torch.cat(parts, -1)
+
+
+# ------------------------------------------------------------------------------------------------
+# A9: the radiance/density MLP                       (core/networks/nerf.py:94-148)
+# ------------------------------------------------------------------------------------------------
+def mlp(cfg, P, X, eval_mean_code=False):
+    """P: dict 'pts_linears.i.weight' ... (reference state_dict names); X [...,dim_x+dim_d(+1)] -> raw [...,4]."""
+    x = X[..., :cfg.dim_x]
+    u = X[..., cfg.dim_x:cfg.dim_x + cfg.dim_d]
+    h = x
+    for i in range(cfg.D):
+        h = F.relu(F.linear(h, P[f"pts_linears.{i}.weight"], P[f"pts_linears.{i}.bias"]))
+        if i == cfg.skip:
+            h = torch.cat([x, h], -1)
+    sigma = F.linear(h, P["alpha_linear.weight"], P["alpha_linear.bias"])
+    feat = F.linear(h, P["feature_linear.weight"], P["feature_linear.bias"])
+    vin = [feat, u]
+    if cfg.framecode_ch > 0:
+        idx = X[..., cfg.dim_x + cfg.dim_d]
+        E = P["framecodes.codes.weight"]
+        if eval_mean_code and float(idx.max()) < 0:            # embedding.py:21-22
+            code = E.mean(0, keepdim=True).expand(*idx.shape, -1)
+        else:
+            code = E[idx.long()]
+        vin.append(code)
+    g = F.relu(F.linear(torch.cat(vin, -1), P["views_linears.0.weight"], P["views_linears.0.bias"]))
+    rgb = F.linear(g, P["rgb_linear.weight"], P["rgb_linear.bias"])
+    return torch.cat([rgb, sigma], -1)
+
+
+# ------------------------------------------------------------------------------------------------
+# A10: alpha compositing                             (core/networks/nerf.py:150-205)
+# ------------------------------------------------------------------------------------------------
+def density_act(cfg, x):
+    if cfg.softplus_shift is None:
+        return F.relu(x)
+    return F.softplus(x - cfg.softplus_shift, beta=1)
+
+
+def composite(cfg, raw, z, rays_d, noise=None):
+    """raw [N,S,4], z [N,S], rays_d [N,3], noise [N,S] or None (already scaled as the caller wants)."""
+    B = cfg.density_scale
+    dn = rays_d.norm(dim=-1, keepdim=True)
+    delta = torch.cat([z[:, 1:] - z[:, :-1], torch.full_like(z[:, :1], 1e10)], -1) * dn
+    rgb = torch.sigmoid(raw[..., :3]) * 1.002 - 0.001
+    pre = raw[..., 3] / B
+    if noise is not None:
+        pre = pre + noise
+    alpha = 1.0 - torch.exp(-density_act(cfg, pre) * delta)
+    T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha + 1e-10], -1), -1)[:, :-1]
+    w = alpha * T
+    rgb_map = (w[..., None] * rgb).sum(-2)
+    depth = (w * z).sum(-1)
+    acc = w.sum(-1)
+    disp = 1.0 / torch.maximum(torch.full_like(depth, 1e-10), depth / (acc + 1e-10))
+    disp = disp * (~torch.isclose(acc, torch.zeros(()))).float()
+    return {"rgb_map": rgb_map, "disp_map": disp, "acc_map": torch.minimum(acc, torch.ones(())),
+            "weights": w, "alpha": alpha}
+
+
+# ------------------------------------------------------------------------------------------------
+# A11: importance resampling                          (core/utils/ray_utils.py:157-201,255-289)
+# ------------------------------------------------------------------------------------------------
+def importance_z(z, weights, n_imp, u=None, single_net=False):
+    """z [N,S], weights [N,S] -> z_samples [N,Ni] (detached), z_merged [N,S+Ni], sorted_idx [N,S+Ni].
+    u [N,Ni] uniform numbers (perturb>0) or None -> linspace(0,1,Ni) (deterministic)."""
+    bins = 0.5 * (z[:, 1:] + z[:, :-1])
+    if single_net:
+        wl, wk, wu = weights[:, :-2], weights[:, 1:-1], weights[:, 2:]
+        pw = 0.5 * (torch.maximum(wl, wk) + torch.maximum(wk, wu)) + 0.01
+    else:
+        pw = weights[:, 1:-1]
+    pw = pw + 1e-5
+    pdf = pw / pw.sum(-1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[:, :1]), torch.cumsum(pdf, -1)], -1)
+    if u is None:
+        u = torch.linspace(0.0, 1.0, n_imp)[None].expand(z.shape[0], -1)
+    u = u.contiguous()
+    k = torch.searchsorted(cdf.detach(), u, right=True)
+    lo = (k - 1).clamp(min=0)
+    hi = k.clamp(max=cdf.shape[-1] - 1)
+    c_lo, c_hi = torch.gather(cdf, 1, lo), torch.gather(cdf, 1, hi)
+    b_lo, b_hi = torch.gather(bins, 1, lo), torch.gather(bins, 1, hi)
+    den = c_hi - c_lo
+    den = torch.where(den < 1e-5, torch.ones_like(den), den)
+    zs = (b_lo + (u - c_lo) / den * (b_hi - b_lo)).detach()
+    zm, idx = torch.sort(torch.cat([z, zs], -1), -1)
+    return zs, zm, idx
+
+
+# ------------------------------------------------------------------------------------------------
+# A1/A13: the whole caster call                       (core/raycasters.py:361-474,711-724)
+# ------------------------------------------------------------------------------------------------
+def render_rays(cfg, P, P_fine, ray_batch, skts, cyls, n_samples, n_importance=0,
+                tau_v=20.0, tau_d=20.0, cut_v=None, cut_d=None, cam_idx=None,
+                t_rand=None, u_imp=None, noise=None, noise_fine=None, lindisp=False,
+                single_net=False, eval_mean_code=False, return_extras=False):
+    """ray_batch [N,>=8] = (o3,d3,near,far[,viewdirs3]); returns the reference's output dict."""
+    cut_v = torch.full((N_JOINTS,), 0.5) if cut_v is None else cut_v
+    cut_d = torch.full((N_JOINTS,), 0.5) if cut_d is None else cut_d
+    o, d = ray_batch[:, 0:3], ray_batch[:, 3:6]
+    near, far = ray_bounds(o, d, cyls, ray_batch[:, 6:7], ray_batch[:, 7:8])
+    z = coarse_z(near, far, n_samples, t_rand, lindisp)
+    pts = o[:, None] + d[:, None] * z[..., None]
+    X = encode(cfg, pts, d, skts, tau_v, tau_d, cut_v, cut_d, cam_idx)
+    raw = mlp(cfg, P, X, eval_mean_code)
+    out = composite(cfg, raw, z, d, noise)
+    extras = {"near": near, "far": far, "z_vals": z, "X": X, "raw": raw, "weights": out["weights"]}
+    ret = {"rgb_map": out["rgb_map"], "disp_map": out["disp_map"], "acc_map": out["acc_map"], "alpha": out["alpha"]}
+    if n_importance > 0:
+        zs, zm, idx = importance_z(z, out["weights"], n_importance, u_imp, single_net)
+        pts_f = o[:, None] + d[:, None] * zm[..., None]
+        Xf = encode(cfg, pts_f, d, skts, tau_v, tau_d, cut_v, cut_d, cam_idx)
+        if single_net:
+            # only the new samples go through the (shared) net; raw outputs are merged (raycasters.py:462-469)
+            Xn = encode(cfg, o[:, None] + d[:, None] * zs[..., None], d, skts, tau_v, tau_d, cut_v, cut_d, cam_idx)
+            raw_n = mlp(cfg, P_fine, Xn, eval_mean_code)
+            raw_f = torch.gather(torch.cat([raw, raw_n], 1), 1, idx[..., None].expand(-1, -1, 4))
+        else:
+            raw_f = mlp(cfg, P_fine, Xf, eval_mean_code)
+        fine = composite(cfg, raw_f, zm, d, noise_fine)
+        ret = {"rgb_map": fine["rgb_map"], "disp_map": fine["disp_map"], "acc_map": fine["acc_map"],
+               "alpha": fine["alpha"], "rgb0": ret["rgb_map"], "disp0": ret["disp_map"],
+               "acc0": ret["acc_map"], "alpha0": ret["alpha"]}
+        extras.update({"z_samples": zs, "z_fine": zm, "sorted_idx": idx, "raw_fine": raw_f,
+                       "weights_fine": fine["weights"]})
+    if return_extras:
+        ret["_extras"] = extras
+    return ret
+
+
+def make_ray_batch(rays_o, rays_d, near=0.0, far=1.0):
+    """render()'s ray-batch assembly [N,11] (core/trainer.py:116-135, use_viewdirs=True)."""
+    vd = rays_d / rays_d.norm(dim=-1, keepdim=True)
+    ones = torch.ones_like(rays_d[:, :1])
+    return torch.cat([rays_o, rays_d, near * ones, far * ones, vd], -1)
+
+
+def render_chunked(chunk, ray_batch, skts, cyls, cam_idx=None, **kw):
+    """batchify_rays (core/trainer.py:64-79): chunk over rays, concatenate dict entries."""
+    outs = []
+    per_ray = {k: kw.pop(k) for k in ["t_rand", "u_imp", "noise", "noise_fine"] if k in kw and kw[k] is not None}
+    for i in range(0, ray_batch.shape[0], chunk):
+        sl = slice(i, i + chunk)
+        sk = skts[sl] if skts.shape[0] > 1 else skts
+        outs.append(render_rays(ray_batch=ray_batch[sl], skts=sk, cyls=cyls[sl],
+                                cam_idx=None if cam_idx is None else cam_idx[sl],
+                                **{k: v[sl] for k, v in per_ray.items()}, **kw))
+    return {k: torch.cat([o[k] for o in outs], 0) for k in outs[0] if k != "_extras"}
+
+
+# ------------------------------------------------------------------------------------------------
+# caller-side loss / PSNR                             (core/trainer.py:8,353-380)
+# ------------------------------------------------------------------------------------------------
+def nerf_loss(ret, target, bgs, loss="MSE", coarse_weight=1.0):
+    fn = (lambda a, b: ((a - b) ** 2).mean()) if loss == "MSE" else (lambda a, b: (a - b).abs().mean())
+    pred = ret["rgb_map"] + (1.0 - ret["acc_map"])[..., None] * bgs
+    total = fn(pred, target)
+    if "rgb0" in ret:
+        pred0 = ret["rgb0"] + (1.0 - ret["acc0"])[..., None] * bgs
+        total = total + coarse_weight * fn(pred0, target)
+    return total, pred
+
+
+def psnr(pred, target):
+    return float(-10.0 * torch.log10(((pred - target) ** 2).mean()))
+
+
+def params_from_numpy(d, requires_grad=False):
+    return {k: torch.tensor(np.asarray(v), dtype=torch.float32, requires_grad=requires_grad) for k, v in d.items()}

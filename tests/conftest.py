@@ -1,0 +1,34 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def synth():
+    return importlib.import_module("a-nerf_amd.synth")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    return importlib.import_module("anerf_oracle")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+
+    def load(name):
+        return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+    return load

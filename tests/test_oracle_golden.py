@@ -1,0 +1,141 @@
+"""CPU: the oracle restatement vs the reference's golden vectors (tests/golden/*.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from cases import build
+
+TOL = dict(rtol=2e-5, atol=2e-6)
+
+
+def t(x):
+    return torch.tensor(np.asarray(x), dtype=torch.float32)
+
+
+def run_case(oracle, c, requires_grad=False, eval_mean_code=False, cams=None):
+    cfg = oracle.OracleConfig(**c["cfg"])
+    Pc = oracle.params_from_numpy(c["Pc"], requires_grad)
+    Pf = oracle.params_from_numpy(c["Pf"], requires_grad)
+    rb = oracle.make_ray_batch(t(c["rays_o"]), t(c["rays_d"]))
+    skts = t(c["skts"]).requires_grad_(requires_grad)
+    kw = {}
+    for k in ["t_rand", "u_imp", "noise", "noise_fine"]:
+        if k in c:
+            kw[k] = t(c[k])
+    cams = c.get("cams") if cams is None else cams
+    out = oracle.render_rays(cfg, Pc, Pc if c.get("single_net") else Pf, rb, skts, t(c["cyls"]), c["S"], c["Ni"],
+                             cam_idx=None if cams is None else t(cams), single_net=bool(c.get("single_net")),
+                             eval_mean_code=eval_mean_code, return_extras=True, **kw)
+    return out, Pc, Pf, skts
+
+
+def test_synth_matches_reference_helpers(synth, golden):
+    g = golden("synth_pins")
+    pose = synth.make_pose(3)
+    np.testing.assert_allclose(pose["l2ws"], g["l2ws"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(synth.bounding_cylinder(pose["kp"]), g["cyl"], rtol=1e-6, atol=1e-7)
+    ro, rd = synth.camera_rays(64, 64, 75.0, synth.default_c2w())
+    np.testing.assert_allclose(rd, g["rays_d_64"], rtol=1e-6, atol=1e-7)
+    cyl = synth.bounding_cylinder(pose["kp"])
+    _, _, idx = synth.frame_rays(64, 64, 75.0, cyl)
+    np.testing.assert_array_equal(idx, g["valid_idx_64"])
+    _, _, idx512 = synth.frame_rays(512, 512, 600.0, cyl)
+    assert len(idx512) == int(g["n_valid_512"]) == 261121
+    np.testing.assert_array_equal(idx512[:8], g["valid_idx_512_head"])
+    np.testing.assert_array_equal(idx512[-8:], g["valid_idx_512_tail"])
+
+
+def test_eval_s32_stages(oracle, golden):
+    g = golden("eval_s32")
+    out, *_ = run_case(oracle, build("eval_s32"))
+    ex = out["_extras"]
+    np.testing.assert_allclose(ex["near"].numpy(), g["near"], **TOL)
+    np.testing.assert_allclose(ex["far"].numpy(), g["far"], **TOL)
+    np.testing.assert_allclose(ex["z_vals"].numpy(), g["z_vals"], **TOL)
+    np.testing.assert_allclose(ex["X"][:4].numpy(), g["X_head"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(ex["raw"].detach().numpy(), g["raw"], rtol=1e-4, atol=2e-5)
+    for k in ["rgb_map", "disp_map", "acc_map", "alpha"]:
+        np.testing.assert_allclose(out[k].detach().numpy(), g[k], rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+def test_eval_hier(oracle, golden):
+    g = golden("eval_hier")
+    out, *_ = run_case(oracle, build("eval_hier"))
+    for k in ["rgb_map", "disp_map", "acc_map", "alpha", "rgb0", "disp0", "acc0", "alpha0"]:
+        np.testing.assert_allclose(out[k].detach().numpy(), g[k], rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+def test_importance_stage(oracle, golden):
+    g = golden("importance")
+    zs, zm, idx = oracle.importance_z(t(g["z"]), t(g["weights"]), 16)
+    np.testing.assert_allclose(zs.numpy(), g["z_samples"], **TOL)
+    np.testing.assert_allclose(zm.numpy(), g["z_merged"], **TOL)
+    np.testing.assert_array_equal(idx.numpy(), g["sorted_idx"])
+    zs, zm, _ = oracle.importance_z(t(g["z"]), t(g["weights"]), 128)
+    np.testing.assert_allclose(zs.numpy(), g["z_samples128"], **TOL)
+    np.testing.assert_allclose(zm.numpy(), g["z_merged128"], **TOL)
+
+
+def test_nan_fallback(oracle, golden):
+    g = golden("nan_fallback")
+    out, *_ = run_case(oracle, build("nan_fallback"))
+    np.testing.assert_allclose(out["_extras"]["near"].numpy(), g["near"], **TOL)
+    np.testing.assert_allclose(out["_extras"]["far"].numpy(), g["far"], **TOL)
+    for k in ["rgb_map", "disp_map", "acc_map", "alpha"]:
+        np.testing.assert_allclose(out[k].detach().numpy(), g[k], rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("name", ["train_pytest", "mixamo_train"])
+def test_train_mode_and_grads(oracle, golden, name):
+    g = golden(name)
+    c = build(name)
+    out, Pc, Pf, skts = run_case(oracle, c, requires_grad=True)
+    for k in ["rgb_map", "disp_map", "acc_map", "alpha", "rgb0", "disp0", "acc0", "alpha0"]:
+        np.testing.assert_allclose(out[k].detach().numpy(), g[k], rtol=1e-4, atol=1e-5, err_msg=k)
+    seed = 1 if name == "train_pytest" else 2
+    target = t(np.random.default_rng(seed).random((c["n"], 3)))
+    loss, _ = oracle.nerf_loss(out, target, torch.ones(c["n"], 3), loss=c.get("loss", "MSE"))
+    assert abs(float(loss) - float(g["loss"])) < 1e-6
+    loss.backward()
+    np.testing.assert_allclose(skts.grad.numpy(), g["dskts"], rtol=2e-3, atol=2e-8)
+    for tag, P in [("c", Pc), ("f", Pf)]:
+        for n, p in P.items():
+            gn = float(p.grad.norm()) if p.grad is not None else 0.0
+            ref = float(g[f"gnorm_{tag}.{n}"])
+            assert abs(gn - ref) <= 1e-3 * ref + 1e-9, (tag, n, gn, ref)
+            gs = p.grad.reshape(-1)[:64].numpy() if p.grad is not None else np.zeros(64, np.float32)
+            np.testing.assert_allclose(gs, g[f"gslice_{tag}.{n}"][:len(gs)], rtol=2e-3, atol=1e-7, err_msg=n)
+
+
+def test_mixamo_eval_mean_code(oracle, golden):
+    g = golden("mixamo_train")
+    c = build("mixamo_train")
+    for k in ["t_rand", "u_imp", "noise", "noise_fine"]:
+        c.pop(k)
+    out, *_ = run_case(oracle, c, eval_mean_code=True, cams=-np.ones(c["n"], np.float32))
+    for k in ["rgb_map", "acc_map", "alpha", "rgb0"]:
+        np.testing.assert_allclose(out[k].detach().numpy(), g["eval_" + k], rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+def test_single_net(oracle, golden):
+    g = golden("single_net")
+    out, *_ = run_case(oracle, build("single_net"))
+    for k in ["rgb_map", "disp_map", "acc_map", "alpha", "rgb0", "alpha0"]:
+        np.testing.assert_allclose(out[k].detach().numpy(), g[k], rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+def test_frame64_psnr(oracle, synth, golden):
+    """BASELINE config 1: 64x64 frame, 32 samples -> image parity (1e-4 RGB, 1e-3 dB PSNR)."""
+    g = golden("frame64")
+    sc = synth.make_scene(0, 64, 64, 75.0)
+    n = len(sc["rays_o"])
+    assert n == int(g["n_rays"])
+    cfg = oracle.OracleConfig()
+    P = oracle.params_from_numpy(synth.make_net_params(11))
+    rb = oracle.make_ray_batch(t(sc["rays_o"]), t(sc["rays_d"]))
+    with torch.no_grad():
+        out = oracle.render_chunked(4096, rb, t(sc["pose"]["skts"])[None], t(sc["cyl"])[None].expand(n, -1),
+                                    cfg=cfg, P=P, P_fine=None, n_samples=32)
+    assert np.abs(out["rgb_map"].numpy() - g["rgb_map"]).max() < 1e-4
+    target = t(np.random.default_rng(7).random((n, 3)))
+    assert abs(oracle.psnr(out["rgb_map"], target) - oracle.psnr(t(g["rgb_map"]), target)) < 1e-3
