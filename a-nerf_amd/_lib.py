@@ -1,0 +1,80 @@
+"""ctypes binding of libanerf_hip.so (the C ABI declared in include/anerf.h).
+
+The library is the product path: if it is missing this module raises at import of the symbols --
+there is no CPU fallback (oracle/ is test infrastructure and is never imported from here).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libanerf_hip.so")
+
+c_f32p = C.c_void_p  # device pointers are passed as integers (tensor.data_ptr())
+
+
+class AnerfConfig(C.Structure):
+    _fields_ = [("n_joints", C.c_int32), ("multires", C.c_int32), ("multires_views", C.c_int32),
+                ("framecode_ch", C.c_int32), ("netdepth", C.c_int32), ("netwidth", C.c_int32),
+                ("skip", C.c_int32), ("density_act", C.c_int32), ("density_scale", C.c_float),
+                ("softplus_shift", C.c_float)]
+
+
+class AnerfNetParams(C.Structure):
+    _fields_ = [("w", C.c_void_p * 12), ("b", C.c_void_p * 12), ("codes", C.c_void_p), ("n_codes", C.c_int32)]
+
+
+class AnerfLayout(C.Structure):
+    _fields_ = [("stream_floats", C.c_int64), ("aux_floats", C.c_int64), ("n_stages", C.c_int32),
+                ("x_width", C.c_int32)]
+
+
+# name -> (restype, argtypes); every symbol include/anerf.h declares must be listed here
+SIGNATURES = {
+    "anerf_last_error": (C.c_char_p, []),
+    "anerf_version": (C.c_int, []),
+    "anerf_layout": (C.c_int, [C.POINTER(AnerfConfig), C.c_int, C.POINTER(AnerfLayout)]),
+    "anerf_build_pack_table": (C.c_int, [C.POINTER(AnerfConfig), C.c_int, C.c_void_p]),
+    "anerf_pack_params": (C.c_int, [C.POINTER(AnerfNetParams), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "anerf_ray_bounds": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "anerf_coarse_z": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                 C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "anerf_mlp_raw": (C.c_int, [C.POINTER(AnerfConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float,
+                                C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "anerf_mlp_forward": (C.c_int, [C.POINTER(AnerfConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                    C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "anerf_composite": (C.c_int, [C.POINTER(AnerfConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                  C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]),
+    "anerf_importance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises if the HIP library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
+                           "(make -C a-nerf_amd/csrc).  There is no CPU fallback for the hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class AnerfError(RuntimeError):
+    pass
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().anerf_last_error().decode()
+        raise AnerfError(f"{what} failed with code {rc}: {msg}")

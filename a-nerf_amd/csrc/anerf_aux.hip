@@ -1,0 +1,319 @@
+// anerf_aux.hip -- the small per-ray kernels around the fused MLP (gfx950):
+//   k_ray_bounds   get_near_far_in_cylinder            core/utils/ray_utils.py:292-344
+//   k_coarse_z     sample_from_lineseg                 core/utils/ray_utils.py:204-251
+//   k_composite    NeRF.raw2outputs                    core/networks/nerf.py:150-205
+//   k_importance   isample_from_lineseg + sample_pdf   core/utils/ray_utils.py:157-201,255-289
+//   k_pack         parameter gather into the packed weight images
+// All are HBM/latency-bound byte movers: coalesced loads, one wavefront per ray where a scan is needed.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "anerf_dev.h"
+
+namespace anerf {
+
+// ------------------------------------------------------------------------------------------------
+__global__ void k_pack(AnerfNetParams P, const int32_t* __restrict__ table, long long n, float* __restrict__ out) {
+  const float* tens[24];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    tens[i] = P.w[i];
+    tens[12 + i] = P.b[i];
+  }
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int32_t e = table[i];
+    float val = 0.f;
+    if (e >= 0) {
+      const int id = e >> 24, off = e & 0xFFFFFF;
+      const float* src = P.w[0];
+#pragma unroll
+      for (int k = 0; k < 24; ++k)
+        if (id == k) src = tens[k];
+      val = src[off];
+    }
+    out[i] = val;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// A2.  One thread per ray.  stats = {sum_near, sum_far, cnt_near, cnt_far} over non-NaN rows (for the fallback).
+__global__ void k_ray_bounds(const float* __restrict__ rays, int ray_stride, const float* __restrict__ cyls, int n,
+                             float* __restrict__ near_far, float* __restrict__ stats) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float sn = 0.f, sf = 0.f, cn = 0.f, cf = 0.f;
+  if (i < n) {
+    const float* r = rays + (long long)i * ray_stride;
+    const float ox = r[0], oz = r[2], dx = r[3], dz = r[5], near = r[6], far = r[7];
+    const float pnx = fmaf(dx, near, ox), pnz = fmaf(dz, near, oz);
+    const float pfx = fmaf(dx, far, ox), pfz = fmaf(dz, far, oz);
+    const float* c = cyls + (long long)i * 5;
+    const float ncx = c[0] - pnx, ncz = c[1] - pnz;
+    const float nfx = pfx - pnx, nfz = pfz - pnz;
+    const float nf_len = sqrtf(nfx * nfx + nfz * nfz);
+    const float scale = sqrtf(dx * dx + dz * dz);
+    const float cross = ncx * nfz - ncz * nfx;
+    const float dist = fabsf(cross) / nf_len;
+    const float Q = sqrtf(c[2] * c[2] - dist * dist);   // NaN when the ray misses the circle
+    const float K = (ncx * nfx + ncz * nfz) / nf_len;
+    const float inside = (Q < K) ? 1.f : 0.f;
+    const float nn = near + inside * (K - Q) / scale;
+    const float ff = near + (K + Q) / scale;
+    near_far[2 * i + 0] = nn;
+    near_far[2 * i + 1] = ff;
+    if (nn == nn) { sn = nn; cn = 1.f; }
+    if (ff == ff) { sf = ff; cf = 1.f; }
+  }
+  // wave reduce, one atomic per wave
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    sn += __shfl_xor(sn, o);
+    sf += __shfl_xor(sf, o);
+    cn += __shfl_xor(cn, o);
+    cf += __shfl_xor(cf, o);
+  }
+  if ((threadIdx.x & 63) == 0 && (cn + cf) > 0.f) {
+    atomicAdd(stats + 0, sn);
+    atomicAdd(stats + 1, sf);
+    atomicAdd(stats + 2, cn);
+    atomicAdd(stats + 3, cf);
+  }
+}
+
+// A3.  One thread per sample; applies the NaN fallback (mean of the call's valid rows, else the placeholder).
+__global__ void k_coarse_z(const float* __restrict__ near_far, const float* __restrict__ stats,
+                           const float* __restrict__ rays, int ray_stride, int n, int S,
+                           const float* __restrict__ t_rand, int lindisp, float* __restrict__ z_out,
+                           float* __restrict__ near_far_fixed) {
+  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (idx >= (long long)n * S) return;
+  const int ray = (int)(idx / S), s = (int)(idx - (long long)ray * S);
+  float nn = near_far[2 * ray], ff = near_far[2 * ray + 1];
+  if (!(nn == nn) || !(ff == ff)) {
+    // torch.where(isnan(Q)) rows: both replaced (ray_utils.py:331-342)
+    const float* r = rays + (long long)ray * ray_stride;
+    nn = stats[2] > 0.f ? stats[0] / stats[2] : r[6];
+    ff = stats[3] > 0.f ? stats[1] / stats[3] : r[7];
+  }
+  if (s == 0 && near_far_fixed) {
+    near_far_fixed[2 * ray] = nn;
+    near_far_fixed[2 * ray + 1] = ff;
+  }
+  auto zat = [&](int k) -> float {
+    const float t = (float)k / (float)(S - 1);
+    return lindisp ? 1.f / (1.f / nn * (1.f - t) + 1.f / ff * t) : nn * (1.f - t) + ff * t;
+  };
+  float z = zat(s);
+  if (t_rand) {
+    const float lo = s == 0 ? z : 0.5f * (z + zat(s - 1));
+    const float hi = s == S - 1 ? z : 0.5f * (zat(s + 1) + z);
+    z = lo + (hi - lo) * t_rand[idx];
+  }
+  z_out[idx] = z;
+}
+
+// ------------------------------------------------------------------------------------------------
+// A10.  One wavefront per ray; lane i owns the contiguous samples [i*C, (i+1)*C), C = ceil(S/64) <= 8.
+// Transmittance = exclusive product scan: in-lane running product + wave-level shuffle scan.
+__device__ __forceinline__ float density_act(int act, float x, float shift) {
+  if (act == 0) return fmaxf(x, 0.f);
+  const float y = x - shift;            // F.softplus(beta=1, threshold=20)
+  return y > 20.f ? y : log1pf(expf(y));
+}
+
+__global__ __launch_bounds__(256) void k_composite(const float* __restrict__ raw, const float* __restrict__ z,
+                                                   const float* __restrict__ rays, int ray_stride,
+                                                   const float* __restrict__ noise, int n, int S, int act,
+                                                   float inv_B, float shift, float* __restrict__ rgb_map,
+                                                   float* __restrict__ disp_map, float* __restrict__ acc_map,
+                                                   float* __restrict__ weights, float* __restrict__ alpha_out,
+                                                   float* __restrict__ depth_map) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= n) return;
+  const int C = (S + 63) >> 6;
+  const float* rp = rays + (long long)ray * ray_stride;
+  const float dn = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);
+  const long long base = (long long)ray * S;
+  float al[8], cr[8], cg[8], cb[8], zz[8];
+  float prod = 1.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int s = lane * C + c;
+    al[c] = 0.f; cr[c] = cg[c] = cb[c] = 0.f; zz[c] = 0.f;
+    if (c < C && s < S) {
+      const f32x4 rw = *reinterpret_cast<const f32x4*>(raw + (base + s) * 4);
+      const float zc = z[base + s];
+      const float delta = (s == S - 1 ? 1e10f : (z[base + s + 1] - zc)) * dn;
+      float pre = rw.w * inv_B;
+      if (noise) pre += noise[base + s];
+      const float a = 1.f - expf(-density_act(act, pre, shift) * delta);
+      al[c] = a;
+      zz[c] = zc;
+      cr[c] = 1.002f / (1.f + expf(-rw.x)) - 0.001f;
+      cg[c] = 1.002f / (1.f + expf(-rw.y)) - 0.001f;
+      cb[c] = 1.002f / (1.f + expf(-rw.z)) - 0.001f;
+      prod *= (1.f - a + 1e-10f);
+    }
+  }
+  // inclusive product scan of per-lane products, then shift to exclusive
+  float incl = prod;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float up = __shfl_up(incl, o);
+    if (lane >= o) incl *= up;
+  }
+  float T = __shfl_up(incl, 1);
+  if (lane == 0) T = 1.f;
+  float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int s = lane * C + c;
+    if (c < C && s < S) {
+      const float w = al[c] * T;
+      weights[base + s] = w;
+      alpha_out[base + s] = al[c];
+      sr = fmaf(w, cr[c], sr);
+      sg = fmaf(w, cg[c], sg);
+      sb = fmaf(w, cb[c], sb);
+      sd = fmaf(w, zz[c], sd);
+      sa += w;
+      T *= (1.f - al[c] + 1e-10f);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    sr += __shfl_xor(sr, o);
+    sg += __shfl_xor(sg, o);
+    sb += __shfl_xor(sb, o);
+    sd += __shfl_xor(sd, o);
+    sa += __shfl_xor(sa, o);
+  }
+  if (lane == 0) {
+    rgb_map[3 * ray + 0] = sr;
+    rgb_map[3 * ray + 1] = sg;
+    rgb_map[3 * ray + 2] = sb;
+    float disp = 1.f / fmaxf(1e-10f, sd / (sa + 1e-10f));
+    if (fabsf(sa) <= 1e-8f) disp = 0.f;          // torch.isclose(sum_w, 0): atol 1e-8 (+ rtol * 0)
+    disp_map[ray] = disp;
+    acc_map[ray] = fminf(sa, 1.f);
+    if (depth_map) depth_map[ray] = sd;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// A11.  One wavefront per ray, 4 rays per block.  LDS per wave: cdf[S-1], bins[S-1], cat[S+Ni].
+__global__ __launch_bounds__(256) void k_importance(const float* __restrict__ z, const float* __restrict__ w, int n,
+                                                    int S, int Ni, const float* __restrict__ u, int single_net,
+                                                    float* __restrict__ z_samples, float* __restrict__ z_merged,
+                                                    long long* __restrict__ sorted_idx) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ray = blockIdx.x * 4 + wv;
+  const int T = S + Ni, nb = S - 1;       // nb bins / cdf entries
+  float* cdf = lds + wv * (2 * nb + T);
+  float* bins = cdf + nb;
+  float* cat = bins + nb;
+  if (ray >= n) return;
+  const float* zr = z + (long long)ray * S;
+  const float* wr = w + (long long)ray * S;
+  // pdf weights p[i], i in [0, S-2): from weights[1:-1] (+ smoothing for single_net), + 1e-5
+  float part = 0.f;
+  for (int i = lane; i < S - 2; i += 64) {
+    float pw;
+    if (single_net) pw = 0.5f * (fmaxf(wr[i], wr[i + 1]) + fmaxf(wr[i + 1], wr[i + 2])) + 0.01f;
+    else pw = wr[i + 1];
+    pw += 1e-5f;
+    cdf[i + 1] = pw;      // stash, normalised below
+    part += pw;
+  }
+  for (int i = lane; i < nb; i += 64) bins[i] = 0.5f * (zr[i] + zr[i + 1]);
+  for (int i = lane; i < S; i += 64) cat[i] = zr[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+  __builtin_amdgcn_wave_barrier();
+  // sequential cumulative sum of pdf (torch.cumsum order) by lane 0; S <= 512 so this is a few hundred adds
+  if (lane == 0) {
+    float run = 0.f;
+    cdf[0] = 0.f;
+    for (int i = 1; i < nb; ++i) {
+      run += cdf[i] / part;
+      cdf[i] = run;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  for (int k = lane; k < Ni; k += 64) {
+    float uu;
+    if (u) uu = u[(long long)ray * Ni + k];
+    else uu = Ni > 1 ? (float)k / (float)(Ni - 1) : 0.f;       // torch.linspace(0,1,Ni)
+    // searchsorted(cdf, u, right=True): first index with cdf[idx] > u
+    int lo = 0, hi = nb;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cdf[mid] <= uu) lo = mid + 1; else hi = mid;
+    }
+    const int below = lo - 1 > 0 ? lo - 1 : 0;
+    const int above = lo < nb - 1 ? lo : nb - 1;
+    const float c0 = cdf[below], c1 = cdf[above];
+    float den = c1 - c0;
+    if (den < 1e-5f) den = 1.f;
+    const float t = (uu - c0) / den;
+    const float zs = bins[below] + t * (bins[above] - bins[below]);
+    z_samples[(long long)ray * Ni + k] = zs;
+    cat[S + k] = zs;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  // stable rank sort of cat[0..T): rank = #{j : cat[j] < cat[i]  or  (cat[j] == cat[i] and j < i)}
+  for (int i = lane; i < T; i += 64) {
+    const float ci = cat[i];
+    int rank = 0;
+    for (int j = 0; j < T; ++j) {
+      const float cj = cat[j];
+      rank += (cj < ci) || (cj == ci && j < i);
+    }
+    z_merged[(long long)ray * T + rank] = ci;
+    if (sorted_idx) sorted_idx[(long long)ray * T + rank] = i;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------------
+int launch_pack(const AnerfNetParams* P, const int32_t* table, long long n, float* out, hipStream_t st) {
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(k_pack, dim3(blocks), dim3(256), 0, st, *P, table, n, out);
+  return check_launch("k_pack");
+}
+
+int launch_ray_bounds(const float* rays, int ray_stride, const float* cyls, int n, float* near_far, float* stats,
+                      hipStream_t st) {
+  if (hipMemsetAsync(stats, 0, 4 * sizeof(float), st) != hipSuccess) return set_error(ANERF_E_LAUNCH, "memset stats");
+  hipLaunchKernelGGL(k_ray_bounds, dim3((n + 255) / 256), dim3(256), 0, st, rays, ray_stride, cyls, n, near_far, stats);
+  return check_launch("k_ray_bounds");
+}
+
+int launch_coarse_z(const float* near_far, const float* stats, const float* rays, int ray_stride, int n, int S,
+                    const float* t_rand, int lindisp, float* z, float* nf_fixed, hipStream_t st) {
+  const long long tot = (long long)n * S;
+  hipLaunchKernelGGL(k_coarse_z, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, near_far, stats, rays,
+                     ray_stride, n, S, t_rand, lindisp, z, nf_fixed);
+  return check_launch("k_coarse_z");
+}
+
+int launch_composite(const AnerfConfig* cfg, const float* raw, const float* z, const float* rays, int ray_stride,
+                     const float* noise, int n, int S, float* rgb, float* disp, float* acc, float* weights,
+                     float* alpha, float* depth, hipStream_t st) {
+  hipLaunchKernelGGL(k_composite, dim3((n + 3) / 4), dim3(256), 0, st, raw, z, rays, ray_stride, noise, n, S,
+                     cfg->density_act, 1.0f / cfg->density_scale, cfg->softplus_shift, rgb, disp, acc, weights, alpha,
+                     depth);
+  return check_launch("k_composite");
+}
+
+int launch_importance(const float* z, const float* w, int n, int S, int Ni, const float* u, int single_net,
+                      float* zs, float* zm, long long* sidx, hipStream_t st) {
+  const size_t lds = 4 * (size_t)(2 * (S - 1) + S + Ni) * sizeof(float);
+  hipLaunchKernelGGL(k_importance, dim3((n + 3) / 4), dim3(256), lds, st, z, w, n, S, Ni, u, single_net, zs, zm, sidx);
+  return check_launch("k_importance");
+}
+
+}  // namespace anerf

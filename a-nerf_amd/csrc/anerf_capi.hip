@@ -1,0 +1,237 @@
+// anerf_capi.hip -- the extern "C" boundary of libanerf_hip.so (declared in include/anerf.h).
+// Host-side only: argument checking, weight-image layout / pack tables, kernel dispatch.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include "anerf_dev.h"
+
+namespace anerf {
+
+static thread_local char g_err[256] = "";
+
+int set_error(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+
+int check_launch(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return ANERF_OK;
+  snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+  return ANERF_E_LAUNCH;
+}
+
+// launchers defined in the kernel translation units
+struct MlpArgs;
+int launch_pack(const AnerfNetParams*, const int32_t*, long long, float*, hipStream_t);
+int launch_ray_bounds(const float*, int, const float*, int, float*, float*, hipStream_t);
+int launch_coarse_z(const float*, const float*, const float*, int, int, int, const float*, int, float*, float*,
+                    hipStream_t);
+int launch_composite(const AnerfConfig*, const float*, const float*, const float*, int, const float*, int, int, float*,
+                     float*, float*, float*, float*, float*, hipStream_t);
+int launch_importance(const float*, const float*, int, int, int, const float*, int, float*, float*, long long*,
+                      hipStream_t);
+int mlp_raw_entry(const AnerfConfig* cfg, const float* packed, const float* aux, const float* rays, int ray_stride,
+                  const float* z, const float* skts, long long skt_stride, const float* cam, const float* codes,
+                  int n_codes, float tau_v, float tau_d, const float* cut_v, const float* cut_d, const float* x,
+                  int x_width, long long P, int N, int S, int nstages, float* raw, bool pre, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------------
+// weight-stream layout.  A segment = one Linear layer; its k-groups (8 input columns: 4 per lane half) are laid
+// out [kg][nb][lane][4] and padded to whole 32-fragment stages.
+// ------------------------------------------------------------------------------------------------
+struct Seg {
+  int tensor;  // index into AnerfNetParams.w
+  int K;       // torch in_features (row length)
+  int NB;      // out_features / 32
+  int nkg;     // k-groups
+  int kind;    // 0 hidden (natural), 1 pts0, 2 pts5, 3 views
+};
+
+static bool config_ok(const AnerfConfig* c) {
+  return c && c->n_joints == 24 && c->multires == 7 && (c->multires_views == 4 || c->multires_views == 0) &&
+         (c->framecode_ch == 0 || c->framecode_ch == 16) && c->netdepth == 8 && c->netwidth == 256 && c->skip == 4 &&
+         !(c->multires_views == 0 && c->framecode_ch != 0) && c->density_scale > 0.f;
+}
+
+static int dim_v(const AnerfConfig* c) { return 24 * (1 + 2 * c->multires); }
+static int dim_x(const AnerfConfig* c) { return dim_v(c) + 72; }
+static int dim_d(const AnerfConfig* c) { return 72 * (1 + 2 * c->multires_views); }
+
+static std::vector<Seg> fwd_segments(const AnerfConfig* c) {
+  std::vector<Seg> s;
+  const int kx = dim_x(c) / 8;
+  s.push_back({0, dim_x(c), 8, kx, 1});
+  for (int i = 1; i <= 4; ++i) s.push_back({i, 256, 8, 32, 0});
+  s.push_back({5, dim_x(c) + 256, 8, kx + 32, 2});
+  s.push_back({6, 256, 8, 32, 0});
+  s.push_back({7, 256, 8, 32, 0});
+  s.push_back({9, 256, 8, 32, 0});
+  const int kv = 256 + dim_d(c) + c->framecode_ch;
+  s.push_back({10, kv, 4, kv / 8, 3});
+  return s;
+}
+
+static int seg_stages(const Seg& s) { return (s.nkg * s.NB + STAGE_FRAGS - 1) / STAGE_FRAGS; }
+
+// input column read by lane half h, slot t of k-group kg
+static int seg_col(const AnerfConfig* c, const Seg& s, int kg, int h, int t) {
+  auto owned = [&](int base, int g) {  // permuted (joint-owned) 3-vector channels: flat = 4g+t -> (a, comp)
+    const int flat = 4 * g + t, a = flat / 3, comp = flat % 3;
+    return base + 3 * (8 * (a >> 2) + 4 * h + (a & 3)) + comp;
+  };
+  const int kv = dim_v(c) / 8, kx = dim_x(c) / 8;
+  switch (s.kind) {
+    case 0: return 8 * kg + 4 * h + t;
+    case 1:
+    case 2:
+      if (kg < kv) return 8 * kg + 4 * h + t;
+      if (kg < kx) return owned(dim_v(c), kg - kv);
+      return dim_x(c) + 8 * (kg - kx) + 4 * h + t;
+    case 3: {
+      if (kg < 32) return 8 * kg + 4 * h + t;
+      const int nd = dim_d(c) / 8;
+      if (kg < 32 + nd) {
+        const int b = (kg - 32) / 9, g = (kg - 32) % 9;
+        return owned(256 + 72 * b, g);
+      }
+      return 256 + dim_d(c) + 8 * (kg - 32 - nd) + 4 * h + t;
+    }
+  }
+  return -1;
+}
+
+}  // namespace anerf
+
+using namespace anerf;
+
+extern "C" {
+
+const char* anerf_last_error(void) { return g_err; }
+int anerf_version(void) { return 1; }
+
+int anerf_layout(const AnerfConfig* cfg, int which, AnerfLayout* out) {
+  if (!out) return set_error(ANERF_E_NULL, "out is NULL");
+  if (!config_ok(cfg)) return set_error(ANERF_E_CONFIG, "unsupported AnerfConfig");
+  if (which != 0) return set_error(ANERF_E_CONFIG, "only the forward image (which=0) exists in this build");
+  int stages = 0;
+  for (const Seg& s : fwd_segments(cfg)) stages += seg_stages(s);
+  out->n_stages = stages;
+  out->stream_floats = (int64_t)stages * STAGE_FLOATS;
+  out->aux_floats = AUX_FLOATS;
+  out->x_width = dim_x(cfg) + dim_d(cfg) + (cfg->framecode_ch ? 1 : 0);
+  return ANERF_OK;
+}
+
+int anerf_build_pack_table(const AnerfConfig* cfg, int which, int32_t* table) {
+  AnerfLayout L;
+  const int rc = anerf_layout(cfg, which, &L);
+  if (rc) return rc;
+  if (!table) return set_error(ANERF_E_NULL, "table is NULL");
+  for (int64_t i = 0; i < L.stream_floats + L.aux_floats; ++i) table[i] = -1;
+  int64_t pos = 0;
+  for (const Seg& s : fwd_segments(cfg)) {
+    for (int kg = 0; kg < s.nkg; ++kg)
+      for (int nb = 0; nb < s.NB; ++nb)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int t = 0; t < 4; ++t) {
+            const int n = 32 * nb + (lane & 31), h = lane >> 5;
+            const int col = seg_col(cfg, s, kg, h, t);
+            table[pos + ((int64_t)(kg * s.NB + nb) * 64 + lane) * 4 + t] = (s.tensor << 24) | (n * s.K + col);
+          }
+    pos += (int64_t)seg_stages(s) * STAGE_FLOATS;
+  }
+  int32_t* aux = table + L.stream_floats;
+  for (int i = 0; i < 8; ++i)
+    for (int n = 0; n < 256; ++n) aux[AUX_B0 + 256 * i + n] = ((12 + i) << 24) | n;
+  for (int n = 0; n < 256; ++n) aux[AUX_BF + n] = ((12 + 9) << 24) | n;
+  for (int n = 0; n < 128; ++n) aux[AUX_BV + n] = ((12 + 10) << 24) | n;
+  for (int n = 0; n < 256; ++n) aux[AUX_WA + n] = (8 << 24) | n;
+  aux[AUX_BA] = ((12 + 8) << 24) | 0;
+  for (int n = 0; n < 384; ++n) aux[AUX_WC + n] = (11 << 24) | n;
+  for (int n = 0; n < 3; ++n) aux[AUX_BC + n] = ((12 + 11) << 24) | n;
+  return ANERF_OK;
+}
+
+int anerf_pack_params(const AnerfNetParams* params, const int32_t* table, int64_t n, float* out, void* stream) {
+  if (!params || !table || !out) return set_error(ANERF_E_NULL, "pack: NULL pointer");
+  for (int i = 0; i < 12; ++i)
+    if (!params->w[i] || !params->b[i]) return set_error(ANERF_E_NULL, "pack: NULL tensor");
+  return launch_pack(params, table, n, out, (hipStream_t)stream);
+}
+
+int anerf_ray_bounds(const float* rays, int32_t ray_stride, const float* cyls, int32_t n_rays, float* near_far,
+                     float* stats_ws, void* stream) {
+  if (!rays || !cyls || !near_far || !stats_ws) return set_error(ANERF_E_NULL, "ray_bounds: NULL pointer");
+  if (ray_stride < 8 || n_rays < 0) return set_error(ANERF_E_SHAPE, "ray_bounds: ray_stride >= 8 required");
+  if (n_rays == 0) return ANERF_OK;
+  return launch_ray_bounds(rays, ray_stride, cyls, n_rays, near_far, stats_ws, (hipStream_t)stream);
+}
+
+int anerf_coarse_z(const float* near_far, const float* stats_ws, const float* rays, int32_t ray_stride,
+                    int32_t n_rays, int32_t n_samples, const float* t_rand, int32_t lindisp, float* z_vals,
+                    float* near_far_fixed, void* stream) {
+  if (!near_far || !stats_ws || !rays || !z_vals) return set_error(ANERF_E_NULL, "coarse_z: NULL pointer");
+  if (n_samples < 2 || n_samples > MAX_SAMPLES) return set_error(ANERF_E_SHAPE, "coarse_z: 2 <= N_samples <= 512");
+  if (n_rays == 0) return ANERF_OK;
+  return launch_coarse_z(near_far, stats_ws, rays, ray_stride, n_rays, n_samples, t_rand, lindisp, z_vals,
+                         near_far_fixed, (hipStream_t)stream);
+}
+
+int anerf_mlp_raw(const AnerfConfig* cfg, const float* packed, const float* aux, const float* rays,
+                  int32_t ray_stride, const float* z_vals, const float* skts, int64_t skt_ray_stride,
+                  const float* cam_idx, const float* codes, int32_t n_codes, float tau_v, float tau_d,
+                  const float* cutoff_v, const float* cutoff_d, int32_t n_rays, int32_t n_samples, float* raw,
+                  void* stream) {
+  AnerfLayout L;
+  const int rc = anerf_layout(cfg, 0, &L);
+  if (rc) return rc;
+  if (!packed || !aux || !rays || !z_vals || !skts || !cutoff_v || !cutoff_d || !raw)
+    return set_error(ANERF_E_NULL, "mlp_raw: NULL pointer");
+  if (cfg->framecode_ch && (!cam_idx || !codes || n_codes < 1)) return set_error(ANERF_E_NULL, "mlp_raw: frame codes");
+  if (n_samples < MIN_SAMPLES || n_samples > MAX_SAMPLES)
+    return set_error(ANERF_E_SHAPE, "mlp_raw: 8 <= samples per ray <= 512");
+  if (skt_ray_stride != 0 && skt_ray_stride != 384) return set_error(ANERF_E_SHAPE, "mlp_raw: skt_ray_stride 0|384");
+  if (ray_stride < 6) return set_error(ANERF_E_SHAPE, "mlp_raw: ray_stride >= 6");
+  return mlp_raw_entry(cfg, packed, aux, rays, ray_stride, z_vals, skts, skt_ray_stride, cam_idx, codes, n_codes,
+                       tau_v, tau_d, cutoff_v, cutoff_d, nullptr, 0, (long long)n_rays * n_samples, n_rays, n_samples,
+                       L.n_stages, raw, false, (hipStream_t)stream);
+}
+
+int anerf_mlp_forward(const AnerfConfig* cfg, const float* packed, const float* aux, const float* x,
+                      int64_t n_points, const float* codes, int32_t n_codes, float* raw, void* stream) {
+  AnerfLayout L;
+  const int rc = anerf_layout(cfg, 0, &L);
+  if (rc) return rc;
+  if (!packed || !aux || !x || !raw) return set_error(ANERF_E_NULL, "mlp_forward: NULL pointer");
+  if (cfg->framecode_ch && (!codes || n_codes < 1)) return set_error(ANERF_E_NULL, "mlp_forward: frame codes");
+  if (n_points < 0) return set_error(ANERF_E_SHAPE, "mlp_forward: n_points < 0");
+  return mlp_raw_entry(cfg, packed, aux, nullptr, 0, nullptr, nullptr, 0, nullptr, codes, n_codes, 0.f, 0.f, nullptr,
+                       nullptr, x, L.x_width, n_points, 0, 1, L.n_stages, raw, true, (hipStream_t)stream);
+}
+
+int anerf_composite(const AnerfConfig* cfg, const float* raw, const float* z_vals, const float* rays,
+                    int32_t ray_stride, const float* noise, int32_t n_rays, int32_t n_samples, float* rgb_map,
+                    float* disp_map, float* acc_map, float* weights, float* alpha, float* depth_map, void* stream) {
+  if (!cfg || !raw || !z_vals || !rays || !rgb_map || !disp_map || !acc_map || !weights || !alpha)
+    return set_error(ANERF_E_NULL, "composite: NULL pointer");
+  if (n_samples < 1 || n_samples > MAX_SAMPLES) return set_error(ANERF_E_SHAPE, "composite: 1 <= samples <= 512");
+  if (cfg->density_act != 0 && cfg->density_act != 1) return set_error(ANERF_E_CONFIG, "composite: density_act");
+  if (n_rays == 0) return ANERF_OK;
+  return launch_composite(cfg, raw, z_vals, rays, ray_stride, noise, n_rays, n_samples, rgb_map, disp_map, acc_map,
+                          weights, alpha, depth_map, (hipStream_t)stream);
+}
+
+int anerf_importance(const float* z_vals, const float* weights, int32_t n_rays, int32_t n_samples,
+                     int32_t n_importance, const float* u, int32_t single_net, float* z_samples, float* z_merged,
+                     int64_t* sorted_idx, void* stream) {
+  if (!z_vals || !weights || !z_samples || !z_merged) return set_error(ANERF_E_NULL, "importance: NULL pointer");
+  if (n_samples < 3 || n_importance < 1 || n_samples + n_importance > MAX_SAMPLES)
+    return set_error(ANERF_E_SHAPE, "importance: need S >= 3, Ni >= 1, S + Ni <= 512");
+  if (n_rays == 0) return ANERF_OK;
+  return launch_importance(z_vals, weights, n_rays, n_samples, n_importance, u, single_net, z_samples, z_merged,
+                           (long long*)sorted_idx, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,67 @@
+// anerf_dev.h -- shared device/host definitions for libanerf_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "anerf.h"
+
+namespace anerf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+constexpr int TILE = 128;                       // samples per workgroup (4 waves x 32)
+constexpr int FRAG_FLOATS = 256;                // one MFMA weight fragment x 4 k-steps: 64 lanes x float4
+constexpr int FRAG_BYTES = 1024;
+constexpr int STAGE_FRAGS = 32;                 // fragments per LDS stage
+constexpr int STAGE_FLOATS = STAGE_FRAGS * FRAG_FLOATS;
+constexpr int STAGE_BYTES = STAGE_FRAGS * FRAG_BYTES;   // 32 KiB
+constexpr int MAX_TILE_RAYS = 18;               // rays a 128-sample tile can touch when N_samples >= 8
+constexpr int MIN_SAMPLES = 8;
+constexpr int MAX_SAMPLES = 512;
+
+// aux image (natural order): biases of pts_linears.0..7, feature, views; alpha / rgb head weights and biases
+constexpr int AUX_B0 = 0;          // 8 x 256
+constexpr int AUX_BF = 2048;       // 256
+constexpr int AUX_BV = 2304;       // 128
+constexpr int AUX_WA = 2432;       // 256
+constexpr int AUX_BA = 2688;       // 1 (+3 pad)
+constexpr int AUX_WC = 2692;       // 3 x 128
+constexpr int AUX_BC = 3076;       // 3 (+1 pad)
+constexpr int AUX_FLOATS = 3080;
+
+int set_error(int code, const char* msg);
+int check_launch(const char* what);
+
+#if defined(__HIPCC__)
+// sin and cos of x for |x| < ~1e4: Cody-Waite reduction by pi/2 (3 constants, exact products for |k| < 2^16)
+// + cephes-style minimax polynomials on [-pi/4, pi/4]; max abs error ~1e-7 (covers 2^6 * distance, 2^3 * unit dir).
+__device__ __forceinline__ void sincos_f32(float x, float& s, float& c) {
+  const float k = rintf(x * 0.636619772367581343f);
+  float r = fmaf(k, -1.5703125f, x);
+  r = fmaf(k, -4.837512969970703125e-4f, r);
+  r = fmaf(k, -7.54978995489188216e-8f, r);
+  const float r2 = r * r;
+  float ps = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+  ps = fmaf(ps, r2, -1.6666654611e-1f);
+  const float sr = fmaf(ps * r2, r, r);
+  float pc = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  pc = fmaf(pc, r2, 4.166664568298827e-2f);
+  const float cr = fmaf(pc * r2, r2, fmaf(r2, -0.5f, 1.0f));
+  const int q = (int)k;
+  const float ss = (q & 1) ? cr : sr;
+  const float cc = (q & 1) ? sr : cr;
+  s = (q & 2) ? -ss : ss;
+  c = ((q + 1) & 2) ? -cc : cc;
+}
+
+// cutoff gate w = 1 - sigmoid(tau * (dist - cutoff))  (core/cutoff_embedder.py:149-155), evaluated as
+// 1 / (1 + exp(a)): same value without the cancellation of "1 - sigmoid".
+__device__ __forceinline__ float cutoff_gate(float tau, float dist, float cutoff) {
+  const float a = tau * (dist - cutoff);
+  return 1.0f / (1.0f + __expf(a));
+}
+#endif
+
+}  // namespace anerf

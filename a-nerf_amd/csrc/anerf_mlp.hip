@@ -1,0 +1,428 @@
+// anerf_mlp.hip -- fused "encode + 11-layer MLP" forward kernel for gfx950 (MI355X, CDNA4).
+//
+// Replaces, per sample point, the reference op sequence
+//   transform_batch_pts / transform_batch_rays      core/encoders.py:8-37
+//   RelDistEncoder / VecNormEncoder                 core/encoders.py:110-122,181-193
+//   CutoffEmbedder._embed (x2) + identity embedder  core/cutoff_embedder.py:111-174
+//   run_network cat + NeRF.forward                  core/raycasters.py:557-577, core/networks/nerf.py:94-148
+// The 1080-wide encoding and the 256-wide activations never exist in HBM.
+//
+// Execution model (see DESIGN.md for the derivation)
+//   * workgroup = 4 waves = one 128-sample tile; every wave owns 32 samples for the whole network.
+//   * each layer is computed TRANSPOSED on the fp32 matrix cores: D^T[n][m] = sum_k W[n][k] * act[m][k] with
+//     v_mfma_f32_32x32x2_f32, A = weight fragment (from LDS), B = activation (a register), D = 32 features x
+//     32 samples.  Lane l holds sample m = l&31; lanes 0-31 / 32-63 hold the two k-halves.  The accumulator layout
+//     of layer i (feature n = 32nb + (r&3) + 8(r>>2) + 4(l>>5) in register r of block nb) IS the B-operand layout
+//     of layer i+1, so activations stay in registers across all layers: no LDS round trip, no barrier for them.
+//   * weights are pre-packed (anerf_pack.hip) into a linear stream of 1 KiB MFMA fragments in consumption order
+//     and streamed HBM/L2 -> LDS with global_load_lds_dwordx4 through a 2 x 32 KiB ring, one barrier per stage
+//     (= 8192 MFMA cycles per wave), shared by the 4 waves.
+//   * the encoding is produced in registers just in time as B operands: lane half h owns joints
+//     {j : ((j>>2)&1) == h}; bone matrices of the tile's rays are staged in LDS.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "anerf_dev.h"
+
+namespace anerf {
+
+// ------------------------------------------------------------------------------------------------
+// weight-stream pipe: global -> LDS ring (2 stages x 32 KiB), all 4 waves cooperate
+// ------------------------------------------------------------------------------------------------
+struct Pipe {
+  const char* gsrc;   // per-lane source of this wave's first fragment of stage 0
+  char* smem;
+  unsigned wave_dst;  // wave-uniform LDS byte offset of this wave's 8 fragments inside a stage
+  unsigned lane16;    // lane * 16
+  unsigned cur;       // LDS byte offset (lane-relative) of the stage being consumed
+  int stage;          // index of the next stage to consume
+  int nstages;
+
+  __device__ __forceinline__ void init(const float* packed, char* smem_, int wave, int lane, int nstages_) {
+    gsrc = reinterpret_cast<const char*>(packed) + wave * (8 * FRAG_BYTES) + lane * 16;
+    smem = smem_;
+    wave_dst = wave * (8 * FRAG_BYTES);
+    lane16 = lane * 16;
+    cur = 0;
+    stage = 0;
+    nstages = nstages_;
+  }
+  __device__ __forceinline__ void issue(int s) {
+    const char* g = gsrc + (size_t)s * STAGE_BYTES;
+    char* l = smem + (s & 1) * STAGE_BYTES + wave_dst;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(g + i * FRAG_BYTES), (lds_ptr_t)(l + i * FRAG_BYTES), 16, 0, 0);
+  }
+  // Called before the first k-group of every stage.
+  __device__ __forceinline__ void next_stage() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of stage `stage` has landed
+    __syncthreads();                                   // ... everybody's has; slot (stage+1)&1 is no longer read
+    if (stage + 1 < nstages) issue(stage + 1);
+    cur = lane16 + (stage & 1) * STAGE_BYTES;
+    ++stage;
+  }
+};
+
+// One k-group (8 contraction indices: 4 from each lane half) against NB 32-row feature blocks.
+// kg = k-group index relative to the segment start (compile-time after unrolling).
+template <int NB>
+__device__ __forceinline__ void kgroup(Pipe& pipe, f32x16 (&acc)[NB], int kg, float b0, float b1, float b2, float b3) {
+  constexpr int KPS = STAGE_FRAGS / NB;  // k-groups per stage
+  if (kg % KPS == 0) pipe.next_stage();
+  const unsigned off = pipe.cur + (kg % KPS) * NB * FRAG_BYTES;
+  f32x4 a[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) a[nb] = *reinterpret_cast<const f32x4*>(pipe.smem + off + nb * FRAG_BYTES);
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nb].x, b0, acc[nb], 0, 0, 0);
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nb].y, b1, acc[nb], 0, 0, 0);
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nb].z, b2, acc[nb], 0, 0, 0);
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nb].w, b3, acc[nb], 0, 0, 0);
+}
+
+// acc[nb][r] <- bias[n(nb,r,h)]; natural-order bias vector, float4 per (nb,q).
+template <int NB>
+__device__ __forceinline__ void init_bias(f32x16 (&acc)[NB], const float* __restrict__ bias, int h) {
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(bias + 32 * nb + 8 * q + 4 * h);
+      acc[nb][4 * q + 0] = b.x;
+      acc[nb][4 * q + 1] = b.y;
+      acc[nb][4 * q + 2] = b.z;
+      acc[nb][4 * q + 3] = b.w;
+    }
+}
+
+// 32 k-groups whose B operands are the 256 hidden activations held in registers.
+template <int NB, int KG0>
+__device__ __forceinline__ void hidden_part(Pipe& pipe, f32x16 (&acc)[NB], const float (&hin)[128]) {
+#pragma unroll
+  for (int kg = 0; kg < 32; ++kg)
+    kgroup<NB>(pipe, acc, KG0 + kg, hin[4 * kg + 0], hin[4 * kg + 1], hin[4 * kg + 2], hin[4 * kg + 3]);
+}
+
+template <int NB, bool RELU>
+__device__ __forceinline__ void to_hidden(float (&hin)[128], const f32x16 (&acc)[NB]) {
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hin[nb * 16 + r] = RELU ? fmaxf(acc[nb][r], 0.f) : acc[nb][r];
+}
+
+// dot of the lane's 16*NB held activations with a natural-order weight row, reduced over both lane halves
+template <int NB>
+__device__ __forceinline__ float head_dot(const float (&act)[128], const float* __restrict__ wrow, int h) {
+  float s = 0.f;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + 32 * nb + 8 * q + 4 * h);
+      s = fmaf(act[nb * 16 + 4 * q + 0], w.x, s);
+      s = fmaf(act[nb * 16 + 4 * q + 1], w.y, s);
+      s = fmaf(act[nb * 16 + 4 * q + 2], w.z, s);
+      s = fmaf(act[nb * 16 + 4 * q + 3], w.w, s);
+    }
+  return s + __shfl_xor(s, 32);
+}
+
+// ------------------------------------------------------------------------------------------------
+// the x-part (432 = 360 distance-PE + 72 bone-direction channels) as 54 k-groups.
+// Encoded just in time (PRE = false) or read from a pre-encoded row (PRE = true, NeRF.forward seam).
+// ------------------------------------------------------------------------------------------------
+template <int LV, bool PRE>
+__device__ __forceinline__ void x_part(Pipe& pipe, f32x16 (&acc)[8], const float (&v)[12], const float (&wv)[12],
+                                       const float (&rh)[36], const float* __restrict__ xrow, int h) {
+  if constexpr (PRE) {
+#pragma unroll
+    for (int kg = 0; kg < 3 * (1 + 2 * LV); ++kg) {
+      const float* c = xrow + 8 * kg + 4 * h;
+      kgroup<8>(pipe, acc, kg, c[0], c[1], c[2], c[3]);
+    }
+#pragma unroll
+    for (int g = 0; g < 9; ++g) {
+      float b[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int a = (4 * g + t) / 3, c = (4 * g + t) % 3;
+        b[t] = xrow[24 * (1 + 2 * LV) + 3 * (8 * (a >> 2) + (a & 3)) + c + 12 * h];
+      }
+      kgroup<8>(pipe, acc, 3 * (1 + 2 * LV) + g, b[0], b[1], b[2], b[3]);
+    }
+  } else {
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+      kgroup<8>(pipe, acc, g, v[4 * g] * wv[4 * g], v[4 * g + 1] * wv[4 * g + 1], v[4 * g + 2] * wv[4 * g + 2],
+                v[4 * g + 3] * wv[4 * g + 3]);
+#pragma unroll
+    for (int f = 0; f < LV; ++f) {
+      float sv[12], cv[12];
+#pragma unroll
+      for (int a = 0; a < 12; ++a) {
+        float s, c;
+        sincos_f32(v[a] * (float)(1 << f), s, c);
+        sv[a] = s * wv[a];
+        cv[a] = c * wv[a];
+      }
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+        kgroup<8>(pipe, acc, 3 + 6 * f + g, sv[4 * g], sv[4 * g + 1], sv[4 * g + 2], sv[4 * g + 3]);
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+        kgroup<8>(pipe, acc, 6 + 6 * f + g, cv[4 * g], cv[4 * g + 1], cv[4 * g + 2], cv[4 * g + 3]);
+    }
+#pragma unroll
+    for (int g = 0; g < 9; ++g)
+      kgroup<8>(pipe, acc, 3 * (1 + 2 * LV) + g, rh[4 * g], rh[4 * g + 1], rh[4 * g + 2], rh[4 * g + 3]);
+  }
+}
+
+struct MlpArgs {
+  const float* packed;
+  const float* aux;
+  const float* rays;
+  const float* z;
+  const float* skts;
+  const float* cam;
+  const float* codes;
+  const float* cut_v;
+  const float* cut_d;
+  const float* x;  // PRE
+  float* raw;
+  long long P;
+  long long skt_stride;
+  int S, N, ray_stride, n_codes, x_width, nstages;
+  float tau_v, tau_d;
+};
+
+template <int LV, int LD, int CODE, bool PRE>
+__global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 31, h = lane >> 5;
+
+  Pipe pipe;
+  pipe.init(A.packed, smem, wave, lane, A.nstages);
+  pipe.issue(0);
+
+  const long long p = (long long)blockIdx.x * TILE + wave * 32 + m;
+  const bool valid = p < A.P;
+  const long long pc = valid ? p : A.P - 1;
+
+  float v[12], wv[12], rh[36];
+  float dray[3] = {0.f, 0.f, 0.f};
+  int lr = 0;
+  long long ray = 0;
+  const float* xrow = nullptr;
+  const f32x4* bones4 = reinterpret_cast<const f32x4*>(smem + 2 * STAGE_BYTES);
+
+  if constexpr (PRE) {
+    xrow = A.x + pc * A.x_width;
+#pragma unroll
+    for (int a = 0; a < 12; ++a) v[a] = wv[a] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 36; ++a) rh[a] = 0.f;
+  } else {
+    // ---- stage the bone matrices (rows 0..2 of each 4x4 world->bone matrix) of this tile's rays in LDS
+    const long long tile_p0 = (long long)blockIdx.x * TILE;
+    const long long ray0 = tile_p0 / A.S;
+    long long ray1 = (tile_p0 + TILE - 1) / A.S;
+    if (ray1 > A.N - 1) ray1 = A.N - 1;
+    ray = pc / A.S;
+    const int n_stage_rays = A.skt_stride == 0 ? 1 : (int)(ray1 - ray0 + 1);
+    lr = A.skt_stride == 0 ? 0 : (int)(ray - ray0);
+    f32x4* bw = reinterpret_cast<f32x4*>(smem + 2 * STAGE_BYTES);
+    for (int i = tid; i < n_stage_rays * 72; i += 256) {
+      const int ri = i / 72, rem = i - ri * 72, j = rem / 3, row = rem - 3 * j;
+      bw[i] = *reinterpret_cast<const f32x4*>(A.skts + (ray0 + ri) * A.skt_stride + j * 16 + row * 4);
+    }
+    __syncthreads();
+    const float* rp = A.rays + ray * A.ray_stride;
+    const float z = A.z[pc];
+    dray[0] = rp[3];
+    dray[1] = rp[4];
+    dray[2] = rp[5];
+    const float x0 = fmaf(dray[0], z, rp[0]), x1 = fmaf(dray[1], z, rp[1]), x2 = fmaf(dray[2], z, rp[2]);
+#pragma unroll
+    for (int a = 0; a < 12; ++a) {
+      const int j = 8 * (a >> 2) + 4 * h + (a & 3);
+      const f32x4 r0 = bones4[(lr * 24 + j) * 3 + 0], r1 = bones4[(lr * 24 + j) * 3 + 1],
+                  r2 = bones4[(lr * 24 + j) * 3 + 2];
+      const float y0 = r0.x * x0 + r0.y * x1 + r0.z * x2 + r0.w;
+      const float y1 = r1.x * x0 + r1.y * x1 + r1.z * x2 + r1.w;
+      const float y2 = r2.x * x0 + r2.y * x1 + r2.z * x2 + r2.w;
+      const float n = sqrtf(y0 * y0 + y1 * y1 + y2 * y2);
+      const float inv = 1.0f / fmaxf(n, 1e-12f);
+      v[a] = n;
+      rh[3 * a + 0] = y0 * inv;
+      rh[3 * a + 1] = y1 * inv;
+      rh[3 * a + 2] = y2 * inv;
+      wv[a] = cutoff_gate(A.tau_v, n, A.cut_v[j]);
+    }
+  }
+
+  float hin[128];
+  f32x16 acc[8];
+
+  // ---- layer 0: x(432) -> 256
+  init_bias<8>(acc, A.aux + AUX_B0, h);
+  x_part<LV, PRE>(pipe, acc, v, wv, rh, xrow, h);
+  to_hidden<8, true>(hin, acc);
+  // ---- layers 1..4
+#pragma unroll 1
+  for (int L = 1; L <= 4; ++L) {
+    init_bias<8>(acc, A.aux + AUX_B0 + 256 * L, h);
+    hidden_part<8, 0>(pipe, acc, hin);
+    to_hidden<8, true>(hin, acc);
+  }
+  // ---- layer 5: [x(432); h4(256)] -> 256   (skip connection: x is re-encoded, never stored)
+  init_bias<8>(acc, A.aux + AUX_B0 + 256 * 5, h);
+  x_part<LV, PRE>(pipe, acc, v, wv, rh, xrow, h);
+  hidden_part<8, 3 * (1 + 2 * LV) + 9>(pipe, acc, hin);
+  to_hidden<8, true>(hin, acc);
+  // ---- layers 6, 7
+#pragma unroll 1
+  for (int L = 6; L <= 7; ++L) {
+    init_bias<8>(acc, A.aux + AUX_B0 + 256 * L, h);
+    hidden_part<8, 0>(pipe, acc, hin);
+    to_hidden<8, true>(hin, acc);
+  }
+  // ---- density head (VALU): sigma_raw = w_alpha . h7 + b_alpha
+  const float sigma_raw = head_dot<8>(hin, A.aux + AUX_WA, h) + A.aux[AUX_BA];
+  // ---- feature layer (no activation)
+  init_bias<8>(acc, A.aux + AUX_BF, h);
+  hidden_part<8, 0>(pipe, acc, hin);
+  to_hidden<8, false>(hin, acc);
+  // ---- view layer: [feature(256); D(72*(1+2LD)); code(CODE)] -> 128, ReLU
+  f32x16 accv[4];
+  init_bias<4>(accv, A.aux + AUX_BV, h);
+  hidden_part<4, 0>(pipe, accv, hin);
+  constexpr int DIMX = 24 * (1 + 2 * LV) + 72;
+  constexpr int DIMD = 72 * (1 + 2 * LD);
+  if constexpr (PRE) {
+#pragma unroll
+    for (int b = 0; b < 1 + 2 * LD; ++b)
+#pragma unroll
+      for (int g = 0; g < 9; ++g) {
+        float bb[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int a = (4 * g + t) / 3, c = (4 * g + t) % 3;
+          bb[t] = xrow[DIMX + 72 * b + 3 * (8 * (a >> 2) + (a & 3)) + c + 12 * h];
+        }
+        kgroup<4>(pipe, accv, 32 + 9 * b + g, bb[0], bb[1], bb[2], bb[3]);
+      }
+  } else {
+    // per-ray unit direction in each owned bone frame, gated per sample by the distance gate (tau_d, cut_d)
+    float e[36], wd[12];
+#pragma unroll
+    for (int a = 0; a < 12; ++a) {
+      const int j = 8 * (a >> 2) + 4 * h + (a & 3);
+      const f32x4 r0 = bones4[(lr * 24 + j) * 3 + 0], r1 = bones4[(lr * 24 + j) * 3 + 1],
+                  r2 = bones4[(lr * 24 + j) * 3 + 2];
+      const float y0 = r0.x * dray[0] + r0.y * dray[1] + r0.z * dray[2];
+      const float y1 = r1.x * dray[0] + r1.y * dray[1] + r1.z * dray[2];
+      const float y2 = r2.x * dray[0] + r2.y * dray[1] + r2.z * dray[2];
+      const float inv = 1.0f / fmaxf(sqrtf(y0 * y0 + y1 * y1 + y2 * y2), 1e-12f);
+      e[3 * a + 0] = y0 * inv;
+      e[3 * a + 1] = y1 * inv;
+      e[3 * a + 2] = y2 * inv;
+      wd[a] = cutoff_gate(A.tau_d, v[a], A.cut_d[j]);
+    }
+#pragma unroll
+    for (int g = 0; g < 9; ++g)
+      kgroup<4>(pipe, accv, 32 + g, e[4 * g] * wd[(4 * g) / 3], e[4 * g + 1] * wd[(4 * g + 1) / 3],
+                e[4 * g + 2] * wd[(4 * g + 2) / 3], e[4 * g + 3] * wd[(4 * g + 3) / 3]);
+#pragma unroll
+    for (int f = 0; f < LD; ++f) {
+      float se[36], ce[36];
+#pragma unroll
+      for (int i = 0; i < 36; ++i) {
+        float s, c;
+        sincos_f32(e[i] * (float)(1 << f), s, c);
+        se[i] = s * wd[i / 3];
+        ce[i] = c * wd[i / 3];
+      }
+#pragma unroll
+      for (int g = 0; g < 9; ++g)
+        kgroup<4>(pipe, accv, 32 + 9 * (1 + 2 * f) + g, se[4 * g], se[4 * g + 1], se[4 * g + 2], se[4 * g + 3]);
+#pragma unroll
+      for (int g = 0; g < 9; ++g)
+        kgroup<4>(pipe, accv, 32 + 9 * (2 + 2 * f) + g, ce[4 * g], ce[4 * g + 1], ce[4 * g + 2], ce[4 * g + 3]);
+    }
+  }
+  if constexpr (CODE > 0) {
+    float fidx;
+    if constexpr (PRE) fidx = xrow[DIMX + DIMD];
+    else fidx = A.cam[ray];
+    int ci = (int)fidx;
+    ci = ci < 0 ? 0 : (ci >= A.n_codes ? A.n_codes - 1 : ci);
+    const float* crow = A.codes + (long long)ci * CODE;
+#pragma unroll
+    for (int g = 0; g < CODE / 8; ++g) {
+      const f32x4 c4 = *reinterpret_cast<const f32x4*>(crow + 8 * g + 4 * h);
+      kgroup<4>(pipe, accv, 32 + 9 * (1 + 2 * LD) + g, c4.x, c4.y, c4.z, c4.w);
+    }
+  }
+  float gact[128];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gact[nb * 16 + r] = fmaxf(accv[nb][r], 0.f);
+  // ---- rgb head (VALU)
+  const float c0 = head_dot<4>(gact, A.aux + AUX_WC + 0, h) + A.aux[AUX_BC + 0];
+  const float c1 = head_dot<4>(gact, A.aux + AUX_WC + 128, h) + A.aux[AUX_BC + 1];
+  const float c2 = head_dot<4>(gact, A.aux + AUX_WC + 256, h) + A.aux[AUX_BC + 2];
+  if (valid && h == 0) {
+    f32x4 o = {c0, c1, c2, sigma_raw};
+    *reinterpret_cast<f32x4*>(A.raw + p * 4) = o;
+  }
+}
+
+template <int LV, int LD, int CODE, bool PRE>
+static int launch(const MlpArgs& a, hipStream_t st) {
+  const long long nblk = (a.P + TILE - 1) / TILE;
+  if (nblk <= 0) return ANERF_OK;
+  const size_t lds = 2 * STAGE_BYTES + (PRE ? 0 : MAX_TILE_RAYS * 72 * 16);
+  auto kern = k_mlp_fwd<LV, LD, CODE, PRE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, a);
+  return check_launch("k_mlp_fwd");
+}
+
+int mlp_dispatch(const AnerfConfig* cfg, const MlpArgs& a, bool pre, hipStream_t st) {
+  const int lv = cfg->multires, ld = cfg->multires_views, cd = cfg->framecode_ch;
+  if (lv != 7) return set_error(ANERF_E_CONFIG, "multires must be 7");
+#define ANERF_CASE(LD_, CD_)                                                         \
+  if (ld == LD_ && cd == CD_) return pre ? launch<7, LD_, CD_, true>(a, st) : launch<7, LD_, CD_, false>(a, st);
+  ANERF_CASE(4, 0)
+  ANERF_CASE(4, 16)
+  ANERF_CASE(0, 0)
+#undef ANERF_CASE
+  return set_error(ANERF_E_CONFIG, "unsupported (multires_views, framecode_ch); built: (4,0) (4,16) (0,0)");
+}
+
+int mlp_raw_entry(const AnerfConfig* cfg, const float* packed, const float* aux, const float* rays, int ray_stride,
+                  const float* z, const float* skts, long long skt_stride, const float* cam, const float* codes,
+                  int n_codes, float tau_v, float tau_d, const float* cut_v, const float* cut_d, const float* x,
+                  int x_width, long long P, int N, int S, int nstages, float* raw, bool pre, hipStream_t st) {
+  MlpArgs a;
+  a.packed = packed; a.aux = aux; a.rays = rays; a.z = z; a.skts = skts; a.cam = cam; a.codes = codes;
+  a.cut_v = cut_v; a.cut_d = cut_d; a.x = x; a.raw = raw; a.P = P; a.skt_stride = skt_stride;
+  a.S = S; a.N = N; a.ray_stride = ray_stride; a.n_codes = n_codes; a.x_width = x_width; a.nstages = nstages;
+  a.tau_v = tau_v; a.tau_d = tau_d;
+  return mlp_dispatch(cfg, a, pre, st);
+}
+
+}  // namespace anerf

@@ -1,0 +1,191 @@
+"""Tensor-level wrappers over the C ABI (include/anerf.h).  PyTorch is plumbing here: it owns device
+memory and the stream; every op below enqueues hand-written HIP kernels from libanerf_hip.so on
+torch's current stream and returns torch tensors that alias the buffers the kernels wrote.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+PARAM_ORDER = [f"pts_linears.{i}" for i in range(8)] + ["alpha_linear", "feature_linear", "views_linears.0", "rgb_linear"]
+
+
+class PathConfig:
+    """Static configuration of the path (reference: create_raycaster, core/raycasters.py:17-184)."""
+
+    def __init__(self, multires=7, multires_views=4, framecode_ch=0, density_scale=1.0, softplus_shift=None,
+                 n_joints=24, netdepth=8, netwidth=256, skip=4):
+        self.multires, self.multires_views, self.framecode_ch = multires, multires_views, framecode_ch
+        self.density_scale, self.softplus_shift = float(density_scale), softplus_shift
+        self.n_joints, self.netdepth, self.netwidth, self.skip = n_joints, netdepth, netwidth, skip
+        self.dim_v = n_joints * (1 + 2 * multires)
+        self.dim_x = self.dim_v + 3 * n_joints
+        self.dim_d = 3 * n_joints * (1 + 2 * multires_views)
+        self.x_width = self.dim_x + self.dim_d + (1 if framecode_ch else 0)
+
+    def key(self):
+        return (self.multires, self.multires_views, self.framecode_ch, self.n_joints, self.netdepth, self.netwidth, self.skip)
+
+    def c(self):
+        return _lib.AnerfConfig(self.n_joints, self.multires, self.multires_views, self.framecode_ch, self.netdepth,
+                                self.netwidth, self.skip, 0 if self.softplus_shift is None else 1, self.density_scale,
+                                0.0 if self.softplus_shift is None else float(self.softplus_shift))
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _f32c(t, name):
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise TypeError(f"{name}: expected a float32 CUDA(ROCm) tensor, got {t.dtype} on {t.device}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+_layout_cache = {}
+_table_cache = {}
+
+
+def layout(cfg, which=0):
+    k = (cfg.key(), which)
+    if k not in _layout_cache:
+        L = _lib.AnerfLayout()
+        cc = cfg.c()
+        _lib.check(_lib.load().anerf_layout(C.byref(cc), which, C.byref(L)), "anerf_layout")
+        _layout_cache[k] = (int(L.stream_floats), int(L.aux_floats), int(L.n_stages), int(L.x_width))
+    return _layout_cache[k]
+
+
+def pack_table(cfg, device, which=0):
+    """Device copy of the parameter-gather table (built on the host once per config and device)."""
+    k = (cfg.key(), which, str(device))
+    if k not in _table_cache:
+        sf, af, _, _ = layout(cfg, which)
+        host = np.empty(sf + af, dtype=np.int32)
+        cc = cfg.c()
+        _lib.check(_lib.load().anerf_build_pack_table(C.byref(cc), which, host.ctypes.data_as(C.c_void_p)), "anerf_build_pack_table")
+        _table_cache[k] = torch.from_numpy(host).to(device)
+    return _table_cache[k]
+
+
+def net_params_struct(params, codes=None):
+    """params: dict name -> CUDA tensor with the reference's state_dict names."""
+    st = _lib.AnerfNetParams()
+    keep = []
+    for i, n in enumerate(PARAM_ORDER):
+        w = _f32c(params[n + ".weight"], n + ".weight")
+        b = _f32c(params[n + ".bias"], n + ".bias")
+        keep += [w, b]
+        st.w[i] = w.data_ptr()
+        st.b[i] = b.data_ptr()
+    if codes is not None:
+        codes = _f32c(codes, "codes")
+        keep.append(codes)
+        st.codes = codes.data_ptr()
+        st.n_codes = codes.shape[0]
+    return st, keep
+
+
+def pack_params(cfg, params, which=0, out=None):
+    """Gather one network's parameters into the packed (stream, aux) images the MLP kernels consume."""
+    dev = params[PARAM_ORDER[0] + ".weight"].device
+    sf, af, _, _ = layout(cfg, which)
+    table = pack_table(cfg, dev, which)
+    if out is None:
+        out = torch.empty(sf + af, dtype=torch.float32, device=dev)
+    st, keep = net_params_struct(params)
+    _lib.check(_lib.load().anerf_pack_params(C.byref(st), _p(table), sf + af, _p(out), _stream()), "anerf_pack_params")
+    return out[:sf], out[sf:]
+
+
+def ray_bounds(rays, cyls):
+    """get_near_far_in_cylinder (ray_utils.py:292): rays [N,>=8], cyls [N,5] -> (near_far [N,2] raw, stats [4])."""
+    rays, cyls = _f32c(rays, "rays"), _f32c(cyls, "cyls")
+    n = rays.shape[0]
+    nf = torch.empty(n, 2, dtype=torch.float32, device=rays.device)
+    stats = torch.empty(4, dtype=torch.float32, device=rays.device)
+    _lib.check(_lib.load().anerf_ray_bounds(_p(rays), rays.shape[1], _p(cyls), n, _p(nf), _p(stats), _stream()), "anerf_ray_bounds")
+    return nf, stats
+
+
+def coarse_z(near_far, stats, rays, n_samples, t_rand=None, lindisp=False):
+    rays = _f32c(rays, "rays")
+    n = rays.shape[0]
+    t_rand = _f32c(t_rand, "t_rand")
+    z = torch.empty(n, n_samples, dtype=torch.float32, device=rays.device)
+    nf_fixed = torch.empty(n, 2, dtype=torch.float32, device=rays.device)
+    _lib.check(_lib.load().anerf_coarse_z(_p(near_far), _p(stats), _p(rays), rays.shape[1], n, n_samples, _p(t_rand),
+                                          int(bool(lindisp)), _p(z), _p(nf_fixed), _stream()), "anerf_coarse_z")
+    return z, nf_fixed
+
+
+def mlp_raw(cfg, packed, aux, rays, z_vals, skts, tau_v, tau_d, cut_v, cut_d, cam_idx=None, codes=None):
+    """Fused encode + MLP: raw [N,S,4].  skts [N,24,4,4] or [1,24,4,4] (shared pose)."""
+    rays, z_vals, skts = _f32c(rays, "rays"), _f32c(z_vals, "z_vals"), _f32c(skts, "skts")
+    n, s = z_vals.shape
+    if skts.shape[0] not in (1, n):
+        raise ValueError(f"skts batch {skts.shape[0]} must be 1 or N={n}")
+    stride = 0 if skts.shape[0] == 1 else 16 * cfg.n_joints
+    cam_idx, codes = _f32c(cam_idx, "cam_idx"), _f32c(codes, "codes")
+    raw = torch.empty(n, s, 4, dtype=torch.float32, device=rays.device)
+    cc = cfg.c()
+    _lib.check(_lib.load().anerf_mlp_raw(C.byref(cc), _p(packed), _p(aux), _p(rays), rays.shape[1], _p(z_vals), _p(skts),
+                                         stride, _p(cam_idx), _p(codes), 0 if codes is None else codes.shape[0],
+                                         float(tau_v), float(tau_d), _p(_f32c(cut_v, "cut_v")), _p(_f32c(cut_d, "cut_d")),
+                                         n, s, _p(raw), _stream()), "anerf_mlp_raw")
+    return raw
+
+
+def mlp_forward(cfg, packed, aux, x, codes=None):
+    """NeRF.forward seam: x [..., x_width] pre-encoded -> raw [..., 4]."""
+    x = _f32c(x, "x")
+    if x.shape[-1] != cfg.x_width:
+        raise ValueError(f"x last dim {x.shape[-1]} != {cfg.x_width}")
+    flat = x.reshape(-1, x.shape[-1])
+    codes = _f32c(codes, "codes")
+    raw = torch.empty(flat.shape[0], 4, dtype=torch.float32, device=x.device)
+    cc = cfg.c()
+    _lib.check(_lib.load().anerf_mlp_forward(C.byref(cc), _p(packed), _p(aux), _p(flat), flat.shape[0], _p(codes),
+                                             0 if codes is None else codes.shape[0], _p(raw), _stream()), "anerf_mlp_forward")
+    return raw.reshape(*x.shape[:-1], 4)
+
+
+def composite(cfg, raw, z_vals, rays, noise=None, want_depth=False):
+    """raw2outputs (nerf.py:150-205)."""
+    raw, z_vals, rays, noise = _f32c(raw, "raw"), _f32c(z_vals, "z_vals"), _f32c(rays, "rays"), _f32c(noise, "noise")
+    n, s = z_vals.shape
+    dev = raw.device
+    rgb = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    disp = torch.empty(n, dtype=torch.float32, device=dev)
+    acc = torch.empty(n, dtype=torch.float32, device=dev)
+    w = torch.empty(n, s, dtype=torch.float32, device=dev)
+    al = torch.empty(n, s, dtype=torch.float32, device=dev)
+    depth = torch.empty(n, dtype=torch.float32, device=dev) if want_depth else None
+    cc = cfg.c()
+    _lib.check(_lib.load().anerf_composite(C.byref(cc), _p(raw), _p(z_vals), _p(rays), rays.shape[1], _p(noise), n, s,
+                                           _p(rgb), _p(disp), _p(acc), _p(w), _p(al), _p(depth), _stream()), "anerf_composite")
+    out = {"rgb_map": rgb, "disp_map": disp, "acc_map": acc, "weights": w, "alpha": al}
+    if want_depth:
+        out["depth_map"] = depth
+    return out
+
+
+def importance(z_vals, weights, n_importance, u=None, single_net=False, want_idx=True):
+    """isample_from_lineseg (ray_utils.py:255-289): -> z_samples [N,Ni], z_merged [N,S+Ni], sorted_idx int64."""
+    z_vals, weights, u = _f32c(z_vals, "z_vals"), _f32c(weights, "weights"), _f32c(u, "u")
+    n, s = z_vals.shape
+    dev = z_vals.device
+    zs = torch.empty(n, n_importance, dtype=torch.float32, device=dev)
+    zm = torch.empty(n, s + n_importance, dtype=torch.float32, device=dev)
+    idx = torch.empty(n, s + n_importance, dtype=torch.int64, device=dev) if want_idx else None
+    _lib.check(_lib.load().anerf_importance(_p(z_vals), _p(weights), n, s, n_importance, _p(u), int(bool(single_net)),
+                                            _p(zs), _p(zm), _p(idx), _stream()), "anerf_importance")
+    return zs, zm, idx

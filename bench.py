@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- rays/sec of the MI355X-native A-NeRF ray-march hot path (BASELINE.json metric).
+
+Workload (BASELINE config 2): synthetic SURREAL-shaped 512x512 frame, 261 121 bbox rays, 64 samples/ray,
+forward-only render (ray bounds -> z -> fused encode+MLP -> composite), fp32.  One "step" = one frame.
+With --gpus N the frame's rays are split into N contiguous slices (strong scaling: total work fixed), one
+process per GPU, and the per-ray outputs are all-gathered over RCCL at the end of every step.
+
+  python bench.py [--gpus N --steps K --warmup W] [--workload render64|hier|render64x64]
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel
+(k_mlp_fwd, MFMA-bound: algorithmic FLOPs / HIP-event time on the launch stream vs the 157.3 TFLOP/s fp32
+matrix peak) and `cpu_baseline` (the torch-CPU oracle = port of the reference path, timed on this host's
+cores over a bounded ray sample of the same frame).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F_MLP = 2 * 861824          # FLOP per network evaluation of one sample
+PEAK_FP32_MFMA = 157.3e12   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="render64", choices=["render64", "hier", "render64x64"])
+    ap.add_argument("--cpu-rays", type=int, default=8192, help="ray sample for the CPU baseline (0 = skip)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    synth = importlib.import_module("a-nerf_amd.synth")
+    ops = importlib.import_module("a-nerf_amd.ops")
+    pipeline = importlib.import_module("a-nerf_amd.pipeline")
+
+    if args.workload == "render64x64":
+        H = W = 64; focal = 75.0; S, Ni = 32, 0
+        name = "SURREAL-shaped 64x64 frame, 32 samples/ray, forward render (BASELINE config 1)"
+    elif args.workload == "hier":
+        H = W = 512; focal = 600.0; S, Ni = 64, 16
+        name = "SURREAL-shaped 512x512 frame, 64+16 samples/ray (surreal.txt), forward render"
+    else:
+        H = W = 512; focal = 600.0; S, Ni = 64, 0
+        name = "SURREAL-shaped 512x512 frame, 64 samples/ray, forward render (BASELINE config 2)"
+    sc = synth.make_scene(0, H, W, focal)
+    n_total = len(sc["rays_o"])
+    dev = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32, device=device)
+    cfg = ops.PathConfig()
+    Pc, Pf = synth.make_net_params(11), synth.make_net_params(12)
+    net_c = ops.pack_params(cfg, {k: dev(v) for k, v in Pc.items()})
+    net_f = ops.pack_params(cfg, {k: dev(v) for k, v in Pf.items()}) if Ni else None
+
+    # this rank's contiguous slice of the frame's rays (inputs resident in HBM before timing starts)
+    per = (n_total + world - 1) // world
+    lo, hi = rank * per, min(n_total, (rank + 1) * per)
+    rb = pipeline.make_ray_batch(dev(sc["rays_o"][lo:hi]), dev(sc["rays_d"][lo:hi]))
+    cyl = dev(sc["cyl"])[None].expand(hi - lo, -1).contiguous()
+    skt = dev(sc["pose"]["skts"])[None]          # one pose per frame: shared (stride-0) bone matrices
+    cut = torch.full((24,), 0.5, device=device)
+    gather_buf = torch.empty(world * per, 5, device=device) if world > 1 else None
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None):
+        nf_raw, stats = ops.ray_bounds(rb, cyl)
+        z, _ = ops.coarse_z(nf_raw, stats, rb, S)
+        if i is not None:
+            ev[i][0].record()
+        raw = ops.mlp_raw(cfg, net_c[0], net_c[1], rb, z, skt, 20.0, 20.0, cut, cut)
+        if i is not None:
+            ev[i][1].record()
+        co = ops.composite(cfg, raw, z, rb)
+        if Ni:
+            zs, zm, _ = ops.importance(z, co["weights"], Ni, want_idx=False)
+            raw_f = ops.mlp_raw(cfg, net_f[0], net_f[1], rb, zm, skt, 20.0, 20.0, cut, cut)
+            co = ops.composite(cfg, raw_f, zm, rb)
+        if world > 1:
+            mine = torch.zeros(per, 5, device=device)
+            mine[:hi - lo, 0:3] = co["rgb_map"]; mine[:hi - lo, 3] = co["acc_map"]; mine[:hi - lo, 4] = co["disp_map"]
+            dist.all_gather_into_tensor(gather_buf, mine)
+        return co
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], device=device)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    mlp_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        rays_s = n_total * args.steps / dt
+        # dominant kernel: k_mlp_fwd over this rank's (hi-lo)*S samples, timed with HIP events on its launch stream
+        flops_launch = F_MLP * (hi - lo) * S
+        achieved = flops_launch / (mlp_ms * 1e-3)
+        res = {
+            "metric": "rays/sec", "value": rays_s, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": name, "rays_per_step": n_total, "samples_per_ray": S, "n_importance": Ni,
+                       "parallelism": f"ray-sharded x{world}", "weights": "numpy-seeded random init (alpha bias +1)"},
+            "roofline": {"bound": "mfma", "kernel": "k_mlp_fwd<7,4,0,false>", "achieved": achieved / 1e12,
+                         "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA,
+                         "avg_launch_ms": mlp_ms, "flop_per_launch": flops_launch, "traffic": None},
+        }
+        if args.cpu_rays > 0:
+            res["cpu_baseline"], res["parity"] = cpu_baseline(sc, S, Ni, Pc, Pf, out, lo, min(args.cpu_rays, hi - lo))
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sc, S, Ni, Pc, Pf, gpu_out, lo, n_cpu):
+    """Time the torch-CPU oracle (port of the reference op sequence) on the first n_cpu rays of the same frame,
+    all host cores, chunk 4096 as in the reference configs; also report GPU-vs-oracle parity on those rays."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    oracle = importlib.import_module("anerf_oracle")
+    t = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32)
+    ocfg = oracle.OracleConfig()
+    P, PF = oracle.params_from_numpy(Pc), oracle.params_from_numpy(Pf)
+    rb = oracle.make_ray_batch(t(sc["rays_o"][:n_cpu]), t(sc["rays_d"][:n_cpu]))
+    skts = t(sc["pose"]["skts"])[None]
+    cyls = t(sc["cyl"])[None].expand(n_cpu, -1)
+    kw = dict(cfg=ocfg, P=P, P_fine=PF if Ni else None, n_samples=S, n_importance=Ni)
+    with torch.no_grad():
+        # torch-CPU does not scale to every hardware thread of a large host: probe a few thread counts on a
+        # 1024-ray slice (this is also the warm-up) and time the sample with the fastest one.
+        ncpu = os.cpu_count() or 1
+        best, best_dt = 1, float("inf")
+        for th in sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu)}):
+            torch.set_num_threads(th)
+            oracle.render_chunked(4096, rb[:256], skts, cyls[:256], **kw)
+            t0 = time.perf_counter()
+            oracle.render_chunked(4096, rb[:1024], skts, cyls[:1024], **kw)
+            d = time.perf_counter() - t0
+            if d < best_dt:
+                best, best_dt = th, d
+        torch.set_num_threads(best)
+        t0 = time.perf_counter()
+        ref = oracle.render_chunked(4096, rb, skts, cyls, **kw)
+        dt = time.perf_counter() - t0
+    base = {"value": n_cpu / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"first {n_cpu} rays of the same frame, chunk 4096, {dt:.1f} s of CPU work; best of "
+                      f"8/16/32/64/{ncpu} torch threads on this {ncpu}-thread host"}
+    parity = None
+    if lo == 0:
+        g = gpu_out["rgb_map"][:n_cpu].cpu()
+        target = t(np.random.default_rng(7).random((n_cpu, 3)))
+        parity = {"max_abs_rgb": float((g - ref["rgb_map"]).abs().max()),
+                  "psnr_gpu_db": oracle.psnr(g, target), "psnr_oracle_db": oracle.psnr(ref["rgb_map"], target)}
+    return base, parity
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,125 @@
+/*
+ * anerf.h -- C ABI of the MI355X-native A-NeRF ray-march hot path (libanerf_hip.so).
+ *
+ * Drop-in boundary for the reference's caster call
+ *     ray_caster(rays_flat[i:i+chunk], **batch_kwargs)          core/trainer.py:70-72
+ *     RayCaster.forward / render_rays                           core/raycasters.py:349-474
+ *     NeRF.forward / forward_batchify / raw2outputs             core/networks/nerf.py:90,133,150
+ *     get_near_far_in_cylinder / sample_from_lineseg /
+ *     isample_from_lineseg / sample_pdf                         core/utils/ray_utils.py:157-344
+ *     CutoffEmbedder._embed, transform_batch_pts/rays,
+ *     RelDistEncoder, VecNormEncoder                            core/cutoff_embedder.py:111, core/encoders.py:8-193
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer unless the name says host.  The library never allocates,
+ *     frees or retains device memory: the caller owns all inputs, outputs and workspaces.
+ *   - All work is enqueued on `stream` (a hipStream_t passed as void*); no call synchronises the
+ *     device or reads device memory on the host.
+ *   - Return value: 0 = ok, negative = error (see ANERF_E_*).  No exceptions cross the ABI.
+ *   - Re-entrant, no global mutable state.
+ *   - fp32 everywhere; `sorted_idx` is int64 as in torch.sort.
+ */
+#ifndef ANERF_H
+#define ANERF_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ANERF_OK 0
+#define ANERF_E_CONFIG (-1)   /* configuration outside the built template set            */
+#define ANERF_E_SHAPE (-2)    /* bad sizes (N_samples < 8, > 512, ...)                   */
+#define ANERF_E_NULL (-3)     /* required pointer is NULL                                */
+#define ANERF_E_WORKSPACE (-4)/* workspace too small                                     */
+#define ANERF_E_LAUNCH (-5)   /* hipLaunch failed (hipGetLastError text via anerf_last_error) */
+
+/* Static configuration of the path; reference: create_raycaster(), core/raycasters.py:17-184. */
+typedef struct AnerfConfig {
+  int32_t n_joints;        /* 24 (SMPL)                                                   */
+  int32_t multires;        /* 7   -> 24*(1+14)  = 360 distance-PE channels                */
+  int32_t multires_views;  /* 4   -> 72*(1+8)   = 648 view-PE channels (0 -> 72)          */
+  int32_t framecode_ch;    /* 0, or 16 with opt_framecode (core/networks/embedding.py)    */
+  int32_t netdepth;        /* 8                                                           */
+  int32_t netwidth;        /* 256                                                         */
+  int32_t skip;            /* 4                                                           */
+  int32_t density_act;     /* 0 = relu, 1 = softplus(x - softplus_shift)  raycasters.py:230 */
+  float density_scale;     /* B in raw2outputs, nerf.py:150                               */
+  float softplus_shift;
+} AnerfConfig;
+
+/* One network's parameters in the reference's state_dict order (torch Linear [out,in] row-major):
+ *   w[0..7]  pts_linears.{0..7}.weight   w[8] alpha_linear  w[9] feature_linear
+ *   w[10]    views_linears.0             w[11] rgb_linear   ;  b[] likewise.
+ *   codes    framecodes.codes.weight [n_codes, framecode_ch] or NULL.                      */
+typedef struct AnerfNetParams {
+  const float* w[12];
+  const float* b[12];
+  const float* codes;
+  int32_t n_codes;
+} AnerfNetParams;
+
+/* Sizes of the packed weight images the kernels consume (see DESIGN.md "weight stream"). */
+typedef struct AnerfLayout {
+  int64_t stream_floats;   /* MFMA-fragment-ordered weights, multiple of 8192 (one 32 KiB stage)  */
+  int64_t aux_floats;      /* biases + alpha/rgb head weights, natural order                      */
+  int32_t n_stages;        /* stream_floats / 8192                                                */
+  int32_t x_width;         /* MLP input width (1080, 1081 with frame code column, 504 ...)        */
+} AnerfLayout;
+
+const char* anerf_last_error(void);
+int anerf_version(void);
+
+/* which: 0 = forward image (W), 1 = backward-data image (W^T). */
+int anerf_layout(const AnerfConfig* cfg, int which, AnerfLayout* out);
+/* HOST: fill table[stream_floats + aux_floats]: entry = (tensor_id << 24) | element offset, -1 = 0.0f;
+ * tensor_id = index into {w[0..11], b[0..11]} (0..23).  Upload once per config. */
+int anerf_build_pack_table(const AnerfConfig* cfg, int which, int32_t* host_table);
+/* Gather the parameters into the packed image: out[i] = table[i] < 0 ? 0 : tensor[id][off]. */
+int anerf_pack_params(const AnerfNetParams* params, const int32_t* table, int64_t n, float* out, void* stream);
+
+/* A2: get_near_far_in_cylinder (ray_utils.py:292-344).  rays [N, ray_stride] = (o3,d3,near,far,...),
+ * cyls [N,5].  near_far [N,2]; stats_ws: 4 floats of scratch (sum_near, sum_far, cnt_near, cnt_far),
+ * zeroed by this call.  Rows whose ray misses the circle take the nan-mean of this call's rays. */
+int anerf_ray_bounds(const float* rays, int32_t ray_stride, const float* cyls, int32_t n_rays,
+                     float* near_far, float* stats_ws, void* stream);
+/* A3: sample_from_lineseg (ray_utils.py:204-251) on the bounds of anerf_ray_bounds, NaN rows patched with the
+ * call's nan-mean (or the placeholder bounds in rays[:,6:8] when every row is NaN).  t_rand [N,S] or NULL
+ * (perturb == 0).  z_vals [N,S]; near_far_fixed [N,2] optional (the bounds actually used). */
+int anerf_coarse_z(const float* near_far, const float* stats_ws, const float* rays, int32_t ray_stride,
+                   int32_t n_rays, int32_t n_samples, const float* t_rand, int32_t lindisp, float* z_vals,
+                   float* near_far_fixed, void* stream);
+
+/* A4-A9 fused: per sample, world->bone transform, skeleton-relative features, cutoff PE and the whole
+ * MLP; raw [N*S,4] = (r,g,b logits, sigma logit).  skts [N,24,4,4] (skt_ray_stride = 384) or one shared
+ * pose (skt_ray_stride = 0).  cam_idx [N] float or NULL.  packed/aux from anerf_pack_params(which=0). */
+int anerf_mlp_raw(const AnerfConfig* cfg, const float* packed, const float* aux,
+                  const float* rays, int32_t ray_stride, const float* z_vals,
+                  const float* skts, int64_t skt_ray_stride, const float* cam_idx,
+                  const float* codes, int32_t n_codes,
+                  float tau_v, float tau_d, const float* cutoff_v, const float* cutoff_d,
+                  int32_t n_rays, int32_t n_samples, float* raw, void* stream);
+
+/* A9 alone (NeRF.forward seam, nerf.py:133): x [P, x_width] already encoded -> raw [P,4]. */
+int anerf_mlp_forward(const AnerfConfig* cfg, const float* packed, const float* aux,
+                      const float* x, int64_t n_points, const float* codes, int32_t n_codes,
+                      float* raw, void* stream);
+
+/* A10: raw2outputs (nerf.py:150-205).  noise [N,S] or NULL (added to raw_sigma / B before the activation).
+ * Outputs: rgb_map [N,3], disp_map [N], acc_map [N], weights [N,S], alpha [N,S]; depth_map [N] optional. */
+int anerf_composite(const AnerfConfig* cfg, const float* raw, const float* z_vals, const float* rays,
+                    int32_t ray_stride, const float* noise, int32_t n_rays, int32_t n_samples,
+                    float* rgb_map, float* disp_map, float* acc_map, float* weights, float* alpha,
+                    float* depth_map, void* stream);
+
+/* A11: isample_from_lineseg + sample_pdf + sort (ray_utils.py:157-201,255-289).  u [N,Ni] or NULL
+ * (deterministic linspace).  z_samples [N,Ni], z_merged [N,S+Ni], sorted_idx [N,S+Ni] int64 or NULL. */
+int anerf_importance(const float* z_vals, const float* weights, int32_t n_rays, int32_t n_samples,
+                     int32_t n_importance, const float* u, int32_t single_net,
+                     float* z_samples, float* z_merged, int64_t* sorted_idx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ANERF_H */

@@ -1,0 +1,51 @@
+"""CPU: libanerf_hip.so loads and exports every symbol include/anerf.h declares (no compute calls)."""
+import ctypes
+import importlib
+import os
+import re
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib_mod = importlib.import_module("a-nerf_amd._lib")
+    lib = lib_mod.load()
+    hdr = open(os.path.join(ROOT, "include", "anerf.h")).read()
+    declared = set(re.findall(r"\b(anerf_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in anerf.h but not exported"
+    assert declared == set(lib_mod.SIGNATURES), (declared ^ set(lib_mod.SIGNATURES))
+    assert lib.anerf_version() >= 1
+
+
+def test_layout_and_pack_table_host_side():
+    """Host-only entry points: layout sizes and the gather table are consistent with the layer shapes."""
+    ops = importlib.import_module("a-nerf_amd.ops")
+    lib_mod = importlib.import_module("a-nerf_amd._lib")
+    synth = importlib.import_module("a-nerf_amd.synth")
+    for kw, xw in [({}, 1080), ({"framecode_ch": 16}, 1081), ({"multires_views": 0}, 504)]:
+        cfg = ops.PathConfig(**kw)
+        sf, af, nst, x_width = ops.layout(cfg)
+        assert x_width == xw and sf == nst * 8192 and af == 3080
+        host = np.empty(sf + af, dtype=np.int32)
+        cc = cfg.c()
+        assert lib_mod.load().anerf_build_pack_table(ctypes.byref(cc), 0, host.ctypes.data_as(ctypes.c_void_p)) == 0
+        used = host[host >= 0]
+        ids, offs = used >> 24, used & 0xFFFFFF
+        shapes = synth.net_shapes(7, cfg.multires_views, cfg.framecode_ch)
+        names = ops.PARAM_ORDER
+        # every weight element of every layer appears exactly once across stream + aux
+        for i, n in enumerate(names):
+            o, k = shapes[n]
+            cnt = np.bincount(offs[ids == i], minlength=o * k)
+            assert cnt.shape[0] == o * k and (cnt == 1).all(), n
+            b = np.bincount(offs[ids == 12 + i], minlength=o)
+            assert (b == 1).all(), n + ".bias"
+    bad = ops.PathConfig(multires=5)
+    cc = bad.c()
+    L = lib_mod.AnerfLayout()
+    assert lib_mod.load().anerf_layout(ctypes.byref(cc), 0, ctypes.byref(L)) == -1
+    assert b"unsupported" in lib_mod.load().anerf_last_error()
