@@ -28,6 +28,20 @@ class AnerfLayout(C.Structure):
                 ("x_width", C.c_int32)]
 
 
+class AnerfSaved(C.Structure):
+    _fields_ = [("h", C.c_void_p), ("f", C.c_void_p), ("g", C.c_void_p), ("x", C.c_void_p), ("u", C.c_void_p),
+                ("p_pad", C.c_int64)]
+
+
+class AnerfNetGrads(C.Structure):
+    _fields_ = [("w", C.c_void_p * 12), ("b", C.c_void_p * 12)]
+
+
+class AnerfTrainLayout(C.Structure):
+    _fields_ = [("p_pad", C.c_int64), ("x_width", C.c_int32), ("u_width", C.c_int32), ("gemm_chunks", C.c_int32),
+                ("gemm_ws_floats", C.c_int64)]
+
+
 # name -> (restype, argtypes); every symbol include/anerf.h declares must be listed here
 SIGNATURES = {
     "anerf_last_error": (C.c_char_p, []),
@@ -48,6 +62,20 @@ SIGNATURES = {
                                   C.c_void_p, C.c_void_p]),
     "anerf_importance": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "anerf_train_layout": (C.c_int, [C.POINTER(AnerfConfig), C.c_int64, C.POINTER(AnerfTrainLayout)]),
+    "anerf_build_perm_tables": (C.c_int, [C.POINTER(AnerfConfig), C.c_void_p, C.c_void_p]),
+    "anerf_mlp_raw_train": (C.c_int, [C.POINTER(AnerfConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                      C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float,
+                                      C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(AnerfSaved),
+                                      C.c_void_p]),
+    "anerf_composite_backward": (C.c_int, [C.POINTER(AnerfConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                           C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "anerf_mlp_backward": (C.c_int, [C.POINTER(AnerfConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AnerfSaved),
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "anerf_weight_grads": (C.c_int, [C.POINTER(AnerfConfig), C.POINTER(AnerfSaved), C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(AnerfNetGrads), C.c_void_p,
+                                     C.c_int64, C.c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,172 @@
+"""Training path: the same kernel pipeline as pipeline.py, bridged into torch.autograd so that the reference's
+trainer (`loss.backward()` -> Adam, core/trainer.py:451-483) drives it unchanged.
+
+Two autograd Functions wrap HIP launches only (no torch math inside):
+  _MlpRawFn     parameters -> raw [N,S,4]   fwd: k_mlp_fwd<TRAIN> (saves activations)
+                                            bwd: k_mlp_bwd + grouped k_gemm_tn/k_reduce_dw (weight gradients)
+  _CompositeFn  raw -> rgb/disp/acc/alpha/weights      fwd: k_composite   bwd: k_composite_bwd
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .ops import _p, _stream, PARAM_ORDER
+
+_perm_cache = {}
+
+
+def train_layout(cfg, n_points):
+    T = _lib.AnerfTrainLayout()
+    cc = cfg.c()
+    _lib.check(_lib.load().anerf_train_layout(C.byref(cc), n_points, C.byref(T)), "anerf_train_layout")
+    return T
+
+
+def perm_tables(cfg, device):
+    k = (cfg.key(), str(device))
+    if k not in _perm_cache:
+        T = train_layout(cfg, 128)
+        px, pu = np.empty(T.x_width, np.int32), np.empty(T.u_width, np.int32)
+        cc = cfg.c()
+        _lib.check(_lib.load().anerf_build_perm_tables(C.byref(cc), px.ctypes.data_as(C.c_void_p),
+                                                       pu.ctypes.data_as(C.c_void_p)), "anerf_build_perm_tables")
+        _perm_cache[k] = (torch.from_numpy(px).to(device), torch.from_numpy(pu).to(device))
+    return _perm_cache[k]
+
+
+def _planes(rows_pad, rows, width, n_planes, device):
+    """[n_planes][rows_pad][width] buffer whose pad rows are zero (the GEMM reads them)."""
+    buf = torch.empty(n_planes, rows_pad, width, dtype=torch.float32, device=device)
+    if rows_pad > rows:
+        buf[:, rows:].zero_()
+    return buf
+
+
+class _MlpRawFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, meta, *params):
+        cfg, dev = meta["cfg"], meta["rays"].device
+        z = meta["z"]
+        n, s = z.shape
+        P = n * s
+        T = train_layout(cfg, P)
+        pp = T.p_pad
+        sv = {"h": _planes(pp, P, 256, 8, dev), "f": _planes(pp, P, 256, 1, dev), "g": _planes(pp, P, 128, 1, dev),
+              "x": _planes(pp, P, T.x_width, 1, dev), "u": _planes(pp, P, T.u_width, 1, dev)}
+        st = _lib.AnerfSaved(_p(sv["h"]), _p(sv["f"]), _p(sv["g"]), _p(sv["x"]), _p(sv["u"]), pp)
+        raw = torch.empty(n, s, 4, dtype=torch.float32, device=dev)
+        skts = meta["skts"]
+        stride = 0 if skts.shape[0] == 1 else 16 * cfg.n_joints
+        codes = meta.get("codes")
+        cc = cfg.c()
+        packed, aux = meta["packed"]
+        _lib.check(_lib.load().anerf_mlp_raw_train(
+            C.byref(cc), _p(packed), _p(aux), _p(meta["rays"]), meta["rays"].shape[1], _p(z), _p(skts), stride,
+            _p(meta.get("cam")), _p(codes), 0 if codes is None else codes.shape[0], float(meta["tau_v"]),
+            float(meta["tau_d"]), _p(meta["cut_v"]), _p(meta["cut_d"]), n, s, _p(raw), C.byref(st), _stream()),
+            "anerf_mlp_raw_train")
+        ctx.meta, ctx.sv, ctx.T, ctx.P = meta, sv, T, P
+        ctx.shapes = [tuple(p.shape) for p in params]
+        return raw
+
+    @staticmethod
+    def backward(ctx, g_raw):
+        meta, sv, T, P = ctx.meta, ctx.sv, ctx.T, ctx.P
+        cfg, dev, pp = meta["cfg"], g_raw.device, T.p_pad
+        draw = torch.zeros(pp, 4, dtype=torch.float32, device=dev)
+        draw[:P] = g_raw.reshape(P, 4)
+        dz = _planes(pp, P, 256, 8, dev)
+        df = _planes(pp, P, 256, 1, dev)
+        dzv = _planes(pp, P, 128, 1, dev)
+        st = _lib.AnerfSaved(_p(sv["h"]), _p(sv["f"]), _p(sv["g"]), _p(sv["x"]), _p(sv["u"]), pp)
+        cc = cfg.c()
+        packed_t, _ = meta["packed_t"]
+        _, aux = meta["packed"]
+        lib = _lib.load()
+        _lib.check(lib.anerf_mlp_backward(C.byref(cc), _p(packed_t), _p(aux), _p(draw), C.byref(st), _p(dz), _p(df), _p(dzv),
+                                          P, _stream()), "anerf_mlp_backward")
+        grads = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in ctx.shapes]
+        gs = _lib.AnerfNetGrads()
+        for i in range(12):
+            gs.w[i] = grads[2 * i].data_ptr()
+            gs.b[i] = grads[2 * i + 1].data_ptr()
+        ws = torch.empty(T.gemm_ws_floats, dtype=torch.float32, device=dev)
+        px, pu = perm_tables(cfg, dev)
+        _lib.check(lib.anerf_weight_grads(C.byref(cc), C.byref(st), _p(dz), _p(df), _p(dzv), _p(draw), P, _p(px), _p(pu),
+                                          C.byref(gs), _p(ws), T.gemm_ws_floats, _stream()), "anerf_weight_grads")
+        ctx.sv = None
+        return (None, *grads)
+
+
+class _CompositeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, meta, raw):
+        out = ops.composite(meta["cfg"], raw, meta["z"], meta["rays"], meta.get("noise"))
+        ctx.meta = meta
+        ctx.save_for_backward(raw)
+        ctx.set_materialize_grads(False)
+        return out["rgb_map"], out["disp_map"], out["acc_map"], out["alpha"], out["weights"]
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_disp, g_acc, g_alpha, g_w):
+        meta = ctx.meta
+        (raw,) = ctx.saved_tensors
+        z, rays = meta["z"], meta["rays"]
+        n, s = z.shape
+        if g_rgb is None:
+            g_rgb = torch.zeros(n, 3, dtype=torch.float32, device=raw.device)
+        c = lambda t: None if t is None else t.contiguous()
+        draw = torch.empty(n, s, 4, dtype=torch.float32, device=raw.device)
+        cc = meta["cfg"].c()
+        _lib.check(_lib.load().anerf_composite_backward(
+            C.byref(cc), _p(raw), _p(z), _p(rays), rays.shape[1], _p(meta.get("noise")), n, s, _p(c(g_rgb)), _p(c(g_acc)),
+            _p(c(g_disp)), _p(c(g_alpha)), _p(c(g_w)), _p(draw), _stream()), "anerf_composite_backward")
+        return None, draw
+
+
+def _net_params(net):
+    P = net.named_path_params()
+    out = []
+    for n in PARAM_ORDER:
+        out += [P[n + ".weight"], P[n + ".bias"]]
+    return out
+
+
+def render_rays_train(caster, kw):
+    """Differentiable RayCaster.render_rays (raycasters.py:361-474); kw as assembled by RayCaster.render_rays."""
+    cfg, rays, skts, cyls = kw["cfg"], kw["ray_batch"], kw["skts"], kw["cyls"]
+    S, Ni = kw["n_samples"], kw["n_importance"]
+    if skts.requires_grad:
+        raise NotImplementedError("d(loss)/d(skts) (pose optimisation) is not wired into the HIP backward yet")
+    net_c, net_f = caster.network, caster.network_fine
+    with torch.no_grad():
+        nf_raw, stats = ops.ray_bounds(rays, cyls)
+        z, _ = ops.coarse_z(nf_raw, stats, rays, S, kw["t_rand"], kw["lindisp"])
+
+    def mlp(net, zz):
+        if net.use_framecode:
+            raise NotImplementedError("frame-code gradients are not wired into the HIP backward yet")
+        meta = dict(cfg=cfg, rays=rays, z=zz, skts=skts.detach().contiguous(), tau_v=kw["tau_v"], tau_d=kw["tau_d"],
+                    cut_v=kw["cut_v"], cut_d=kw["cut_d"], cam=None, codes=None, packed=net.packed(0), packed_t=net.packed(1))
+        return _MlpRawFn.apply(meta, *_net_params(net))
+
+    def comp(raw, zz, noise):
+        return _CompositeFn.apply(dict(cfg=cfg, rays=rays, z=zz, noise=noise), raw)
+
+    raw = mlp(net_c, z)
+    rgb, disp, acc, alpha, w = comp(raw, z, kw["noise"])
+    ret = {"rgb_map": rgb, "disp_map": disp, "acc_map": acc, "alpha": alpha}
+    if Ni > 0:
+        with torch.no_grad():
+            zs, zm, idx = ops.importance(z, w.detach(), Ni, kw["u_imp"], kw["single_net"], want_idx=True)
+        if kw["single_net"]:
+            raw_is = mlp(net_f, zs)
+            raw_f = torch.gather(torch.cat([raw, raw_is], 1), 1, idx[..., None].expand(-1, -1, 4)).contiguous()
+        else:
+            raw_f = mlp(net_f, zm)
+        rgb_f, disp_f, acc_f, alpha_f, _ = comp(raw_f, zm, kw["noise_fine"])
+        ret = {"rgb_map": rgb_f, "disp_map": disp_f, "acc_map": acc_f, "alpha": alpha_f,
+               "rgb0": rgb, "disp0": disp, "acc0": acc, "alpha0": alpha}
+    return ret

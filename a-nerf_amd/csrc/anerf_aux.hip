@@ -200,6 +200,124 @@ __global__ __launch_bounds__(256) void k_composite(const float* __restrict__ raw
 }
 
 // ------------------------------------------------------------------------------------------------
+// Backward of A10 (autograd of nerf.py:150-205 w.r.t. raw).  One wavefront per ray, same sample ownership as the
+// forward; recomputes alpha/T/w from raw, then
+//   g_w_i   = g_rgb . c_i + g_depth z_i + g_A (+ g_weights_i)
+//   g_a_k   = g_w_k T_k - (sum_{i>k} g_w_i w_i) / (1 - a_k + 1e-10) (+ g_alpha_k)     [suffix scan over the ray]
+//   d sigma = g_a * delta * (1 - a) * act'(pre) / B ;   d c_raw = g_rgb * w * 1.002 * s (1 - s)
+__global__ __launch_bounds__(256) void k_composite_bwd(const float* __restrict__ raw, const float* __restrict__ z,
+                                                       const float* __restrict__ rays, int ray_stride,
+                                                       const float* __restrict__ noise, int n, int S, int act,
+                                                       float inv_B, float shift, const float* __restrict__ g_rgb,
+                                                       const float* __restrict__ g_acc, const float* __restrict__ g_disp,
+                                                       const float* __restrict__ g_alpha,
+                                                       const float* __restrict__ g_weights, float* __restrict__ draw) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= n) return;
+  const int C = (S + 63) >> 6;
+  const float* rp = rays + (long long)ray * ray_stride;
+  const float dn = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);
+  const long long base = (long long)ray * S;
+  float al[8], sr[8], sg[8], sb[8], zz[8], dl[8], dact[8];
+  float prod = 1.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int s = lane * C + c;
+    al[c] = 0.f; sr[c] = sg[c] = sb[c] = 0.f; zz[c] = 0.f; dl[c] = 0.f; dact[c] = 0.f;
+    if (c < C && s < S) {
+      const f32x4 rw = *reinterpret_cast<const f32x4*>(raw + (base + s) * 4);
+      const float zc = z[base + s];
+      const float delta = (s == S - 1 ? 1e10f : (z[base + s + 1] - zc)) * dn;
+      float pre = rw.w * inv_B;
+      if (noise) pre += noise[base + s];
+      const float a = 1.f - expf(-density_act(act, pre, shift) * delta);
+      al[c] = a;
+      zz[c] = zc;
+      dl[c] = delta;
+      dact[c] = act == 0 ? (pre > 0.f ? 1.f : 0.f) : 1.f / (1.f + expf(-(pre - shift)));
+      sr[c] = 1.f / (1.f + expf(-rw.x));
+      sg[c] = 1.f / (1.f + expf(-rw.y));
+      sb[c] = 1.f / (1.f + expf(-rw.z));
+      prod *= (1.f - a + 1e-10f);
+    }
+  }
+  float incl = prod;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float up = __shfl_up(incl, o);
+    if (lane >= o) incl *= up;
+  }
+  float T0 = __shfl_up(incl, 1);
+  if (lane == 0) T0 = 1.f;
+  // forward sums needed by the disparity / accumulation gradients
+  float T = T0, sd = 0.f, sa = 0.f;
+  float w[8], Ts[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    w[c] = al[c] * T;
+    Ts[c] = T;
+    sd = fmaf(w[c], zz[c], sd);
+    sa += w[c];
+    T *= (1.f - al[c] + 1e-10f);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    sd += __shfl_xor(sd, o);
+    sa += __shfl_xor(sa, o);
+  }
+  const float gr = g_rgb[3 * ray], gg = g_rgb[3 * ray + 1], gb = g_rgb[3 * ray + 2];
+  // acc = min(A, 1): torch.minimum routes the gradient to A when A < 1 (half of it on a tie)
+  float gA = g_acc ? g_acc[ray] * (sa < 1.f ? 1.f : (sa == 1.f ? 0.5f : 0.f)) : 0.f;
+  float gD = 0.f;
+  if (g_disp) {
+    const float q = sd / (sa + 1e-10f);
+    if (q > 1e-10f && fabsf(sa) > 1e-8f) {
+      const float gq = -g_disp[ray] / (q * q);
+      gD = gq / (sa + 1e-10f);
+      gA += -gq * sd / ((sa + 1e-10f) * (sa + 1e-10f));
+    }
+  }
+  // g_w and the suffix sums R_k = sum_{i>k} g_w_i w_i
+  float gw[8], loc = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int s = lane * C + c;
+    gw[c] = 0.f;
+    if (c < C && s < S) {
+      const float cr = sr[c] * 1.002f - 0.001f, cg = sg[c] * 1.002f - 0.001f, cb = sb[c] * 1.002f - 0.001f;
+      gw[c] = gr * cr + gg * cg + gb * cb + gD * zz[c] + gA + (g_weights ? g_weights[base + s] : 0.f);
+      loc += gw[c] * w[c];
+    }
+  }
+  float suf = loc;   // inclusive suffix sum over lanes
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float dn_ = __shfl_down(suf, o);
+    if (lane + o < 64) suf += dn_;
+  }
+  float R = suf - loc;   // contributions of lanes > this one
+  // walk this lane's samples from last to first
+#pragma unroll
+  for (int c = 7; c >= 0; --c) {
+    const int s = lane * C + c;
+    if (c < C && s < S) {
+      const float u = 1.f - al[c] + 1e-10f;
+      float ga = gw[c] * Ts[c] - R / u;
+      if (g_alpha) ga += g_alpha[base + s];
+      const float dsig = ga * dl[c] * (1.f - al[c]) * dact[c] * inv_B;
+      f32x4 o;
+      o.x = gr * w[c] * 1.002f * sr[c] * (1.f - sr[c]);
+      o.y = gg * w[c] * 1.002f * sg[c] * (1.f - sg[c]);
+      o.z = gb * w[c] * 1.002f * sb[c] * (1.f - sb[c]);
+      o.w = dsig;
+      *reinterpret_cast<f32x4*>(draw + (base + s) * 4) = o;
+      R += gw[c] * w[c];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // A11.  One wavefront per ray, 4 rays per block.  LDS per wave: cdf[S-1], bins[S-1], cat[S+Ni].
 __global__ __launch_bounds__(256) void k_importance(const float* __restrict__ z, const float* __restrict__ w, int n,
                                                     int S, int Ni, const float* __restrict__ u, int single_net,
@@ -307,6 +425,15 @@ int launch_composite(const AnerfConfig* cfg, const float* raw, const float* z, c
                      cfg->density_act, 1.0f / cfg->density_scale, cfg->softplus_shift, rgb, disp, acc, weights, alpha,
                      depth);
   return check_launch("k_composite");
+}
+
+int launch_composite_bwd(const AnerfConfig* cfg, const float* raw, const float* z, const float* rays, int ray_stride,
+                         const float* noise, int n, int S, const float* g_rgb, const float* g_acc, const float* g_disp,
+                         const float* g_alpha, const float* g_weights, float* draw, hipStream_t st) {
+  hipLaunchKernelGGL(k_composite_bwd, dim3((n + 3) / 4), dim3(256), 0, st, raw, z, rays, ray_stride, noise, n, S,
+                     cfg->density_act, 1.0f / cfg->density_scale, cfg->softplus_shift, g_rgb, g_acc, g_disp, g_alpha,
+                     g_weights, draw);
+  return check_launch("k_composite_bwd");
 }
 
 int launch_importance(const float* z, const float* w, int n, int S, int Ni, const float* u, int single_net,

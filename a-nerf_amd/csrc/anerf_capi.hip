@@ -5,6 +5,7 @@
 #include <string.h>
 #include <vector>
 #include "anerf_dev.h"
+#include "anerf_gemm.h"
 
 namespace anerf {
 
@@ -32,10 +33,16 @@ int launch_composite(const AnerfConfig*, const float*, const float*, const float
                      float*, float*, float*, float*, float*, hipStream_t);
 int launch_importance(const float*, const float*, int, int, int, const float*, int, float*, float*, long long*,
                       hipStream_t);
+int launch_composite_bwd(const AnerfConfig*, const float*, const float*, const float*, int, const float*, int, int,
+                         const float*, const float*, const float*, const float*, const float*, float*, hipStream_t);
 int mlp_raw_entry(const AnerfConfig* cfg, const float* packed, const float* aux, const float* rays, int ray_stride,
                   const float* z, const float* skts, long long skt_stride, const float* cam, const float* codes,
                   int n_codes, float tau_v, float tau_d, const float* cut_v, const float* cut_d, const float* x,
-                  int x_width, long long P, int N, int S, int nstages, float* raw, bool pre, hipStream_t st);
+                  int x_width, long long P, int N, int S, int nstages, float* raw, bool pre, const AnerfSaved* sv,
+                  hipStream_t st);
+int mlp_bwd_entry(const float* packed_t, const float* aux, const float* draw, const AnerfSaved* sv, float* dz, float* df,
+                  float* dzv, long long P, int nstages, hipStream_t st);
+int launch_weight_grads(GemmBatch& G, float* ws, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------------
 // weight-stream layout.  A segment = one Linear layer; its k-groups (8 input columns: 4 per lane half) are laid
@@ -102,6 +109,22 @@ static int seg_col(const AnerfConfig* c, const Seg& s, int kg, int h, int t) {
   return -1;
 }
 
+// backward-data image: W^T of (views feature columns, feature, pts 7,6,5[hidden cols],4,3,2,1), all 8 output blocks
+struct BSeg { int tensor, K, c0, ncontract; };
+static std::vector<BSeg> bwd_segments(const AnerfConfig* c) {
+  const int kv = 256 + dim_d(c) + c->framecode_ch;
+  std::vector<BSeg> s;
+  s.push_back({10, kv, 0, 128});
+  s.push_back({9, 256, 0, 256});
+  s.push_back({7, 256, 0, 256});
+  s.push_back({6, 256, 0, 256});
+  s.push_back({5, dim_x(c) + 256, dim_x(c), 256});
+  for (int l = 4; l >= 1; --l) s.push_back({l, 256, 0, 256});
+  return s;
+}
+static int bseg_stages(const BSeg& s) { return (s.ncontract / 8) * 8 / STAGE_FRAGS; }
+static int u_width(const AnerfConfig* c) { return dim_d(c) + c->framecode_ch; }
+
 }  // namespace anerf
 
 using namespace anerf;
@@ -114,9 +137,12 @@ int anerf_version(void) { return 1; }
 int anerf_layout(const AnerfConfig* cfg, int which, AnerfLayout* out) {
   if (!out) return set_error(ANERF_E_NULL, "out is NULL");
   if (!config_ok(cfg)) return set_error(ANERF_E_CONFIG, "unsupported AnerfConfig");
-  if (which != 0) return set_error(ANERF_E_CONFIG, "only the forward image (which=0) exists in this build");
+  if (which != 0 && which != 1) return set_error(ANERF_E_CONFIG, "which must be 0 (W) or 1 (W^T)");
   int stages = 0;
-  for (const Seg& s : fwd_segments(cfg)) stages += seg_stages(s);
+  if (which == 0)
+    for (const Seg& s : fwd_segments(cfg)) stages += seg_stages(s);
+  else
+    for (const BSeg& s : bwd_segments(cfg)) stages += bseg_stages(s);
   out->n_stages = stages;
   out->stream_floats = (int64_t)stages * STAGE_FLOATS;
   out->aux_floats = AUX_FLOATS;
@@ -131,7 +157,21 @@ int anerf_build_pack_table(const AnerfConfig* cfg, int which, int32_t* table) {
   if (!table) return set_error(ANERF_E_NULL, "table is NULL");
   for (int64_t i = 0; i < L.stream_floats + L.aux_floats; ++i) table[i] = -1;
   int64_t pos = 0;
+  if (which == 1) {
+    for (const BSeg& s : bwd_segments(cfg)) {
+      for (int kg = 0; kg < s.ncontract / 8; ++kg)
+        for (int nb = 0; nb < 8; ++nb)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int t = 0; t < 4; ++t) {
+              const int n = 8 * kg + 4 * (lane >> 5) + t;          // contraction index = row of W
+              const int col = s.c0 + 32 * nb + (lane & 31);        // produced index   = column of W
+              table[pos + ((int64_t)(kg * 8 + nb) * 64 + lane) * 4 + t] = (s.tensor << 24) | (n * s.K + col);
+            }
+      pos += (int64_t)bseg_stages(s) * STAGE_FLOATS;
+    }
+  }
   for (const Seg& s : fwd_segments(cfg)) {
+    if (which == 1) break;
     for (int kg = 0; kg < s.nkg; ++kg)
       for (int nb = 0; nb < s.NB; ++nb)
         for (int lane = 0; lane < 64; ++lane)
@@ -196,7 +236,7 @@ int anerf_mlp_raw(const AnerfConfig* cfg, const float* packed, const float* aux,
   if (ray_stride < 6) return set_error(ANERF_E_SHAPE, "mlp_raw: ray_stride >= 6");
   return mlp_raw_entry(cfg, packed, aux, rays, ray_stride, z_vals, skts, skt_ray_stride, cam_idx, codes, n_codes,
                        tau_v, tau_d, cutoff_v, cutoff_d, nullptr, 0, (long long)n_rays * n_samples, n_rays, n_samples,
-                       L.n_stages, raw, false, (hipStream_t)stream);
+                       L.n_stages, raw, false, nullptr, (hipStream_t)stream);
 }
 
 int anerf_mlp_forward(const AnerfConfig* cfg, const float* packed, const float* aux, const float* x,
@@ -208,7 +248,7 @@ int anerf_mlp_forward(const AnerfConfig* cfg, const float* packed, const float* 
   if (cfg->framecode_ch && (!codes || n_codes < 1)) return set_error(ANERF_E_NULL, "mlp_forward: frame codes");
   if (n_points < 0) return set_error(ANERF_E_SHAPE, "mlp_forward: n_points < 0");
   return mlp_raw_entry(cfg, packed, aux, nullptr, 0, nullptr, nullptr, 0, nullptr, codes, n_codes, 0.f, 0.f, nullptr,
-                       nullptr, x, L.x_width, n_points, 0, 1, L.n_stages, raw, true, (hipStream_t)stream);
+                       nullptr, x, L.x_width, n_points, 0, 1, L.n_stages, raw, true, nullptr, (hipStream_t)stream);
 }
 
 int anerf_composite(const AnerfConfig* cfg, const float* raw, const float* z_vals, const float* rays,
@@ -232,6 +272,148 @@ int anerf_importance(const float* z_vals, const float* weights, int32_t n_rays, 
   if (n_rays == 0) return ANERF_OK;
   return launch_importance(z_vals, weights, n_rays, n_samples, n_importance, u, single_net, z_samples, z_merged,
                            (long long*)sorted_idx, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// training path
+// ---------------------------------------------------------------------------------------------------------------
+static int gemm_chunks_for(int64_t p_pad) {
+  int64_t c = p_pad / 4096;
+  if (c < 1) c = 1;
+  if (c > 32) c = 32;
+  return (int)c;
+}
+
+int anerf_train_layout(const AnerfConfig* cfg, int64_t n_points, AnerfTrainLayout* out) {
+  if (!out) return set_error(ANERF_E_NULL, "out is NULL");
+  if (!config_ok(cfg)) return set_error(ANERF_E_CONFIG, "unsupported AnerfConfig");
+  if (n_points < 0) return set_error(ANERF_E_SHAPE, "n_points < 0");
+  out->p_pad = (n_points + 127) / 128 * 128;
+  if (out->p_pad == 0) out->p_pad = 128;
+  out->x_width = dim_x(cfg);
+  out->u_width = u_width(cfg);
+  out->gemm_chunks = gemm_chunks_for(out->p_pad);
+  const int64_t kv = 256 + u_width(cfg);
+  // sum over the 14 problems of M*N (+ M for the bias partials)
+  int64_t per_chunk = 256LL * dim_x(cfg) + 256 + 6 * (256LL * 256 + 256) + 256LL * dim_x(cfg) + 256 + 256LL * 256 +
+                      (256LL * 256 + 256) + (128LL * 256 + 128) + 128LL * u_width(cfg) + (4LL * 128 + 4) + (4LL * 256 + 4);
+  (void)kv;
+  out->gemm_ws_floats = per_chunk * out->gemm_chunks;
+  return ANERF_OK;
+}
+
+int anerf_build_perm_tables(const AnerfConfig* cfg, int32_t* perm_x, int32_t* perm_u) {
+  if (!config_ok(cfg)) return set_error(ANERF_E_CONFIG, "unsupported AnerfConfig");
+  if (!perm_x || !perm_u) return set_error(ANERF_E_NULL, "perm tables NULL");
+  const std::vector<Seg> segs = fwd_segments(cfg);
+  const Seg& s0 = segs.front();
+  const Seg& sv = segs.back();
+  for (int kg = 0; kg < dim_x(cfg) / 8; ++kg)
+    for (int h = 0; h < 2; ++h)
+      for (int t = 0; t < 4; ++t) perm_x[8 * kg + 4 * h + t] = seg_col(cfg, s0, kg, h, t);
+  for (int kg = 0; kg < u_width(cfg) / 8; ++kg)
+    for (int h = 0; h < 2; ++h)
+      for (int t = 0; t < 4; ++t) perm_u[8 * kg + 4 * h + t] = seg_col(cfg, sv, 32 + kg, h, t) - 256;
+  return ANERF_OK;
+}
+
+static int saved_ok(const AnerfSaved* s) {
+  return s && s->h && s->f && s->g && s->x && s->u && s->p_pad > 0 && s->p_pad % 128 == 0;
+}
+
+int anerf_mlp_raw_train(const AnerfConfig* cfg, const float* packed, const float* aux, const float* rays,
+                        int32_t ray_stride, const float* z_vals, const float* skts, int64_t skt_ray_stride,
+                        const float* cam_idx, const float* codes, int32_t n_codes, float tau_v, float tau_d,
+                        const float* cutoff_v, const float* cutoff_d, int32_t n_rays, int32_t n_samples, float* raw,
+                        const AnerfSaved* saved, void* stream) {
+  AnerfLayout L;
+  const int rc = anerf_layout(cfg, 0, &L);
+  if (rc) return rc;
+  if (!packed || !aux || !rays || !z_vals || !skts || !cutoff_v || !cutoff_d || !raw)
+    return set_error(ANERF_E_NULL, "mlp_raw_train: NULL pointer");
+  if (!saved_ok(saved) || saved->p_pad < (int64_t)n_rays * n_samples)
+    return set_error(ANERF_E_WORKSPACE, "mlp_raw_train: AnerfSaved planes missing or too small");
+  if (cfg->framecode_ch && (!cam_idx || !codes || n_codes < 1)) return set_error(ANERF_E_NULL, "mlp_raw_train: frame codes");
+  if (n_samples < MIN_SAMPLES || n_samples > MAX_SAMPLES) return set_error(ANERF_E_SHAPE, "mlp_raw_train: 8 <= samples <= 512");
+  if (skt_ray_stride != 0 && skt_ray_stride != 384) return set_error(ANERF_E_SHAPE, "mlp_raw_train: skt_ray_stride 0|384");
+  return mlp_raw_entry(cfg, packed, aux, rays, ray_stride, z_vals, skts, skt_ray_stride, cam_idx, codes, n_codes, tau_v,
+                       tau_d, cutoff_v, cutoff_d, nullptr, 0, (long long)n_rays * n_samples, n_rays, n_samples,
+                       L.n_stages, raw, false, saved, (hipStream_t)stream);
+}
+
+int anerf_composite_backward(const AnerfConfig* cfg, const float* raw, const float* z_vals, const float* rays,
+                             int32_t ray_stride, const float* noise, int32_t n_rays, int32_t n_samples,
+                             const float* g_rgb, const float* g_acc, const float* g_disp, const float* g_alpha,
+                             const float* g_weights, float* draw, void* stream) {
+  if (!cfg || !raw || !z_vals || !rays || !g_rgb || !draw) return set_error(ANERF_E_NULL, "composite_backward: NULL pointer");
+  if (n_samples < 1 || n_samples > MAX_SAMPLES) return set_error(ANERF_E_SHAPE, "composite_backward: 1 <= samples <= 512");
+  if (n_rays == 0) return ANERF_OK;
+  return launch_composite_bwd(cfg, raw, z_vals, rays, ray_stride, noise, n_rays, n_samples, g_rgb, g_acc, g_disp, g_alpha,
+                              g_weights, draw, (hipStream_t)stream);
+}
+
+int anerf_mlp_backward(const AnerfConfig* cfg, const float* packed_t, const float* aux, const float* draw,
+                       const AnerfSaved* saved, float* dz, float* df, float* dzv, int64_t n_points, void* stream) {
+  AnerfLayout L;
+  const int rc = anerf_layout(cfg, 1, &L);
+  if (rc) return rc;
+  if (!packed_t || !aux || !draw || !dz || !df || !dzv) return set_error(ANERF_E_NULL, "mlp_backward: NULL pointer");
+  if (!saved_ok(saved) || saved->p_pad < n_points) return set_error(ANERF_E_WORKSPACE, "mlp_backward: AnerfSaved");
+  return mlp_bwd_entry(packed_t, aux, draw, saved, dz, df, dzv, n_points, L.n_stages, (hipStream_t)stream);
+}
+
+int anerf_weight_grads(const AnerfConfig* cfg, const AnerfSaved* sv, const float* dz, const float* df, const float* dzv,
+                       const float* draw, int64_t n_points, const int32_t* perm_x, const int32_t* perm_u,
+                       const AnerfNetGrads* gr, float* workspace, int64_t ws_floats, void* stream) {
+  AnerfTrainLayout T;
+  const int rc = anerf_train_layout(cfg, n_points, &T);
+  if (rc) return rc;
+  if (!saved_ok(sv) || sv->p_pad != T.p_pad) return set_error(ANERF_E_WORKSPACE, "weight_grads: AnerfSaved.p_pad mismatch");
+  if (!dz || !df || !dzv || !draw || !perm_x || !perm_u || !gr || !workspace) return set_error(ANERF_E_NULL, "weight_grads: NULL");
+  if (ws_floats < T.gemm_ws_floats) return set_error(ANERF_E_WORKSPACE, "weight_grads: workspace too small");
+  for (int i = 0; i < 12; ++i)
+    if (!gr->w[i] || !gr->b[i]) return set_error(ANERF_E_NULL, "weight_grads: NULL gradient tensor");
+  const long long pp = T.p_pad;
+  const int DX = dim_x(cfg), UW = u_width(cfg), KV = 256 + UW;
+  GemmBatch G;
+  memset(&G, 0, sizeof(G));
+  G.chunks = T.gemm_chunks;
+  G.p_pad = pp;
+  G.rows_per_chunk = ((pp / G.chunks) + 31) / 32 * 32;
+  long long ws_pos = 0, out_pos = 0;
+  int tiles = 0, np = 0;
+  auto add = [&](const float* A, int lda, int M, const float* B, int ldb, int N, float* dst, int dst_ld, int col0,
+                 const int* cmap, int m_first, int m_count, float* bias, int bm_first, int bm_count) {
+    GemmProb& p = G.p[np++];
+    p.A = A; p.B = B; p.dst = dst; p.bias_dst = bias; p.colmap = cmap;
+    p.lda = lda; p.ldb = ldb; p.lda_cols = lda; p.ldb_cols = ldb; p.M = M; p.N = N;
+    p.tiles_m = (M + 127) / 128; p.tiles_n = (N + 127) / 128; p.tile_base = tiles;
+    tiles += p.tiles_m * p.tiles_n;
+    p.dst_ld = dst_ld; p.dst_col0 = col0; p.m_first = m_first; p.m_count = m_count;
+    p.bm_first = bm_first; p.bm_count = bm_count;
+    p.part_off = ws_pos; ws_pos += (long long)G.chunks * M * N;
+    p.bias_off = -1;
+    if (bias) { p.bias_off = ws_pos; ws_pos += (long long)G.chunks * M; }
+    p.out_base = out_pos; out_pos += (long long)M * N + (bias ? M : 0);
+  };
+  auto DZ = [&](int l) { return dz + (long long)l * pp * 256; };
+  auto H = [&](int l) { return sv->h + (long long)l * pp * 256; };
+  add(DZ(0), 256, 256, sv->x, DX, DX, gr->w[0], DX, 0, perm_x, 0, 256, gr->b[0], 0, 256);
+  for (int l = 1; l <= 4; ++l) add(DZ(l), 256, 256, H(l - 1), 256, 256, gr->w[l], 256, 0, nullptr, 0, 256, gr->b[l], 0, 256);
+  add(DZ(5), 256, 256, sv->x, DX, DX, gr->w[5], DX + 256, 0, perm_x, 0, 256, gr->b[5], 0, 256);
+  add(DZ(5), 256, 256, H(4), 256, 256, gr->w[5], DX + 256, DX, nullptr, 0, 256, nullptr, 0, 0);
+  add(DZ(6), 256, 256, H(5), 256, 256, gr->w[6], 256, 0, nullptr, 0, 256, gr->b[6], 0, 256);
+  add(DZ(7), 256, 256, H(6), 256, 256, gr->w[7], 256, 0, nullptr, 0, 256, gr->b[7], 0, 256);
+  add(df, 256, 256, H(7), 256, 256, gr->w[9], 256, 0, nullptr, 0, 256, gr->b[9], 0, 256);
+  add(dzv, 128, 128, sv->f, 256, 256, gr->w[10], KV, 0, nullptr, 0, 128, gr->b[10], 0, 128);
+  add(dzv, 128, 128, sv->u, UW, UW, gr->w[10], KV, 256, perm_u, 0, 128, nullptr, 0, 0);
+  add(draw, 4, 4, sv->g, 128, 128, gr->w[11], 128, 0, nullptr, 0, 3, gr->b[11], 0, 3);
+  add(draw, 4, 4, H(7), 256, 256, gr->w[8], 256, 0, nullptr, 3, 1, gr->b[8], 3, 1);
+  G.nprob = np;
+  G.total_tiles = tiles;
+  G.total_out = out_pos;
+  if (ws_pos > ws_floats) return set_error(ANERF_E_WORKSPACE, "weight_grads: workspace accounting");
+  return launch_weight_grads(G, workspace, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -135,14 +135,25 @@ __device__ __forceinline__ float head_dot(const float (&act)[128], const float* 
 // the x-part (432 = 360 distance-PE + 72 bone-direction channels) as 54 k-groups.
 // Encoded just in time (PRE = false) or read from a pre-encoded row (PRE = true, NeRF.forward seam).
 // ------------------------------------------------------------------------------------------------
-template <int LV, bool PRE>
+// STORE: also write the 4 operands of every k-group to xsave[8*kg + 4h .. +3] (stream column order X').
+template <int LV, bool PRE, bool STORE>
 __device__ __forceinline__ void x_part(Pipe& pipe, f32x16 (&acc)[8], const float (&v)[12], const float (&wv)[12],
-                                       const float (&rh)[36], const float* __restrict__ xrow, int h) {
+                                       const float (&rh)[36], const float* __restrict__ xrow, int h,
+                                       float* __restrict__ xsave) {
+  auto KG = [&](int kg, float b0, float b1, float b2, float b3) __attribute__((always_inline)) {
+    if constexpr (STORE) {
+      if (xsave) {
+        f32x4 o = {b0, b1, b2, b3};
+        *reinterpret_cast<f32x4*>(xsave + 8 * kg + 4 * h) = o;
+      }
+    }
+    kgroup<8>(pipe, acc, kg, b0, b1, b2, b3);
+  };
   if constexpr (PRE) {
 #pragma unroll
     for (int kg = 0; kg < 3 * (1 + 2 * LV); ++kg) {
       const float* c = xrow + 8 * kg + 4 * h;
-      kgroup<8>(pipe, acc, kg, c[0], c[1], c[2], c[3]);
+      KG(kg, c[0], c[1], c[2], c[3]);
     }
 #pragma unroll
     for (int g = 0; g < 9; ++g) {
@@ -152,12 +163,12 @@ __device__ __forceinline__ void x_part(Pipe& pipe, f32x16 (&acc)[8], const float
         const int a = (4 * g + t) / 3, c = (4 * g + t) % 3;
         b[t] = xrow[24 * (1 + 2 * LV) + 3 * (8 * (a >> 2) + (a & 3)) + c + 12 * h];
       }
-      kgroup<8>(pipe, acc, 3 * (1 + 2 * LV) + g, b[0], b[1], b[2], b[3]);
+      KG(3 * (1 + 2 * LV) + g, b[0], b[1], b[2], b[3]);
     }
   } else {
 #pragma unroll
     for (int g = 0; g < 3; ++g)
-      kgroup<8>(pipe, acc, g, v[4 * g] * wv[4 * g], v[4 * g + 1] * wv[4 * g + 1], v[4 * g + 2] * wv[4 * g + 2],
+      KG(g, v[4 * g] * wv[4 * g], v[4 * g + 1] * wv[4 * g + 1], v[4 * g + 2] * wv[4 * g + 2],
                 v[4 * g + 3] * wv[4 * g + 3]);
 #pragma unroll
     for (int f = 0; f < LV; ++f) {
@@ -171,14 +182,14 @@ __device__ __forceinline__ void x_part(Pipe& pipe, f32x16 (&acc)[8], const float
       }
 #pragma unroll
       for (int g = 0; g < 3; ++g)
-        kgroup<8>(pipe, acc, 3 + 6 * f + g, sv[4 * g], sv[4 * g + 1], sv[4 * g + 2], sv[4 * g + 3]);
+        KG(3 + 6 * f + g, sv[4 * g], sv[4 * g + 1], sv[4 * g + 2], sv[4 * g + 3]);
 #pragma unroll
       for (int g = 0; g < 3; ++g)
-        kgroup<8>(pipe, acc, 6 + 6 * f + g, cv[4 * g], cv[4 * g + 1], cv[4 * g + 2], cv[4 * g + 3]);
+        KG(6 + 6 * f + g, cv[4 * g], cv[4 * g + 1], cv[4 * g + 2], cv[4 * g + 3]);
     }
 #pragma unroll
     for (int g = 0; g < 9; ++g)
-      kgroup<8>(pipe, acc, 3 * (1 + 2 * LV) + g, rh[4 * g], rh[4 * g + 1], rh[4 * g + 2], rh[4 * g + 3]);
+      KG(3 * (1 + 2 * LV) + g, rh[4 * g], rh[4 * g + 1], rh[4 * g + 2], rh[4 * g + 3]);
   }
 }
 
@@ -194,13 +205,32 @@ struct MlpArgs {
   const float* cut_d;
   const float* x;  // PRE
   float* raw;
+  // TRAIN: saved activations, row-major planes with Ppad rows (rows >= P are never written)
+  float* save_h;   // [8][Ppad][256]  h0..h7 (post-ReLU)
+  float* save_f;   // [Ppad][256]     feature (no activation)
+  float* save_g;   // [Ppad][128]     view-layer output (post-ReLU)
+  float* save_x;   // [Ppad][432]     x in stream column order
+  float* save_u;   // [Ppad][UW]      view inputs (D, code) in stream column order
   long long P;
+  long long Ppad;
   long long skt_stride;
   int S, N, ray_stride, n_codes, x_width, nstages;
   float tau_v, tau_d;
 };
 
-template <int LV, int LD, int CODE, bool PRE>
+// row-major store of the lane's 16*NB activations: features 32nb+8q+4h .. +3 of row `row`
+template <int NB>
+__device__ __forceinline__ void store_row(float* __restrict__ row, const float (&a)[128], int h) {
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 o = {a[nb * 16 + 4 * q], a[nb * 16 + 4 * q + 1], a[nb * 16 + 4 * q + 2], a[nb * 16 + 4 * q + 3]};
+      *reinterpret_cast<f32x4*>(row + 32 * nb + 8 * q + 4 * h) = o;
+    }
+}
+
+template <int LV, int LD, int CODE, bool PRE, bool TRAIN>
 __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -215,6 +245,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
   const long long p = (long long)blockIdx.x * TILE + wave * 32 + m;
   const bool valid = p < A.P;
   const long long pc = valid ? p : A.P - 1;
+  const bool save = TRAIN && valid;
 
   float v[12], wv[12], rh[36];
   float dray[3] = {0.f, 0.f, 0.f};
@@ -268,31 +299,38 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
     }
   }
 
+  constexpr int DIMX = 24 * (1 + 2 * LV) + 72;
+  constexpr int DIMD = 72 * (1 + 2 * LD);
+  constexpr int UW = DIMD + CODE;
   float hin[128];
   f32x16 acc[8];
 
   // ---- layer 0: x(432) -> 256
   init_bias<8>(acc, A.aux + AUX_B0, h);
-  x_part<LV, PRE>(pipe, acc, v, wv, rh, xrow, h);
+  x_part<LV, PRE, TRAIN>(pipe, acc, v, wv, rh, xrow, h, save ? A.save_x + p * DIMX : nullptr);
   to_hidden<8, true>(hin, acc);
+  if (save) store_row<8>(A.save_h + p * 256, hin, h);
   // ---- layers 1..4
 #pragma unroll 1
   for (int L = 1; L <= 4; ++L) {
     init_bias<8>(acc, A.aux + AUX_B0 + 256 * L, h);
     hidden_part<8, 0>(pipe, acc, hin);
     to_hidden<8, true>(hin, acc);
+    if (save) store_row<8>(A.save_h + ((long long)L * A.Ppad + p) * 256, hin, h);
   }
   // ---- layer 5: [x(432); h4(256)] -> 256   (skip connection: x is re-encoded, never stored)
   init_bias<8>(acc, A.aux + AUX_B0 + 256 * 5, h);
-  x_part<LV, PRE>(pipe, acc, v, wv, rh, xrow, h);
+  x_part<LV, PRE, false>(pipe, acc, v, wv, rh, xrow, h, nullptr);
   hidden_part<8, 3 * (1 + 2 * LV) + 9>(pipe, acc, hin);
   to_hidden<8, true>(hin, acc);
+  if (save) store_row<8>(A.save_h + (5 * A.Ppad + p) * 256, hin, h);
   // ---- layers 6, 7
 #pragma unroll 1
   for (int L = 6; L <= 7; ++L) {
     init_bias<8>(acc, A.aux + AUX_B0 + 256 * L, h);
     hidden_part<8, 0>(pipe, acc, hin);
     to_hidden<8, true>(hin, acc);
+    if (save) store_row<8>(A.save_h + ((long long)L * A.Ppad + p) * 256, hin, h);
   }
   // ---- density head (VALU): sigma_raw = w_alpha . h7 + b_alpha
   const float sigma_raw = head_dot<8>(hin, A.aux + AUX_WA, h) + A.aux[AUX_BA];
@@ -300,12 +338,21 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
   init_bias<8>(acc, A.aux + AUX_BF, h);
   hidden_part<8, 0>(pipe, acc, hin);
   to_hidden<8, false>(hin, acc);
+  if (save) store_row<8>(A.save_f + p * 256, hin, h);
   // ---- view layer: [feature(256); D(72*(1+2LD)); code(CODE)] -> 128, ReLU
   f32x16 accv[4];
   init_bias<4>(accv, A.aux + AUX_BV, h);
   hidden_part<4, 0>(pipe, accv, hin);
-  constexpr int DIMX = 24 * (1 + 2 * LV) + 72;
-  constexpr int DIMD = 72 * (1 + 2 * LD);
+  float* usave = save ? A.save_u + p * UW : nullptr;
+  auto KGV = [&](int kgu, float b0, float b1, float b2, float b3) __attribute__((always_inline)) {
+    if constexpr (TRAIN) {
+      if (usave) {
+        f32x4 o = {b0, b1, b2, b3};
+        *reinterpret_cast<f32x4*>(usave + 8 * kgu + 4 * h) = o;
+      }
+    }
+    kgroup<4>(pipe, accv, 32 + kgu, b0, b1, b2, b3);
+  };
   if constexpr (PRE) {
 #pragma unroll
     for (int b = 0; b < 1 + 2 * LD; ++b)
@@ -317,7 +364,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
           const int a = (4 * g + t) / 3, c = (4 * g + t) % 3;
           bb[t] = xrow[DIMX + 72 * b + 3 * (8 * (a >> 2) + (a & 3)) + c + 12 * h];
         }
-        kgroup<4>(pipe, accv, 32 + 9 * b + g, bb[0], bb[1], bb[2], bb[3]);
+        KGV(9 * b + g, bb[0], bb[1], bb[2], bb[3]);
       }
   } else {
     // per-ray unit direction in each owned bone frame, gated per sample by the distance gate (tau_d, cut_d)
@@ -338,8 +385,8 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
     }
 #pragma unroll
     for (int g = 0; g < 9; ++g)
-      kgroup<4>(pipe, accv, 32 + g, e[4 * g] * wd[(4 * g) / 3], e[4 * g + 1] * wd[(4 * g + 1) / 3],
-                e[4 * g + 2] * wd[(4 * g + 2) / 3], e[4 * g + 3] * wd[(4 * g + 3) / 3]);
+      KGV(g, e[4 * g] * wd[(4 * g) / 3], e[4 * g + 1] * wd[(4 * g + 1) / 3], e[4 * g + 2] * wd[(4 * g + 2) / 3],
+          e[4 * g + 3] * wd[(4 * g + 3) / 3]);
 #pragma unroll
     for (int f = 0; f < LD; ++f) {
       float se[36], ce[36];
@@ -351,11 +398,9 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
         ce[i] = c * wd[i / 3];
       }
 #pragma unroll
-      for (int g = 0; g < 9; ++g)
-        kgroup<4>(pipe, accv, 32 + 9 * (1 + 2 * f) + g, se[4 * g], se[4 * g + 1], se[4 * g + 2], se[4 * g + 3]);
+      for (int g = 0; g < 9; ++g) KGV(9 * (1 + 2 * f) + g, se[4 * g], se[4 * g + 1], se[4 * g + 2], se[4 * g + 3]);
 #pragma unroll
-      for (int g = 0; g < 9; ++g)
-        kgroup<4>(pipe, accv, 32 + 9 * (2 + 2 * f) + g, ce[4 * g], ce[4 * g + 1], ce[4 * g + 2], ce[4 * g + 3]);
+      for (int g = 0; g < 9; ++g) KGV(9 * (2 + 2 * f) + g, ce[4 * g], ce[4 * g + 1], ce[4 * g + 2], ce[4 * g + 3]);
     }
   }
   if constexpr (CODE > 0) {
@@ -368,7 +413,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
 #pragma unroll
     for (int g = 0; g < CODE / 8; ++g) {
       const f32x4 c4 = *reinterpret_cast<const f32x4*>(crow + 8 * g + 4 * h);
-      kgroup<4>(pipe, accv, 32 + 9 * (1 + 2 * LD) + g, c4.x, c4.y, c4.z, c4.w);
+      KGV(9 * (1 + 2 * LD) + g, c4.x, c4.y, c4.z, c4.w);
     }
   }
   float gact[128];
@@ -376,6 +421,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
   for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
     for (int r = 0; r < 16; ++r) gact[nb * 16 + r] = fmaxf(accv[nb][r], 0.f);
+  if (save) store_row<4>(A.save_g + p * 128, gact, h);
   // ---- rgb head (VALU)
   const float c0 = head_dot<4>(gact, A.aux + AUX_WC + 0, h) + A.aux[AUX_BC + 0];
   const float c1 = head_dot<4>(gact, A.aux + AUX_WC + 128, h) + A.aux[AUX_BC + 1];
@@ -386,26 +432,136 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
   }
 }
 
-template <int LV, int LD, int CODE, bool PRE>
+// ------------------------------------------------------------------------------------------------
+// backward-data kernel: d(raw) -> d(pre-activation) of every layer, same register-resident transposed scheme
+// with the W^T weight image (anerf_layout which=1).  Per layer l:  dh_{l-1} = W_l^T dz_l ;  dz_{l-1} = dh_{l-1}
+// * [h_{l-1} > 0].  Writes dz0..dz7 [8][Ppad][256], dF [Ppad][256], dZv [Ppad][128] for the weight-gradient GEMMs
+// (anerf_gemm.hip).  Autograd of NeRF.forward (core/networks/nerf.py:94-148) w.r.t. activations.
+// ------------------------------------------------------------------------------------------------
+struct BwdArgs {
+  const float* packed_t;   // W^T image
+  const float* aux;        // natural-order head weights (forward aux)
+  const float* draw;       // [P][4]
+  const float* save_h;     // [8][Ppad][256]
+  const float* save_g;     // [Ppad][128]
+  float* dz;               // [8][Ppad][256]
+  float* df;               // [Ppad][256]
+  float* dzv;              // [Ppad][128]
+  long long P, Ppad;
+  int nstages;
+};
+
+// act[i] <- act[i] * (saved[i] > 0)
+template <int NB>
+__device__ __forceinline__ void relu_mask(float (&d)[128], const float* __restrict__ row, int h) {
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 s = *reinterpret_cast<const f32x4*>(row + 32 * nb + 8 * q + 4 * h);
+      d[nb * 16 + 4 * q + 0] = s.x > 0.f ? d[nb * 16 + 4 * q + 0] : 0.f;
+      d[nb * 16 + 4 * q + 1] = s.y > 0.f ? d[nb * 16 + 4 * q + 1] : 0.f;
+      d[nb * 16 + 4 * q + 2] = s.z > 0.f ? d[nb * 16 + 4 * q + 2] : 0.f;
+      d[nb * 16 + 4 * q + 3] = s.w > 0.f ? d[nb * 16 + 4 * q + 3] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mlp_bwd(const BwdArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 31, h = lane >> 5;
+  Pipe pipe;
+  pipe.init(A.packed_t, smem, wave, lane, A.nstages);
+  pipe.issue(0);
+  const long long p = (long long)blockIdx.x * TILE + wave * 32 + m;
+  const bool valid = p < A.P;
+  const long long pc = valid ? p : A.P - 1;
+  const f32x4 dr = *reinterpret_cast<const f32x4*>(A.draw + pc * 4);
+
+  float d[128];
+  f32x16 acc[8];
+  // ---- rgb head: dg = Wc^T dc ; dzv = dg * [g > 0]
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int o = 32 * nb + 8 * q + 4 * h;
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(A.aux + AUX_WC + o);
+      const f32x4 w1 = *reinterpret_cast<const f32x4*>(A.aux + AUX_WC + 128 + o);
+      const f32x4 w2 = *reinterpret_cast<const f32x4*>(A.aux + AUX_WC + 256 + o);
+      d[nb * 16 + 4 * q + 0] = w0.x * dr.x + w1.x * dr.y + w2.x * dr.z;
+      d[nb * 16 + 4 * q + 1] = w0.y * dr.x + w1.y * dr.y + w2.y * dr.z;
+      d[nb * 16 + 4 * q + 2] = w0.z * dr.x + w1.z * dr.y + w2.z * dr.z;
+      d[nb * 16 + 4 * q + 3] = w0.w * dr.x + w1.w * dr.y + w2.w * dr.z;
+    }
+#pragma unroll
+  for (int i = 64; i < 128; ++i) d[i] = 0.f;
+  relu_mask<4>(d, A.save_g + pc * 128, h);
+  if (valid) store_row<4>(A.dzv + p * 128, d, h);
+  // ---- view layer, feature columns: df = Wv[:, :256]^T dzv      (16 k-groups of the 128 view units)
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+#pragma unroll
+  for (int kg = 0; kg < 16; ++kg) kgroup<8>(pipe, acc, kg, d[4 * kg], d[4 * kg + 1], d[4 * kg + 2], d[4 * kg + 3]);
+  to_hidden<8, false>(d, acc);
+  if (valid) store_row<8>(A.df + p * 256, d, h);
+  // ---- feature layer + density head: dh7 = Wf^T df + w_alpha * dsigma
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 wa = *reinterpret_cast<const f32x4*>(A.aux + AUX_WA + 32 * nb + 8 * q + 4 * h);
+      acc[nb][4 * q + 0] = wa.x * dr.w;
+      acc[nb][4 * q + 1] = wa.y * dr.w;
+      acc[nb][4 * q + 2] = wa.z * dr.w;
+      acc[nb][4 * q + 3] = wa.w * dr.w;
+    }
+  hidden_part<8, 0>(pipe, acc, d);
+  to_hidden<8, false>(d, acc);
+  relu_mask<8>(d, A.save_h + (7 * A.Ppad + pc) * 256, h);
+  if (valid) store_row<8>(A.dz + (7 * A.Ppad + p) * 256, d, h);
+  // ---- trunk: dz_{l-1} = (W_l^T dz_l) * [h_{l-1} > 0],  l = 7..1   (W_5: hidden columns only)
+#pragma unroll 1
+  for (int L = 7; L >= 1; --L) {
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+    hidden_part<8, 0>(pipe, acc, d);
+    to_hidden<8, false>(d, acc);
+    relu_mask<8>(d, A.save_h + ((long long)(L - 1) * A.Ppad + pc) * 256, h);
+    if (valid) store_row<8>(A.dz + ((long long)(L - 1) * A.Ppad + p) * 256, d, h);
+  }
+}
+
+template <int LV, int LD, int CODE, bool PRE, bool TRAIN>
 static int launch(const MlpArgs& a, hipStream_t st) {
   const long long nblk = (a.P + TILE - 1) / TILE;
   if (nblk <= 0) return ANERF_OK;
   const size_t lds = 2 * STAGE_BYTES + (PRE ? 0 : MAX_TILE_RAYS * 72 * 16);
-  auto kern = k_mlp_fwd<LV, LD, CODE, PRE>;
+  auto kern = k_mlp_fwd<LV, LD, CODE, PRE, TRAIN>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, a);
   return check_launch("k_mlp_fwd");
 }
 
-int mlp_dispatch(const AnerfConfig* cfg, const MlpArgs& a, bool pre, hipStream_t st) {
+int mlp_dispatch(const AnerfConfig* cfg, const MlpArgs& a, bool pre, bool train, hipStream_t st) {
   const int lv = cfg->multires, ld = cfg->multires_views, cd = cfg->framecode_ch;
   if (lv != 7) return set_error(ANERF_E_CONFIG, "multires must be 7");
-#define ANERF_CASE(LD_, CD_)                                                         \
-  if (ld == LD_ && cd == CD_) return pre ? launch<7, LD_, CD_, true>(a, st) : launch<7, LD_, CD_, false>(a, st);
+  if (pre && train) return set_error(ANERF_E_CONFIG, "training forward needs the fused (not pre-encoded) path");
+#define ANERF_CASE(LD_, CD_)                                               \
+  if (ld == LD_ && cd == CD_) {                                            \
+    if (pre) return launch<7, LD_, CD_, true, false>(a, st);               \
+    return train ? launch<7, LD_, CD_, false, true>(a, st) : launch<7, LD_, CD_, false, false>(a, st); \
+  }
   ANERF_CASE(4, 0)
   ANERF_CASE(4, 16)
   ANERF_CASE(0, 0)
@@ -416,13 +572,36 @@ int mlp_dispatch(const AnerfConfig* cfg, const MlpArgs& a, bool pre, hipStream_t
 int mlp_raw_entry(const AnerfConfig* cfg, const float* packed, const float* aux, const float* rays, int ray_stride,
                   const float* z, const float* skts, long long skt_stride, const float* cam, const float* codes,
                   int n_codes, float tau_v, float tau_d, const float* cut_v, const float* cut_d, const float* x,
-                  int x_width, long long P, int N, int S, int nstages, float* raw, bool pre, hipStream_t st) {
+                  int x_width, long long P, int N, int S, int nstages, float* raw, bool pre, const AnerfSaved* sv,
+                  hipStream_t st) {
   MlpArgs a;
   a.packed = packed; a.aux = aux; a.rays = rays; a.z = z; a.skts = skts; a.cam = cam; a.codes = codes;
   a.cut_v = cut_v; a.cut_d = cut_d; a.x = x; a.raw = raw; a.P = P; a.skt_stride = skt_stride;
   a.S = S; a.N = N; a.ray_stride = ray_stride; a.n_codes = n_codes; a.x_width = x_width; a.nstages = nstages;
   a.tau_v = tau_v; a.tau_d = tau_d;
-  return mlp_dispatch(cfg, a, pre, st);
+  a.save_h = a.save_f = a.save_g = a.save_x = a.save_u = nullptr;
+  a.Ppad = P;
+  if (sv) {
+    a.save_h = sv->h; a.save_f = sv->f; a.save_g = sv->g; a.save_x = sv->x; a.save_u = sv->u; a.Ppad = sv->p_pad;
+  }
+  return mlp_dispatch(cfg, a, pre, sv != nullptr, st);
+}
+
+int mlp_bwd_entry(const float* packed_t, const float* aux, const float* draw, const AnerfSaved* sv, float* dz, float* df,
+                  float* dzv, long long P, int nstages, hipStream_t st) {
+  BwdArgs b;
+  b.packed_t = packed_t; b.aux = aux; b.draw = draw; b.save_h = sv->h; b.save_g = sv->g;
+  b.dz = dz; b.df = df; b.dzv = dzv; b.P = P; b.Ppad = sv->p_pad; b.nstages = nstages;
+  const long long nblk = (P + TILE - 1) / TILE;
+  if (nblk <= 0) return ANERF_OK;
+  const size_t lds = 2 * STAGE_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_mlp_bwd, dim3((unsigned)nblk), dim3(256), lds, st, b);
+  return check_launch("k_mlp_bwd");
 }
 
 }  // namespace anerf

@@ -1,0 +1,229 @@
+"""Host-side mirror of core/networks/{nerf,embedding}.py and core/cutoff_embedder.py.
+
+These modules own the PARAMETERS (same names and shapes as the reference's state_dict, so its
+checkpoints load unchanged: pts_linears.{0..7}, alpha_linear, feature_linear, views_linears.0,
+rgb_linear, framecodes.codes; embedders: cutoff_dist [24] + tau buffer) and the reference's call
+signatures.  All arithmetic runs in the HIP library through ops.py -- none of it is torch math.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+class SoftplusShift:
+    """density_fn for --density_type softplus (core/raycasters.py:230-238); carries the shift for the kernel."""
+
+    def __init__(self, shift):
+        self.softplus_shift = float(shift)
+
+    def __call__(self, x):
+        return F.softplus(x - self.softplus_shift, beta=1)
+
+
+def density_shift_of(act_fn):
+    """Map the reference's act_fn argument to the kernel's density activation: None -> relu."""
+    if act_fn is None or act_fn is F.relu or act_fn is torch.relu:
+        return None
+    if hasattr(act_fn, "softplus_shift"):
+        return act_fn.softplus_shift
+    raise NotImplementedError("density_fn must be F.relu or SoftplusShift(shift) for the HIP path")
+
+
+class Optcodes(nn.Module):
+    """Per-frame appearance codes (core/networks/embedding.py:4-45); lookup happens inside the fused kernel."""
+
+    def __init__(self, n_codes, code_ch, idx_map=None, transform_code=False, mean=None, std=None):
+        super().__init__()
+        if idx_map is not None or transform_code:
+            raise NotImplementedError("idx_map / transform_code are not used by any shipped config")
+        self.n_codes, self.code_ch = n_codes, code_ch
+        self.codes = nn.Embedding(n_codes, code_ch)
+        if mean is None:
+            nn.init.xavier_normal_(self.codes.weight)
+        elif std > 0.:
+            nn.init.normal_(self.codes.weight, mean=mean, std=std)
+        else:
+            nn.init.constant_(self.codes.weight, mean)
+
+    def table_for(self, idx, training):
+        """(table, idx) the kernel should use: eval with all idx < 0 -> the mean code (embedding.py:21-22)."""
+        if (not training) and idx is not None and bool((idx.max() < 0)):
+            return self.codes.weight.mean(0, keepdim=True), torch.zeros_like(idx)
+        return self.codes.weight, idx
+
+
+class NeRF(nn.Module):
+    """Mirror of core/networks/nerf.py:12-205 (constructor signature, parameter names, forward / raw2outputs)."""
+
+    def __init__(self, D=8, W=256, input_ch=3, input_ch_bones=0, input_ch_views=3, output_ch=4, skips=[4],
+                 use_viewdirs=False, use_framecode=False, framecode_ch=16, n_framecodes=0, skel_type=None,
+                 density_scale=1.0):
+        super().__init__()
+        if not use_viewdirs:
+            raise NotImplementedError("HIP path is built for use_viewdirs=True (all shipped configs)")
+        self.D, self.W = D, W
+        self.input_ch, self.input_ch_bones, self.input_ch_views = input_ch, input_ch_bones, input_ch_views
+        self.skips, self.use_viewdirs = skips, use_viewdirs
+        self.use_framecode, self.framecode_ch, self.n_framecodes = use_framecode, framecode_ch, n_framecodes
+        self.cam_ch = 1 if use_framecode else 0
+        self.N_joints = 24
+        self.output_ch, self.skel_type, self.density_scale = output_ch, skel_type, density_scale
+        dnet = input_ch + input_ch_bones
+        layers = [nn.Linear(dnet, W)]
+        for i in range(D - 1):
+            layers += [nn.Linear(W, W)] if i not in skips else [nn.Linear(W + dnet, W)]
+        self.pts_linears = nn.ModuleList(layers)
+        self.alpha_linear = nn.Linear(W, 1)
+        vin = input_ch_views + (framecode_ch if use_framecode else 0) + W
+        self.views_linears = nn.ModuleList([nn.Linear(vin, W // 2)])
+        self.feature_linear = nn.Linear(W, W)
+        self.rgb_linear = nn.Linear(W // 2, 3)
+        if use_framecode:
+            self.framecodes = Optcodes(n_framecodes, framecode_ch)
+        n_j = self.N_joints
+        mv = (input_ch // n_j - 1) // 2
+        md = (input_ch_views // (3 * n_j) - 1) // 2
+        self.path_cfg = ops.PathConfig(multires=mv, multires_views=md, framecode_ch=framecode_ch if use_framecode else 0,
+                                       density_scale=density_scale, netdepth=D, netwidth=W, skip=skips[0])
+        if input_ch_bones != 3 * n_j or self.path_cfg.dim_v != input_ch or self.path_cfg.dim_d != input_ch_views:
+            raise NotImplementedError("input widths do not match the reldist/reldir/relray encoders the HIP path fuses")
+        self._packed = {}
+
+    @property
+    def dnet_input(self):
+        return self.input_ch + self.input_ch_bones
+
+    @property
+    def vnet_input(self):
+        return self.input_ch_views + (self.framecode_ch if self.use_framecode else 0) + self.W
+
+    def named_path_params(self):
+        return {n: p for n, p in self.named_parameters() if not n.startswith("framecodes")}
+
+    def packed(self, which=0):
+        """(stream, aux) weight images for the kernels; re-gathered only when a parameter changed."""
+        P = self.named_path_params()
+        ver = tuple((p.data_ptr(), p._version) for p in P.values())
+        sf, af, _, _ = ops.layout(self.path_cfg, which)
+        hit = self._packed.get(which)
+        if hit is None or hit[0] != ver:
+            dev = next(iter(P.values())).device
+            flat = hit[1] if hit is not None and hit[1].device == dev else torch.empty(sf + af, dtype=torch.float32, device=dev)
+            with torch.no_grad():
+                ops.pack_params(self.path_cfg, {k: v.detach() for k, v in P.items()}, which, out=flat)
+            self._packed[which] = (ver, flat)
+        flat = self._packed[which][1]
+        return flat[:sf], flat[sf:]
+
+    def codes_table(self, cam_idx):
+        if not self.use_framecode:
+            return None, None
+        return self.framecodes.table_for(cam_idx, self.training)
+
+    def forward(self, x):
+        """x [..., input_ch+input_ch_bones+input_ch_views(+1)] -> [..., 4]   (nerf.py:133-148)."""
+        stream, aux = self.packed()
+        codes = self.framecodes.codes.weight if self.use_framecode else None
+        if self.use_framecode and not self.training:
+            idx = x[..., -1]
+            if bool(idx.max() < 0):
+                codes = codes.mean(0, keepdim=True)
+                x = torch.cat([x[..., :-1], torch.zeros_like(x[..., -1:])], -1)
+        return ops.mlp_forward(self.path_cfg, stream, aux, x, codes)
+
+    def forward_batchify(self, inputs, chunk=1024 * 64, **kwargs):
+        # the fused kernel tiles internally; `chunk` is accepted for signature compatibility (nerf.py:90-92)
+        return self.forward(inputs)
+
+    def raw2outputs(self, raw, z_vals, rays_d, raw_noise_std=0, pytest=False, B=0.01, rgb_act=torch.sigmoid,
+                    act_fn=F.relu, rgb_eps=0.001, **kwargs):
+        """nerf.py:150-205.  Noise: N(0,1)*std*B, or numpy-seeded uniform*std when pytest (nerf.py:176-182)."""
+        if rgb_act is not torch.sigmoid or rgb_eps != 0.001:
+            raise NotImplementedError("HIP composite implements rgb = sigmoid(raw)*1.002 - 0.001")
+        cfg = ops.PathConfig(self.path_cfg.multires, self.path_cfg.multires_views, self.path_cfg.framecode_ch,
+                             density_scale=B, softplus_shift=density_shift_of(act_fn))
+        noise = None
+        if raw_noise_std > 0.:
+            if pytest:
+                np.random.seed(0)
+                noise = torch.tensor(np.random.rand(*raw.shape[:-1]) * raw_noise_std, dtype=torch.float32, device=raw.device)
+            else:
+                noise = torch.randn(raw.shape[:-1], device=raw.device) * (raw_noise_std * B)
+        rays = torch.cat([torch.zeros_like(rays_d), rays_d], -1).contiguous()
+        out = ops.composite(cfg, raw, z_vals, rays, noise)
+        return out
+
+
+class Embedder(nn.Module):
+    """Plain positional-encoding descriptor (core/cutoff_embedder.py:9-58).  The encoding itself is fused into the
+    MLP kernel; this object carries out_dim and the (no-op) schedule hooks."""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        self.kwargs = kwargs
+        d, nf = kwargs["input_dims"], kwargs["num_freqs"]
+        self.out_dim = d * ((1 if kwargs["include_input"] else 0) + 2 * nf)
+        self.freq_bands = 2. ** torch.linspace(0., kwargs["max_freq_log2"], steps=nf) if nf > 0 else torch.zeros(0)
+
+    def forward(self, inputs, **kwargs):
+        raise NotImplementedError("positional encoding is fused into the HIP MLP kernel (anerf_mlp_raw)")
+
+    def update_threshold(self, *args, **kwargs):
+        pass
+
+    def update_tau(self, *args, **kwargs):
+        pass
+
+    def update_alpha(self, *args, **kwargs):
+        pass
+
+    def get_tau(self):
+        return 0.0
+
+
+class CutoffEmbedder(Embedder):
+    """Cutoff PE state (core/cutoff_embedder.py:61-197): cutoff_dist [cutoff_dim] parameter (frozen), tau buffer,
+    tau schedule.  tau and cutoff_dist are runtime kernel arguments."""
+
+    def __init__(self, cutoff_dist=500 * 0.00035, std=0.1, normalize=False, dist_inputs=False, cutoff_inputs=False,
+                 opt_cutoff=False, cutoff_dim=24, freq_schedule=False, init_alpha=0., cut_to_cutoff=False,
+                 shift_inputs=False, **kwargs):
+        super().__init__(**kwargs)
+        if normalize or opt_cutoff or freq_schedule or cut_to_cutoff or shift_inputs or not cutoff_inputs:
+            raise NotImplementedError("HIP path implements the shipped configs: cutoff_inputs=True, no normalize/"
+                                      "opt_cutoff/freq_schedule/cut_to_dist/cutoff_shift")
+        self.dist_inputs, self.cutoff_inputs, self.cutoff_dim = dist_inputs, cutoff_inputs, cutoff_dim
+        self.cutoff_dist = nn.Parameter(torch.ones(cutoff_dim) * cutoff_dist, requires_grad=False)
+        self.init_tau = 20.
+        self.register_buffer("tau", torch.tensor(self.init_tau))
+
+    def get_tau(self):
+        return self.tau.item()
+
+    def get_cutoff_dist(self):
+        return self.cutoff_dist
+
+    def update_threshold(self, global_step, tau_step, tau_rate, alpha_step, alpha_target):
+        self.update_tau(global_step, tau_step, tau_rate)
+
+    def update_tau(self, global_step, step, rate):
+        # cutoff_embedder.py:181-183
+        self.tau = (self.init_tau * torch.ones_like(self.tau) * rate ** (global_step / float(step * 1000))).clamp(max=2000.)
+
+
+def get_embedder(multires, i=0, input_dims=3, cutoff_kwargs={"cutoff": False}, skel_type=None, kc=False):
+    """core/cutoff_embedder.py:199-224."""
+    if i == -1:
+        return nn.Identity(), input_dims
+    embed_kwargs = {"include_input": True, "input_dims": input_dims, "max_freq_log2": multires - 1,
+                    "num_freqs": multires, "log_sampling": True, "periodic_fns": [torch.sin, torch.cos],
+                    "skel_type": skel_type}
+    if cutoff_kwargs["cutoff"]:
+        ck = {k: v for k, v in cutoff_kwargs.items() if k != "cutoff"}
+        obj = CutoffEmbedder(**ck, **embed_kwargs)
+    else:
+        obj = Embedder(**embed_kwargs)
+    return obj, obj.out_dim

@@ -1,0 +1,262 @@
+"""Host-side mirror of core/raycasters.py: `create_raycaster`, `RayCaster` (forward / render_rays with the
+reference's signatures, state_dict key mapping, embedder schedule), and the train-side wrapper that exposes
+`.module` like nn.DataParallel but runs one process per GPU with an RCCL all-reduce of gradients.
+
+Everything numeric happens in libanerf_hip.so (pipeline.py / autograd_path.py); this file is argument plumbing.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops, pipeline
+from .networks import NeRF, SoftplusShift, density_shift_of, get_embedder
+
+SUPPORTED = dict(pts_tr_type="local", kp_dist_type="reldist", bone_type="reldir", view_type="relray")
+
+
+class _EncoderTag:
+    """Stand-in for the reference's encoder objects in preproc_kwargs (core/encoders.py): the fused kernel
+    implements exactly WorldToLocal + RelDist + VecNorm(bones) + VecNorm(rays); the tag lets callers that
+    inspect `encoder_name` / `dims` keep working."""
+
+    def __init__(self, name, dims):
+        self.encoder_name, self.dims = name, dims
+
+    def __call__(self, *a, **k):
+        raise NotImplementedError(f"{self.encoder_name} is fused into the HIP MLP kernel")
+
+
+def get_density_fn(args):
+    if args.density_type == "relu":
+        return F.relu
+    if args.density_type == "softplus":
+        return SoftplusShift(args.softplus_shift)
+    raise NotImplementedError(f"density activation {args.density_type} is undefined")
+
+
+class RayCaster(nn.Module):
+    """core/raycasters.py:326-794."""
+
+    def __init__(self, network, embed_fn, embedbones_fn, embeddirs_fn, network_fine=None, joint_coords=None,
+                 single_net=False):
+        super().__init__()
+        self.network = network
+        self.network_fine = network_fine
+        self.embed_fn = embed_fn
+        self.embedbones_fn = embedbones_fn
+        self.embeddirs_fn = embeddirs_fn
+        if joint_coords is not None:
+            n_j = joint_coords.shape[-3]
+            self.register_buffer("joint_coords", joint_coords.reshape(-1, n_j, 3, 3))
+        self.single_net = single_net
+
+    @torch.no_grad()
+    def forward_eval(self, *args, **kwargs):
+        return self.render_rays(*args, **kwargs)
+
+    def forward(self, *args, fwd_type="", **kwargs):
+        if fwd_type in ("density", "density_color", "mesh"):
+            raise NotImplementedError(f"fwd_type={fwd_type!r}: density/mesh queries are listed as 'next' in SURVEY.md 8(f)")
+        if not self.training:
+            return self.forward_eval(*args, **kwargs)
+        return self.render_rays(*args, **kwargs)
+
+    def _taus(self):
+        tv = self.embed_fn.get_tau() if hasattr(self.embed_fn, "cutoff_dist") else 0.0
+        td = self.embeddirs_fn.get_tau() if hasattr(self.embeddirs_fn, "cutoff_dist") else 0.0
+        return tv, td
+
+    def render_rays(self, ray_batch, N_samples, kp_batch, skts=None, cyls=None, bones=None, cams=None,
+                    subject_idxs=None, retraw=False, lindisp=False, perturb=0., N_importance=0, network_fine=None,
+                    raw_noise_std=0., ray_noise_std=0., verbose=False, ext_scale=0.001, pytest=False,
+                    preproc_kwargs={}, nerf_type="nerf"):
+        """Same arguments and returned dict as core/raycasters.py:361-474."""
+        if skts is None or cyls is None:
+            raise ValueError("skts and cyls are required (world->bone transforms and bounding cylinders)")
+        if subject_idxs is not None:
+            raise NotImplementedError("subject_idxs (multi-subject column) is not used by the shipped configs")
+        if ray_noise_std > 0.:
+            raise NotImplementedError("ray_noise_std > 0 is not used by the shipped configs")
+        n = ray_batch.shape[0]
+        dev = ray_batch.device
+        net_c, net_f = self.network, self.network_fine
+        cfg = net_c.path_cfg
+        B = preproc_kwargs.get("density_scale", net_c.density_scale)
+        shift = density_shift_of(preproc_kwargs.get("density_fn", F.relu))
+        cfg = ops.PathConfig(cfg.multires, cfg.multires_views, cfg.framecode_ch, density_scale=B, softplus_shift=shift)
+        # randomness is generated here (device tensors) and handed to the kernels as inputs
+        t_rand = u_imp = noise = noise_f = None
+        if perturb > 0.:
+            t_rand = _rand(pytest, (n, N_samples), dev)
+            if N_importance > 0:
+                u_imp = _rand(pytest, (n, N_importance), dev)
+        if raw_noise_std > 0.:
+            if pytest:
+                noise = _rand(True, (n, N_samples), dev) * raw_noise_std
+                if N_importance > 0:
+                    noise_f = _rand(True, (n, N_samples + N_importance), dev) * raw_noise_std
+            else:
+                noise = torch.randn(n, N_samples, device=dev) * (raw_noise_std * B)
+                if N_importance > 0:
+                    noise_f = torch.randn(n, N_samples + N_importance, device=dev) * (raw_noise_std * B)
+        tau_v, tau_d = self._taus()
+        cut_v = self.embed_fn.cutoff_dist.detach()
+        cut_d = self.embeddirs_fn.cutoff_dist.detach() if hasattr(self.embeddirs_fn, "cutoff_dist") else cut_v
+        cam_idx = None if cams is None else cams.reshape(-1).float()
+        codes_c, cam_c = net_c.codes_table(cam_idx)
+        codes_f, cam_f = (net_f.codes_table(cam_idx) if net_f is not None else (None, None))
+        kw = dict(cfg=cfg, ray_batch=ray_batch.contiguous(), skts=skts, cyls=cyls, n_samples=N_samples,
+                  n_importance=N_importance, tau_v=tau_v, tau_d=tau_d, cut_v=cut_v, cut_d=cut_d,
+                  cam_idx=cam_c if cam_c is not None else cam_idx, t_rand=t_rand, u_imp=u_imp, noise=noise,
+                  noise_fine=noise_f, lindisp=lindisp, single_net=self.single_net)
+        needs_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or skts.requires_grad)
+        if needs_grad:
+            from . import autograd_path
+            return autograd_path.render_rays_train(self, kw)
+        return pipeline.render_rays_forward(net_c=net_c.packed(), net_f=None if net_f is None else net_f.packed(),
+                                            codes_c=codes_c, codes_f=codes_f, **kw)
+
+    # ------------------------------------------------------------------ bookkeeping identical to the reference
+    def update_embed_fns(self, global_step, args):
+        fns = [self.embed_fn, self.embeddirs_fn] + ([self.embedbones_fn] if self.embedbones_fn is not None else [])
+        for f in fns:
+            f.update_threshold(global_step, args.cutoff_step, args.cutoff_rate, args.freq_schedule_step, args.multires - 1)
+
+    @staticmethod
+    def _ckpt_key(k):
+        if k.endswith("_fine"):
+            return f"{k}_state_dict"
+        if k.endswith("_fn"):
+            return f"{k.split('_fn')[0]}_state_dict"
+        if k == "network":
+            return "network_fn_state_dict"
+        return f"{k}_state_dict"
+
+    def state_dict(self):
+        """Checkpoint layout of the reference (raycasters.py:752-766): one sub-dict per child module."""
+        return {self._ckpt_key(k): m.state_dict() for k, m in self._modules.items() if m is not None}
+
+    def load_state_dict(self, ckpt, strict=True):
+        for k, m in self._modules.items():
+            if m is None:
+                continue
+            key = self._ckpt_key(k)
+            try:
+                m.load_state_dict(ckpt[key], strict=strict)
+            except (KeyError, RuntimeError):
+                if k.startswith("network"):
+                    cur = m.state_dict()
+                    ok = {n: v for n, v in ckpt[key].items() if n in cur and cur[n].shape == v.shape}
+                    m.load_state_dict(ok, strict=False)
+                else:
+                    print(f"Error occurred when loading state dict for {key}. The entity is not in the state dict?")
+
+    def get_embed_fns(self):
+        return self.embed_fn, self.embedbones_fn, self.embeddirs_fn
+
+    def get_networks(self):
+        return self.network, self.network_fine
+
+
+def _rand(pytest, shape, dev):
+    """torch.rand on the device, or the reference's numpy-seeded override (ray_utils.py:171-180,240-244)."""
+    if pytest:
+        np.random.seed(0)
+        return torch.tensor(np.random.rand(*shape), dtype=torch.float32, device=dev)
+    return torch.rand(*shape, device=dev)
+
+
+class RayParallel(nn.Module):
+    """Train-side wrapper standing where the reference puts nn.DataParallel (raycasters.py:157): exposes `.module`
+    (trainer.py:265,270,504 reach through it).  Parallelism is one process per GPU: each rank renders its own
+    ray batch and `sync_gradients()` all-reduces one flat fp32 bucket over RCCL (see parallel.py)."""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+
+def get_grad_vars(args, ray_caster):
+    network, network_fine = ray_caster.get_networks()
+    if getattr(args, "finetune", False) and getattr(args, "fix_layer", 0) > 0:
+        for net in (network, network_fine):
+            for i, l in enumerate(net.pts_linears):
+                if i < args.fix_layer:
+                    for p in l.parameters():
+                        p.requires_grad = False
+    out = []
+    mods = [network] + ([network_fine] if not args.single_net else []) + list(ray_caster.get_embed_fns())
+    for m in mods:
+        if m is not None:
+            out += [p for p in m.parameters() if p.requires_grad]
+    return out
+
+
+def create_raycaster(args, data_attrs, device=None):
+    """core/raycasters.py:17-184: same arguments, same 6-tuple
+    (render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer, loaded_ckpt)."""
+    for k, v in SUPPORTED.items():
+        if getattr(args, k) != v:
+            raise NotImplementedError(f"{k}={getattr(args, k)!r}: the HIP path fuses {SUPPORTED} (all shipped configs)")
+    if not (args.use_cutoff and args.cutoff_viewdir and args.cutoff_inputs and args.use_viewdirs) or args.cutoff_bones:
+        raise NotImplementedError("HIP path needs use_cutoff, cutoff_viewdir, cutoff_inputs, use_viewdirs, no cutoff_bones")
+    if args.multires_bones != 0:
+        raise NotImplementedError("multires_bones must be 0 (identity bone embedding)")
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    skel_type = data_attrs["skel_type"]
+    n_j = len(skel_type.joint_names)
+    n_framecodes = data_attrs["n_views"] if args.n_framecodes is None else args.n_framecodes
+    cutoff_kwargs = {"cutoff": True, "normalize_cutoff": args.normalize_cutoff, "cutoff_dist": args.cutoff_mm * args.ext_scale,
+                     "cutoff_inputs": args.cutoff_inputs, "opt_cutoff": args.opt_cutoff, "cutoff_dim": n_j,
+                     "freq_schedule": args.freq_schedule, "init_alpha": args.init_freq}
+    embed_fn, input_ch = get_embedder(args.multires, args.i_embed, input_dims=n_j, skel_type=skel_type,
+                                      cutoff_kwargs=dict(cutoff_kwargs, dist_inputs=False, cut_to_cutoff=args.cut_to_dist,
+                                                         shift_inputs=args.cutoff_shift))
+    embedbones_fn, input_ch_bones = get_embedder(0, args.i_embed, input_dims=3 * n_j, skel_type=skel_type,
+                                                 cutoff_kwargs={"cutoff": False})
+    embeddirs_fn, input_ch_views = get_embedder(args.multires_views, args.i_embed, input_dims=3 * n_j, skel_type=skel_type,
+                                                cutoff_kwargs=dict(cutoff_kwargs, dist_inputs=True))
+    nerf_kwargs = dict(D=args.netdepth, W=args.netwidth, input_ch=input_ch, input_ch_bones=input_ch_bones,
+                       input_ch_views=input_ch_views, output_ch=5 if args.N_importance > 0 else 4, skips=[4],
+                       use_viewdirs=args.use_viewdirs, use_framecode=args.opt_framecode, framecode_ch=args.framecode_size,
+                       n_framecodes=n_framecodes, skel_type=skel_type, density_scale=args.density_scale)
+    model = NeRF(**nerf_kwargs)
+    model_fine = None
+    if args.N_importance > 0:
+        model_fine = model if args.single_net else NeRF(**nerf_kwargs)
+    ray_caster = RayCaster(model, embed_fn, embedbones_fn, embeddirs_fn, network_fine=model_fine,
+                           joint_coords=torch.tensor(data_attrs["joint_coords"]), single_net=args.single_net).to(device)
+    grad_vars = get_grad_vars(args, ray_caster)
+    optimizer = torch.optim.Adam(params=grad_vars, lr=args.lrate, betas=(0.9, 0.999))
+    start, loaded_ckpt = 0, None
+    if args.ft_path is not None and args.ft_path != "None":
+        ckpts = [args.ft_path]
+    else:
+        d = os.path.join(args.basedir, args.expname)
+        ckpts = [os.path.join(d, f) for f in sorted(os.listdir(d)) if "tar" in f and "pose" not in f] if os.path.isdir(d) else []
+    if len(ckpts) > 0 and not args.no_reload:
+        loaded_ckpt = torch.load(ckpts[-1], map_location=device)
+        start = loaded_ckpt["global_step"]
+        ray_caster.load_state_dict(loaded_ckpt)
+        if not args.finetune and "optimizer_state_dict" in loaded_ckpt:
+            optimizer.load_state_dict(loaded_ckpt["optimizer_state_dict"])
+        if args.finetune:
+            start = 0
+    preproc_kwargs = {"pts_tr_fn": _EncoderTag("W2LEncoder", n_j), "kp_input_fn": _EncoderTag("RelDist", n_j),
+                      "view_input_fn": _EncoderTag("VecNorm", 3 * n_j), "bone_input_fn": _EncoderTag("VecNorm", 3 * n_j),
+                      "density_scale": args.density_scale, "density_fn": get_density_fn(args)}
+    render_kwargs_train = {"ray_caster": RayParallel(ray_caster), "perturb": args.perturb, "N_importance": args.N_importance,
+                           "N_samples": args.N_samples, "use_viewdirs": args.use_viewdirs, "raw_noise_std": args.raw_noise_std,
+                           "ray_noise_std": args.ray_noise_std, "ext_scale": args.ext_scale, "preproc_kwargs": preproc_kwargs,
+                           "lindisp": args.lindisp, "nerf_type": args.nerf_type}
+    render_kwargs_test = dict(render_kwargs_train)
+    render_kwargs_test.update(ray_caster=ray_caster, preproc_kwargs=dict(preproc_kwargs), perturb=False, raw_noise_std=0.,
+                              ray_noise_std=0.)
+    optimizer.zero_grad()
+    return render_kwargs_train, render_kwargs_test, start, grad_vars, optimizer, loaded_ckpt

@@ -71,7 +71,7 @@ typedef struct AnerfLayout {
 const char* anerf_last_error(void);
 int anerf_version(void);
 
-/* which: 0 = forward image (W), 1 = backward-data image (W^T). */
+/* which: 0 = forward image (W), 1 = backward-data image (W^T of the hidden trunk, feature and view layers). */
 int anerf_layout(const AnerfConfig* cfg, int which, AnerfLayout* out);
 /* HOST: fill table[stream_floats + aux_floats]: entry = (tensor_id << 24) | element offset, -1 = 0.0f;
  * tensor_id = index into {w[0..11], b[0..11]} (0..23).  Upload once per config. */
@@ -118,6 +118,68 @@ int anerf_composite(const AnerfConfig* cfg, const float* raw, const float* z_val
 int anerf_importance(const float* z_vals, const float* weights, int32_t n_rays, int32_t n_samples,
                      int32_t n_importance, const float* u, int32_t single_net,
                      float* z_samples, float* z_merged, int64_t* sorted_idx, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Training path (A12: autograd of A9/A10 -- Trainer.optimize -> loss.backward(), core/trainer.py:451-483).
+ * forward:  anerf_mlp_raw_train (= anerf_mlp_raw + saved activations)
+ * backward: anerf_composite_backward -> anerf_mlp_backward -> anerf_weight_grads
+ * ------------------------------------------------------------------------------------------------------------- */
+
+/* Activations the training forward saves for the backward; caller-allocated row-major planes of p_pad rows
+ * (p_pad = multiple of 128 >= N*S; rows >= N*S must be ZERO).  x/u are in "stream column order" (see
+ * anerf_build_perm_tables). */
+typedef struct AnerfSaved {
+  float* h;       /* [8][p_pad][256]   h0..h7, post-ReLU                       */
+  float* f;       /* [p_pad][256]      feature_linear output                    */
+  float* g;       /* [p_pad][128]      views_linears.0 output, post-ReLU        */
+  float* x;       /* [p_pad][432]      density-net input                        */
+  float* u;       /* [p_pad][u_width]  view-net input without the feature part  */
+  int64_t p_pad;
+} AnerfSaved;
+
+/* Gradient tensors, same order and shapes as AnerfNetParams (torch layout); all written (not accumulated). */
+typedef struct AnerfNetGrads {
+  float* w[12];
+  float* b[12];
+} AnerfNetGrads;
+
+typedef struct AnerfTrainLayout {
+  int64_t p_pad;          /* rows per saved plane for n_points                          */
+  int32_t x_width;        /* 432                                                         */
+  int32_t u_width;        /* 648 (+16 with frame codes), 72 for multires_views = 0       */
+  int32_t gemm_chunks;    /* p-chunks the weight-gradient GEMM splits the sample axis in */
+  int64_t gemm_ws_floats; /* workspace floats anerf_weight_grads needs                   */
+} AnerfTrainLayout;
+
+int anerf_train_layout(const AnerfConfig* cfg, int64_t n_points, AnerfTrainLayout* out);
+/* HOST: perm_x[432], perm_u[u_width]: stream column -> torch input column (of pts_linears.0 / of
+ * views_linears.0 minus 256). */
+int anerf_build_perm_tables(const AnerfConfig* cfg, int32_t* perm_x, int32_t* perm_u);
+
+int anerf_mlp_raw_train(const AnerfConfig* cfg, const float* packed, const float* aux,
+                        const float* rays, int32_t ray_stride, const float* z_vals,
+                        const float* skts, int64_t skt_ray_stride, const float* cam_idx,
+                        const float* codes, int32_t n_codes,
+                        float tau_v, float tau_d, const float* cutoff_v, const float* cutoff_d,
+                        int32_t n_rays, int32_t n_samples, float* raw, const AnerfSaved* saved, void* stream);
+
+/* d(loss)/d(outputs of anerf_composite) -> draw [N,S,4].  Any of g_acc, g_disp, g_alpha, g_weights may be NULL. */
+int anerf_composite_backward(const AnerfConfig* cfg, const float* raw, const float* z_vals, const float* rays,
+                             int32_t ray_stride, const float* noise, int32_t n_rays, int32_t n_samples,
+                             const float* g_rgb, const float* g_acc, const float* g_disp, const float* g_alpha,
+                             const float* g_weights, float* draw, void* stream);
+
+/* draw [P,4] -> d(pre-activations): dz [8][p_pad][256], df [p_pad][256], dzv [p_pad][128] (rows >= P untouched:
+ * caller zeroes them).  packed_t: image which=1 (W^T); aux: the forward aux image. */
+int anerf_mlp_backward(const AnerfConfig* cfg, const float* packed_t, const float* aux, const float* draw,
+                       const AnerfSaved* saved, float* dz, float* df, float* dzv, int64_t n_points, void* stream);
+
+/* Weight and bias gradients of all 12 Linear layers: one grouped fp32-MFMA GEMM over the sample axis + a
+ * deterministic chunk reduction.  perm_x / perm_u: DEVICE copies of anerf_build_perm_tables. */
+int anerf_weight_grads(const AnerfConfig* cfg, const AnerfSaved* saved, const float* dz, const float* df,
+                       const float* dzv, const float* draw, int64_t n_points, const int32_t* perm_x,
+                       const int32_t* perm_u, const AnerfNetGrads* grads, float* workspace, int64_t ws_floats,
+                       void* stream);
 
 #ifdef __cplusplus
 }
