@@ -1,0 +1,69 @@
+"""Ray-batch data parallelism: one process per GPU, one RCCL all-reduce per step.
+
+The reference wraps the caster in single-process nn.DataParallel (core/raycasters.py:157): per call it
+re-broadcasts both networks, scatters every per-ray tensor, gathers the output dict and reduce-adds gradients
+to device 0.  Here each rank owns N_rand / world rays of the step (rays are independent; the loss is a mean
+over rays), runs the fused forward/backward locally and the gradients of all parameters are summed with ONE
+all-reduce over a single flat fp32 bucket (2 x 864 260 floats = 6.9 MB; xGMI ring time << one step), then
+scaled by 1/world -- identical to the gradient of the global-batch mean loss.
+Backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradBucket:
+    """Flat fp32 gradient bucket over a fixed parameter list."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = None
+
+    def _ensure(self, device):
+        if self.flat is None or self.flat.device != device:
+            self.flat = torch.zeros(self.numel, dtype=torch.float32, device=device)
+            self.views, o = [], 0
+            for p in self.params:
+                self.views.append(self.flat[o:o + p.numel()].view_as(p))
+                o += p.numel()
+
+    def all_reduce_mean(self, group=None):
+        """Sum gradients over ranks, divide by world size, write back into p.grad.  Returns the flat bucket."""
+        if not self.params:
+            return None
+        self._ensure(self.params[0].device)
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
+        torch._foreach_copy_(self.views, grads)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+            self.flat.div_(dist.get_world_size(group))
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                p.grad = v.clone()
+            else:
+                p.grad.copy_(v)
+        return self.flat
+
+
+def shard_rays(n_rays, rank=None, world=None):
+    """Contiguous slice [lo, hi) of a ray batch owned by `rank` (last rank may be short)."""
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    per = (n_rays + world - 1) // world
+    return min(n_rays, rank * per), min(n_rays, (rank + 1) * per)
+
+
+def gather_rays(local, n_total, group=None):
+    """All-gather per-ray outputs of a sharded render into [n_total, ...] (frame assembly on every rank)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    per = (n_total + world - 1) // world
+    pad = torch.zeros((per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    out = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    return out[:n_total]

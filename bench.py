@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="render64", choices=["render64", "hier", "render64x64"])
+    ap.add_argument("--workload", default="render64", choices=["render64", "hier", "render64x64", "train"])
     ap.add_argument("--cpu-rays", type=int, default=8192, help="ray sample for the CPU baseline (0 = skip)")
     return ap.parse_args()
 
@@ -57,6 +57,8 @@ def main():
     synth = importlib.import_module("a-nerf_amd.synth")
     ops = importlib.import_module("a-nerf_amd.ops")
     pipeline = importlib.import_module("a-nerf_amd.pipeline")
+    if args.workload == "train":
+        return bench_train(args, rank, world, device, dist, synth)
 
     if args.workload == "render64x64":
         H = W = 64; focal = 75.0; S, Ni = 32, 0
@@ -141,6 +143,91 @@ def main():
         }
         if args.cpu_rays > 0:
             res["cpu_baseline"], res["parity"] = cpu_baseline(sc, S, Ni, Pc, Pf, out, lo, min(args.cpu_rays, hi - lo))
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_train(args, rank, world, device, dist, synth):
+    """BASELINE config 3: SURREAL training step, N_rand = 3072 rays (global), 64 + 16 samples, fwd + bwd + Adam,
+    through the reference-shaped API (RayCaster mirror + render() + loss).  Strong scaling: each rank takes
+    N_rand / world rays; gradients are averaged with one RCCL all-reduce of a flat bucket per step."""
+    networks = importlib.import_module("a-nerf_amd.networks")
+    raycaster = importlib.import_module("a-nerf_amd.raycaster")
+    render_mod = importlib.import_module("a-nerf_amd.render")
+    parallel = importlib.import_module("a-nerf_amd.parallel")
+    N_rand, S, Ni = 3072, 64, 16
+    dev = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32, device=device)
+    kw = dict(D=8, W=256, input_ch=360, input_ch_bones=72, input_ch_views=648, use_viewdirs=True)
+    net_c, net_f = networks.NeRF(**kw), networks.NeRF(**kw)
+    net_c.load_state_dict({k: torch.tensor(v) for k, v in synth.make_net_params(11).items()})
+    net_f.load_state_dict({k: torch.tensor(v) for k, v in synth.make_net_params(12).items()})
+    ck = {"cutoff": True, "cutoff_dist": 0.5, "cutoff_inputs": True, "cutoff_dim": 24}
+    e_v, _ = networks.get_embedder(7, input_dims=24, cutoff_kwargs=dict(ck, dist_inputs=False))
+    e_b, _ = networks.get_embedder(0, input_dims=72, cutoff_kwargs={"cutoff": False})
+    e_d, _ = networks.get_embedder(4, input_dims=72, cutoff_kwargs=dict(ck, dist_inputs=True))
+    caster = raycaster.RayCaster(net_c, e_v, e_b, e_d, network_fine=net_f).to(device)
+    caster.train()
+    params = [p for p in caster.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.999))
+    bucket = parallel.GradBucket(params)
+    # per-ray replicated pose batch as the reference's collate produces it (dataset.py:813-820), 8 poses
+    ro, rd, kp, skts, bones, cyls, _ = synth.scene_batch(N_rand, list(range(8)), H=512, W=512, focal=600.0, ray_seed=3,
+                                                         per_ray_pose=True)
+    lo, hi = parallel.shard_rays(N_rand, rank, world)
+    sl = slice(lo, hi)
+    rays = (dev(ro[sl]), dev(rd[sl]))
+    batch = dict(kp_batch=dev(kp[sl]), skts=dev(skts[sl]), cyls=dev(cyls[sl]), bones=dev(bones[sl]))
+    target = dev(np.random.default_rng(1).random((N_rand, 3))[sl])
+    pk = {"density_scale": 1.0, "density_fn": torch.nn.functional.relu}
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None):
+        if i is not None:
+            ev[i][0].record()
+        out = render_mod.render(512, 512, 600.0, chunk=4096, rays=rays, use_viewdirs=True, ray_caster=caster, cams=None,
+                                subject_idxs=None, N_samples=S, N_importance=Ni, perturb=1.0, raw_noise_std=1.0,
+                                preproc_kwargs=pk, **batch)
+        loss, _ = render_mod.nerf_loss(out, target, bgs=1.0)
+        loss.backward()
+        if i is not None:
+            ev[i][1].record()
+        bucket.all_reduce_mean()
+        opt.step()
+        opt.zero_grad(set_to_none=False)
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], device=device)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    fb_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if rank == 0:
+        flop_step_rank = 3 * F_MLP * (hi - lo) * (S + S + Ni)        # fwd + 2x bwd, coarse S + fine S+Ni evaluations
+        achieved = flop_step_rank / (fb_ms * 1e-3)
+        res = {"metric": "rays/sec", "value": N_rand * args.steps / dt, "unit": "rays/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "SURREAL-shaped training step, N_rand=3072, 64+16 samples, fwd+bwd+Adam (BASELINE config 3)",
+                          "rays_per_step": N_rand, "samples_per_ray": S, "n_importance": Ni,
+                          "parallelism": f"ray-sharded x{world}, 1 all-reduce/step", "loss": float(loss)},
+               "roofline": {"bound": "mfma", "kernel": "k_mlp_fwd<train> + k_mlp_bwd + k_gemm_tn (both nets), HIP-event time of fwd+bwd",
+                            "achieved": achieved / 1e12, "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
+                            "frac": achieved / PEAK_FP32_MFMA, "avg_launch_ms": fb_ms, "flop_per_launch": flop_step_rank,
+                            "traffic": None}}
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
