@@ -76,6 +76,13 @@ SIGNATURES = {
     "anerf_weight_grads": (C.c_int, [C.POINTER(AnerfConfig), C.POINTER(AnerfSaved), C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(AnerfNetGrads), C.c_void_p,
                                      C.c_int64, C.c_void_p]),
+    "anerf_input_grads": (C.c_int, [C.POINTER(AnerfConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
+    "anerf_encode_backward": (C.c_int, [C.POINTER(AnerfConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                        C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int32,
+                                        C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "anerf_code_grads": (C.c_int, [C.POINTER(AnerfConfig), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                   C.c_int32, C.c_void_p]),
 }
 
 _lib = None

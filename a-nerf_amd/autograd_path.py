@@ -46,7 +46,7 @@ def _planes(rows_pad, rows, width, n_planes, device):
 
 class _MlpRawFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, meta, *params):
+    def forward(ctx, meta, skts_in, codes_in, *params):
         cfg, dev = meta["cfg"], meta["rays"].device
         z = meta["z"]
         n, s = z.shape
@@ -96,8 +96,33 @@ class _MlpRawFn(torch.autograd.Function):
         px, pu = perm_tables(cfg, dev)
         _lib.check(lib.anerf_weight_grads(C.byref(cc), C.byref(st), _p(dz), _p(df), _p(dzv), _p(draw), P, _p(px), _p(pu),
                                           C.byref(gs), _p(ws), T.gemm_ws_floats, _stream()), "anerf_weight_grads")
+        g_skts = g_codes = None
+        need_skts, need_codes = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        if need_skts or need_codes:
+            packed_i, _ = meta["packed_i"]()
+            dx = torch.empty(pp, T.x_width, dtype=torch.float32, device=dev)
+            du = torch.empty(pp, T.u_width, dtype=torch.float32, device=dev)
+            _lib.check(lib.anerf_input_grads(C.byref(cc), _p(packed_i), _p(dz), _p(dzv), pp, P, _p(dx), _p(du), _stream()),
+                       "anerf_input_grads")
+            z, rays, skts = meta["z"], meta["rays"], meta["skts"]
+            n, s = z.shape
+            if need_skts:
+                if skts.shape[0] != n:
+                    raise NotImplementedError("skts.requires_grad needs per-ray skts [N,24,4,4]")
+                g_skts = torch.zeros_like(skts)
+                dyw = torch.empty(P, 72, dtype=torch.float32, device=dev)
+                dqw = torch.empty(P, 72, dtype=torch.float32, device=dev)
+                _lib.check(lib.anerf_encode_backward(
+                    C.byref(cc), _p(dx), _p(du), _p(rays), rays.shape[1], _p(z), _p(skts), 16 * cfg.n_joints,
+                    float(meta["tau_v"]), float(meta["tau_d"]), _p(meta["cut_v"]), _p(meta["cut_d"]), n, s, _p(dyw), _p(dqw),
+                    _p(g_skts), _stream()), "anerf_encode_backward")
+            if need_codes:
+                codes = meta["codes"]
+                g_codes = torch.zeros_like(codes)
+                _lib.check(lib.anerf_code_grads(C.byref(cc), _p(du), _p(meta["cam"]), n, s, _p(g_codes), codes.shape[0],
+                                                _stream()), "anerf_code_grads")
         ctx.sv = None
-        return (None, *grads)
+        return (None, g_skts, g_codes, *grads)
 
 
 class _CompositeFn(torch.autograd.Function):
@@ -138,19 +163,19 @@ def render_rays_train(caster, kw):
     """Differentiable RayCaster.render_rays (raycasters.py:361-474); kw as assembled by RayCaster.render_rays."""
     cfg, rays, skts, cyls = kw["cfg"], kw["ray_batch"], kw["skts"], kw["cyls"]
     S, Ni = kw["n_samples"], kw["n_importance"]
-    if skts.requires_grad:
-        raise NotImplementedError("d(loss)/d(skts) (pose optimisation) is not wired into the HIP backward yet")
     net_c, net_f = caster.network, caster.network_fine
+    skts_c = skts.contiguous()
     with torch.no_grad():
         nf_raw, stats = ops.ray_bounds(rays, cyls)
         z, _ = ops.coarse_z(nf_raw, stats, rays, S, kw["t_rand"], kw["lindisp"])
 
     def mlp(net, zz):
-        if net.use_framecode:
-            raise NotImplementedError("frame-code gradients are not wired into the HIP backward yet")
-        meta = dict(cfg=cfg, rays=rays, z=zz, skts=skts.detach().contiguous(), tau_v=kw["tau_v"], tau_d=kw["tau_d"],
-                    cut_v=kw["cut_v"], cut_d=kw["cut_d"], cam=None, codes=None, packed=net.packed(0), packed_t=net.packed(1))
-        return _MlpRawFn.apply(meta, *_net_params(net))
+        codes = net.framecodes.codes.weight if net.use_framecode else None
+        cam = kw["cam_idx"].contiguous() if net.use_framecode else None
+        meta = dict(cfg=cfg, rays=rays, z=zz, skts=skts_c.detach(), tau_v=kw["tau_v"], tau_d=kw["tau_d"],
+                    cut_v=kw["cut_v"], cut_d=kw["cut_d"], cam=cam, codes=None if codes is None else codes.detach(),
+                    packed=net.packed(0), packed_t=net.packed(1), packed_i=lambda: net.packed(2))
+        return _MlpRawFn.apply(meta, skts_c, codes, *_net_params(net))
 
     def comp(raw, zz, noise):
         return _CompositeFn.apply(dict(cfg=cfg, rays=rays, z=zz, noise=noise), raw)

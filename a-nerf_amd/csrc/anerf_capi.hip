@@ -43,6 +43,12 @@ int mlp_raw_entry(const AnerfConfig* cfg, const float* packed, const float* aux,
 int mlp_bwd_entry(const float* packed_t, const float* aux, const float* draw, const AnerfSaved* sv, float* dz, float* df,
                   float* dzv, long long P, int nstages, hipStream_t st);
 int launch_weight_grads(GemmBatch& G, float* ws, hipStream_t st);
+int mlp_bwd_in_entry(const float* packed_i, const float* dz, const float* dzv, float* dx, float* du, long long P,
+                     long long Ppad, int nstages, int uw, hipStream_t st);
+int launch_encode_bwd(int ld, const float* dx, const float* du, int uw, const float* rays, int ray_stride, const float* z,
+                      const float* skts, long long skt_stride, float tau_v, float tau_d, const float* cut_v,
+                      const float* cut_d, int n, int S, float* dY, float* dQ, float* dskts, hipStream_t st);
+int launch_code_reduce(const float* du, int uw, const float* cam, int n, int S, int n_codes, float* dcodes, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------------
 // weight-stream layout.  A segment = one Linear layer; its k-groups (8 input columns: 4 per lane half) are laid
@@ -137,12 +143,14 @@ int anerf_version(void) { return 1; }
 int anerf_layout(const AnerfConfig* cfg, int which, AnerfLayout* out) {
   if (!out) return set_error(ANERF_E_NULL, "out is NULL");
   if (!config_ok(cfg)) return set_error(ANERF_E_CONFIG, "unsupported AnerfConfig");
-  if (which != 0 && which != 1) return set_error(ANERF_E_CONFIG, "which must be 0 (W) or 1 (W^T)");
+  if (which < 0 || which > 2) return set_error(ANERF_E_CONFIG, "which must be 0 (W), 1 (W^T) or 2 (input-gradient image)");
   int stages = 0;
   if (which == 0)
     for (const Seg& s : fwd_segments(cfg)) stages += seg_stages(s);
-  else
+  else if (which == 1)
     for (const BSeg& s : bwd_segments(cfg)) stages += bseg_stages(s);
+  else
+    stages = 2 * (8 + 8) + ((u_width(cfg) + 255) / 256) * 4;
   out->n_stages = stages;
   out->stream_floats = (int64_t)stages * STAGE_FLOATS;
   out->aux_floats = AUX_FLOATS;
@@ -170,8 +178,30 @@ int anerf_build_pack_table(const AnerfConfig* cfg, int which, int32_t* table) {
       pos += (int64_t)bseg_stages(s) * STAGE_FLOATS;
     }
   }
+  if (which == 2) {
+    // [x columns 256*gi .. +255 of W0^T (32 kg) then of W5^T (32 kg)] for gi = 0,1; then [u columns of Wv^T (16 kg)]
+    std::vector<int32_t> px(dim_x(cfg)), pu(u_width(cfg));
+    anerf_build_perm_tables(cfg, px.data(), pu.data());
+    auto emit = [&](int tensor, int K, int colbase, const std::vector<int32_t>& perm, int gi, int nkg) {
+      for (int kg = 0; kg < nkg; ++kg)
+        for (int nb = 0; nb < 8; ++nb)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int t = 0; t < 4; ++t) {
+              const int n = 8 * kg + 4 * (lane >> 5) + t;
+              const int cs = 256 * gi + 32 * nb + (lane & 31);     // stream column
+              if (cs < (int)perm.size())
+                table[pos + ((int64_t)(kg * 8 + nb) * 64 + lane) * 4 + t] = (tensor << 24) | (n * K + colbase + perm[cs]);
+            }
+      pos += (int64_t)(nkg * 8 / STAGE_FRAGS) * STAGE_FLOATS;
+    };
+    for (int gi = 0; gi < 2; ++gi) {
+      emit(0, dim_x(cfg), 0, px, gi, 32);
+      emit(5, dim_x(cfg) + 256, 0, px, gi, 32);
+    }
+    for (int gi = 0; gi < (u_width(cfg) + 255) / 256; ++gi) emit(10, 256 + u_width(cfg), 256, pu, gi, 16);
+  }
   for (const Seg& s : fwd_segments(cfg)) {
-    if (which == 1) break;
+    if (which != 0) break;
     for (int kg = 0; kg < s.nkg; ++kg)
       for (int nb = 0; nb < s.NB; ++nb)
         for (int lane = 0; lane < 64; ++lane)
@@ -414,6 +444,37 @@ int anerf_weight_grads(const AnerfConfig* cfg, const AnerfSaved* sv, const float
   G.total_out = out_pos;
   if (ws_pos > ws_floats) return set_error(ANERF_E_WORKSPACE, "weight_grads: workspace accounting");
   return launch_weight_grads(G, workspace, (hipStream_t)stream);
+}
+
+int anerf_input_grads(const AnerfConfig* cfg, const float* packed_i, const float* dz, const float* dzv, int64_t p_pad,
+                      int64_t n_points, float* dx, float* du, void* stream) {
+  AnerfLayout L;
+  const int rc = anerf_layout(cfg, 2, &L);
+  if (rc) return rc;
+  if (!packed_i || !dz || !dzv || !dx || !du) return set_error(ANERF_E_NULL, "input_grads: NULL pointer");
+  if (p_pad < n_points || p_pad % 128) return set_error(ANERF_E_WORKSPACE, "input_grads: p_pad");
+  return mlp_bwd_in_entry(packed_i, dz, dzv, dx, du, n_points, p_pad, L.n_stages, u_width(cfg), (hipStream_t)stream);
+}
+
+int anerf_encode_backward(const AnerfConfig* cfg, const float* dx, const float* du, const float* rays,
+                          int32_t ray_stride, const float* z_vals, const float* skts, int64_t skt_ray_stride, float tau_v,
+                          float tau_d, const float* cutoff_v, const float* cutoff_d, int32_t n_rays, int32_t n_samples,
+                          float* dy_ws, float* dq_ws, float* dskts, void* stream) {
+  if (!config_ok(cfg)) return set_error(ANERF_E_CONFIG, "unsupported AnerfConfig");
+  if (!dx || !du || !rays || !z_vals || !skts || !cutoff_v || !cutoff_d || !dy_ws || !dq_ws || !dskts)
+    return set_error(ANERF_E_NULL, "encode_backward: NULL pointer");
+  if (skt_ray_stride != 384) return set_error(ANERF_E_SHAPE, "encode_backward: skts must be per ray (stride 384)");
+  if (n_rays == 0) return ANERF_OK;
+  return launch_encode_bwd(cfg->multires_views, dx, du, u_width(cfg), rays, ray_stride, z_vals, skts, skt_ray_stride, tau_v,
+                           tau_d, cutoff_v, cutoff_d, n_rays, n_samples, dy_ws, dq_ws, dskts, (hipStream_t)stream);
+}
+
+int anerf_code_grads(const AnerfConfig* cfg, const float* du, const float* cam_idx, int32_t n_rays, int32_t n_samples,
+                     float* dcodes, int32_t n_codes, void* stream) {
+  if (!config_ok(cfg) || cfg->framecode_ch != 16) return set_error(ANERF_E_CONFIG, "code_grads: framecode_ch must be 16");
+  if (!du || !cam_idx || !dcodes || n_codes < 1) return set_error(ANERF_E_NULL, "code_grads: NULL pointer");
+  if (n_rays == 0) return ANERF_OK;
+  return launch_code_reduce(du, u_width(cfg), cam_idx, n_rays, n_samples, n_codes, dcodes, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -538,6 +538,109 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(const BwdArgs A) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// input-gradient kernel (pose optimisation / frame codes only): gradients w.r.t. the ENCODED inputs, in stream
+// column order, on the which=2 weight image:
+//     dX'[p][432] = W0'^T dz0 + W5x'^T dz5          dU'[p][UW] = Wvu'^T dzv
+// Output columns are produced 256 at a time (8 blocks); lane (m,h) receives exactly the columns whose forward
+// B operands it generated (k-group 4*nb+q, half h), which is what k_encode_bwd consumes.
+// ------------------------------------------------------------------------------------------------
+struct BwdInArgs {
+  const float* packed_i;
+  const float* dz;     // [8][Ppad][256]
+  const float* dzv;    // [Ppad][128]
+  float* dx;           // [Ppad][432]
+  float* du;           // [Ppad][UW]
+  long long P, Ppad;
+  int nstages, uw;
+};
+
+template <int NB>
+__device__ __forceinline__ void load_row(float (&a)[128], const float* __restrict__ row, int h) {
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(row + 32 * nb + 8 * q + 4 * h);
+      a[nb * 16 + 4 * q + 0] = v.x;
+      a[nb * 16 + 4 * q + 1] = v.y;
+      a[nb * 16 + 4 * q + 2] = v.z;
+      a[nb * 16 + 4 * q + 3] = v.w;
+    }
+}
+
+// store the 8 accumulator blocks as columns [c0, c0+256) of a row of width `w` (columns >= w dropped)
+__device__ __forceinline__ void store_cols(float* __restrict__ row, const f32x16 (&acc)[8], int c0, int w, int h) {
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = c0 + 32 * nb + 8 * q + 4 * h;
+      if (c < w) {
+        f32x4 o = {acc[nb][4 * q], acc[nb][4 * q + 1], acc[nb][4 * q + 2], acc[nb][4 * q + 3]};
+        *reinterpret_cast<f32x4*>(row + c) = o;
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mlp_bwd_in(const BwdInArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 31, h = lane >> 5;
+  Pipe pipe;
+  pipe.init(A.packed_i, smem, wave, lane, A.nstages);
+  pipe.issue(0);
+  const long long p = (long long)blockIdx.x * TILE + wave * 32 + m;
+  const bool valid = p < A.P;
+  const long long pc = valid ? p : A.P - 1;
+  float d[128];
+  f32x16 acc[8];
+#pragma unroll 1
+  for (int gi = 0; gi < 2; ++gi) {
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+    load_row<8>(d, A.dz + pc * 256, h);                          // dz0
+    hidden_part<8, 0>(pipe, acc, d);
+    load_row<8>(d, A.dz + (5 * A.Ppad + pc) * 256, h);           // dz5
+    hidden_part<8, 0>(pipe, acc, d);
+    if (valid) store_cols(A.dx + p * 432, acc, 256 * gi, 432, h);
+  }
+  const int ngu = (A.uw + 255) / 256;
+#pragma unroll
+  for (int i = 64; i < 128; ++i) d[i] = 0.f;
+  load_row<4>(d, A.dzv + pc * 128, h);
+#pragma unroll 1
+  for (int gi = 0; gi < ngu; ++gi) {
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+#pragma unroll
+    for (int kg = 0; kg < 16; ++kg) kgroup<8>(pipe, acc, kg, d[4 * kg], d[4 * kg + 1], d[4 * kg + 2], d[4 * kg + 3]);
+    if (valid) store_cols(A.du + p * A.uw, acc, 256 * gi, A.uw, h);
+  }
+}
+
+int mlp_bwd_in_entry(const float* packed_i, const float* dz, const float* dzv, float* dx, float* du, long long P,
+                     long long Ppad, int nstages, int uw, hipStream_t st) {
+  BwdInArgs b;
+  b.packed_i = packed_i; b.dz = dz; b.dzv = dzv; b.dx = dx; b.du = du; b.P = P; b.Ppad = Ppad; b.nstages = nstages; b.uw = uw;
+  const long long nblk = (P + TILE - 1) / TILE;
+  if (nblk <= 0) return ANERF_OK;
+  const size_t lds = 2 * STAGE_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_in), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_mlp_bwd_in, dim3((unsigned)nblk), dim3(256), lds, st, b);
+  return check_launch("k_mlp_bwd_in");
+}
+
 template <int LV, int LD, int CODE, bool PRE, bool TRAIN>
 static int launch(const MlpArgs& a, hipStream_t st) {
   const long long nblk = (a.P + TILE - 1) / TILE;

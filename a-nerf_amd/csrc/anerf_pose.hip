@@ -1,0 +1,199 @@
+// anerf_pose.hip -- backward of the fused encoding (A4-A6) for pose optimisation and frame codes:
+//   k_encode_bwd   dX'/dU' (stream column order, from k_mlp_bwd_in) -> d y_j (bone-space point) and d q_j
+//                  (q_j = R_j d, bone-space ray direction) per sample; autograd of core/encoders.py:8-37,110-122,
+//                  181-193 + core/cutoff_embedder.py:111-174 restated by hand
+//   k_pose_reduce  sum over the samples of a ray: d skts[n][j][r][:] = (sum dy_r x^T + (sum dq_r) d^T | sum dy_r)
+//                  (deterministic: one thread per (ray, joint, row), no atomics)
+//   k_code_reduce  d codes[cam_idx[ray]] += sum over the ray's samples of dU'[code columns]
+// VALU / HBM-bound helpers; only run when skts or frame codes require gradients (Mixamo config).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "anerf_dev.h"
+
+namespace anerf {
+
+template <int LD>
+__global__ __launch_bounds__(256) void k_encode_bwd(const float* __restrict__ dx, const float* __restrict__ du, int uw,
+                                                    const float* __restrict__ rays, int ray_stride,
+                                                    const float* __restrict__ z, const float* __restrict__ skts,
+                                                    long long skt_stride, float tau_v, float tau_d,
+                                                    const float* __restrict__ cut_v, const float* __restrict__ cut_d,
+                                                    long long P, int S, float* __restrict__ dY, float* __restrict__ dQ) {
+  constexpr int LV = 7;
+  const long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const long long p = gid >> 1;
+  const int h = (int)(gid & 1);
+  if (p >= P) return;
+  const long long ray = p / S;
+  const float* rp = rays + ray * ray_stride;
+  const float zz = z[p];
+  const float d0 = rp[3], d1 = rp[4], d2 = rp[5];
+  const float x0 = fmaf(d0, zz, rp[0]), x1 = fmaf(d1, zz, rp[1]), x2 = fmaf(d2, zz, rp[2]);
+  const float* sk = skts + ray * skt_stride;
+  float v[12], wv[12], wvp[12], wd[12], wdp[12], rh[36], e[36], qn[12], dv[12], dr[36], de[36];
+#pragma unroll
+  for (int a = 0; a < 12; ++a) {
+    const int j = 8 * (a >> 2) + 4 * h + (a & 3);
+    const f32x4 r0 = *reinterpret_cast<const f32x4*>(sk + j * 16), r1 = *reinterpret_cast<const f32x4*>(sk + j * 16 + 4),
+                r2 = *reinterpret_cast<const f32x4*>(sk + j * 16 + 8);
+    const float y0 = r0.x * x0 + r0.y * x1 + r0.z * x2 + r0.w;
+    const float y1 = r1.x * x0 + r1.y * x1 + r1.z * x2 + r1.w;
+    const float y2 = r2.x * x0 + r2.y * x1 + r2.z * x2 + r2.w;
+    const float n = sqrtf(y0 * y0 + y1 * y1 + y2 * y2);
+    const float inv = 1.f / fmaxf(n, 1e-12f);
+    v[a] = n;
+    rh[3 * a] = y0 * inv; rh[3 * a + 1] = y1 * inv; rh[3 * a + 2] = y2 * inv;
+    const float q0 = r0.x * d0 + r0.y * d1 + r0.z * d2, q1 = r1.x * d0 + r1.y * d1 + r1.z * d2,
+                q2 = r2.x * d0 + r2.y * d1 + r2.z * d2;
+    const float qq = sqrtf(q0 * q0 + q1 * q1 + q2 * q2);
+    const float qi = 1.f / fmaxf(qq, 1e-12f);
+    qn[a] = qq;
+    e[3 * a] = q0 * qi; e[3 * a + 1] = q1 * qi; e[3 * a + 2] = q2 * qi;
+    wv[a] = cutoff_gate(tau_v, n, cut_v[j]);
+    wvp[a] = -tau_v * wv[a] * (1.f - wv[a]);
+    wd[a] = cutoff_gate(tau_d, n, cut_d[j]);
+    wdp[a] = -tau_d * wd[a] * (1.f - wd[a]);
+    dv[a] = 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 36; ++i) { dr[i] = 0.f; de[i] = 0.f; }
+  // ---- x part: 3 raw + 42 sin/cos + 9 bone-direction k-groups
+  const float* gx = dx + p * 432 + 4 * h;
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    const f32x4 G = *reinterpret_cast<const f32x4*>(gx + 8 * g);
+    const float Gt[4] = {G.x, G.y, G.z, G.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dv[4 * g + t] += Gt[t] * (wv[4 * g + t] + v[4 * g + t] * wvp[4 * g + t]);
+  }
+#pragma unroll
+  for (int f = 0; f < LV; ++f)
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      const f32x4 Gs = *reinterpret_cast<const f32x4*>(gx + 8 * (3 + 6 * f + g));
+      const f32x4 Gc = *reinterpret_cast<const f32x4*>(gx + 8 * (6 + 6 * f + g));
+      const float gs[4] = {Gs.x, Gs.y, Gs.z, Gs.w}, gc[4] = {Gc.x, Gc.y, Gc.z, Gc.w};
+      const float F = (float)(1 << f);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int a = 4 * g + t;
+        float s, c;
+        sincos_f32(v[a] * F, s, c);
+        dv[a] += gs[t] * (F * c * wv[a] + s * wvp[a]) + gc[t] * (-F * s * wv[a] + c * wvp[a]);
+      }
+    }
+#pragma unroll
+  for (int g = 0; g < 9; ++g) {
+    const f32x4 G = *reinterpret_cast<const f32x4*>(gx + 8 * (45 + g));
+    dr[4 * g] = G.x; dr[4 * g + 1] = G.y; dr[4 * g + 2] = G.z; dr[4 * g + 3] = G.w;
+  }
+  // ---- view part: raw + LD sin/cos bands of the 36 owned direction components, gated by wd(v)
+  const float* gu = du + p * uw + 4 * h;
+#pragma unroll
+  for (int g = 0; g < 9; ++g) {
+    const f32x4 G = *reinterpret_cast<const f32x4*>(gu + 8 * g);
+    const float Gt[4] = {G.x, G.y, G.z, G.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int i = 4 * g + t, a = i / 3;
+      de[i] += Gt[t] * wd[a];
+      dv[a] += Gt[t] * e[i] * wdp[a];
+    }
+  }
+#pragma unroll
+  for (int f = 0; f < LD; ++f)
+#pragma unroll
+    for (int g = 0; g < 9; ++g) {
+      const f32x4 Gs = *reinterpret_cast<const f32x4*>(gu + 8 * (9 * (1 + 2 * f) + g));
+      const f32x4 Gc = *reinterpret_cast<const f32x4*>(gu + 8 * (9 * (2 + 2 * f) + g));
+      const float gs[4] = {Gs.x, Gs.y, Gs.z, Gs.w}, gc[4] = {Gc.x, Gc.y, Gc.z, Gc.w};
+      const float F = (float)(1 << f);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int i = 4 * g + t, a = i / 3;
+        float s, c;
+        sincos_f32(e[i] * F, s, c);
+        de[i] += (gs[t] * c - gc[t] * s) * F * wd[a];
+        dv[a] += (gs[t] * s + gc[t] * c) * wdp[a];
+      }
+    }
+  // ---- through the norms: y -> (v, r),  q -> e
+#pragma unroll
+  for (int a = 0; a < 12; ++a) {
+    const int j = 8 * (a >> 2) + 4 * h + (a & 3);
+    const float dot = dr[3 * a] * rh[3 * a] + dr[3 * a + 1] * rh[3 * a + 1] + dr[3 * a + 2] * rh[3 * a + 2];
+    const float iv = 1.f / fmaxf(v[a], 1e-12f);
+    const float dote = de[3 * a] * e[3 * a] + de[3 * a + 1] * e[3 * a + 1] + de[3 * a + 2] * e[3 * a + 2];
+    const float iq = 1.f / fmaxf(qn[a], 1e-12f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      dY[p * 72 + 3 * j + c] = dv[a] * rh[3 * a + c] + (dr[3 * a + c] - dot * rh[3 * a + c]) * iv;
+      dQ[p * 72 + 3 * j + c] = (de[3 * a + c] - dote * e[3 * a + c]) * iq;
+    }
+  }
+}
+
+// one thread per (ray, joint, row r<3); 128 threads per ray, 72 active
+__global__ __launch_bounds__(128) void k_pose_reduce(const float* __restrict__ dY, const float* __restrict__ dQ,
+                                                     const float* __restrict__ rays, int ray_stride,
+                                                     const float* __restrict__ z, int n, int S, float* __restrict__ dskts) {
+  const int ray = blockIdx.x, l = threadIdx.x;
+  if (ray >= n || l >= 72) return;
+  const float* rp = rays + (long long)ray * ray_stride;
+  const float o0 = rp[0], o1 = rp[1], o2 = rp[2], d0 = rp[3], d1 = rp[4], d2 = rp[5];
+  float R0 = 0.f, R1 = 0.f, R2 = 0.f, T = 0.f, Q = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const long long p = (long long)ray * S + s;
+    const float zz = z[p];
+    const float dy = dY[p * 72 + l], dq = dQ[p * 72 + l];
+    R0 = fmaf(dy, fmaf(d0, zz, o0), R0);
+    R1 = fmaf(dy, fmaf(d1, zz, o1), R1);
+    R2 = fmaf(dy, fmaf(d2, zz, o2), R2);
+    T += dy;
+    Q += dq;
+  }
+  const int j = l / 3, r = l - 3 * j;
+  float* o = dskts + ((long long)ray * 24 + j) * 16 + r * 4;
+  o[0] = fmaf(Q, d0, R0);
+  o[1] = fmaf(Q, d1, R1);
+  o[2] = fmaf(Q, d2, R2);
+  o[3] = T;
+}
+
+// one wave per ray: lanes 0..15 sum the code columns over the ray's samples, then one atomic per lane
+__global__ __launch_bounds__(256) void k_code_reduce(const float* __restrict__ du, int uw, const float* __restrict__ cam,
+                                                     int n, int S, int n_codes, float* __restrict__ dcodes) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= n || lane >= 16) return;
+  float s = 0.f;
+  for (int k = 0; k < S; ++k) s += du[((long long)ray * S + k) * uw + (uw - 16) + lane];
+  int ci = (int)cam[ray];
+  ci = ci < 0 ? 0 : (ci >= n_codes ? n_codes - 1 : ci);
+  atomicAdd(dcodes + ci * 16 + lane, s);
+}
+
+int launch_encode_bwd(int ld, const float* dx, const float* du, int uw, const float* rays, int ray_stride, const float* z,
+                      const float* skts, long long skt_stride, float tau_v, float tau_d, const float* cut_v,
+                      const float* cut_d, int n, int S, float* dY, float* dQ, float* dskts, hipStream_t st) {
+  const long long P = (long long)n * S;
+  const unsigned blocks = (unsigned)((2 * P + 255) / 256);
+  if (ld == 4)
+    hipLaunchKernelGGL(k_encode_bwd<4>, dim3(blocks), dim3(256), 0, st, dx, du, uw, rays, ray_stride, z, skts, skt_stride,
+                       tau_v, tau_d, cut_v, cut_d, P, S, dY, dQ);
+  else
+    hipLaunchKernelGGL(k_encode_bwd<0>, dim3(blocks), dim3(256), 0, st, dx, du, uw, rays, ray_stride, z, skts, skt_stride,
+                       tau_v, tau_d, cut_v, cut_d, P, S, dY, dQ);
+  int rc = check_launch("k_encode_bwd");
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_pose_reduce, dim3(n), dim3(128), 0, st, (const float*)dY, (const float*)dQ, rays, ray_stride, z, n, S,
+                     dskts);
+  return check_launch("k_pose_reduce");
+}
+
+int launch_code_reduce(const float* du, int uw, const float* cam, int n, int S, int n_codes, float* dcodes, hipStream_t st) {
+  hipLaunchKernelGGL(k_code_reduce, dim3((n + 3) / 4), dim3(256), 0, st, du, uw, cam, n, S, n_codes, dcodes);
+  return check_launch("k_code_reduce");
+}
+
+}  // namespace anerf

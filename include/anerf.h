@@ -71,7 +71,8 @@ typedef struct AnerfLayout {
 const char* anerf_last_error(void);
 int anerf_version(void);
 
-/* which: 0 = forward image (W), 1 = backward-data image (W^T of the hidden trunk, feature and view layers). */
+/* which: 0 = forward image (W), 1 = backward-data image (W^T of the hidden trunk, feature and view layers),
+ * 2 = input-gradient image (W^T of the encoded-input columns of pts_linears.0/.5 and views_linears.0). */
 int anerf_layout(const AnerfConfig* cfg, int which, AnerfLayout* out);
 /* HOST: fill table[stream_floats + aux_floats]: entry = (tensor_id << 24) | element offset, -1 = 0.0f;
  * tensor_id = index into {w[0..11], b[0..11]} (0..23).  Upload once per config. */
@@ -180,6 +181,25 @@ int anerf_weight_grads(const AnerfConfig* cfg, const AnerfSaved* saved, const fl
                        const float* dzv, const float* draw, int64_t n_points, const int32_t* perm_x,
                        const int32_t* perm_u, const AnerfNetGrads* grads, float* workspace, int64_t ws_floats,
                        void* stream);
+
+/* ---- pose optimisation / frame codes (A12: d(loss)/d(skts), d(loss)/d(framecodes)) --------------------------------
+ * anerf_layout / anerf_build_pack_table / anerf_pack_params with which=2 give the input-gradient weight image. */
+
+/* dz planes + dzv (from anerf_mlp_backward) -> gradients w.r.t. the encoded inputs in stream column order:
+ * dx [p_pad][432], du [p_pad][u_width]. */
+int anerf_input_grads(const AnerfConfig* cfg, const float* packed_i, const float* dz, const float* dzv,
+                      int64_t p_pad, int64_t n_points, float* dx, float* du, void* stream);
+
+/* Backward of the fused encoding: dx/du -> dskts [N,24,4,4] (rows 0..2 written; caller zero-fills the tensor once).
+ * skts must be per ray (stride 384).  dy_ws, dq_ws: scratch [N*S][72] each. */
+int anerf_encode_backward(const AnerfConfig* cfg, const float* dx, const float* du, const float* rays,
+                          int32_t ray_stride, const float* z_vals, const float* skts, int64_t skt_ray_stride,
+                          float tau_v, float tau_d, const float* cutoff_v, const float* cutoff_d,
+                          int32_t n_rays, int32_t n_samples, float* dy_ws, float* dq_ws, float* dskts, void* stream);
+
+/* dcodes [n_codes,16] += per-ray sums of du's code columns, indexed by cam_idx (caller zero-fills dcodes). */
+int anerf_code_grads(const AnerfConfig* cfg, const float* du, const float* cam_idx, int32_t n_rays, int32_t n_samples,
+                     float* dcodes, int32_t n_codes, void* stream);
 
 #ifdef __cplusplus
 }
