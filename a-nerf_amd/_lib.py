@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libanerf_hip.so")
+LIB_PATH = os.environ.get("ANERF_LIB", os.path.join(_HERE, "libanerf_hip.so"))   # ANERF_LIB: ablation builds only
 
 c_f32p = C.c_void_p  # device pointers are passed as integers (tensor.data_ptr())
 

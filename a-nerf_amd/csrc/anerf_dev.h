@@ -38,6 +38,9 @@ int check_launch(const char* what);
 // sin and cos of x for |x| < ~1e4: Cody-Waite reduction by pi/2 (3 constants, exact products for |k| < 2^16)
 // + cephes-style minimax polynomials on [-pi/4, pi/4]; max abs error ~1e-7 (covers 2^6 * distance, 2^3 * unit dir).
 __device__ __forceinline__ void sincos_f32(float x, float& s, float& c) {
+#ifdef ANERF_EXP_CHEAPSINCOS   // ablation build only: wrong values, ~2 VALU instead of ~25
+  s = x * 0.5f; c = x + 1.0f; return;
+#endif
   const float k = rintf(x * 0.636619772367581343f);
   float r = fmaf(k, -1.5703125f, x);
   r = fmaf(k, -4.837512969970703125e-4f, r);

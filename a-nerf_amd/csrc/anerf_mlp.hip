@@ -14,9 +14,13 @@
 //     32 samples.  Lane l holds sample m = l&31; lanes 0-31 / 32-63 hold the two k-halves.  The accumulator layout
 //     of layer i (feature n = 32nb + (r&3) + 8(r>>2) + 4(l>>5) in register r of block nb) IS the B-operand layout
 //     of layer i+1, so activations stay in registers across all layers: no LDS round trip, no barrier for them.
-//   * weights are pre-packed (anerf_pack.hip) into a linear stream of 1 KiB MFMA fragments in consumption order
-//     and streamed HBM/L2 -> LDS with global_load_lds_dwordx4 through a 2 x 32 KiB ring, one barrier per stage
-//     (= 8192 MFMA cycles per wave), shared by the 4 waves.
+//   * two accumulator sets ping-pong between layers: a layer's accumulators start from its bias (read from an LDS
+//     copy), get ONE in-place ReLU pass when the layer is done, and are then read directly as the next layer's B
+//     operands -- no activation copy, and no VALU inside the MFMA stream of the hidden layers.
+//   * weights are pre-packed (k_pack) into a linear stream of 1 KiB MFMA fragments in consumption order and streamed
+//     L2 -> LDS with global_load_lds_dwordx4 through a 3 x 32 KiB ring, issued two stages ahead; one barrier per
+//     stage (= 8192 MFMA cycles per wave); the first fragments of the next stage are prefetched into registers
+//     BEFORE that barrier, so no LDS-read latency is exposed after it.
 //   * the encoding is produced in registers just in time as B operands: lane half h owns joints
 //     {j : ((j>>2)&1) == h}; bone matrices of the tile's rays are staged in LDS.
 #include <hip/hip_runtime.h>
@@ -25,54 +29,94 @@
 
 namespace anerf {
 
+constexpr int RING_SLOTS = 3;
+constexpr int LDS_AUX_OFF = RING_SLOTS * STAGE_BYTES;             // biases + head rows (AUX_FLOATS floats)
+constexpr int LDS_AUX_BYTES = (AUX_FLOATS * 4 + 255) / 256 * 256;
+constexpr int LDS_BONES_OFF = LDS_AUX_OFF + LDS_AUX_BYTES;        // MAX_TILE_RAYS x 24 x 3 float4
+
 // ------------------------------------------------------------------------------------------------
-// weight-stream pipe: global -> LDS ring (2 stages x 32 KiB), all 4 waves cooperate
+// weight-stream pipe: global -> LDS ring (3 slots x 32 KiB), all 4 waves cooperate.  Invariant while stage s is
+// being consumed: stages s and s+1 are complete and visible to every wave; stage s+2 is in flight.
 // ------------------------------------------------------------------------------------------------
-struct Pipe {
+struct Pipe3 {
   const char* gsrc;   // per-lane source of this wave's first fragment of stage 0
   char* smem;
   unsigned wave_dst;  // wave-uniform LDS byte offset of this wave's 8 fragments inside a stage
   unsigned lane16;    // lane * 16
-  unsigned cur;       // LDS byte offset (lane-relative) of the stage being consumed
-  int stage;          // index of the next stage to consume
+  unsigned cur;       // lane-relative LDS byte offset of the stage being consumed
+  unsigned nxt;       // ... of the following stage
+  int slot;           // ring slot of the stage being consumed
+  int stage;          // stage being consumed
   int nstages;
+  f32x4 pref[8];      // fragments of the next stage's first k-group, loaded before the stage barrier
 
+  __device__ __forceinline__ void issue(int s, int sl) {
+#ifdef ANERF_EXP_NOGLDS   // ablation build only (tools/ablate.sh): never load weights
+    (void)s; (void)sl; return;
+#endif
+    const char* g = gsrc + (size_t)s * STAGE_BYTES;
+    char* l = smem + sl * STAGE_BYTES + wave_dst;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(g + i * FRAG_BYTES), (lds_ptr_t)(l + i * FRAG_BYTES), 16, 0, 0);
+  }
+  __device__ __forceinline__ void set_offsets() {
+    cur = lane16 + slot * STAGE_BYTES;
+    nxt = lane16 + (slot == RING_SLOTS - 1 ? 0 : slot + 1) * STAGE_BYTES;
+  }
   __device__ __forceinline__ void init(const float* packed, char* smem_, int wave, int lane, int nstages_) {
     gsrc = reinterpret_cast<const char*>(packed) + wave * (8 * FRAG_BYTES) + lane * 16;
     smem = smem_;
     wave_dst = wave * (8 * FRAG_BYTES);
     lane16 = lane * 16;
-    cur = 0;
+    slot = 0;
     stage = 0;
     nstages = nstages_;
+    set_offsets();
+    issue(0, 0);
+    if (nstages > 1) issue(1, 1);
   }
-  __device__ __forceinline__ void issue(int s) {
-    const char* g = gsrc + (size_t)s * STAGE_BYTES;
-    char* l = smem + (s & 1) * STAGE_BYTES + wave_dst;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(g + i * FRAG_BYTES), (lds_ptr_t)(l + i * FRAG_BYTES), 16, 0, 0);
+  // after everybody's prologue LDS writes: stages 0 and 1 landed; start stage 2
+  __device__ __forceinline__ void begin() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (nstages > 2) issue(2, 2);
   }
-  // Called before the first k-group of every stage.
-  __device__ __forceinline__ void next_stage() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of stage `stage` has landed
-    __syncthreads();                                   // ... everybody's has; slot (stage+1)&1 is no longer read
-    if (stage + 1 < nstages) issue(stage + 1);
-    cur = lane16 + (stage & 1) * STAGE_BYTES;
+  // end of the stage being consumed: its slot is refilled with stage+3
+  __device__ __forceinline__ void end_stage() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of stages +1 / +2 has landed
+#ifndef ANERF_EXP_NOBARRIER   // ablation build only: results are wrong without the barrier
+    __syncthreads();                                    // everybody's has; nobody reads slot `slot` any more
+#endif
+    if (stage + RING_SLOTS < nstages) issue(stage + RING_SLOTS, slot);
+    slot = slot == RING_SLOTS - 1 ? 0 : slot + 1;
     ++stage;
+    set_offsets();
   }
 };
 
 // One k-group (8 contraction indices: 4 from each lane half) against NB 32-row feature blocks.
-// kg = k-group index relative to the segment start (compile-time after unrolling).
+// kg: k-group index relative to the segment (layer) start; first: first k-group of the layer (informational);
+// last: final k-group of the segment (segments are padded to whole stages).  All three fold at compile time.
 template <int NB>
-__device__ __forceinline__ void kgroup(Pipe& pipe, f32x16 (&acc)[NB], int kg, float b0, float b1, float b2, float b3) {
+__device__ __forceinline__ void kgroup(Pipe3& pipe, f32x16 (&acc)[NB], int kg, bool first, bool last, float b0, float b1,
+                                       float b2, float b3) {
   constexpr int KPS = STAGE_FRAGS / NB;  // k-groups per stage
-  if (kg % KPS == 0) pipe.next_stage();
-  const unsigned off = pipe.cur + (kg % KPS) * NB * FRAG_BYTES;
+  const int ks = kg % KPS;
   f32x4 a[NB];
+  if (ks == 0 && kg != 0) {
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) a[nb] = *reinterpret_cast<const f32x4*>(pipe.smem + off + nb * FRAG_BYTES);
+    for (int nb = 0; nb < NB; ++nb) a[nb] = pipe.pref[nb];
+  } else {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+      a[nb] = *reinterpret_cast<const f32x4*>(pipe.smem + pipe.cur + (ks * NB + nb) * FRAG_BYTES);
+  }
+  if (ks == KPS - 1 && !last) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) pipe.pref[nb] = *reinterpret_cast<const f32x4*>(pipe.smem + pipe.nxt + nb * FRAG_BYTES);
+  }
+  (void)first;
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nb].x, b0, acc[nb], 0, 0, 0);
 #pragma unroll
@@ -81,16 +125,17 @@ __device__ __forceinline__ void kgroup(Pipe& pipe, f32x16 (&acc)[NB], int kg, fl
   for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nb].z, b2, acc[nb], 0, 0, 0);
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nb].w, b3, acc[nb], 0, 0, 0);
+  if (ks == KPS - 1 || last) pipe.end_stage();
 }
 
-// acc[nb][r] <- bias[n(nb,r,h)]; natural-order bias vector, float4 per (nb,q).
+// acc[nb][r] <- bias[n(nb,r,h)] from the LDS copy of the natural-order bias vector (bias_h = vector + 4h)
 template <int NB>
-__device__ __forceinline__ void init_bias(f32x16 (&acc)[NB], const float* __restrict__ bias, int h) {
+__device__ __forceinline__ void init_bias(f32x16 (&acc)[NB], const float* bias_h) {
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const f32x4 b = *reinterpret_cast<const f32x4*>(bias + 32 * nb + 8 * q + 4 * h);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(bias_h + 32 * nb + 8 * q);
       acc[nb][4 * q + 0] = b.x;
       acc[nb][4 * q + 1] = b.y;
       acc[nb][4 * q + 2] = b.z;
@@ -98,48 +143,66 @@ __device__ __forceinline__ void init_bias(f32x16 (&acc)[NB], const float* __rest
     }
 }
 
-// 32 k-groups whose B operands are the 256 hidden activations held in registers.
-template <int NB, int KG0>
-__device__ __forceinline__ void hidden_part(Pipe& pipe, f32x16 (&acc)[NB], const float (&hin)[128]) {
-#pragma unroll
-  for (int kg = 0; kg < 32; ++kg)
-    kgroup<NB>(pipe, acc, KG0 + kg, hin[4 * kg + 0], hin[4 * kg + 1], hin[4 * kg + 2], hin[4 * kg + 3]);
-}
-
-template <int NB, bool RELU>
-__device__ __forceinline__ void to_hidden(float (&hin)[128], const f32x16 (&acc)[NB]) {
+// in-place ReLU of a finished layer (one VALU pass; measured 0.7 % of a layer, vs 4.3 % when the max is
+// interleaved with the consuming MFMAs -- tools/probe/mfma_probe2.hip)
+template <int NB>
+__device__ __forceinline__ void relu_pass(f32x16 (&acc)[NB]) {
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) hin[nb * 16 + r] = RELU ? fmaxf(acc[nb][r], 0.f) : acc[nb][r];
+    for (int r = 0; r < 16; ++r) acc[nb][r] = fmaxf(acc[nb][r], 0.f);
 }
 
-// dot of the lane's 16*NB held activations with a natural-order weight row, reduced over both lane halves
+// 32 k-groups whose B operands are the previous layer's 256 outputs, read straight from its accumulator set
+// `prev` (bias added by the accumulator init, ReLU already applied in place): no copy, no VALU in the MFMA stream.
+template <int NB, int KG0>
+__device__ __forceinline__ void hidden_part(Pipe3& pipe, f32x16 (&acc)[NB], const f32x16 (&prev)[8], bool first,
+                                            bool last) {
+#pragma unroll
+  for (int kg = 0; kg < 32; ++kg)
+    kgroup<NB>(pipe, acc, KG0 + kg, first && kg == 0, last && kg == 31, prev[kg >> 2][4 * (kg & 3) + 0],
+               prev[kg >> 2][4 * (kg & 3) + 1], prev[kg >> 2][4 * (kg & 3) + 2], prev[kg >> 2][4 * (kg & 3) + 3]);
+}
+
+// dot of the lane's 16*NB activation values with a natural-order weight row (LDS), summed over both halves
 template <int NB>
-__device__ __forceinline__ float head_dot(const float (&act)[128], const float* __restrict__ wrow, int h) {
+__device__ __forceinline__ float head_dot(const f32x16* acc, const float* wrow_h) {
   float s = 0.f;
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + 32 * nb + 8 * q + 4 * h);
-      s = fmaf(act[nb * 16 + 4 * q + 0], w.x, s);
-      s = fmaf(act[nb * 16 + 4 * q + 1], w.y, s);
-      s = fmaf(act[nb * 16 + 4 * q + 2], w.z, s);
-      s = fmaf(act[nb * 16 + 4 * q + 3], w.w, s);
+      const f32x4 w = *reinterpret_cast<const f32x4*>(wrow_h + 32 * nb + 8 * q);
+      s = fmaf(acc[nb][4 * q + 0], w.x, s);
+      s = fmaf(acc[nb][4 * q + 1], w.y, s);
+      s = fmaf(acc[nb][4 * q + 2], w.z, s);
+      s = fmaf(acc[nb][4 * q + 3], w.w, s);
     }
   return s + __shfl_xor(s, 32);
+}
+
+// TRAIN: row-major store of a finished layer: features 32nb+8q+4h .. +3 of `row`
+template <int NB>
+__device__ __forceinline__ void store_act(float* __restrict__ row, const f32x16* acc, int h) {
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 o = {acc[nb][4 * q], acc[nb][4 * q + 1], acc[nb][4 * q + 2], acc[nb][4 * q + 3]};
+      *reinterpret_cast<f32x4*>(row + 32 * nb + 8 * q + 4 * h) = o;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
 // the x-part (432 = 360 distance-PE + 72 bone-direction channels) as 54 k-groups.
 // Encoded just in time (PRE = false) or read from a pre-encoded row (PRE = true, NeRF.forward seam).
-// ------------------------------------------------------------------------------------------------
 // STORE: also write the 4 operands of every k-group to xsave[8*kg + 4h .. +3] (stream column order X').
+// ------------------------------------------------------------------------------------------------
 template <int LV, bool PRE, bool STORE>
-__device__ __forceinline__ void x_part(Pipe& pipe, f32x16 (&acc)[8], const float (&v)[12], const float (&wv)[12],
+__device__ __forceinline__ void x_part(Pipe3& pipe, f32x16 (&acc)[8], const float (&v)[12], const float (&wv)[12],
                                        const float (&rh)[36], const float* __restrict__ xrow, int h,
-                                       float* __restrict__ xsave) {
+                                       float* __restrict__ xsave, bool last) {
+  constexpr int NKG = 3 * (1 + 2 * LV) + 9;
   auto KG = [&](int kg, float b0, float b1, float b2, float b3) __attribute__((always_inline)) {
     if constexpr (STORE) {
       if (xsave) {
@@ -147,7 +210,7 @@ __device__ __forceinline__ void x_part(Pipe& pipe, f32x16 (&acc)[8], const float
         *reinterpret_cast<f32x4*>(xsave + 8 * kg + 4 * h) = o;
       }
     }
-    kgroup<8>(pipe, acc, kg, b0, b1, b2, b3);
+    kgroup<8>(pipe, acc, kg, kg == 0, last && kg == NKG - 1, b0, b1, b2, b3);
   };
   if constexpr (PRE) {
 #pragma unroll
@@ -169,23 +232,29 @@ __device__ __forceinline__ void x_part(Pipe& pipe, f32x16 (&acc)[8], const float
 #pragma unroll
     for (int g = 0; g < 3; ++g)
       KG(g, v[4 * g] * wv[4 * g], v[4 * g + 1] * wv[4 * g + 1], v[4 * g + 2] * wv[4 * g + 2],
-                v[4 * g + 3] * wv[4 * g + 3]);
+         v[4 * g + 3] * wv[4 * g + 3]);
+    // bands f = 0..LV-1 of sin/cos(2^f v): precise evaluation every 3rd band, double-angle steps in between
+    // (sin 2x = 2 s c, cos 2x = 1 - 2 s^2): error grows <= 4x over two steps (~4e-7), 3 VALU instead of ~25.
+    float sb[12], cb[12];
 #pragma unroll
     for (int f = 0; f < LV; ++f) {
       float sv[12], cv[12];
 #pragma unroll
       for (int a = 0; a < 12; ++a) {
-        float s, c;
-        sincos_f32(v[a] * (float)(1 << f), s, c);
-        sv[a] = s * wv[a];
-        cv[a] = c * wv[a];
+        if (f % 3 == 0) {
+          sincos_f32(v[a] * (float)(1 << f), sb[a], cb[a]);
+        } else {
+          const float s_old = sb[a], c_old = cb[a];
+          sb[a] = 2.f * s_old * c_old;
+          cb[a] = fmaf(-2.f * s_old, s_old, 1.f);
+        }
+        sv[a] = sb[a] * wv[a];
+        cv[a] = cb[a] * wv[a];
       }
 #pragma unroll
-      for (int g = 0; g < 3; ++g)
-        KG(3 + 6 * f + g, sv[4 * g], sv[4 * g + 1], sv[4 * g + 2], sv[4 * g + 3]);
+      for (int g = 0; g < 3; ++g) KG(3 + 6 * f + g, sv[4 * g], sv[4 * g + 1], sv[4 * g + 2], sv[4 * g + 3]);
 #pragma unroll
-      for (int g = 0; g < 3; ++g)
-        KG(6 + 6 * f + g, cv[4 * g], cv[4 * g + 1], cv[4 * g + 2], cv[4 * g + 3]);
+      for (int g = 0; g < 3; ++g) KG(6 + 6 * f + g, cv[4 * g], cv[4 * g + 1], cv[4 * g + 2], cv[4 * g + 3]);
     }
 #pragma unroll
     for (int g = 0; g < 9; ++g)
@@ -218,18 +287,6 @@ struct MlpArgs {
   float tau_v, tau_d;
 };
 
-// row-major store of the lane's 16*NB activations: features 32nb+8q+4h .. +3 of row `row`
-template <int NB>
-__device__ __forceinline__ void store_row(float* __restrict__ row, const float (&a)[128], int h) {
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 o = {a[nb * 16 + 4 * q], a[nb * 16 + 4 * q + 1], a[nb * 16 + 4 * q + 2], a[nb * 16 + 4 * q + 3]};
-      *reinterpret_cast<f32x4*>(row + 32 * nb + 8 * q + 4 * h) = o;
-    }
-}
-
 template <int LV, int LD, int CODE, bool PRE, bool TRAIN>
 __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -238,21 +295,26 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 31, h = lane >> 5;
 
-  Pipe pipe;
+  Pipe3 pipe;
   pipe.init(A.packed, smem, wave, lane, A.nstages);
-  pipe.issue(0);
 
   const long long p = (long long)blockIdx.x * TILE + wave * 32 + m;
   const bool valid = p < A.P;
   const long long pc = valid ? p : A.P - 1;
   const bool save = TRAIN && valid;
 
+  // ---- biases / head rows -> LDS (natural order), read back as float4 per k-group
+  float* aux_l = reinterpret_cast<float*>(smem + LDS_AUX_OFF);
+  for (int i = tid; i < AUX_FLOATS / 4; i += 256)
+    reinterpret_cast<f32x4*>(aux_l)[i] = reinterpret_cast<const f32x4*>(A.aux)[i];
+  const float* aux_h = aux_l + 4 * h;   // this lane half's float4 inside every 8-feature group
+
   float v[12], wv[12], rh[36];
   float dray[3] = {0.f, 0.f, 0.f};
   int lr = 0;
   long long ray = 0;
   const float* xrow = nullptr;
-  const f32x4* bones4 = reinterpret_cast<const f32x4*>(smem + 2 * STAGE_BYTES);
+  const f32x4* bones4 = reinterpret_cast<const f32x4*>(smem + LDS_BONES_OFF);
 
   if constexpr (PRE) {
     xrow = A.x + pc * A.x_width;
@@ -260,6 +322,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
     for (int a = 0; a < 12; ++a) v[a] = wv[a] = 0.f;
 #pragma unroll
     for (int a = 0; a < 36; ++a) rh[a] = 0.f;
+    pipe.begin();
   } else {
     // ---- stage the bone matrices (rows 0..2 of each 4x4 world->bone matrix) of this tile's rays in LDS
     const long long tile_p0 = (long long)blockIdx.x * TILE;
@@ -269,18 +332,18 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
     ray = pc / A.S;
     const int n_stage_rays = A.skt_stride == 0 ? 1 : (int)(ray1 - ray0 + 1);
     lr = A.skt_stride == 0 ? 0 : (int)(ray - ray0);
-    f32x4* bw = reinterpret_cast<f32x4*>(smem + 2 * STAGE_BYTES);
+    f32x4* bw = reinterpret_cast<f32x4*>(smem + LDS_BONES_OFF);
     for (int i = tid; i < n_stage_rays * 72; i += 256) {
       const int ri = i / 72, rem = i - ri * 72, j = rem / 3, row = rem - 3 * j;
       bw[i] = *reinterpret_cast<const f32x4*>(A.skts + (ray0 + ri) * A.skt_stride + j * 16 + row * 4);
     }
-    __syncthreads();
     const float* rp = A.rays + ray * A.ray_stride;
     const float z = A.z[pc];
     dray[0] = rp[3];
     dray[1] = rp[4];
     dray[2] = rp[5];
     const float x0 = fmaf(dray[0], z, rp[0]), x1 = fmaf(dray[1], z, rp[1]), x2 = fmaf(dray[2], z, rp[2]);
+    pipe.begin();   // barrier: aux + bones visible, weight stages 0/1 landed
 #pragma unroll
     for (int a = 0; a < 12; ++a) {
       const int j = 8 * (a >> 2) + 4 * h + (a & 3);
@@ -302,47 +365,58 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
   constexpr int DIMX = 24 * (1 + 2 * LV) + 72;
   constexpr int DIMD = 72 * (1 + 2 * LD);
   constexpr int UW = DIMD + CODE;
-  float hin[128];
-  f32x16 acc[8];
+  constexpr int KGX = DIMX / 8;
+  f32x16 accA[8], accB[8];   // ping-pong accumulator sets (pre-bias sums)
 
-  // ---- layer 0: x(432) -> 256
-  init_bias<8>(acc, A.aux + AUX_B0, h);
-  x_part<LV, PRE, TRAIN>(pipe, acc, v, wv, rh, xrow, h, save ? A.save_x + p * DIMX : nullptr);
-  to_hidden<8, true>(hin, acc);
-  if (save) store_row<8>(A.save_h + p * 256, hin, h);
-  // ---- layers 1..4
+  // ---- layer 0: x(432) -> A
+  init_bias<8>(accA, aux_h + AUX_B0);
+  x_part<LV, PRE, TRAIN>(pipe, accA, v, wv, rh, xrow, h, save ? A.save_x + p * DIMX : nullptr, true);
+  relu_pass<8>(accA);
+  if (save) store_act<8>(A.save_h + p * 256, accA, h);
+  // ---- layers 1..4: A -> B -> A -> B -> A
 #pragma unroll 1
-  for (int L = 1; L <= 4; ++L) {
-    init_bias<8>(acc, A.aux + AUX_B0 + 256 * L, h);
-    hidden_part<8, 0>(pipe, acc, hin);
-    to_hidden<8, true>(hin, acc);
-    if (save) store_row<8>(A.save_h + ((long long)L * A.Ppad + p) * 256, hin, h);
+  for (int L = 1; L <= 3; L += 2) {
+    init_bias<8>(accB, aux_h + AUX_B0 + 256 * L);
+    hidden_part<8, 0>(pipe, accB, accA, true, true);
+    relu_pass<8>(accB);
+    if (save) store_act<8>(A.save_h + ((long long)L * A.Ppad + p) * 256, accB, h);
+    init_bias<8>(accA, aux_h + AUX_B0 + 256 * (L + 1));
+    hidden_part<8, 0>(pipe, accA, accB, true, true);
+    relu_pass<8>(accA);
+    if (save) store_act<8>(A.save_h + ((long long)(L + 1) * A.Ppad + p) * 256, accA, h);
   }
-  // ---- layer 5: [x(432); h4(256)] -> 256   (skip connection: x is re-encoded, never stored)
-  init_bias<8>(acc, A.aux + AUX_B0 + 256 * 5, h);
-  x_part<LV, PRE, false>(pipe, acc, v, wv, rh, xrow, h, nullptr);
-  hidden_part<8, 3 * (1 + 2 * LV) + 9>(pipe, acc, hin);
-  to_hidden<8, true>(hin, acc);
-  if (save) store_row<8>(A.save_h + (5 * A.Ppad + p) * 256, hin, h);
-  // ---- layers 6, 7
-#pragma unroll 1
-  for (int L = 6; L <= 7; ++L) {
-    init_bias<8>(acc, A.aux + AUX_B0 + 256 * L, h);
-    hidden_part<8, 0>(pipe, acc, hin);
-    to_hidden<8, true>(hin, acc);
-    if (save) store_row<8>(A.save_h + ((long long)L * A.Ppad + p) * 256, hin, h);
+  // ---- layer 5: [x(432); h4(256)] -> B   (skip connection: x is re-encoded, never stored).  The asm makes v/wv
+  // opaque so the compiler re-derives the sin/cos products here instead of keeping 168 of them live (spilled to
+  // scratch) since layer 0.
+  if constexpr (!PRE) {
+#pragma unroll
+    for (int a = 0; a < 12; ++a) asm volatile("" : "+v"(v[a]), "+v"(wv[a]));
   }
+  init_bias<8>(accB, aux_h + AUX_B0 + 256 * 5);
+  x_part<LV, PRE, false>(pipe, accB, v, wv, rh, xrow, h, nullptr, false);
+  hidden_part<8, KGX>(pipe, accB, accA, false, true);
+  relu_pass<8>(accB);
+  if (save) store_act<8>(A.save_h + (5 * A.Ppad + p) * 256, accB, h);
+  // ---- layers 6, 7: B -> A -> B
+  init_bias<8>(accA, aux_h + AUX_B0 + 256 * 6);
+  hidden_part<8, 0>(pipe, accA, accB, true, true);
+  relu_pass<8>(accA);
+  if (save) store_act<8>(A.save_h + (6 * A.Ppad + p) * 256, accA, h);
+  init_bias<8>(accB, aux_h + AUX_B0 + 256 * 7);
+  hidden_part<8, 0>(pipe, accB, accA, true, true);
+  relu_pass<8>(accB);
+  if (save) store_act<8>(A.save_h + (7 * A.Ppad + p) * 256, accB, h);
   // ---- density head (VALU): sigma_raw = w_alpha . h7 + b_alpha
-  const float sigma_raw = head_dot<8>(hin, A.aux + AUX_WA, h) + A.aux[AUX_BA];
-  // ---- feature layer (no activation)
-  init_bias<8>(acc, A.aux + AUX_BF, h);
-  hidden_part<8, 0>(pipe, acc, hin);
-  to_hidden<8, false>(hin, acc);
-  if (save) store_row<8>(A.save_f + p * 256, hin, h);
-  // ---- view layer: [feature(256); D(72*(1+2LD)); code(CODE)] -> 128, ReLU
+  const float sigma_raw = head_dot<8>(accB, aux_h + AUX_WA) + aux_l[AUX_BA];
+  // ---- feature layer (no activation on its output): B -> A
+  init_bias<8>(accA, aux_h + AUX_BF);
+  hidden_part<8, 0>(pipe, accA, accB, true, true);
+  if (save) store_act<8>(A.save_f + p * 256, accA, h);
+  // ---- view layer: [feature(256); D(72*(1+2LD)); code(CODE)] -> 128 units
   f32x16 accv[4];
-  init_bias<4>(accv, A.aux + AUX_BV, h);
-  hidden_part<4, 0>(pipe, accv, hin);
+  constexpr int NKGU = UW / 8;
+  init_bias<4>(accv, aux_h + AUX_BV);
+  hidden_part<4, 0>(pipe, accv, accA, true, false);
   float* usave = save ? A.save_u + p * UW : nullptr;
   auto KGV = [&](int kgu, float b0, float b1, float b2, float b3) __attribute__((always_inline)) {
     if constexpr (TRAIN) {
@@ -351,7 +425,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
         *reinterpret_cast<f32x4*>(usave + 8 * kgu + 4 * h) = o;
       }
     }
-    kgroup<4>(pipe, accv, 32 + kgu, b0, b1, b2, b3);
+    kgroup<4>(pipe, accv, 32 + kgu, false, kgu == NKGU - 1, b0, b1, b2, b3);
   };
   if constexpr (PRE) {
 #pragma unroll
@@ -387,15 +461,21 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
     for (int g = 0; g < 9; ++g)
       KGV(g, e[4 * g] * wd[(4 * g) / 3], e[4 * g + 1] * wd[(4 * g + 1) / 3], e[4 * g + 2] * wd[(4 * g + 2) / 3],
           e[4 * g + 3] * wd[(4 * g + 3) / 3]);
+    float sbe[36], cbe[36];   // running sin/cos(2^f e): precise every 3rd band, double-angle steps in between
 #pragma unroll
     for (int f = 0; f < LD; ++f) {
       float se[36], ce[36];
 #pragma unroll
       for (int i = 0; i < 36; ++i) {
-        float s, c;
-        sincos_f32(e[i] * (float)(1 << f), s, c);
-        se[i] = s * wd[i / 3];
-        ce[i] = c * wd[i / 3];
+        if (f % 3 == 0) {
+          sincos_f32(e[i] * (float)(1 << f), sbe[i], cbe[i]);
+        } else {
+          const float s_old = sbe[i], c_old = cbe[i];
+          sbe[i] = 2.f * s_old * c_old;
+          cbe[i] = fmaf(-2.f * s_old, s_old, 1.f);
+        }
+        se[i] = sbe[i] * wd[i / 3];
+        ce[i] = cbe[i] * wd[i / 3];
       }
 #pragma unroll
       for (int g = 0; g < 9; ++g) KGV(9 * (1 + 2 * f) + g, se[4 * g], se[4 * g + 1], se[4 * g + 2], se[4 * g + 3]);
@@ -416,236 +496,23 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
       KGV(9 * (1 + 2 * LD) + g, c4.x, c4.y, c4.z, c4.w);
     }
   }
-  float gact[128];
-#pragma unroll
-  for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) gact[nb * 16 + r] = fmaxf(accv[nb][r], 0.f);
-  if (save) store_row<4>(A.save_g + p * 128, gact, h);
+  relu_pass<4>(accv);
+  if (save) store_act<4>(A.save_g + p * 128, accv, h);
   // ---- rgb head (VALU)
-  const float c0 = head_dot<4>(gact, A.aux + AUX_WC + 0, h) + A.aux[AUX_BC + 0];
-  const float c1 = head_dot<4>(gact, A.aux + AUX_WC + 128, h) + A.aux[AUX_BC + 1];
-  const float c2 = head_dot<4>(gact, A.aux + AUX_WC + 256, h) + A.aux[AUX_BC + 2];
+  const float c0 = head_dot<4>(accv, aux_h + AUX_WC + 0) + aux_l[AUX_BC + 0];
+  const float c1 = head_dot<4>(accv, aux_h + AUX_WC + 128) + aux_l[AUX_BC + 1];
+  const float c2 = head_dot<4>(accv, aux_h + AUX_WC + 256) + aux_l[AUX_BC + 2];
   if (valid && h == 0) {
     f32x4 o = {c0, c1, c2, sigma_raw};
     *reinterpret_cast<f32x4*>(A.raw + p * 4) = o;
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// backward-data kernel: d(raw) -> d(pre-activation) of every layer, same register-resident transposed scheme
-// with the W^T weight image (anerf_layout which=1).  Per layer l:  dh_{l-1} = W_l^T dz_l ;  dz_{l-1} = dh_{l-1}
-// * [h_{l-1} > 0].  Writes dz0..dz7 [8][Ppad][256], dF [Ppad][256], dZv [Ppad][128] for the weight-gradient GEMMs
-// (anerf_gemm.hip).  Autograd of NeRF.forward (core/networks/nerf.py:94-148) w.r.t. activations.
-// ------------------------------------------------------------------------------------------------
-struct BwdArgs {
-  const float* packed_t;   // W^T image
-  const float* aux;        // natural-order head weights (forward aux)
-  const float* draw;       // [P][4]
-  const float* save_h;     // [8][Ppad][256]
-  const float* save_g;     // [Ppad][128]
-  float* dz;               // [8][Ppad][256]
-  float* df;               // [Ppad][256]
-  float* dzv;              // [Ppad][128]
-  long long P, Ppad;
-  int nstages;
-};
-
-// act[i] <- act[i] * (saved[i] > 0)
-template <int NB>
-__device__ __forceinline__ void relu_mask(float (&d)[128], const float* __restrict__ row, int h) {
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 s = *reinterpret_cast<const f32x4*>(row + 32 * nb + 8 * q + 4 * h);
-      d[nb * 16 + 4 * q + 0] = s.x > 0.f ? d[nb * 16 + 4 * q + 0] : 0.f;
-      d[nb * 16 + 4 * q + 1] = s.y > 0.f ? d[nb * 16 + 4 * q + 1] : 0.f;
-      d[nb * 16 + 4 * q + 2] = s.z > 0.f ? d[nb * 16 + 4 * q + 2] : 0.f;
-      d[nb * 16 + 4 * q + 3] = s.w > 0.f ? d[nb * 16 + 4 * q + 3] : 0.f;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_mlp_bwd(const BwdArgs A) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m = lane & 31, h = lane >> 5;
-  Pipe pipe;
-  pipe.init(A.packed_t, smem, wave, lane, A.nstages);
-  pipe.issue(0);
-  const long long p = (long long)blockIdx.x * TILE + wave * 32 + m;
-  const bool valid = p < A.P;
-  const long long pc = valid ? p : A.P - 1;
-  const f32x4 dr = *reinterpret_cast<const f32x4*>(A.draw + pc * 4);
-
-  float d[128];
-  f32x16 acc[8];
-  // ---- rgb head: dg = Wc^T dc ; dzv = dg * [g > 0]
-#pragma unroll
-  for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int o = 32 * nb + 8 * q + 4 * h;
-      const f32x4 w0 = *reinterpret_cast<const f32x4*>(A.aux + AUX_WC + o);
-      const f32x4 w1 = *reinterpret_cast<const f32x4*>(A.aux + AUX_WC + 128 + o);
-      const f32x4 w2 = *reinterpret_cast<const f32x4*>(A.aux + AUX_WC + 256 + o);
-      d[nb * 16 + 4 * q + 0] = w0.x * dr.x + w1.x * dr.y + w2.x * dr.z;
-      d[nb * 16 + 4 * q + 1] = w0.y * dr.x + w1.y * dr.y + w2.y * dr.z;
-      d[nb * 16 + 4 * q + 2] = w0.z * dr.x + w1.z * dr.y + w2.z * dr.z;
-      d[nb * 16 + 4 * q + 3] = w0.w * dr.x + w1.w * dr.y + w2.w * dr.z;
-    }
-#pragma unroll
-  for (int i = 64; i < 128; ++i) d[i] = 0.f;
-  relu_mask<4>(d, A.save_g + pc * 128, h);
-  if (valid) store_row<4>(A.dzv + p * 128, d, h);
-  // ---- view layer, feature columns: df = Wv[:, :256]^T dzv      (16 k-groups of the 128 view units)
-#pragma unroll
-  for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-#pragma unroll
-  for (int kg = 0; kg < 16; ++kg) kgroup<8>(pipe, acc, kg, d[4 * kg], d[4 * kg + 1], d[4 * kg + 2], d[4 * kg + 3]);
-  to_hidden<8, false>(d, acc);
-  if (valid) store_row<8>(A.df + p * 256, d, h);
-  // ---- feature layer + density head: dh7 = Wf^T df + w_alpha * dsigma
-#pragma unroll
-  for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 wa = *reinterpret_cast<const f32x4*>(A.aux + AUX_WA + 32 * nb + 8 * q + 4 * h);
-      acc[nb][4 * q + 0] = wa.x * dr.w;
-      acc[nb][4 * q + 1] = wa.y * dr.w;
-      acc[nb][4 * q + 2] = wa.z * dr.w;
-      acc[nb][4 * q + 3] = wa.w * dr.w;
-    }
-  hidden_part<8, 0>(pipe, acc, d);
-  to_hidden<8, false>(d, acc);
-  relu_mask<8>(d, A.save_h + (7 * A.Ppad + pc) * 256, h);
-  if (valid) store_row<8>(A.dz + (7 * A.Ppad + p) * 256, d, h);
-  // ---- trunk: dz_{l-1} = (W_l^T dz_l) * [h_{l-1} > 0],  l = 7..1   (W_5: hidden columns only)
-#pragma unroll 1
-  for (int L = 7; L >= 1; --L) {
-#pragma unroll
-    for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-    hidden_part<8, 0>(pipe, acc, d);
-    to_hidden<8, false>(d, acc);
-    relu_mask<8>(d, A.save_h + ((long long)(L - 1) * A.Ppad + pc) * 256, h);
-    if (valid) store_row<8>(A.dz + ((long long)(L - 1) * A.Ppad + p) * 256, d, h);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// input-gradient kernel (pose optimisation / frame codes only): gradients w.r.t. the ENCODED inputs, in stream
-// column order, on the which=2 weight image:
-//     dX'[p][432] = W0'^T dz0 + W5x'^T dz5          dU'[p][UW] = Wvu'^T dzv
-// Output columns are produced 256 at a time (8 blocks); lane (m,h) receives exactly the columns whose forward
-// B operands it generated (k-group 4*nb+q, half h), which is what k_encode_bwd consumes.
-// ------------------------------------------------------------------------------------------------
-struct BwdInArgs {
-  const float* packed_i;
-  const float* dz;     // [8][Ppad][256]
-  const float* dzv;    // [Ppad][128]
-  float* dx;           // [Ppad][432]
-  float* du;           // [Ppad][UW]
-  long long P, Ppad;
-  int nstages, uw;
-};
-
-template <int NB>
-__device__ __forceinline__ void load_row(float (&a)[128], const float* __restrict__ row, int h) {
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(row + 32 * nb + 8 * q + 4 * h);
-      a[nb * 16 + 4 * q + 0] = v.x;
-      a[nb * 16 + 4 * q + 1] = v.y;
-      a[nb * 16 + 4 * q + 2] = v.z;
-      a[nb * 16 + 4 * q + 3] = v.w;
-    }
-}
-
-// store the 8 accumulator blocks as columns [c0, c0+256) of a row of width `w` (columns >= w dropped)
-__device__ __forceinline__ void store_cols(float* __restrict__ row, const f32x16 (&acc)[8], int c0, int w, int h) {
-#pragma unroll
-  for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c = c0 + 32 * nb + 8 * q + 4 * h;
-      if (c < w) {
-        f32x4 o = {acc[nb][4 * q], acc[nb][4 * q + 1], acc[nb][4 * q + 2], acc[nb][4 * q + 3]};
-        *reinterpret_cast<f32x4*>(row + c) = o;
-      }
-    }
-}
-
-__global__ __launch_bounds__(256) void k_mlp_bwd_in(const BwdInArgs A) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m = lane & 31, h = lane >> 5;
-  Pipe pipe;
-  pipe.init(A.packed_i, smem, wave, lane, A.nstages);
-  pipe.issue(0);
-  const long long p = (long long)blockIdx.x * TILE + wave * 32 + m;
-  const bool valid = p < A.P;
-  const long long pc = valid ? p : A.P - 1;
-  float d[128];
-  f32x16 acc[8];
-#pragma unroll 1
-  for (int gi = 0; gi < 2; ++gi) {
-#pragma unroll
-    for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-    load_row<8>(d, A.dz + pc * 256, h);                          // dz0
-    hidden_part<8, 0>(pipe, acc, d);
-    load_row<8>(d, A.dz + (5 * A.Ppad + pc) * 256, h);           // dz5
-    hidden_part<8, 0>(pipe, acc, d);
-    if (valid) store_cols(A.dx + p * 432, acc, 256 * gi, 432, h);
-  }
-  const int ngu = (A.uw + 255) / 256;
-#pragma unroll
-  for (int i = 64; i < 128; ++i) d[i] = 0.f;
-  load_row<4>(d, A.dzv + pc * 128, h);
-#pragma unroll 1
-  for (int gi = 0; gi < ngu; ++gi) {
-#pragma unroll
-    for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-#pragma unroll
-    for (int kg = 0; kg < 16; ++kg) kgroup<8>(pipe, acc, kg, d[4 * kg], d[4 * kg + 1], d[4 * kg + 2], d[4 * kg + 3]);
-    if (valid) store_cols(A.du + p * A.uw, acc, 256 * gi, A.uw, h);
-  }
-}
-
-int mlp_bwd_in_entry(const float* packed_i, const float* dz, const float* dzv, float* dx, float* du, long long P,
-                     long long Ppad, int nstages, int uw, hipStream_t st) {
-  BwdInArgs b;
-  b.packed_i = packed_i; b.dz = dz; b.dzv = dzv; b.dx = dx; b.du = du; b.P = P; b.Ppad = Ppad; b.nstages = nstages; b.uw = uw;
-  const long long nblk = (P + TILE - 1) / TILE;
-  if (nblk <= 0) return ANERF_OK;
-  const size_t lds = 2 * STAGE_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_in), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(k_mlp_bwd_in, dim3((unsigned)nblk), dim3(256), lds, st, b);
-  return check_launch("k_mlp_bwd_in");
-}
-
 template <int LV, int LD, int CODE, bool PRE, bool TRAIN>
 static int launch(const MlpArgs& a, hipStream_t st) {
   const long long nblk = (a.P + TILE - 1) / TILE;
   if (nblk <= 0) return ANERF_OK;
-  const size_t lds = 2 * STAGE_BYTES + (PRE ? 0 : MAX_TILE_RAYS * 72 * 16);
+  const size_t lds = LDS_BONES_OFF + (PRE ? 0 : MAX_TILE_RAYS * 72 * 16);
   auto kern = k_mlp_fwd<LV, LD, CODE, PRE, TRAIN>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -688,23 +555,6 @@ int mlp_raw_entry(const AnerfConfig* cfg, const float* packed, const float* aux,
     a.save_h = sv->h; a.save_f = sv->f; a.save_g = sv->g; a.save_x = sv->x; a.save_u = sv->u; a.Ppad = sv->p_pad;
   }
   return mlp_dispatch(cfg, a, pre, sv != nullptr, st);
-}
-
-int mlp_bwd_entry(const float* packed_t, const float* aux, const float* draw, const AnerfSaved* sv, float* dz, float* df,
-                  float* dzv, long long P, int nstages, hipStream_t st) {
-  BwdArgs b;
-  b.packed_t = packed_t; b.aux = aux; b.draw = draw; b.save_h = sv->h; b.save_g = sv->g;
-  b.dz = dz; b.df = df; b.dzv = dzv; b.P = P; b.Ppad = sv->p_pad; b.nstages = nstages;
-  const long long nblk = (P + TILE - 1) / TILE;
-  if (nblk <= 0) return ANERF_OK;
-  const size_t lds = 2 * STAGE_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(k_mlp_bwd, dim3((unsigned)nblk), dim3(256), lds, st, b);
-  return check_launch("k_mlp_bwd");
 }
 
 }  // namespace anerf
