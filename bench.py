@@ -137,10 +137,17 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": name, "rays_per_step": n_total, "samples_per_ray": S, "n_importance": Ni,
                        "parallelism": f"ray-sharded x{world}", "weights": "numpy-seeded random init (alpha bias +1)"},
-            "roofline": {"bound": "mfma", "kernel": "k_mlp_fwd<7,4,0,false>", "achieved": achieved / 1e12,
+            "roofline": {"bound": "mfma", "kernel": "k_mlp_fwd<7,4,0,false,false>", "achieved": achieved / 1e12,
                          "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA,
                          "avg_launch_ms": mlp_ms, "flop_per_launch": flops_launch, "traffic": None},
         }
+        try:   # HBM bytes per launch come from a separate rocprofv3 --pmc run (committed under profiles/)
+            tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload)
+            if tr and world == 1:
+                res["roofline"]["traffic"] = tr["hbm_bytes"]
+                res["roofline"]["traffic_note"] = f"bytes/launch, FETCH_SIZE(x2)+WRITE_SIZE, {tr['source']}; algorithmic {tr['algorithmic_bytes']:.3g} B"
+        except (OSError, ValueError):
+            pass
         if args.cpu_rays > 0:
             res["cpu_baseline"], res["parity"] = cpu_baseline(sc, S, Ni, Pc, Pf, out, lo, min(args.cpu_rays, hi - lo))
         print(json.dumps(res))
