@@ -395,6 +395,43 @@ __global__ __launch_bounds__(256) void k_importance(const float* __restrict__ z,
 }
 
 // ------------------------------------------------------------------------------------------------
+// Caller-side frame helpers: per-pixel rays of a bbox (get_rays, core/utils/ray_utils.py:6-28, on the
+// pixels kp_to_valid_rays selects, :83-136) written straight into the [N,11] ray batch render() assembles
+// (core/trainer.py:116-135), and the background composite + scatter of render_path (run_nerf.py:118-131).
+__global__ void k_gen_rays(int W, int x0, int y0, int bw, int bh, float fx, float fy, float cx, float cy,
+                           const float* __restrict__ c2w /*[3,4] row-major*/, float near, float far,
+                           float* __restrict__ ray_batch, long long* __restrict__ valid_idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= bw * bh) return;
+  const int py = y0 + i / bw, px = x0 + i % bw;
+  const float dx = ((float)px - cx) / fx, dy = -((float)py - cy) / fy, dz = -1.f;
+  const float d0 = dx * c2w[0] + dy * c2w[1] + dz * c2w[2];
+  const float d1 = dx * c2w[4] + dy * c2w[5] + dz * c2w[6];
+  const float d2 = dx * c2w[8] + dy * c2w[9] + dz * c2w[10];
+  const float inv = 1.f / sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+  float* r = ray_batch + (long long)i * 11;
+  r[0] = c2w[3]; r[1] = c2w[7]; r[2] = c2w[11];
+  r[3] = d0; r[4] = d1; r[5] = d2;
+  r[6] = near; r[7] = far;
+  r[8] = d0 * inv; r[9] = d1 * inv; r[10] = d2 * inv;
+  valid_idx[i] = (long long)py * W + px;
+}
+
+// rgb_img [H*W,3] must be pre-filled with the background; pixel valid_idx[i] <- rgb + (1-acc) * bg
+__global__ void k_assemble(const float* __restrict__ rgb, const float* __restrict__ acc, const float* __restrict__ disp,
+                           const long long* __restrict__ valid_idx, int n, float* __restrict__ rgb_img,
+                           float* __restrict__ disp_img, float* __restrict__ acc_img) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long long px = valid_idx[i];
+  const float a = acc[i], t = 1.f - a;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) rgb_img[px * 3 + c] = rgb[3 * i + c] + t * rgb_img[px * 3 + c];
+  if (disp_img) disp_img[px] = disp[i];
+  if (acc_img) acc_img[px] = a;
+}
+
+// ------------------------------------------------------------------------------------------------
 // host launchers
 // ------------------------------------------------------------------------------------------------
 int launch_pack(const AnerfNetParams* P, const int32_t* table, long long n, float* out, hipStream_t st) {
@@ -434,6 +471,21 @@ int launch_composite_bwd(const AnerfConfig* cfg, const float* raw, const float* 
                      cfg->density_act, 1.0f / cfg->density_scale, cfg->softplus_shift, g_rgb, g_acc, g_disp, g_alpha,
                      g_weights, draw);
   return check_launch("k_composite_bwd");
+}
+
+int launch_gen_rays(int W, int x0, int y0, int bw, int bh, float fx, float fy, float cx, float cy, const float* c2w,
+                    float near, float far, float* ray_batch, long long* valid_idx, hipStream_t st) {
+  const int n = bw * bh;
+  hipLaunchKernelGGL(k_gen_rays, dim3((n + 255) / 256), dim3(256), 0, st, W, x0, y0, bw, bh, fx, fy, cx, cy, c2w, near, far,
+                     ray_batch, valid_idx);
+  return check_launch("k_gen_rays");
+}
+
+int launch_assemble(const float* rgb, const float* acc, const float* disp, const long long* valid_idx, int n, float* rgb_img,
+                    float* disp_img, float* acc_img, hipStream_t st) {
+  hipLaunchKernelGGL(k_assemble, dim3((n + 255) / 256), dim3(256), 0, st, rgb, acc, disp, valid_idx, n, rgb_img, disp_img,
+                     acc_img);
+  return check_launch("k_assemble");
 }
 
 int launch_importance(const float* z, const float* w, int n, int S, int Ni, const float* u, int single_net,

@@ -43,6 +43,12 @@ int mlp_raw_entry(const AnerfConfig* cfg, const float* packed, const float* aux,
 int mlp_bwd_entry(const float* packed_t, const float* aux, const float* draw, const AnerfSaved* sv, float* dz, float* df,
                   float* dzv, long long P, int nstages, hipStream_t st);
 int launch_weight_grads(GemmBatch& G, float* ws, hipStream_t st);
+int mlp_density_entry(const float* packed, const float* aux, const float* pts, const float* skts, float tau_v,
+                      const float* cut_v, long long P, int nstages_trunk, float* sigma, hipStream_t st);
+int launch_gen_rays(int W, int x0, int y0, int bw, int bh, float fx, float fy, float cx, float cy, const float* c2w,
+                    float near, float far, float* ray_batch, long long* valid_idx, hipStream_t st);
+int launch_assemble(const float* rgb, const float* acc, const float* disp, const long long* valid_idx, int n, float* rgb_img,
+                    float* disp_img, float* acc_img, hipStream_t st);
 int mlp_bwd_in_entry(const float* packed_i, const float* dz, const float* dzv, float* dx, float* du, long long P,
                      long long Ppad, int nstages, int uw, hipStream_t st);
 int launch_encode_bwd(int ld, const float* dx, const float* du, int uw, const float* rays, int ray_stride, const float* z,
@@ -475,6 +481,38 @@ int anerf_code_grads(const AnerfConfig* cfg, const float* du, const float* cam_i
   if (!du || !cam_idx || !dcodes || n_codes < 1) return set_error(ANERF_E_NULL, "code_grads: NULL pointer");
   if (n_rays == 0) return ANERF_OK;
   return launch_code_reduce(du, u_width(cfg), cam_idx, n_rays, n_samples, n_codes, dcodes, (hipStream_t)stream);
+}
+
+int anerf_density(const AnerfConfig* cfg, const float* packed, const float* aux, const float* pts, const float* skts,
+                  float tau_v, const float* cutoff_v, int64_t n_points, float* sigma_raw, void* stream) {
+  if (!config_ok(cfg)) return set_error(ANERF_E_CONFIG, "unsupported AnerfConfig");
+  if (!packed || !aux || !pts || !skts || !cutoff_v || !sigma_raw) return set_error(ANERF_E_NULL, "density: NULL pointer");
+  if (n_points < 0) return set_error(ANERF_E_SHAPE, "density: n_points < 0");
+  int stages = 0, k = 0;
+  for (const Seg& s : fwd_segments(cfg)) {
+    if (k++ == 8) break;                 // segments 0..7 = pts_linears.0..7
+    stages += seg_stages(s);
+  }
+  return mlp_density_entry(packed, aux, pts, skts, tau_v, cutoff_v, n_points, stages, sigma_raw, (hipStream_t)stream);
+}
+
+int anerf_gen_rays(int32_t H, int32_t W, float focal_x, float focal_y, float center_x, float center_y, const float* c2w,
+                   int32_t x0, int32_t y0, int32_t x1, int32_t y1, float near, float far, float* ray_batch,
+                   int64_t* valid_idx, void* stream) {
+  if (!c2w || !ray_batch || !valid_idx) return set_error(ANERF_E_NULL, "gen_rays: NULL pointer");
+  if (x0 < 0 || y0 < 0 || x1 > W || y1 > H || x1 < x0 || y1 < y0) return set_error(ANERF_E_SHAPE, "gen_rays: bbox");
+  if (x1 == x0 || y1 == y0) return ANERF_OK;
+  return launch_gen_rays(W, x0, y0, x1 - x0, y1 - y0, focal_x, focal_y, center_x, center_y, c2w, near, far, ray_batch,
+                         (long long*)valid_idx, (hipStream_t)stream);
+}
+
+int anerf_assemble_frame(const float* rgb_map, const float* acc_map, const float* disp_map, const int64_t* valid_idx,
+                         int32_t n_rays, float* rgb_img, float* disp_img, float* acc_img, void* stream) {
+  if (!rgb_map || !acc_map || !valid_idx || !rgb_img) return set_error(ANERF_E_NULL, "assemble_frame: NULL pointer");
+  if (disp_img && !disp_map) return set_error(ANERF_E_NULL, "assemble_frame: disp_map");
+  if (n_rays == 0) return ANERF_OK;
+  return launch_assemble(rgb_map, acc_map, disp_map, (const long long*)valid_idx, n_rays, rgb_img, disp_img, acc_img,
+                         (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -25,6 +25,7 @@
 //     {j : ((j>>2)&1) == h}; bone matrices of the tile's rays are staged in LDS.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include "anerf_dev.h"
 
 namespace anerf {
@@ -287,7 +288,9 @@ struct MlpArgs {
   float tau_v, tau_d;
 };
 
-template <int LV, int LD, int CODE, bool PRE, bool TRAIN>
+// MODE 0: rays + depths -> raw [P,4].   MODE 1 (density query, raycasters.py:597-648): points A.z = pts [P,3] under ONE
+// shared pose -> sigma logit [P]; only the trunk (layers 0..7 + alpha head) runs, the stream stops after layer 7.
+template <int LV, int LD, int CODE, bool PRE, bool TRAIN, int MODE = 0>
 __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -329,20 +332,29 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
     const long long ray0 = tile_p0 / A.S;
     long long ray1 = (tile_p0 + TILE - 1) / A.S;
     if (ray1 > A.N - 1) ray1 = A.N - 1;
-    ray = pc / A.S;
-    const int n_stage_rays = A.skt_stride == 0 ? 1 : (int)(ray1 - ray0 + 1);
-    lr = A.skt_stride == 0 ? 0 : (int)(ray - ray0);
+    ray = MODE == 1 ? 0 : pc / A.S;
+    const int n_stage_rays = (A.skt_stride == 0 || MODE == 1) ? 1 : (int)(ray1 - ray0 + 1);
+    lr = (A.skt_stride == 0 || MODE == 1) ? 0 : (int)(ray - ray0);
     f32x4* bw = reinterpret_cast<f32x4*>(smem + LDS_BONES_OFF);
     for (int i = tid; i < n_stage_rays * 72; i += 256) {
       const int ri = i / 72, rem = i - ri * 72, j = rem / 3, row = rem - 3 * j;
       bw[i] = *reinterpret_cast<const f32x4*>(A.skts + (ray0 + ri) * A.skt_stride + j * 16 + row * 4);
     }
-    const float* rp = A.rays + ray * A.ray_stride;
-    const float z = A.z[pc];
-    dray[0] = rp[3];
-    dray[1] = rp[4];
-    dray[2] = rp[5];
-    const float x0 = fmaf(dray[0], z, rp[0]), x1 = fmaf(dray[1], z, rp[1]), x2 = fmaf(dray[2], z, rp[2]);
+    float x0, x1, x2;
+    if constexpr (MODE == 1) {
+      x0 = A.z[3 * pc];
+      x1 = A.z[3 * pc + 1];
+      x2 = A.z[3 * pc + 2];
+    } else {
+      const float* rp = A.rays + ray * A.ray_stride;
+      const float z = A.z[pc];
+      dray[0] = rp[3];
+      dray[1] = rp[4];
+      dray[2] = rp[5];
+      x0 = fmaf(dray[0], z, rp[0]);
+      x1 = fmaf(dray[1], z, rp[1]);
+      x2 = fmaf(dray[2], z, rp[2]);
+    }
     pipe.begin();   // barrier: aux + bones visible, weight stages 0/1 landed
 #pragma unroll
     for (int a = 0; a < 12; ++a) {
@@ -408,6 +420,10 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
   if (save) store_act<8>(A.save_h + (7 * A.Ppad + p) * 256, accB, h);
   // ---- density head (VALU): sigma_raw = w_alpha . h7 + b_alpha
   const float sigma_raw = head_dot<8>(accB, aux_h + AUX_WA) + aux_l[AUX_BA];
+  if constexpr (MODE == 1) {
+    if (valid && h == 0) A.raw[p] = sigma_raw;
+    return;
+  }
   // ---- feature layer (no activation on its output): B -> A
   init_bias<8>(accA, aux_h + AUX_BF);
   hidden_part<8, 0>(pipe, accA, accB, true, true);
@@ -537,6 +553,26 @@ int mlp_dispatch(const AnerfConfig* cfg, const MlpArgs& a, bool pre, bool train,
   ANERF_CASE(0, 0)
 #undef ANERF_CASE
   return set_error(ANERF_E_CONFIG, "unsupported (multires_views, framecode_ch); built: (4,0) (4,16) (0,0)");
+}
+
+// density query: pts [P,3] under one pose -> sigma logit [P]
+int mlp_density_entry(const float* packed, const float* aux, const float* pts, const float* skts, float tau_v,
+                      const float* cut_v, long long P, int nstages_trunk, float* sigma, hipStream_t st) {
+  MlpArgs a;
+  memset(&a, 0, sizeof(a));
+  a.packed = packed; a.aux = aux; a.z = pts; a.skts = skts; a.cut_v = cut_v; a.cut_d = cut_v; a.raw = sigma;
+  a.P = P; a.Ppad = P; a.skt_stride = 0; a.S = 1; a.N = 1; a.nstages = nstages_trunk; a.tau_v = tau_v; a.tau_d = tau_v;
+  const long long nblk = (P + TILE - 1) / TILE;
+  if (nblk <= 0) return ANERF_OK;
+  const size_t lds = LDS_BONES_OFF + MAX_TILE_RAYS * 72 * 16;
+  auto kern = k_mlp_fwd<7, 0, 0, false, false, 1>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, a);
+  return check_launch("k_mlp_fwd<density>");
 }
 
 int mlp_raw_entry(const AnerfConfig* cfg, const float* packed, const float* aux, const float* rays, int ray_stride,

@@ -189,3 +189,42 @@ def importance(z_vals, weights, n_importance, u=None, single_net=False, want_idx
     _lib.check(_lib.load().anerf_importance(_p(z_vals), _p(weights), n, s, n_importance, _p(u), int(bool(single_net)),
                                             _p(zs), _p(zm), _p(idx), _stream()), "anerf_importance")
     return zs, zm, idx
+
+
+def density(cfg, packed, aux, pts, skts, tau_v, cut_v):
+    """Density query (raycasters.py:597-648): pts [...,3] under ONE pose skts [1,24,4,4] -> sigma logits [...,1]."""
+    pts, skts = _f32c(pts, "pts"), _f32c(skts, "skts")
+    if skts.numel() != 16 * cfg.n_joints:
+        raise NotImplementedError("density query supports a single pose (skts [1,24,4,4]) as in render_mesh_density")
+    flat = pts.reshape(-1, 3)
+    out = torch.empty(flat.shape[0], dtype=torch.float32, device=pts.device)
+    cc = cfg.c()
+    _lib.check(_lib.load().anerf_density(C.byref(cc), _p(packed), _p(aux), _p(flat), _p(skts), float(tau_v),
+                                         _p(_f32c(cut_v, "cut_v")), flat.shape[0], _p(out), _stream()), "anerf_density")
+    return out.reshape(*pts.shape[:-1], 1)
+
+
+def gen_rays(H, W, focal, c2w, bbox, center=None, near=0.0, far=1.0):
+    """Ray batch [N,11] + valid_idx [N] (int64) for the pixel box bbox = (x0, y0, x1, y1)   (ray_utils.py:6-28,83-136)."""
+    c2w = _f32c(c2w, "c2w")[:3, :4].contiguous()
+    x0, y0, x1, y1 = [int(b) for b in bbox]
+    n = max(0, x1 - x0) * max(0, y1 - y0)
+    fx, fy = (focal, focal) if not hasattr(focal, "__len__") else (float(focal[0]), float(focal[1]))
+    cx, cy = (W * 0.5, H * 0.5) if center is None else (float(center[0]), float(center[1]))
+    rb = torch.empty(n, 11, dtype=torch.float32, device=c2w.device)
+    idx = torch.empty(n, dtype=torch.int64, device=c2w.device)
+    _lib.check(_lib.load().anerf_gen_rays(H, W, float(fx), float(fy), cx, cy, _p(c2w), x0, y0, x1, y1, float(near), float(far),
+                                          _p(rb), _p(idx), _stream()), "anerf_gen_rays")
+    return rb, idx
+
+
+def assemble_frame(rgb_map, acc_map, disp_map, valid_idx, rgb_img, want_acc=False):
+    """run_nerf.py:118-131: rgb_img [H*W,3] holds the background and is updated in place; returns (rgb_img, disp_img, acc_img)."""
+    n = rgb_map.shape[0]
+    dev = rgb_map.device
+    disp_img = torch.zeros(rgb_img.shape[0], dtype=torch.float32, device=dev)
+    acc_img = torch.zeros(rgb_img.shape[0], dtype=torch.float32, device=dev) if want_acc else None
+    _lib.check(_lib.load().anerf_assemble_frame(_p(_f32c(rgb_map, "rgb")), _p(_f32c(acc_map, "acc")), _p(_f32c(disp_map, "disp")),
+                                                _p(valid_idx), n, _p(rgb_img), _p(disp_img), _p(acc_img), _stream()),
+               "anerf_assemble_frame")
+    return rgb_img, disp_img, acc_img

@@ -32,17 +32,18 @@ class GradBucket:
         """Sum gradients over ranks, divide by world size, write back into p.grad.  Returns the flat bucket."""
         if not self.params:
             return None
+        world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        if world == 1:
+            return None                      # single process: gradients are already the global-batch gradients
         self._ensure(self.params[0].device)
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
-        torch._foreach_copy_(self.views, grads)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-            self.flat.div_(dist.get_world_size(group))
-        for p, v in zip(self.params, self.views):
+        for p in self.params:
             if p.grad is None:
-                p.grad = v.clone()
-            else:
-                p.grad.copy_(v)
+                p.grad = torch.zeros_like(p)
+        grads = [p.grad for p in self.params]
+        torch._foreach_copy_(self.views, grads)          # one multi-tensor launch each way
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        self.flat.div_(world)
+        torch._foreach_copy_(grads, self.views)
         return self.flat
 
 

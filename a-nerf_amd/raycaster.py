@@ -58,8 +58,12 @@ class RayCaster(nn.Module):
         return self.render_rays(*args, **kwargs)
 
     def forward(self, *args, fwd_type="", **kwargs):
-        if fwd_type in ("density", "density_color", "mesh"):
-            raise NotImplementedError(f"fwd_type={fwd_type!r}: density/mesh queries are listed as 'next' in SURVEY.md 8(f)")
+        if fwd_type == "density":
+            return self.render_pts_density(*args, **kwargs)
+        if fwd_type == "mesh":
+            return self.render_mesh_density(*args, **kwargs)
+        if fwd_type == "density_color":
+            raise NotImplementedError("fwd_type='density_color' needs texture layers no shipped config has")
         if not self.training:
             return self.forward_eval(*args, **kwargs)
         return self.render_rays(*args, **kwargs)
@@ -118,6 +122,29 @@ class RayCaster(nn.Module):
             return autograd_path.render_rays_train(self, kw)
         return pipeline.render_rays_forward(net_c=net_c.packed(), net_f=None if net_f is None else net_f.packed(),
                                             codes_c=codes_c, codes_f=codes_f, **kw)
+
+    @torch.no_grad()
+    def render_pts_density(self, pts, kps, skts, bones, render_kwargs=None, subject_idxs=None, netchunk=1024 * 64,
+                           network=None, color=False, v=None):
+        """core/raycasters.py:597-648: raw density alpha_linear(forward_density(embed(pts))) for pts [N,1,3]
+        under one pose; uses the fine network when there is one."""
+        if color or v is not None or subject_idxs is not None:
+            raise NotImplementedError("color / precomputed v / subject_idxs are not used by the shipped configs")
+        net = network if network is not None else (self.network_fine if self.network_fine is not None else self.network)
+        stream, aux = net.packed()
+        tau_v, _ = self._taus()
+        return ops.density(net.path_cfg, stream, aux, pts, skts, tau_v, self.embed_fn.cutoff_dist.detach())
+
+    @torch.no_grad()
+    def render_mesh_density(self, kps, skts, bones, subject_idxs=None, radius=1.0, res=64, render_kwargs=None,
+                            netchunk=1024 * 64, v=None):
+        """core/raycasters.py:579-595: density on a (res+1)^3 grid centred at the root joint, for marching cubes."""
+        t = np.linspace(-radius, radius, res + 1)
+        grid = np.stack(np.meshgrid(t, t, t), axis=-1).astype(np.float32)
+        sh = grid.shape
+        pts = torch.tensor(grid.reshape(-1, 3), device=kps.device) + kps[0, 0]
+        raw = self.render_pts_density(pts.reshape(-1, 1, 3), kps, skts, bones, render_kwargs, subject_idxs, netchunk, v=v)
+        return raw[..., :1].reshape(*sh[:-1]).transpose(1, 0)
 
     # ------------------------------------------------------------------ bookkeeping identical to the reference
     def update_embed_fns(self, global_step, args):

@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="render64", choices=["render64", "hier", "render64x64", "train"])
     ap.add_argument("--cpu-rays", type=int, default=8192, help="ray sample for the CPU baseline (0 = skip)")
+    ap.add_argument("--n-rand", type=int, default=3072, help="train workload: global rays per step")
     return ap.parse_args()
 
 
@@ -163,7 +164,7 @@ def bench_train(args, rank, world, device, dist, synth):
     raycaster = importlib.import_module("a-nerf_amd.raycaster")
     render_mod = importlib.import_module("a-nerf_amd.render")
     parallel = importlib.import_module("a-nerf_amd.parallel")
-    N_rand, S, Ni = 3072, 64, 16
+    N_rand, S, Ni = args.n_rand, 64, 16
     dev = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32, device=device)
     kw = dict(D=8, W=256, input_ch=360, input_ch_bones=72, input_ch_views=648, use_viewdirs=True)
     net_c, net_f = networks.NeRF(**kw), networks.NeRF(**kw)
@@ -201,7 +202,7 @@ def bench_train(args, rank, world, device, dist, synth):
             ev[i][1].record()
         bucket.all_reduce_mean()
         opt.step()
-        opt.zero_grad(set_to_none=False)
+        opt.zero_grad()
         return loss
 
     def barrier():
@@ -228,7 +229,7 @@ def bench_train(args, rank, world, device, dist, synth):
         res = {"metric": "rays/sec", "value": N_rand * args.steps / dt, "unit": "rays/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "SURREAL-shaped training step, N_rand=3072, 64+16 samples, fwd+bwd+Adam (BASELINE config 3)",
+               "config": {"workload": f"SURREAL-shaped training step, N_rand={N_rand}, 64+16 samples, fwd+bwd+Adam (BASELINE config 3)",
                           "rays_per_step": N_rand, "samples_per_ray": S, "n_importance": Ni,
                           "parallelism": f"ray-sharded x{world}, 1 all-reduce/step", "loss": float(loss)},
                "roofline": {"bound": "mfma", "kernel": "k_mlp_fwd<train> + k_mlp_bwd + k_gemm_tn (both nets), HIP-event time of fwd+bwd",

@@ -201,6 +201,24 @@ int anerf_encode_backward(const AnerfConfig* cfg, const float* dx, const float* 
 int anerf_code_grads(const AnerfConfig* cfg, const float* du, const float* cam_idx, int32_t n_rays, int32_t n_samples,
                      float* dcodes, int32_t n_codes, void* stream);
 
+/* ---- next rows of SURVEY 8(f) ----------------------------------------------------------------------------------- */
+
+/* Density query (RayCaster.render_pts_density / fwd_type='density'|'mesh', core/raycasters.py:579-648):
+ * pts [P,3] world points under ONE pose skts [24,4,4] -> sigma_raw [P] = alpha_linear(forward_density(...)). */
+int anerf_density(const AnerfConfig* cfg, const float* packed, const float* aux, const float* pts, const float* skts,
+                  float tau_v, const float* cutoff_v, int64_t n_points, float* sigma_raw, void* stream);
+
+/* get_rays (core/utils/ray_utils.py:6-28) for the pixels [x0,x1) x [y0,y1) that kp_to_valid_rays selects (:83-136),
+ * written as the [N,11] ray batch of render() (core/trainer.py:116-135); valid_idx[i] = y*W + x.  c2w [3,4]. */
+int anerf_gen_rays(int32_t H, int32_t W, float focal_x, float focal_y, float center_x, float center_y, const float* c2w,
+                   int32_t x0, int32_t y0, int32_t x1, int32_t y1, float near, float far, float* ray_batch,
+                   int64_t* valid_idx, void* stream);
+
+/* render_path's composite + scatter (run_nerf.py:118-131): rgb_img [H*W,3] holds the background on entry and
+ * rgb + (1-acc)*bg at valid_idx on exit; disp_img / acc_img [H*W] optional. */
+int anerf_assemble_frame(const float* rgb_map, const float* acc_map, const float* disp_map, const int64_t* valid_idx,
+                         int32_t n_rays, float* rgb_img, float* disp_img, float* acc_img, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

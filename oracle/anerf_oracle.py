@@ -164,6 +164,29 @@ def mlp(cfg, P, X, eval_mean_code=False):
     return torch.cat([rgb, sigma], -1)
 
 
+def density_query(cfg, P, pts, skts, tau_v=20.0, cut_v=None):
+    """RayCaster.render_pts_density (core/raycasters.py:597-648): pts [N,1,3] under one pose -> alpha_linear(
+    forward_density([embed(v), r])) [N,1,1]."""
+    cut_v = torch.full((N_JOINTS,), 0.5) if cut_v is None else cut_v
+    v, r, _ = bone_features(pts, torch.ones(pts.shape[0], 3), skts)
+    x = torch.cat([cutoff_pe(v, v, cfg.multires, tau_v, cut_v, 1), r], -1)
+    h = x
+    for i in range(cfg.D):
+        h = F.relu(F.linear(h, P[f"pts_linears.{i}.weight"], P[f"pts_linears.{i}.bias"]))
+        if i == cfg.skip:
+            h = torch.cat([x, h], -1)
+    return F.linear(h, P["alpha_linear.weight"], P["alpha_linear.bias"])
+
+
+def mesh_density(cfg, P, kps, skts, radius=1.0, res=64, tau_v=20.0, cut_v=None):
+    """RayCaster.render_mesh_density (core/raycasters.py:579-595)."""
+    t = np.linspace(-radius, radius, res + 1)
+    grid = np.stack(np.meshgrid(t, t, t), axis=-1).astype(np.float32)
+    pts = torch.tensor(grid.reshape(-1, 3)) + kps[0, 0]
+    raw = density_query(cfg, P, pts.reshape(-1, 1, 3), skts, tau_v, cut_v)
+    return raw[..., :1].reshape(*grid.shape[:-1]).transpose(1, 0)
+
+
 # ------------------------------------------------------------------------------------------------
 # A10: alpha compositing                             (core/networks/nerf.py:150-205)
 # ------------------------------------------------------------------------------------------------

@@ -245,6 +245,17 @@ def main():
                         disp_map=out["disp_map"].numpy(), n_rays=np.array(n))
     print("G6 rays", n)
 
+    # G8: density / mesh query path (fwd_type='density' | 'mesh'), fine network, single pose
+    caster.eval()
+    pose = synth.make_pose(10)
+    kps1, skts1, bones1 = t(pose["kp"])[None], t(pose["skts"])[None], t(pose["bones"])[None]
+    qpts = t(np.random.default_rng(3).uniform(-0.8, 0.8, (333, 1, 3)).astype(np.float32)) + kps1[0, 0]
+    with torch.no_grad():
+        dens = caster(qpts, kps1, skts1, bones1, render_kwargs=rk_test["preproc_kwargs"], fwd_type="density")
+        mesh = caster(kps1, skts1, bones1, radius=0.9, res=6, render_kwargs=rk_test["preproc_kwargs"], fwd_type="mesh")
+    np.savez_compressed(os.path.join(OUT, "density.npz"), density=dens.numpy(), mesh=mesh.numpy())
+    print("G8", dens.shape, mesh.shape, float(dens.abs().mean()))
+
     # G7: surreal_single (single_net, multires_views=0)
     args_s, caster_s, rk_train_s, rk_test_s = build_caster(cp, "configs/surreal/surreal_single.txt", 31, 31)
     caster_s.eval()

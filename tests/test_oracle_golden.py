@@ -139,3 +139,15 @@ def test_frame64_psnr(oracle, synth, golden):
     assert np.abs(out["rgb_map"].numpy() - g["rgb_map"]).max() < 1e-4
     target = t(np.random.default_rng(7).random((n, 3)))
     assert abs(oracle.psnr(out["rgb_map"], target) - oracle.psnr(t(g["rgb_map"]), target)) < 1e-3
+
+
+def test_density_and_mesh_query(oracle, synth, golden):
+    g = golden("density")
+    cfg = oracle.OracleConfig()
+    P = oracle.params_from_numpy(synth.make_net_params(12))      # fine network (render_pts_density default)
+    pose = synth.make_pose(10)
+    kps, skts = t(pose["kp"])[None], t(pose["skts"])[None]
+    pts = t(np.random.default_rng(3).uniform(-0.8, 0.8, (333, 1, 3)).astype(np.float32)) + kps[0, 0]
+    with torch.no_grad():
+        np.testing.assert_allclose(oracle.density_query(cfg, P, pts, skts).numpy(), g["density"], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(oracle.mesh_density(cfg, P, kps, skts, radius=0.9, res=6).numpy(), g["mesh"], rtol=1e-4, atol=2e-5)

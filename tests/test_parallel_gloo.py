@@ -93,6 +93,6 @@ def test_bucket_single_process_is_identity():
     a, b = torch.nn.Parameter(torch.randn(3, 4)), torch.nn.Parameter(torch.randn(5))
     a.grad, b.grad = torch.randn(3, 4), torch.randn(5)
     ga, gb = a.grad.clone(), b.grad.clone()
-    parallel.GradBucket([a, b]).all_reduce_mean()
+    assert parallel.GradBucket([a, b]).all_reduce_mean() is None
     assert torch.equal(a.grad, ga) and torch.equal(b.grad, gb)
     assert parallel.shard_rays(10, 1, 4) == (3, 6) and parallel.shard_rays(10, 3, 4) == (9, 10)
