@@ -239,6 +239,7 @@ int anerf_pack_params(const AnerfNetParams* params, const int32_t* table, int64_
 
 int anerf_ray_bounds(const float* rays, int32_t ray_stride, const float* cyls, int32_t n_rays, float* near_far,
                      float* stats_ws, void* stream) {
+  if (n_rays == 0) return ANERF_OK;   /* empty batch: nothing to enqueue, pointers may be NULL */
   if (!rays || !cyls || !near_far || !stats_ws) return set_error(ANERF_E_NULL, "ray_bounds: NULL pointer");
   if (ray_stride < 8 || n_rays < 0) return set_error(ANERF_E_SHAPE, "ray_bounds: ray_stride >= 8 required");
   if (n_rays == 0) return ANERF_OK;
@@ -248,6 +249,7 @@ int anerf_ray_bounds(const float* rays, int32_t ray_stride, const float* cyls, i
 int anerf_coarse_z(const float* near_far, const float* stats_ws, const float* rays, int32_t ray_stride,
                     int32_t n_rays, int32_t n_samples, const float* t_rand, int32_t lindisp, float* z_vals,
                     float* near_far_fixed, void* stream) {
+  if (n_rays == 0) return ANERF_OK;   /* empty batch: nothing to enqueue, pointers may be NULL */
   if (!near_far || !stats_ws || !rays || !z_vals) return set_error(ANERF_E_NULL, "coarse_z: NULL pointer");
   if (n_samples < 2 || n_samples > MAX_SAMPLES) return set_error(ANERF_E_SHAPE, "coarse_z: 2 <= N_samples <= 512");
   if (n_rays == 0) return ANERF_OK;
@@ -260,6 +262,7 @@ int anerf_mlp_raw(const AnerfConfig* cfg, const float* packed, const float* aux,
                   const float* cam_idx, const float* codes, int32_t n_codes, float tau_v, float tau_d,
                   const float* cutoff_v, const float* cutoff_d, int32_t n_rays, int32_t n_samples, float* raw,
                   void* stream) {
+  if (n_rays == 0) return ANERF_OK;   /* empty batch: nothing to enqueue, pointers may be NULL */
   AnerfLayout L;
   const int rc = anerf_layout(cfg, 0, &L);
   if (rc) return rc;
@@ -277,6 +280,7 @@ int anerf_mlp_raw(const AnerfConfig* cfg, const float* packed, const float* aux,
 
 int anerf_mlp_forward(const AnerfConfig* cfg, const float* packed, const float* aux, const float* x,
                       int64_t n_points, const float* codes, int32_t n_codes, float* raw, void* stream) {
+  if (n_points == 0) return ANERF_OK;   /* empty batch: nothing to enqueue, pointers may be NULL */
   AnerfLayout L;
   const int rc = anerf_layout(cfg, 0, &L);
   if (rc) return rc;
@@ -290,6 +294,7 @@ int anerf_mlp_forward(const AnerfConfig* cfg, const float* packed, const float* 
 int anerf_composite(const AnerfConfig* cfg, const float* raw, const float* z_vals, const float* rays,
                     int32_t ray_stride, const float* noise, int32_t n_rays, int32_t n_samples, float* rgb_map,
                     float* disp_map, float* acc_map, float* weights, float* alpha, float* depth_map, void* stream) {
+  if (n_rays == 0) return ANERF_OK;   /* empty batch: nothing to enqueue, pointers may be NULL */
   if (!cfg || !raw || !z_vals || !rays || !rgb_map || !disp_map || !acc_map || !weights || !alpha)
     return set_error(ANERF_E_NULL, "composite: NULL pointer");
   if (n_samples < 1 || n_samples > MAX_SAMPLES) return set_error(ANERF_E_SHAPE, "composite: 1 <= samples <= 512");
@@ -302,6 +307,7 @@ int anerf_composite(const AnerfConfig* cfg, const float* raw, const float* z_val
 int anerf_importance(const float* z_vals, const float* weights, int32_t n_rays, int32_t n_samples,
                      int32_t n_importance, const float* u, int32_t single_net, float* z_samples, float* z_merged,
                      int64_t* sorted_idx, void* stream) {
+  if (n_rays == 0) return ANERF_OK;   /* empty batch: nothing to enqueue, pointers may be NULL */
   if (!z_vals || !weights || !z_samples || !z_merged) return set_error(ANERF_E_NULL, "importance: NULL pointer");
   if (n_samples < 3 || n_importance < 1 || n_samples + n_importance > MAX_SAMPLES)
     return set_error(ANERF_E_SHAPE, "importance: need S >= 3, Ni >= 1, S + Ni <= 512");
@@ -485,6 +491,7 @@ int anerf_code_grads(const AnerfConfig* cfg, const float* du, const float* cam_i
 
 int anerf_density(const AnerfConfig* cfg, const float* packed, const float* aux, const float* pts, const float* skts,
                   float tau_v, const float* cutoff_v, int64_t n_points, float* sigma_raw, void* stream) {
+  if (n_points == 0) return ANERF_OK;   /* empty batch: nothing to enqueue, pointers may be NULL */
   if (!config_ok(cfg)) return set_error(ANERF_E_CONFIG, "unsupported AnerfConfig");
   if (!packed || !aux || !pts || !skts || !cutoff_v || !sigma_raw) return set_error(ANERF_E_NULL, "density: NULL pointer");
   if (n_points < 0) return set_error(ANERF_E_SHAPE, "density: n_points < 0");
@@ -508,6 +515,7 @@ int anerf_gen_rays(int32_t H, int32_t W, float focal_x, float focal_y, float cen
 
 int anerf_assemble_frame(const float* rgb_map, const float* acc_map, const float* disp_map, const int64_t* valid_idx,
                          int32_t n_rays, float* rgb_img, float* disp_img, float* acc_img, void* stream) {
+  if (n_rays == 0) return ANERF_OK;   /* empty batch: nothing to enqueue, pointers may be NULL */
   if (!rgb_map || !acc_map || !valid_idx || !rgb_img) return set_error(ANERF_E_NULL, "assemble_frame: NULL pointer");
   if (disp_img && !disp_map) return set_error(ANERF_E_NULL, "assemble_frame: disp_map");
   if (n_rays == 0) return ANERF_OK;

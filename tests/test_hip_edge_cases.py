@@ -1,0 +1,148 @@
+"""GPU: edge cases and configuration coverage of the HIP path vs the CPU oracle."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from cases import build
+
+pytestmark = pytest.mark.gpu
+
+ops = importlib.import_module("a-nerf_amd.ops")
+pipeline = importlib.import_module("a-nerf_amd.pipeline")
+synth_mod = importlib.import_module("a-nerf_amd.synth")
+
+
+def dev(x):
+    return torch.tensor(np.asarray(x), dtype=torch.float32, device="cuda")
+
+
+def t(x):
+    return torch.tensor(np.asarray(x), dtype=torch.float32)
+
+
+def cuda_params(P):
+    return {k: dev(v) for k, v in P.items()}
+
+
+def both(oracle, c, n, S, Ni, cfg_kw=None, lindisp=False, seed_noise=None):
+    """Run n rays of case c through HIP and oracle with the given sampling config."""
+    cfg_kw = cfg_kw or {}
+    cfg = ops.PathConfig(**cfg_kw)
+    ocfg = oracle.OracleConfig(**cfg_kw)
+    Pc, Pf = c["Pc"], c["Pf"]
+    net_c, net_f = ops.pack_params(cfg, cuda_params(Pc)), ops.pack_params(cfg, cuda_params(Pf))
+    ro, rd, skts, cyls = c["rays_o"][:n], c["rays_d"][:n], c["skts"][:n], c["cyls"][:n]
+    rb = pipeline.make_ray_batch(dev(ro), dev(rd))
+    kw, okw = {}, {}
+    if seed_noise is not None:
+        g = np.random.default_rng(seed_noise)
+        tr, u = g.random((n, S)).astype(np.float32), g.random((n, max(Ni, 1))).astype(np.float32)
+        nz, nzf = g.standard_normal((n, S)).astype(np.float32), g.standard_normal((n, S + Ni)).astype(np.float32)
+        kw = dict(t_rand=dev(tr), u_imp=dev(u) if Ni else None, noise=dev(nz), noise_fine=dev(nzf) if Ni else None)
+        okw = dict(t_rand=t(tr), u_imp=t(u) if Ni else None, noise=t(nz), noise_fine=t(nzf) if Ni else None)
+    out = pipeline.render_rays_forward(cfg, net_c, net_f, rb, dev(skts), dev(cyls), S, Ni, lindisp=lindisp, extras=True, **kw)
+    with torch.no_grad():
+        ref = oracle.render_rays(ocfg, oracle.params_from_numpy(Pc), oracle.params_from_numpy(Pf),
+                                 oracle.make_ray_batch(t(ro), t(rd)), t(skts), t(cyls), S, Ni, lindisp=lindisp,
+                                 return_extras=True, **okw)
+    return out, ref
+
+
+def assert_out(out, ref, keys, atol=1e-4):
+    for k in keys:
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k].numpy(), atol=atol, rtol=0, err_msg=k)
+
+
+def test_empty_batch():
+    cfg = ops.PathConfig()
+    net = ops.pack_params(cfg, cuda_params(synth_mod.make_net_params(11)))
+    rb = torch.zeros(0, 11, device="cuda")
+    out = pipeline.render_rays_forward(cfg, net, net, rb, torch.zeros(0, 24, 4, 4, device="cuda"), torch.zeros(0, 5, device="cuda"), 16, 8)
+    assert out["rgb_map"].shape == (0, 3) and out["alpha"].shape == (0, 24) and out["alpha0"].shape == (0, 16)
+
+
+@pytest.mark.parametrize("n,S,Ni", [(1, 8, 0), (3, 8, 8), (5, 17, 9), (7, 33, 0), (2, 64, 128), (1, 256, 256)])
+def test_ragged_and_extreme_sizes(oracle, n, S, Ni):
+    """single ray, minimum / odd / maximum sample counts, per-ray poses straddling tiles, config-5 shape 64+128."""
+    c = build("train_pytest")       # per-ray poses
+    out, ref = both(oracle, c, n, S, Ni)
+    keys = ["rgb_map", "acc_map", "alpha"] + (["rgb0", "alpha0"] if Ni else [])
+    assert_out(out, ref, keys)
+    assert out["alpha"].shape == (n, S + Ni)
+
+
+def test_softplus_density_scale_lindisp_and_noise(oracle):
+    c = build("eval_hier")
+    out, ref = both(oracle, c, 24, 32, 16, cfg_kw=dict(density_scale=0.5, softplus_shift=1.0), lindisp=True, seed_noise=11)
+    assert_out(out, ref, ["rgb_map", "acc_map", "alpha", "rgb0", "alpha0"])
+    np.testing.assert_allclose(out["disp_map"].cpu().numpy(), ref["disp_map"].numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(out["_extras"]["z_vals"].cpu().numpy(), ref["_extras"]["z_vals"].numpy(), rtol=3e-6)
+
+
+def test_nerf_forward_seam_with_framecodes(oracle):
+    """NeRF.forward(x) (nerf.py:133-148) through the mirror module, frame-code column included."""
+    networks = importlib.import_module("a-nerf_amd.networks")
+    c = build("mixamo_train")
+    net = networks.NeRF(D=8, W=256, input_ch=360, input_ch_bones=72, input_ch_views=648, use_viewdirs=True,
+                        use_framecode=True, framecode_ch=16, n_framecodes=8)
+    net.load_state_dict({k: t(v) for k, v in c["Pc"].items()})
+    net = net.cuda().train()
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(5, 41, 1080, generator=g) - 0.5)
+    idx = torch.randint(0, 8, (5, 41, 1), generator=g).float()
+    X = torch.cat([x, idx], -1)
+    with torch.no_grad():
+        got = net(X.cuda())
+        assert got.shape == (5, 41, 4)
+        ref = oracle.mlp(oracle.OracleConfig(framecode_ch=16), oracle.params_from_numpy(c["Pc"]), X)
+        np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), atol=3e-5)
+        assert torch.equal(net.forward_batchify(X.cuda().reshape(-1, 1081), chunk=64), got.reshape(-1, 4))
+        # eval with idx < 0 -> mean code
+        net.eval()
+        Xe = torch.cat([x, -torch.ones_like(idx)], -1)
+        ref_e = oracle.mlp(oracle.OracleConfig(framecode_ch=16), oracle.params_from_numpy(c["Pc"]), Xe, eval_mean_code=True)
+        np.testing.assert_allclose(net(Xe.cuda()).cpu().numpy(), ref_e.numpy(), atol=3e-5)
+
+
+def test_raw2outputs_seam(oracle):
+    """NeRF.raw2outputs (nerf.py:150-205) through the mirror, incl. the pytest noise override."""
+    networks = importlib.import_module("a-nerf_amd.networks")
+    net = networks.NeRF(D=8, W=256, input_ch=360, input_ch_bones=72, input_ch_views=648, use_viewdirs=True).cuda()
+    g = torch.Generator().manual_seed(2)
+    raw, rd = torch.randn(9, 40, 4, generator=g), torch.randn(9, 3, generator=g)
+    z = torch.sort(torch.rand(9, 40, generator=g) * 2 + 1, -1)[0]
+    out = net.raw2outputs(raw.cuda(), z.cuda(), rd.cuda(), raw_noise_std=1.0, pytest=True, B=1.0)
+    np.random.seed(0)
+    noise = t(np.random.rand(9, 40))
+    ref = oracle.composite(oracle.OracleConfig(), raw, z, rd, noise)
+    for k in ["rgb_map", "disp_map", "acc_map", "weights", "alpha"]:
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k].numpy(), atol=2e-5, rtol=1e-4, err_msg=k)
+
+
+def test_chunking_invariance_and_determinism(synth):
+    """batchify_rays chunking must not change a ray's result (tile alignment differs per chunk), and two identical
+    training steps must give bitwise-identical gradients (fixed-order chunk reduction)."""
+    render_mod = importlib.import_module("a-nerf_amd.render")
+    tb = importlib.import_module("test_hip_backward")
+    c = build("train_pytest")
+    caster = tb.make_caster(c)
+    caster.eval()
+    kw = dict(rays=(dev(c["rays_o"]), dev(c["rays_d"])), use_viewdirs=True, ray_caster=caster, kp_batch=dev(c["kp"]),
+              skts=dev(c["skts"]), cyls=dev(c["cyls"]), bones=dev(c["bones"]), cams=None, subject_idxs=None, N_samples=24,
+              N_importance=8, preproc_kwargs={"density_scale": 1.0, "density_fn": torch.nn.functional.relu})
+    a = render_mod.render(64, 64, 75.0, chunk=4096, **kw)
+    b = render_mod.render(64, 64, 75.0, chunk=7, **kw)
+    for k in ["rgb_map", "acc_map", "alpha", "rgb0"]:
+        assert torch.equal(a[k], b[k]), k
+    caster.train()
+    grads = []
+    for _ in range(2):
+        caster.zero_grad()
+        out = render_mod.render(64, 64, 75.0, chunk=4096, perturb=1.0, raw_noise_std=1.0, pytest=True, **kw)
+        render_mod.nerf_loss(out, torch.full((c["n"], 3), 0.3, device="cuda"))[0].backward()
+        grads.append([p.grad.clone() for p in caster.parameters() if p.grad is not None])
+    assert len(grads[0]) == 48
+    for g0, g1 in zip(*grads):
+        assert torch.equal(g0, g1)

@@ -1,0 +1,101 @@
+"""CPU: host-side mirror of the reference interface (no HIP compute): constructor parity, checkpoint key layout,
+tau schedule, configuration guards."""
+import argparse
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+networks = importlib.import_module("a-nerf_amd.networks")
+raycaster = importlib.import_module("a-nerf_amd.raycaster")
+synth = importlib.import_module("a-nerf_amd.synth")
+
+
+def surreal_args(**over):
+    """The attributes create_raycaster reads, with run_nerf.config_parser defaults + configs/surreal/surreal.txt."""
+    a = dict(n_framecodes=None, use_cutoff=True, normalize_cutoff=False, cutoff_mm=500.0, ext_scale=0.001, cutoff_inputs=True,
+             opt_cutoff=False, freq_schedule=False, init_freq=0.0, cut_to_dist=False, cutoff_shift=False, multires=7, i_embed=0,
+             cutoff_bones=False, multires_bones=0, use_viewdirs=True, cutoff_viewdir=True, multires_views=4, N_importance=16,
+             netdepth=8, netwidth=256, opt_framecode=False, framecode_size=16, density_scale=1.0, single_net=False, lrate=5e-4,
+             basedir="/nonexistent", expname="x", ft_path=None, no_reload=True, finetune=False, fix_layer=0, debug=False,
+             perturb=1.0, N_samples=64, raw_noise_std=1.0, ray_noise_std=0.0, lindisp=False, nerf_type="nerf",
+             pts_tr_type="local", kp_dist_type="reldist", bone_type="reldir", view_type="relray", density_type="relu",
+             softplus_shift=0.0, weight_decay=None, cutoff_step=250, cutoff_rate=10.0, freq_schedule_step=50)
+    a.update(over)
+    return argparse.Namespace(**a)
+
+
+class Skel:
+    joint_names = ["j%d" % i for i in range(24)]
+    joint_trees = np.asarray(synth.SMPL_PARENTS)
+
+
+def data_attrs():
+    return {"skel_type": Skel, "near": 0.0, "far": 1.0, "n_views": 8, "joint_coords": np.tile(np.eye(3, dtype=np.float32), (24, 1, 1))}
+
+
+def test_create_raycaster_tuple_and_checkpoint_layout():
+    rk_train, rk_test, start, grad_vars, optimizer, ckpt = raycaster.create_raycaster(surreal_args(), data_attrs(), device="cpu")
+    assert start == 0 and ckpt is None and len(grad_vars) == 48
+    assert sum(p.numel() for p in grad_vars) == 2 * 864260
+    assert set(rk_train) == {"ray_caster", "perturb", "N_importance", "N_samples", "use_viewdirs", "raw_noise_std",
+                             "ray_noise_std", "ext_scale", "preproc_kwargs", "lindisp", "nerf_type"}
+    assert rk_test["perturb"] is False and rk_test["raw_noise_std"] == 0.0
+    caster = rk_test["ray_caster"]
+    assert rk_train["ray_caster"].module is caster           # trainer.py:265,270,504 reach through .module
+    sd = caster.state_dict()
+    assert set(sd) == {"network_fn_state_dict", "network_fine_state_dict", "embed_state_dict", "embedbones_state_dict",
+                       "embeddirs_state_dict"}
+    ref_names = ["pts_linears.%d.%s" % (i, s) for i in range(8) for s in ("weight", "bias")] + \
+        ["alpha_linear.weight", "alpha_linear.bias", "views_linears.0.weight", "views_linears.0.bias",
+         "feature_linear.weight", "feature_linear.bias", "rgb_linear.weight", "rgb_linear.bias"]
+    assert sorted(sd["network_fn_state_dict"]) == sorted(ref_names)
+    assert sd["network_fn_state_dict"]["pts_linears.5.weight"].shape == (256, 688)
+    assert sd["network_fn_state_dict"]["views_linears.0.weight"].shape == (128, 904)
+    assert sorted(sd["embed_state_dict"]) == ["cutoff_dist", "tau"] and sd["embed_state_dict"]["cutoff_dist"].shape == (24,)
+    assert float(sd["embed_state_dict"]["cutoff_dist"][0]) == pytest.approx(0.5)
+    assert len(sd["embedbones_state_dict"]) == 0
+    # round trip through the reference's checkpoint dict layout (trainer.py:498-505)
+    ck = {"global_step": 7, **{k: {n: v.clone() + 1 for n, v in d.items()} for k, d in sd.items()}}
+    caster.load_state_dict(ck)
+    assert torch.equal(caster.network.pts_linears[0].bias, ck["network_fn_state_dict"]["pts_linears.0.bias"])
+    # shape-mismatched tensors are skipped like run_nerf_helpers.filter_state_dict
+    ck["network_fine_state_dict"]["rgb_linear.weight"] = torch.zeros(3, 64)
+    caster.load_state_dict(ck)
+
+
+def test_mixamo_and_single_net_variants():
+    _, rk, _, gv, _, _ = raycaster.create_raycaster(surreal_args(opt_framecode=True), data_attrs(), device="cpu")
+    net = rk["ray_caster"].network
+    assert net.views_linears[0].weight.shape == (128, 920) and net.framecodes.codes.weight.shape == (8, 16)
+    assert len(gv) == 50
+    _, rk, _, gv, _, _ = raycaster.create_raycaster(surreal_args(single_net=True, multires_views=0, N_samples=96, N_importance=48),
+                                                    data_attrs(), device="cpu")
+    c = rk["ray_caster"]
+    assert c.network_fine is c.network and c.single_net and len(gv) == 24
+    assert c.network.views_linears[0].weight.shape == (128, 328)
+
+
+def test_tau_schedule_matches_reference_formula():
+    _, rk, *_ = raycaster.create_raycaster(surreal_args(), data_attrs(), device="cpu")
+    c = rk["ray_caster"]
+    args = surreal_args()
+    for step in [0, 1000, 150000, 10 ** 7]:
+        c.update_embed_fns(step, args)
+        expect = min(20.0 * 10.0 ** (step / 250000.0), 2000.0)       # cutoff_embedder.py:181-183
+        assert c.embed_fn.get_tau() == pytest.approx(expect, rel=1e-5)
+        assert c.embeddirs_fn.get_tau() == pytest.approx(expect, rel=1e-5)
+    assert c.embedbones_fn.get_tau() == 0.0
+
+
+def test_unsupported_configurations_fail_loudly():
+    for bad in [dict(kp_dist_type="relpos"), dict(view_type="rayangle"), dict(bone_type="axisang"), dict(cutoff_bones=True),
+                dict(multires_bones=2), dict(use_cutoff=False)]:
+        with pytest.raises(NotImplementedError):
+            raycaster.create_raycaster(surreal_args(**bad), data_attrs(), device="cpu")
+    with pytest.raises(NotImplementedError):
+        networks.NeRF(input_ch=360, input_ch_bones=72, input_ch_views=648, use_viewdirs=False)
+    with pytest.raises(NotImplementedError):
+        networks.get_embedder(7, input_dims=24, cutoff_kwargs={"cutoff": True, "cutoff_inputs": True, "cutoff_dim": 24,
+                                                               "dist_inputs": False, "freq_schedule": True})[0]
