@@ -89,6 +89,10 @@ SIGNATURES = {
                                  C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "anerf_assemble_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
+    "anerf_pack_params_b3": (C.c_int, [C.POINTER(AnerfNetParams), C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    "anerf_mlp_raw_b3": (C.c_int, [C.POINTER(AnerfConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                   C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float,
+                                   C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

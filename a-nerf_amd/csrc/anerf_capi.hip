@@ -43,6 +43,11 @@ int mlp_raw_entry(const AnerfConfig* cfg, const float* packed, const float* aux,
 int mlp_bwd_entry(const float* packed_t, const float* aux, const float* draw, const AnerfSaved* sv, float* dz, float* df,
                   float* dzv, long long P, int nstages, hipStream_t st);
 int launch_weight_grads(GemmBatch& G, float* ws, hipStream_t st);
+int mlp_b3_entry(const AnerfConfig* cfg, const float* packed, const float* aux, const float* rays, int ray_stride,
+                 const float* z, const float* skts, long long skt_stride, const float* cam, const float* codes, int n_codes,
+                 float tau_v, float tau_d, const float* cut_v, const float* cut_d, long long P, int N, int S, int nstages,
+                 float* raw, hipStream_t st);
+int launch_pack_b3(const AnerfNetParams* P, const int32_t* table, long long n, void* out, hipStream_t st);
 int mlp_density_entry(const float* packed, const float* aux, const float* pts, const float* skts, float tau_v,
                       const float* cut_v, long long P, int nstages_trunk, float* sigma, hipStream_t st);
 int launch_gen_rays(int W, int x0, int y0, int bw, int bh, float fx, float fy, float cx, float cy, const float* c2w,
@@ -134,6 +139,45 @@ static std::vector<BSeg> bwd_segments(const AnerfConfig* c) {
   for (int l = 4; l >= 1; --l) s.push_back({l, 256, 0, 256});
   return s;
 }
+// ---- bf16x3 forward image (which = 3): k-steps of 16 input columns, (hi, lo) fragment pair per 32-row block
+static int nu_pad(const AnerfConfig* c) { return (36 * (1 + 2 * c->multires_views) + c->framecode_ch / 2 + 7) / 8 * 8; }
+static int b3_ksteps(const AnerfConfig* c, const Seg& s) {
+  switch (s.kind) {
+    case 0: return 16;
+    case 1: return 27;
+    case 2: return 27 + 16;
+    default: return 16 + nu_pad(c) / 8;
+  }
+}
+static int b3_stages(const AnerfConfig* c, const Seg& s) { return (b3_ksteps(c, s) * s.NB * 2 + STAGE_FRAGS - 1) / STAGE_FRAGS; }
+// input column supplied by lane half hh, element e of k-step ks (-1: zero padding)
+static int b3_col(const AnerfConfig* c, const Seg& s, int ks, int hh, int e) {
+  auto own = [&](int a) { return 8 * (a >> 2) + 4 * hh + (a & 3); };
+  auto hid = [&](int k) { return 16 * k + (e & 3) + 8 * (e >> 2) + 4 * hh; };
+  auto xcol = [&](int k) {
+    const int idx = 8 * k + e;
+    if (idx < 180) return 24 * (idx / 12) + own(idx % 12);
+    const int i = idx - 180;
+    return dim_v(c) + 3 * own(i / 3) + i % 3;
+  };
+  switch (s.kind) {
+    case 0: return hid(ks);
+    case 1: return xcol(ks);
+    case 2: return ks < 27 ? xcol(ks) : dim_x(c) + hid(ks - 27);
+    default: {
+      if (ks < 16) return hid(ks);
+      const int idx = 8 * (ks - 16) + e, nband = 1 + 2 * c->multires_views;
+      if (idx < 36 * nband) {
+        const int b = idx / 36, i = idx % 36;
+        return 256 + 72 * b + 3 * own(i / 3) + i % 3;
+      }
+      const int j = idx - 36 * nband;
+      if (j < c->framecode_ch / 2) return 256 + dim_d(c) + 8 * hh + j;
+      return -1;
+    }
+  }
+}
+
 static int bseg_stages(const BSeg& s) { return (s.ncontract / 8) * 8 / STAGE_FRAGS; }
 static int u_width(const AnerfConfig* c) { return dim_d(c) + c->framecode_ch; }
 
@@ -149,14 +193,16 @@ int anerf_version(void) { return 1; }
 int anerf_layout(const AnerfConfig* cfg, int which, AnerfLayout* out) {
   if (!out) return set_error(ANERF_E_NULL, "out is NULL");
   if (!config_ok(cfg)) return set_error(ANERF_E_CONFIG, "unsupported AnerfConfig");
-  if (which < 0 || which > 2) return set_error(ANERF_E_CONFIG, "which must be 0 (W), 1 (W^T) or 2 (input-gradient image)");
+  if (which < 0 || which > 3) return set_error(ANERF_E_CONFIG, "which must be 0 (W), 1 (W^T), 2 (input-gradient image) or 3 (bf16x3 W)");
   int stages = 0;
   if (which == 0)
     for (const Seg& s : fwd_segments(cfg)) stages += seg_stages(s);
   else if (which == 1)
     for (const BSeg& s : bwd_segments(cfg)) stages += bseg_stages(s);
-  else
+  else if (which == 2)
     stages = 2 * (8 + 8) + ((u_width(cfg) + 255) / 256) * 4;
+  else
+    for (const Seg& s : fwd_segments(cfg)) stages += b3_stages(cfg, s);
   out->n_stages = stages;
   out->stream_floats = (int64_t)stages * STAGE_FLOATS;
   out->aux_floats = AUX_FLOATS;
@@ -169,8 +215,25 @@ int anerf_build_pack_table(const AnerfConfig* cfg, int which, int32_t* table) {
   const int rc = anerf_layout(cfg, which, &L);
   if (rc) return rc;
   if (!table) return set_error(ANERF_E_NULL, "table is NULL");
-  for (int64_t i = 0; i < L.stream_floats + L.aux_floats; ++i) table[i] = -1;
+  const int64_t n_stream_entries = which == 3 ? 2 * L.stream_floats : L.stream_floats;   // which=3: one per bf16 element
+  for (int64_t i = 0; i < n_stream_entries + L.aux_floats; ++i) table[i] = -1;
   int64_t pos = 0;
+  if (which == 3) {
+    for (const Seg& s : fwd_segments(cfg)) {
+      for (int ks = 0; ks < b3_ksteps(cfg, s); ++ks)
+        for (int nb = 0; nb < s.NB; ++nb)
+          for (int part = 0; part < 2; ++part)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int e = 0; e < 8; ++e) {
+                const int col = b3_col(cfg, s, ks, lane >> 5, e);
+                if (col < 0) continue;
+                const int n = 32 * nb + (lane & 31);
+                table[pos + ((int64_t)((ks * s.NB + nb) * 2 + part) * 64 + lane) * 8 + e] =
+                    (part << 29) | (s.tensor << 24) | (n * s.K + col);
+              }
+      pos += (int64_t)b3_stages(cfg, s) * STAGE_FRAGS * 512;
+    }
+  }
   if (which == 1) {
     for (const BSeg& s : bwd_segments(cfg)) {
       for (int kg = 0; kg < s.ncontract / 8; ++kg)
@@ -218,7 +281,7 @@ int anerf_build_pack_table(const AnerfConfig* cfg, int which, int32_t* table) {
           }
     pos += (int64_t)seg_stages(s) * STAGE_FLOATS;
   }
-  int32_t* aux = table + L.stream_floats;
+  int32_t* aux = table + n_stream_entries;
   for (int i = 0; i < 8; ++i)
     for (int n = 0; n < 256; ++n) aux[AUX_B0 + 256 * i + n] = ((12 + i) << 24) | n;
   for (int n = 0; n < 256; ++n) aux[AUX_BF + n] = ((12 + 9) << 24) | n;
@@ -235,6 +298,35 @@ int anerf_pack_params(const AnerfNetParams* params, const int32_t* table, int64_
   for (int i = 0; i < 12; ++i)
     if (!params->w[i] || !params->b[i]) return set_error(ANERF_E_NULL, "pack: NULL tensor");
   return launch_pack(params, table, n, out, (hipStream_t)stream);
+}
+
+int anerf_pack_params_b3(const AnerfNetParams* params, const int32_t* table, int64_t stream_floats, int64_t aux_floats,
+                         float* out, void* stream) {
+  if (!params || !table || !out) return set_error(ANERF_E_NULL, "pack_b3: NULL pointer");
+  for (int i = 0; i < 12; ++i)
+    if (!params->w[i] || !params->b[i]) return set_error(ANERF_E_NULL, "pack_b3: NULL tensor");
+  int rc = launch_pack_b3(params, table, 2 * stream_floats, out, (hipStream_t)stream);
+  if (rc) return rc;
+  return launch_pack(params, table + 2 * stream_floats, aux_floats, out + stream_floats, (hipStream_t)stream);
+}
+
+int anerf_mlp_raw_b3(const AnerfConfig* cfg, const float* packed, const float* aux, const float* rays, int32_t ray_stride,
+                     const float* z_vals, const float* skts, int64_t skt_ray_stride, const float* cam_idx,
+                     const float* codes, int32_t n_codes, float tau_v, float tau_d, const float* cutoff_v,
+                     const float* cutoff_d, int32_t n_rays, int32_t n_samples, float* raw, void* stream) {
+  if (n_rays == 0) return ANERF_OK;
+  AnerfLayout L;
+  const int rc = anerf_layout(cfg, 3, &L);
+  if (rc) return rc;
+  if (!packed || !aux || !rays || !z_vals || !skts || !cutoff_v || !cutoff_d || !raw)
+    return set_error(ANERF_E_NULL, "mlp_raw_b3: NULL pointer");
+  if (cfg->framecode_ch && (!cam_idx || !codes || n_codes < 1)) return set_error(ANERF_E_NULL, "mlp_raw_b3: frame codes");
+  if (n_samples < MIN_SAMPLES || n_samples > MAX_SAMPLES) return set_error(ANERF_E_SHAPE, "mlp_raw_b3: 8 <= samples <= 512");
+  if (skt_ray_stride != 0 && skt_ray_stride != 384) return set_error(ANERF_E_SHAPE, "mlp_raw_b3: skt_ray_stride 0|384");
+  if (ray_stride < 6) return set_error(ANERF_E_SHAPE, "mlp_raw_b3: ray_stride >= 6");
+  return mlp_b3_entry(cfg, packed, aux, rays, ray_stride, z_vals, skts, skt_ray_stride, cam_idx, codes, n_codes, tau_v, tau_d,
+                      cutoff_v, cutoff_d, (long long)n_rays * n_samples, n_rays, n_samples, L.n_stages, raw,
+                      (hipStream_t)stream);
 }
 
 int anerf_ray_bounds(const float* rays, int32_t ray_stride, const float* cyls, int32_t n_rays, float* near_far,

@@ -1,0 +1,143 @@
+// anerf_fwd_common.h -- pieces shared by the forward kernels (fp32 k_mlp_fwd, bf16x3 k_mlp_fwd_b3): LDS layout,
+// 3-slot weight-stream pipe, bias init / ReLU pass / head dot on the accumulator sets, kernel argument block.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "anerf_dev.h"
+
+namespace anerf {
+
+constexpr int RING_SLOTS = 3;
+constexpr int LDS_AUX_OFF = RING_SLOTS * STAGE_BYTES;             // biases + head rows (AUX_FLOATS floats)
+constexpr int LDS_AUX_BYTES = (AUX_FLOATS * 4 + 255) / 256 * 256;
+constexpr int LDS_BONES_OFF = LDS_AUX_OFF + LDS_AUX_BYTES;        // MAX_TILE_RAYS x 24 x 3 float4
+
+// ------------------------------------------------------------------------------------------------
+// weight-stream pipe: global -> LDS ring (3 slots x 32 KiB), all 4 waves cooperate.  Invariant while stage s is
+// being consumed: stages s and s+1 are complete and visible to every wave; stage s+2 is in flight.
+// ------------------------------------------------------------------------------------------------
+struct Pipe3 {
+  const char* gsrc;   // per-lane source of this wave's first fragment of stage 0
+  char* smem;
+  unsigned wave_dst;  // wave-uniform LDS byte offset of this wave's 8 fragments inside a stage
+  unsigned lane16;    // lane * 16
+  unsigned cur;       // lane-relative LDS byte offset of the stage being consumed
+  unsigned nxt;       // ... of the following stage
+  int slot;           // ring slot of the stage being consumed
+  int stage;          // stage being consumed
+  int nstages;
+  f32x4 pref[8];      // fragments of the next stage's first k-group, loaded before the stage barrier
+
+  __device__ __forceinline__ void issue(int s, int sl) {
+#ifdef ANERF_EXP_NOGLDS   // ablation build only (tools/ablate.sh): never load weights
+    (void)s; (void)sl; return;
+#endif
+    const char* g = gsrc + (size_t)s * STAGE_BYTES;
+    char* l = smem + sl * STAGE_BYTES + wave_dst;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(g + i * FRAG_BYTES), (lds_ptr_t)(l + i * FRAG_BYTES), 16, 0, 0);
+  }
+  __device__ __forceinline__ void set_offsets() {
+    cur = lane16 + slot * STAGE_BYTES;
+    nxt = lane16 + (slot == RING_SLOTS - 1 ? 0 : slot + 1) * STAGE_BYTES;
+  }
+  __device__ __forceinline__ void init(const float* packed, char* smem_, int wave, int lane, int nstages_) {
+    gsrc = reinterpret_cast<const char*>(packed) + wave * (8 * FRAG_BYTES) + lane * 16;
+    smem = smem_;
+    wave_dst = wave * (8 * FRAG_BYTES);
+    lane16 = lane * 16;
+    slot = 0;
+    stage = 0;
+    nstages = nstages_;
+    set_offsets();
+    issue(0, 0);
+    if (nstages > 1) issue(1, 1);
+  }
+  // after everybody's prologue LDS writes: stages 0 and 1 landed; start stage 2
+  __device__ __forceinline__ void begin() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (nstages > 2) issue(2, 2);
+  }
+  // end of the stage being consumed: its slot is refilled with stage+3
+  __device__ __forceinline__ void end_stage() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of stages +1 / +2 has landed
+#ifndef ANERF_EXP_NOBARRIER   // ablation build only: results are wrong without the barrier
+    __syncthreads();                                    // everybody's has; nobody reads slot `slot` any more
+#endif
+    if (stage + RING_SLOTS < nstages) issue(stage + RING_SLOTS, slot);
+    slot = slot == RING_SLOTS - 1 ? 0 : slot + 1;
+    ++stage;
+    set_offsets();
+  }
+};
+
+// acc[nb][r] <- bias[n(nb,r,h)] from the LDS copy of the natural-order bias vector (bias_h = vector + 4h)
+template <int NB>
+__device__ __forceinline__ void init_bias(f32x16 (&acc)[NB], const float* bias_h) {
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(bias_h + 32 * nb + 8 * q);
+      acc[nb][4 * q + 0] = b.x;
+      acc[nb][4 * q + 1] = b.y;
+      acc[nb][4 * q + 2] = b.z;
+      acc[nb][4 * q + 3] = b.w;
+    }
+}
+
+// in-place ReLU of a finished layer (one VALU pass; measured 0.7 % of a layer, vs 4.3 % when the max is
+// interleaved with the consuming MFMAs -- tools/probe/mfma_probe2.hip)
+template <int NB>
+__device__ __forceinline__ void relu_pass(f32x16 (&acc)[NB]) {
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = fmaxf(acc[nb][r], 0.f);
+}
+
+// dot of the lane's 16*NB activation values with a natural-order weight row (LDS), summed over both halves
+template <int NB>
+__device__ __forceinline__ float head_dot(const f32x16* acc, const float* wrow_h) {
+  float s = 0.f;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(wrow_h + 32 * nb + 8 * q);
+      s = fmaf(acc[nb][4 * q + 0], w.x, s);
+      s = fmaf(acc[nb][4 * q + 1], w.y, s);
+      s = fmaf(acc[nb][4 * q + 2], w.z, s);
+      s = fmaf(acc[nb][4 * q + 3], w.w, s);
+    }
+  return s + __shfl_xor(s, 32);
+}
+
+struct MlpArgs {
+  const float* packed;
+  const float* aux;
+  const float* rays;
+  const float* z;
+  const float* skts;
+  const float* cam;
+  const float* codes;
+  const float* cut_v;
+  const float* cut_d;
+  const float* x;  // PRE
+  float* raw;
+  // TRAIN: saved activations, row-major planes with Ppad rows (rows >= P are never written)
+  float* save_h;   // [8][Ppad][256]  h0..h7 (post-ReLU)
+  float* save_f;   // [Ppad][256]     feature (no activation)
+  float* save_g;   // [Ppad][128]     view-layer output (post-ReLU)
+  float* save_x;   // [Ppad][432]     x in stream column order
+  float* save_u;   // [Ppad][UW]      view inputs (D, code) in stream column order
+  long long P;
+  long long Ppad;
+  long long skt_stride;
+  int S, N, ray_stride, n_codes, x_width, nstages;
+  float tau_v, tau_d;
+};
+
+}  // namespace anerf

@@ -26,75 +26,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
-#include "anerf_dev.h"
+#include "anerf_fwd_common.h"
 
 namespace anerf {
-
-constexpr int RING_SLOTS = 3;
-constexpr int LDS_AUX_OFF = RING_SLOTS * STAGE_BYTES;             // biases + head rows (AUX_FLOATS floats)
-constexpr int LDS_AUX_BYTES = (AUX_FLOATS * 4 + 255) / 256 * 256;
-constexpr int LDS_BONES_OFF = LDS_AUX_OFF + LDS_AUX_BYTES;        // MAX_TILE_RAYS x 24 x 3 float4
-
-// ------------------------------------------------------------------------------------------------
-// weight-stream pipe: global -> LDS ring (3 slots x 32 KiB), all 4 waves cooperate.  Invariant while stage s is
-// being consumed: stages s and s+1 are complete and visible to every wave; stage s+2 is in flight.
-// ------------------------------------------------------------------------------------------------
-struct Pipe3 {
-  const char* gsrc;   // per-lane source of this wave's first fragment of stage 0
-  char* smem;
-  unsigned wave_dst;  // wave-uniform LDS byte offset of this wave's 8 fragments inside a stage
-  unsigned lane16;    // lane * 16
-  unsigned cur;       // lane-relative LDS byte offset of the stage being consumed
-  unsigned nxt;       // ... of the following stage
-  int slot;           // ring slot of the stage being consumed
-  int stage;          // stage being consumed
-  int nstages;
-  f32x4 pref[8];      // fragments of the next stage's first k-group, loaded before the stage barrier
-
-  __device__ __forceinline__ void issue(int s, int sl) {
-#ifdef ANERF_EXP_NOGLDS   // ablation build only (tools/ablate.sh): never load weights
-    (void)s; (void)sl; return;
-#endif
-    const char* g = gsrc + (size_t)s * STAGE_BYTES;
-    char* l = smem + sl * STAGE_BYTES + wave_dst;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(g + i * FRAG_BYTES), (lds_ptr_t)(l + i * FRAG_BYTES), 16, 0, 0);
-  }
-  __device__ __forceinline__ void set_offsets() {
-    cur = lane16 + slot * STAGE_BYTES;
-    nxt = lane16 + (slot == RING_SLOTS - 1 ? 0 : slot + 1) * STAGE_BYTES;
-  }
-  __device__ __forceinline__ void init(const float* packed, char* smem_, int wave, int lane, int nstages_) {
-    gsrc = reinterpret_cast<const char*>(packed) + wave * (8 * FRAG_BYTES) + lane * 16;
-    smem = smem_;
-    wave_dst = wave * (8 * FRAG_BYTES);
-    lane16 = lane * 16;
-    slot = 0;
-    stage = 0;
-    nstages = nstages_;
-    set_offsets();
-    issue(0, 0);
-    if (nstages > 1) issue(1, 1);
-  }
-  // after everybody's prologue LDS writes: stages 0 and 1 landed; start stage 2
-  __device__ __forceinline__ void begin() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (nstages > 2) issue(2, 2);
-  }
-  // end of the stage being consumed: its slot is refilled with stage+3
-  __device__ __forceinline__ void end_stage() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of stages +1 / +2 has landed
-#ifndef ANERF_EXP_NOBARRIER   // ablation build only: results are wrong without the barrier
-    __syncthreads();                                    // everybody's has; nobody reads slot `slot` any more
-#endif
-    if (stage + RING_SLOTS < nstages) issue(stage + RING_SLOTS, slot);
-    slot = slot == RING_SLOTS - 1 ? 0 : slot + 1;
-    ++stage;
-    set_offsets();
-  }
-};
 
 // One k-group (8 contraction indices: 4 from each lane half) against NB 32-row feature blocks.
 // kg: k-group index relative to the segment (layer) start; first: first k-group of the layer (informational);
@@ -129,31 +63,6 @@ __device__ __forceinline__ void kgroup(Pipe3& pipe, f32x16 (&acc)[NB], int kg, b
   if (ks == KPS - 1 || last) pipe.end_stage();
 }
 
-// acc[nb][r] <- bias[n(nb,r,h)] from the LDS copy of the natural-order bias vector (bias_h = vector + 4h)
-template <int NB>
-__device__ __forceinline__ void init_bias(f32x16 (&acc)[NB], const float* bias_h) {
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 b = *reinterpret_cast<const f32x4*>(bias_h + 32 * nb + 8 * q);
-      acc[nb][4 * q + 0] = b.x;
-      acc[nb][4 * q + 1] = b.y;
-      acc[nb][4 * q + 2] = b.z;
-      acc[nb][4 * q + 3] = b.w;
-    }
-}
-
-// in-place ReLU of a finished layer (one VALU pass; measured 0.7 % of a layer, vs 4.3 % when the max is
-// interleaved with the consuming MFMAs -- tools/probe/mfma_probe2.hip)
-template <int NB>
-__device__ __forceinline__ void relu_pass(f32x16 (&acc)[NB]) {
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[nb][r] = fmaxf(acc[nb][r], 0.f);
-}
-
 // 32 k-groups whose B operands are the previous layer's 256 outputs, read straight from its accumulator set
 // `prev` (bias added by the accumulator init, ReLU already applied in place): no copy, no VALU in the MFMA stream.
 template <int NB, int KG0>
@@ -163,23 +72,6 @@ __device__ __forceinline__ void hidden_part(Pipe3& pipe, f32x16 (&acc)[NB], cons
   for (int kg = 0; kg < 32; ++kg)
     kgroup<NB>(pipe, acc, KG0 + kg, first && kg == 0, last && kg == 31, prev[kg >> 2][4 * (kg & 3) + 0],
                prev[kg >> 2][4 * (kg & 3) + 1], prev[kg >> 2][4 * (kg & 3) + 2], prev[kg >> 2][4 * (kg & 3) + 3]);
-}
-
-// dot of the lane's 16*NB activation values with a natural-order weight row (LDS), summed over both halves
-template <int NB>
-__device__ __forceinline__ float head_dot(const f32x16* acc, const float* wrow_h) {
-  float s = 0.f;
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 w = *reinterpret_cast<const f32x4*>(wrow_h + 32 * nb + 8 * q);
-      s = fmaf(acc[nb][4 * q + 0], w.x, s);
-      s = fmaf(acc[nb][4 * q + 1], w.y, s);
-      s = fmaf(acc[nb][4 * q + 2], w.z, s);
-      s = fmaf(acc[nb][4 * q + 3], w.w, s);
-    }
-  return s + __shfl_xor(s, 32);
 }
 
 // TRAIN: row-major store of a finished layer: features 32nb+8q+4h .. +3 of `row`
@@ -262,31 +154,6 @@ __device__ __forceinline__ void x_part(Pipe3& pipe, f32x16 (&acc)[8], const floa
       KG(3 * (1 + 2 * LV) + g, rh[4 * g], rh[4 * g + 1], rh[4 * g + 2], rh[4 * g + 3]);
   }
 }
-
-struct MlpArgs {
-  const float* packed;
-  const float* aux;
-  const float* rays;
-  const float* z;
-  const float* skts;
-  const float* cam;
-  const float* codes;
-  const float* cut_v;
-  const float* cut_d;
-  const float* x;  // PRE
-  float* raw;
-  // TRAIN: saved activations, row-major planes with Ppad rows (rows >= P are never written)
-  float* save_h;   // [8][Ppad][256]  h0..h7 (post-ReLU)
-  float* save_f;   // [Ppad][256]     feature (no activation)
-  float* save_g;   // [Ppad][128]     view-layer output (post-ReLU)
-  float* save_x;   // [Ppad][432]     x in stream column order
-  float* save_u;   // [Ppad][UW]      view inputs (D, code) in stream column order
-  long long P;
-  long long Ppad;
-  long long skt_stride;
-  int S, N, ray_stride, n_codes, x_width, nstages;
-  float tau_v, tau_d;
-};
 
 // MODE 0: rays + depths -> raw [P,4].   MODE 1 (density query, raycasters.py:597-648): points A.z = pts [P,3] under ONE
 // shared pose -> sigma logit [P]; only the trunk (layers 0..7 + alpha head) runs, the stream stops after layer 7.

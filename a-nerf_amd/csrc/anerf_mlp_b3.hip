@@ -1,0 +1,369 @@
+// anerf_mlp_b3.hip -- "bf16x3" variant of the fused encode+MLP forward kernel (render / eval path) for gfx950.
+//
+// Same dataflow as k_mlp_fwd (anerf_mlp.hip): 128-sample tile, 4 waves x 32 samples, layers computed transposed,
+// activations register-resident across all layers, weights streamed L2 -> LDS through the 3-slot ring.  The GEMMs
+// run on the bf16 matrix cores with error-compensated operands: every fp32 value x is split x = hi + lo (two
+// bf16, round-to-nearest; |x - hi - lo| <= 2^-18 |x|) and each product uses three MFMAs
+//     W x ~= Whi*Xhi + Whi*Xlo + Wlo*Xhi          (v_mfma_f32_32x32x16_bf16, fp32 accumulation)
+// i.e. ~2^-17 relative error per product instead of bf16's 2^-9: enough for the path's 1e-4 RGB bar (tests), at
+// ~5x the fp32-MFMA rate (3 x 32 cycles per K=16 instead of 8 x 64).  Weights are split once by k_pack_b3; the
+// activations are split when a k-step's B operands are formed (8 values per lane: 4 v_cvt_pk + 8 sub).
+// A k-step = 16 contraction indices: lane half h supplies 8; for hidden layers these are accumulator registers
+// 8s..8s+7 of block nbk (features 32nbk+16s + (e&3)+8(e>>2)+4h), so as in the fp32 kernel nothing is permuted.
+// Bias, accumulation, ReLU, heads and the encoding stay fp32.
+// Reference ops replaced: identical to anerf_mlp.hip (core/encoders.py, core/cutoff_embedder.py,
+// core/networks/nerf.py:94-148).
+#include "anerf_fwd_common.h"
+
+namespace anerf {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+typedef float f2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// (a, b) -> packed bf16 pairs hi, lo with a = hi.x + lo.x (+ 2^-18 rel.), round-to-nearest both times
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+  const bf2_t h = __builtin_convertvector(f2_t{a, b}, bf2_t);
+  const f2_t hf = __builtin_convertvector(h, f2_t);
+  const bf2_t l = __builtin_convertvector(f2_t{a - hf.x, b - hf.y}, bf2_t);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+
+struct BOp {
+  bf16x8 hi, lo;
+};
+
+__device__ __forceinline__ BOp split8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
+  unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+  split2(v0, v1, h0, l0);
+  split2(v2, v3, h1, l1);
+  split2(v4, v5, h2, l2);
+  split2(v6, v7, h3, l3);
+  const u32x4 h = {h0, h1, h2, h3}, l = {l0, l1, l2, l3};
+  BOp o;
+  o.hi = __builtin_bit_cast(bf16x8, h);
+  o.lo = __builtin_bit_cast(bf16x8, l);
+  return o;
+}
+
+// One k-step (16 contraction indices) against NB 32-row feature blocks: per block a (hi, lo) fragment pair from
+// LDS and three MFMAs.  ks: k-step index relative to the segment start; last: final k-step of the segment.
+template <int NB>
+__device__ __forceinline__ void kstep(Pipe3& pipe, f32x16 (&acc)[NB], int ks, bool last, const BOp& b) {
+  constexpr int KPS = STAGE_FRAGS / (2 * NB);   // k-steps per 32-fragment stage
+  constexpr int NPF = NB < 4 ? NB : 4;          // blocks whose fragments are prefetched across the stage barrier
+  const int kk = ks % KPS;
+  bf16x8 ah[NB], al[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    if (kk == 0 && ks != 0 && nb < NPF) {
+      ah[nb] = __builtin_bit_cast(bf16x8, pipe.pref[2 * nb]);
+      al[nb] = __builtin_bit_cast(bf16x8, pipe.pref[2 * nb + 1]);
+    } else {
+      ah[nb] = *reinterpret_cast<const bf16x8*>(pipe.smem + pipe.cur + ((kk * NB + nb) * 2) * FRAG_BYTES);
+      al[nb] = *reinterpret_cast<const bf16x8*>(pipe.smem + pipe.cur + ((kk * NB + nb) * 2 + 1) * FRAG_BYTES);
+    }
+  }
+  if (kk == KPS - 1 && !last) {
+#pragma unroll
+    for (int i = 0; i < 2 * NPF; ++i) pipe.pref[i] = *reinterpret_cast<const f32x4*>(pipe.smem + pipe.nxt + i * FRAG_BYTES);
+  }
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[nb], b.hi, acc[nb], 0, 0, 0);
+    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[nb], b.lo, acc[nb], 0, 0, 0);
+    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[nb], b.hi, acc[nb], 0, 0, 0);
+  }
+  if (kk == KPS - 1 || last) pipe.end_stage();
+}
+
+// 16 k-steps whose operands are the previous layer's 256 outputs (bias inside, ReLU already applied in place)
+template <int NB, int KS0>
+__device__ __forceinline__ void hidden_part_b3(Pipe3& pipe, f32x16 (&acc)[NB], const f32x16 (&prev)[8], bool last) {
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    const int nbk = ks >> 1, r0 = 8 * (ks & 1);
+    const BOp b = split8(prev[nbk][r0], prev[nbk][r0 + 1], prev[nbk][r0 + 2], prev[nbk][r0 + 3], prev[nbk][r0 + 4],
+                         prev[nbk][r0 + 5], prev[nbk][r0 + 6], prev[nbk][r0 + 7]);
+    kstep<NB>(pipe, acc, KS0 + ks, last && ks == 15, b);
+  }
+}
+
+// emit N/8 k-steps from a value array (N a multiple of 8)
+template <int NB, int N>
+__device__ __forceinline__ void emit(Pipe3& pipe, f32x16 (&acc)[NB], int ks0, int ks_last, const float (&val)[N]) {
+#pragma unroll
+  for (int k = 0; k < N / 8; ++k) {
+    const BOp b = split8(val[8 * k], val[8 * k + 1], val[8 * k + 2], val[8 * k + 3], val[8 * k + 4], val[8 * k + 5],
+                         val[8 * k + 6], val[8 * k + 7]);
+    kstep<NB>(pipe, acc, ks0 + k, ks0 + k == ks_last, b);
+  }
+}
+
+// The lane's 216 x-values, band-major [15 bands x 12 owned joints][36 bone-direction components], as 27 k-steps:
+// 7 band pairs (24 values = 3 k-steps each) then cos_6 (12) + directions (36) = 6 k-steps.
+template <int LV>
+__device__ __forceinline__ void x_part_b3(Pipe3& pipe, f32x16 (&acc)[8], const float (&v)[12], const float (&wv)[12],
+                                          const float (&rh)[36], bool last) {
+  static_assert(LV == 7, "band pairing below is written for multires = 7");
+  constexpr int KS_LAST = 26;
+  float sb[12], cb[12];
+#pragma unroll
+  for (int p = 0; p < LV; ++p) {
+    float val[24];
+#pragma unroll
+    for (int a = 0; a < 12; ++a) {
+      val[a] = (p == 0 ? v[a] : cb[a]) * wv[a];             // band 2p: raw (p = 0) or cos_{p-1}
+      if (p % 3 == 0) {
+        sincos_f32(v[a] * (float)(1 << p), sb[a], cb[a]);   // precise every third band
+      } else {
+        const float s_old = sb[a], c_old = cb[a];
+        sb[a] = 2.f * s_old * c_old;
+        cb[a] = fmaf(-2.f * s_old, s_old, 1.f);
+      }
+      val[12 + a] = sb[a] * wv[a];                           // band 2p+1: sin_p
+    }
+    emit<8, 24>(pipe, acc, 3 * p, last ? KS_LAST : -1, val);
+  }
+  float val[48];
+#pragma unroll
+  for (int a = 0; a < 12; ++a) val[a] = cb[a] * wv[a];       // band 14: cos_6
+#pragma unroll
+  for (int i = 0; i < 36; ++i) val[12 + i] = rh[i];
+  emit<8, 48>(pipe, acc, 3 * LV, last ? KS_LAST : -1, val);
+}
+
+template <int LV, int LD, int CODE>
+__global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 31, h = lane >> 5;
+
+  Pipe3 pipe;
+  pipe.init(A.packed, smem, wave, lane, A.nstages);
+
+  const long long p = (long long)blockIdx.x * TILE + wave * 32 + m;
+  const bool valid = p < A.P;
+  const long long pc = valid ? p : A.P - 1;
+
+  float* aux_l = reinterpret_cast<float*>(smem + LDS_AUX_OFF);
+  for (int i = tid; i < AUX_FLOATS / 4; i += 256)
+    reinterpret_cast<f32x4*>(aux_l)[i] = reinterpret_cast<const f32x4*>(A.aux)[i];
+  const float* aux_h = aux_l + 4 * h;
+
+  float v[12], wv[12], rh[36];
+  float dray[3];
+  const f32x4* bones4 = reinterpret_cast<const f32x4*>(smem + LDS_BONES_OFF);
+  const long long tile_p0 = (long long)blockIdx.x * TILE;
+  const long long ray0 = tile_p0 / A.S;
+  long long ray1 = (tile_p0 + TILE - 1) / A.S;
+  if (ray1 > A.N - 1) ray1 = A.N - 1;
+  const long long ray = pc / A.S;
+  const int n_stage_rays = A.skt_stride == 0 ? 1 : (int)(ray1 - ray0 + 1);
+  const int lr = A.skt_stride == 0 ? 0 : (int)(ray - ray0);
+  {
+    f32x4* bw = reinterpret_cast<f32x4*>(smem + LDS_BONES_OFF);
+    for (int i = tid; i < n_stage_rays * 72; i += 256) {
+      const int ri = i / 72, rem = i - ri * 72, j = rem / 3, row = rem - 3 * j;
+      bw[i] = *reinterpret_cast<const f32x4*>(A.skts + (ray0 + ri) * A.skt_stride + j * 16 + row * 4);
+    }
+  }
+  const float* rp = A.rays + ray * A.ray_stride;
+  const float z = A.z[pc];
+  dray[0] = rp[3];
+  dray[1] = rp[4];
+  dray[2] = rp[5];
+  const float x0 = fmaf(dray[0], z, rp[0]), x1 = fmaf(dray[1], z, rp[1]), x2 = fmaf(dray[2], z, rp[2]);
+  pipe.begin();
+#pragma unroll
+  for (int a = 0; a < 12; ++a) {
+    const int j = 8 * (a >> 2) + 4 * h + (a & 3);
+    const f32x4 r0 = bones4[(lr * 24 + j) * 3 + 0], r1 = bones4[(lr * 24 + j) * 3 + 1], r2 = bones4[(lr * 24 + j) * 3 + 2];
+    const float y0 = r0.x * x0 + r0.y * x1 + r0.z * x2 + r0.w;
+    const float y1 = r1.x * x0 + r1.y * x1 + r1.z * x2 + r1.w;
+    const float y2 = r2.x * x0 + r2.y * x1 + r2.z * x2 + r2.w;
+    const float n = sqrtf(y0 * y0 + y1 * y1 + y2 * y2);
+    const float inv = 1.0f / fmaxf(n, 1e-12f);
+    v[a] = n;
+    rh[3 * a + 0] = y0 * inv;
+    rh[3 * a + 1] = y1 * inv;
+    rh[3 * a + 2] = y2 * inv;
+    wv[a] = cutoff_gate(A.tau_v, n, A.cut_v[j]);
+  }
+
+  constexpr int DIMD = 72 * (1 + 2 * LD);
+  constexpr int KSX = 27;   // k-steps of the x part
+  f32x16 accA[8], accB[8];
+
+  // ---- layer 0
+  init_bias<8>(accA, aux_h + AUX_B0);
+  x_part_b3<LV>(pipe, accA, v, wv, rh, true);
+  relu_pass<8>(accA);
+  // ---- layers 1..4
+#pragma unroll 1
+  for (int L = 1; L <= 3; L += 2) {
+    init_bias<8>(accB, aux_h + AUX_B0 + 256 * L);
+    hidden_part_b3<8, 0>(pipe, accB, accA, true);
+    relu_pass<8>(accB);
+    init_bias<8>(accA, aux_h + AUX_B0 + 256 * (L + 1));
+    hidden_part_b3<8, 0>(pipe, accA, accB, true);
+    relu_pass<8>(accA);
+  }
+  // ---- layer 5 (skip): x re-encoded (opaque so that the compiler does not keep layer 0's products alive)
+#pragma unroll
+  for (int a = 0; a < 12; ++a) asm volatile("" : "+v"(v[a]), "+v"(wv[a]));
+  init_bias<8>(accB, aux_h + AUX_B0 + 256 * 5);
+  x_part_b3<LV>(pipe, accB, v, wv, rh, false);
+  hidden_part_b3<8, KSX>(pipe, accB, accA, true);
+  relu_pass<8>(accB);
+  // ---- layers 6, 7
+  init_bias<8>(accA, aux_h + AUX_B0 + 256 * 6);
+  hidden_part_b3<8, 0>(pipe, accA, accB, true);
+  relu_pass<8>(accA);
+  init_bias<8>(accB, aux_h + AUX_B0 + 256 * 7);
+  hidden_part_b3<8, 0>(pipe, accB, accA, true);
+  relu_pass<8>(accB);
+  const float sigma_raw = head_dot<8>(accB, aux_h + AUX_WA) + aux_l[AUX_BA];
+  // ---- feature layer
+  init_bias<8>(accA, aux_h + AUX_BF);
+  hidden_part_b3<8, 0>(pipe, accA, accB, true);
+  // ---- view layer: [feature (16 k-steps); D bands; code; zero padding to a multiple of 8 values per lane]
+  f32x16 accv[4];
+  init_bias<4>(accv, aux_h + AUX_BV);
+  hidden_part_b3<4, 0>(pipe, accv, accA, false);
+  constexpr int NU = 36 * (1 + 2 * LD) + CODE / 2;          // values per lane
+  constexpr int NUP = (NU + 7) / 8 * 8;
+  constexpr int KSV_LAST = 16 + NUP / 8 - 1;
+  float e[36], wd[12];
+#pragma unroll
+  for (int a = 0; a < 12; ++a) {
+    const int j = 8 * (a >> 2) + 4 * h + (a & 3);
+    const f32x4 r0 = bones4[(lr * 24 + j) * 3 + 0], r1 = bones4[(lr * 24 + j) * 3 + 1], r2 = bones4[(lr * 24 + j) * 3 + 2];
+    const float y0 = r0.x * dray[0] + r0.y * dray[1] + r0.z * dray[2];
+    const float y1 = r1.x * dray[0] + r1.y * dray[1] + r1.z * dray[2];
+    const float y2 = r2.x * dray[0] + r2.y * dray[1] + r2.z * dray[2];
+    const float inv = 1.0f / fmaxf(sqrtf(y0 * y0 + y1 * y1 + y2 * y2), 1e-12f);
+    e[3 * a + 0] = y0 * inv;
+    e[3 * a + 1] = y1 * inv;
+    e[3 * a + 2] = y2 * inv;
+    wd[a] = cutoff_gate(A.tau_d, v[a], A.cut_d[j]);
+  }
+  float sbe[36], cbe[36];
+#pragma unroll
+  for (int pq = 0; pq < LD; ++pq) {       // band pairs (2pq, 2pq+1) = (raw | cos_{pq-1}, sin_pq): 72 values = 9 k-steps
+    float val[72];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) {
+      val[i] = (pq == 0 ? e[i] : cbe[i]) * wd[i / 3];
+      if (pq % 3 == 0) {
+        sincos_f32(e[i] * (float)(1 << pq), sbe[i], cbe[i]);
+      } else {
+        const float s_old = sbe[i], c_old = cbe[i];
+        sbe[i] = 2.f * s_old * c_old;
+        cbe[i] = fmaf(-2.f * s_old, s_old, 1.f);
+      }
+      val[36 + i] = sbe[i] * wd[i / 3];
+    }
+    emit<4, 72>(pipe, accv, 16 + 9 * pq, KSV_LAST, val);
+  }
+  {
+    // last band (cos_{LD-1}, or the raw band when LD == 0) + frame code + zero padding
+    constexpr int NT = NUP - 72 * LD;
+    float val[NT];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) val[i] = (LD == 0 ? e[i] : cbe[i]) * wd[i / 3];
+    if constexpr (CODE > 0) {
+      int ci = (int)A.cam[ray];
+      ci = ci < 0 ? 0 : (ci >= A.n_codes ? A.n_codes - 1 : ci);
+      const float* crow = A.codes + (long long)ci * CODE + 8 * h;
+      const f32x4 c0 = *reinterpret_cast<const f32x4*>(crow), c1 = *reinterpret_cast<const f32x4*>(crow + 4);
+      val[36] = c0.x; val[37] = c0.y; val[38] = c0.z; val[39] = c0.w;
+      val[40] = c1.x; val[41] = c1.y; val[42] = c1.z; val[43] = c1.w;
+    }
+#pragma unroll
+    for (int i = NU - 72 * LD; i < NT; ++i) val[i] = 0.f;
+    emit<4, NT>(pipe, accv, 16 + 9 * LD, KSV_LAST, val);
+  }
+  relu_pass<4>(accv);
+  const float c0 = head_dot<4>(accv, aux_h + AUX_WC + 0) + aux_l[AUX_BC + 0];
+  const float c1 = head_dot<4>(accv, aux_h + AUX_WC + 128) + aux_l[AUX_BC + 1];
+  const float c2 = head_dot<4>(accv, aux_h + AUX_WC + 256) + aux_l[AUX_BC + 2];
+  if (valid && h == 0) {
+    f32x4 o = {c0, c1, c2, sigma_raw};
+    *reinterpret_cast<f32x4*>(A.raw + p * 4) = o;
+  }
+}
+
+template <int LV, int LD, int CODE>
+static int launch_b3(const MlpArgs& a, hipStream_t st) {
+  const long long nblk = (a.P + TILE - 1) / TILE;
+  if (nblk <= 0) return ANERF_OK;
+  const size_t lds = LDS_BONES_OFF + MAX_TILE_RAYS * 72 * 16;
+  auto kern = k_mlp_fwd_b3<LV, LD, CODE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, a);
+  return check_launch("k_mlp_fwd_b3");
+}
+
+int mlp_b3_entry(const AnerfConfig* cfg, const float* packed, const float* aux, const float* rays, int ray_stride,
+                 const float* z, const float* skts, long long skt_stride, const float* cam, const float* codes, int n_codes,
+                 float tau_v, float tau_d, const float* cut_v, const float* cut_d, long long P, int N, int S, int nstages,
+                 float* raw, hipStream_t st) {
+  MlpArgs a;
+  a.packed = packed; a.aux = aux; a.rays = rays; a.z = z; a.skts = skts; a.cam = cam; a.codes = codes;
+  a.cut_v = cut_v; a.cut_d = cut_d; a.x = nullptr; a.raw = raw; a.P = P; a.Ppad = P; a.skt_stride = skt_stride;
+  a.S = S; a.N = N; a.ray_stride = ray_stride; a.n_codes = n_codes; a.x_width = 0; a.nstages = nstages;
+  a.tau_v = tau_v; a.tau_d = tau_d;
+  a.save_h = a.save_f = a.save_g = a.save_x = a.save_u = nullptr;
+  const int ld = cfg->multires_views, cd = cfg->framecode_ch;
+  if (cfg->multires != 7) return set_error(ANERF_E_CONFIG, "multires must be 7");
+  if (ld == 4 && cd == 0) return launch_b3<7, 4, 0>(a, st);
+  if (ld == 4 && cd == 16) return launch_b3<7, 4, 16>(a, st);
+  if (ld == 0 && cd == 0) return launch_b3<7, 0, 0>(a, st);
+  return set_error(ANERF_E_CONFIG, "unsupported (multires_views, framecode_ch); built: (4,0) (4,16) (0,0)");
+}
+
+// ------------------------------------------------------------------------------------------------
+// parameter gather + hi/lo split into the bf16x3 weight image (which = 3).  Table entry per 16-bit element:
+// bit 29 = part (0 hi, 1 lo), bits 24..28 = tensor id, bits 0..23 = element offset; -1 = zero.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_pack_b3(AnerfNetParams P, const int32_t* __restrict__ table, long long n, unsigned short* __restrict__ out) {
+  const float* tens[24];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    tens[i] = P.w[i];
+    tens[12 + i] = P.b[i];
+  }
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int32_t e = table[i];
+    unsigned short val = 0;
+    if (e >= 0) {
+      const int part = (e >> 29) & 1, id = (e >> 24) & 31, off = e & 0xFFFFFF;
+      const float* src = P.w[0];
+#pragma unroll
+      for (int k = 0; k < 24; ++k)
+        if (id == k) src = tens[k];
+      const float x = src[off];
+      const __bf16 hi = (__bf16)x;
+      const __bf16 r = part ? (__bf16)(x - (float)hi) : hi;
+      val = __builtin_bit_cast(unsigned short, r);
+    }
+    out[i] = val;
+  }
+}
+
+int launch_pack_b3(const AnerfNetParams* P, const int32_t* table, long long n, void* out, hipStream_t st) {
+  const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(k_pack_b3, dim3(blocks), dim3(256), 0, st, *P, table, n, (unsigned short*)out);
+  return check_launch("k_pack_b3");
+}
+
+}  // namespace anerf

@@ -69,7 +69,7 @@ def pack_table(cfg, device, which=0):
     k = (cfg.key(), which, str(device))
     if k not in _table_cache:
         sf, af, _, _ = layout(cfg, which)
-        host = np.empty(sf + af, dtype=np.int32)
+        host = np.empty((2 * sf if which == 3 else sf) + af, dtype=np.int32)   # which=3: one entry per bf16 element
         cc = cfg.c()
         _lib.check(_lib.load().anerf_build_pack_table(C.byref(cc), which, host.ctypes.data_as(C.c_void_p)), "anerf_build_pack_table")
         _table_cache[k] = torch.from_numpy(host).to(device)
@@ -102,7 +102,10 @@ def pack_params(cfg, params, which=0, out=None):
     if out is None:
         out = torch.empty(sf + af, dtype=torch.float32, device=dev)
     st, keep = net_params_struct(params)
-    _lib.check(_lib.load().anerf_pack_params(C.byref(st), _p(table), sf + af, _p(out), _stream()), "anerf_pack_params")
+    if which == 3:
+        _lib.check(_lib.load().anerf_pack_params_b3(C.byref(st), _p(table), sf, af, _p(out), _stream()), "anerf_pack_params_b3")
+    else:
+        _lib.check(_lib.load().anerf_pack_params(C.byref(st), _p(table), sf + af, _p(out), _stream()), "anerf_pack_params")
     return out[:sf], out[sf:]
 
 
@@ -127,8 +130,9 @@ def coarse_z(near_far, stats, rays, n_samples, t_rand=None, lindisp=False):
     return z, nf_fixed
 
 
-def mlp_raw(cfg, packed, aux, rays, z_vals, skts, tau_v, tau_d, cut_v, cut_d, cam_idx=None, codes=None):
-    """Fused encode + MLP: raw [N,S,4].  skts [N,24,4,4] or [1,24,4,4] (shared pose)."""
+def mlp_raw(cfg, packed, aux, rays, z_vals, skts, tau_v, tau_d, cut_v, cut_d, cam_idx=None, codes=None, precision="fp32"):
+    """Fused encode + MLP: raw [N,S,4].  skts [N,24,4,4] or [1,24,4,4] (shared pose).
+    precision "fp32" (image which=0) or "bf16x3" (image which=3: hi/lo-split bf16 MFMAs, fp32 accumulation)."""
     rays, z_vals, skts = _f32c(rays, "rays"), _f32c(z_vals, "z_vals"), _f32c(skts, "skts")
     n, s = z_vals.shape
     if skts.shape[0] not in (1, n):
@@ -137,10 +141,13 @@ def mlp_raw(cfg, packed, aux, rays, z_vals, skts, tau_v, tau_d, cut_v, cut_d, ca
     cam_idx, codes = _f32c(cam_idx, "cam_idx"), _f32c(codes, "codes")
     raw = torch.empty(n, s, 4, dtype=torch.float32, device=rays.device)
     cc = cfg.c()
-    _lib.check(_lib.load().anerf_mlp_raw(C.byref(cc), _p(packed), _p(aux), _p(rays), rays.shape[1], _p(z_vals), _p(skts),
-                                         stride, _p(cam_idx), _p(codes), 0 if codes is None else codes.shape[0],
-                                         float(tau_v), float(tau_d), _p(_f32c(cut_v, "cut_v")), _p(_f32c(cut_d, "cut_d")),
-                                         n, s, _p(raw), _stream()), "anerf_mlp_raw")
+    if precision not in ("fp32", "bf16x3"):
+        raise ValueError(f"precision {precision!r}")
+    fn = _lib.load().anerf_mlp_raw if precision == "fp32" else _lib.load().anerf_mlp_raw_b3
+    _lib.check(fn(C.byref(cc), _p(packed), _p(aux), _p(rays), rays.shape[1], _p(z_vals), _p(skts),
+                  stride, _p(cam_idx), _p(codes), 0 if codes is None else codes.shape[0],
+                  float(tau_v), float(tau_d), _p(_f32c(cut_v, "cut_v")), _p(_f32c(cut_d, "cut_d")),
+                  n, s, _p(raw), _stream()), "anerf_mlp_raw[" + precision + "]")
     return raw
 
 

@@ -15,8 +15,9 @@ from . import ops
 def render_rays_forward(cfg, net_c, net_f, ray_batch, skts, cyls, n_samples, n_importance=0,
                         tau_v=20.0, tau_d=20.0, cut_v=None, cut_d=None, cam_idx=None,
                         codes_c=None, codes_f=None, t_rand=None, u_imp=None, noise=None, noise_fine=None,
-                        lindisp=False, single_net=False, extras=False):
-    """net_c / net_f: (packed, aux) images from ops.pack_params.  Returns the reference's output dict
+                        lindisp=False, single_net=False, extras=False, precision="fp32"):
+    """net_c / net_f: (packed, aux) images from ops.pack_params (which=0 for precision "fp32", which=3 for
+    "bf16x3").  Returns the reference's output dict
     (RayCaster._collect_outputs, raycasters.py:711-724); extras adds the intermediates."""
     dev = ray_batch.device
     if cut_v is None:
@@ -25,17 +26,17 @@ def render_rays_forward(cfg, net_c, net_f, ray_batch, skts, cyls, n_samples, n_i
         cut_d = torch.full((cfg.n_joints,), 0.5, device=dev)
     nf_raw, stats = ops.ray_bounds(ray_batch, cyls)
     z, nf = ops.coarse_z(nf_raw, stats, ray_batch, n_samples, t_rand, lindisp)
-    raw = ops.mlp_raw(cfg, net_c[0], net_c[1], ray_batch, z, skts, tau_v, tau_d, cut_v, cut_d, cam_idx, codes_c)
+    raw = ops.mlp_raw(cfg, net_c[0], net_c[1], ray_batch, z, skts, tau_v, tau_d, cut_v, cut_d, cam_idx, codes_c, precision)
     co = ops.composite(cfg, raw, z, ray_batch, noise)
     ret = {"rgb_map": co["rgb_map"], "disp_map": co["disp_map"], "acc_map": co["acc_map"], "alpha": co["alpha"]}
     ex = {"near_far": nf, "z_vals": z, "raw": raw, "weights": co["weights"]}
     if n_importance > 0:
         zs, zm, idx = ops.importance(z, co["weights"], n_importance, u_imp, single_net, want_idx=True)
         if single_net:
-            raw_is = ops.mlp_raw(cfg, net_f[0], net_f[1], ray_batch, zs, skts, tau_v, tau_d, cut_v, cut_d, cam_idx, codes_f)
+            raw_is = ops.mlp_raw(cfg, net_f[0], net_f[1], ray_batch, zs, skts, tau_v, tau_d, cut_v, cut_d, cam_idx, codes_f, precision)
             raw_f = torch.gather(torch.cat([raw, raw_is], 1), 1, idx[..., None].expand(-1, -1, 4)).contiguous()
         else:
-            raw_f = ops.mlp_raw(cfg, net_f[0], net_f[1], ray_batch, zm, skts, tau_v, tau_d, cut_v, cut_d, cam_idx, codes_f)
+            raw_f = ops.mlp_raw(cfg, net_f[0], net_f[1], ray_batch, zm, skts, tau_v, tau_d, cut_v, cut_d, cam_idx, codes_f, precision)
         fo = ops.composite(cfg, raw_f, zm, ray_batch, noise_fine)
         ret = {"rgb_map": fo["rgb_map"], "disp_map": fo["disp_map"], "acc_map": fo["acc_map"], "alpha": fo["alpha"],
                "rgb0": ret["rgb_map"], "disp0": ret["disp_map"], "acc0": ret["acc_map"], "alpha0": ret["alpha"]}

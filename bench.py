@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 F_MLP = 2 * 861824          # FLOP per network evaluation of one sample
 PEAK_FP32_MFMA = 157.3e12   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+PEAK_BF16_MFMA = 2500e12    # dense bf16 MFMA peak (the bf16x3 path issues 3 bf16 MFMA FLOPs per algorithmic FLOP)
 
 
 def parse():
@@ -38,6 +39,8 @@ def parse():
     ap.add_argument("--workload", default="render64", choices=["render64", "hier", "render64x64", "train"])
     ap.add_argument("--cpu-rays", type=int, default=8192, help="ray sample for the CPU baseline (0 = skip)")
     ap.add_argument("--n-rand", type=int, default=3072, help="train workload: global rays per step")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
+                    help="render workloads: exact fp32 MFMA, or hi/lo-split bf16 MFMAs (3 per product, fp32 accumulate)")
     return ap.parse_args()
 
 
@@ -75,8 +78,9 @@ def main():
     dev = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32, device=device)
     cfg = ops.PathConfig()
     Pc, Pf = synth.make_net_params(11), synth.make_net_params(12)
-    net_c = ops.pack_params(cfg, {k: dev(v) for k, v in Pc.items()})
-    net_f = ops.pack_params(cfg, {k: dev(v) for k, v in Pf.items()}) if Ni else None
+    which = 3 if args.precision == "bf16x3" else 0
+    net_c = ops.pack_params(cfg, {k: dev(v) for k, v in Pc.items()}, which)
+    net_f = ops.pack_params(cfg, {k: dev(v) for k, v in Pf.items()}, which) if Ni else None
 
     # this rank's contiguous slice of the frame's rays (inputs resident in HBM before timing starts)
     per = (n_total + world - 1) // world
@@ -93,13 +97,13 @@ def main():
         z, _ = ops.coarse_z(nf_raw, stats, rb, S)
         if i is not None:
             ev[i][0].record()
-        raw = ops.mlp_raw(cfg, net_c[0], net_c[1], rb, z, skt, 20.0, 20.0, cut, cut)
+        raw = ops.mlp_raw(cfg, net_c[0], net_c[1], rb, z, skt, 20.0, 20.0, cut, cut, precision=args.precision)
         if i is not None:
             ev[i][1].record()
         co = ops.composite(cfg, raw, z, rb)
         if Ni:
             zs, zm, _ = ops.importance(z, co["weights"], Ni, want_idx=False)
-            raw_f = ops.mlp_raw(cfg, net_f[0], net_f[1], rb, zm, skt, 20.0, 20.0, cut, cut)
+            raw_f = ops.mlp_raw(cfg, net_f[0], net_f[1], rb, zm, skt, 20.0, 20.0, cut, cut, precision=args.precision)
             co = ops.composite(cfg, raw_f, zm, rb)
         if world > 1:
             mine = torch.zeros(per, 5, device=device)
@@ -132,18 +136,23 @@ def main():
         # dominant kernel: k_mlp_fwd over this rank's (hi-lo)*S samples, timed with HIP events on its launch stream
         flops_launch = F_MLP * (hi - lo) * S
         achieved = flops_launch / (mlp_ms * 1e-3)
+        b3 = args.precision == "bf16x3"
+        peak = PEAK_BF16_MFMA if b3 else PEAK_FP32_MFMA
         res = {
             "metric": "rays/sec", "value": rays_s, "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16x3 (hi/lo-split bf16 MFMA operands, f32 accumulate)" if b3 else "f32",
+            "data": "synthetic",
             "config": {"workload": name, "rays_per_step": n_total, "samples_per_ray": S, "n_importance": Ni,
                        "parallelism": f"ray-sharded x{world}", "weights": "numpy-seeded random init (alpha bias +1)"},
-            "roofline": {"bound": "mfma", "kernel": "k_mlp_fwd<7,4,0,false,false>", "achieved": achieved / 1e12,
-                         "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA,
+            "roofline": {"bound": "mfma", "kernel": "k_mlp_fwd_b3<7,4,0>" if b3 else "k_mlp_fwd<7,4,0,false,false>",
+                         "achieved": (3 if b3 else 1) * achieved / 1e12, "algorithmic": achieved / 1e12,
+                         "peak": peak / 1e12, "unit": "TFLOP/s", "frac": (3 if b3 else 1) * achieved / peak,
                          "avg_launch_ms": mlp_ms, "flop_per_launch": flops_launch, "traffic": None},
         }
         try:   # HBM bytes per launch come from a separate rocprofv3 --pmc run (committed under profiles/)
-            tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(args.workload)
+            tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(
+                args.workload + ("_bf16x3" if b3 else ""))
             if tr and world == 1:
                 res["roofline"]["traffic"] = tr["hbm_bytes"]
                 res["roofline"]["traffic_note"] = f"bytes/launch, FETCH_SIZE(x2)+WRITE_SIZE, {tr['source']}; algorithmic {tr['algorithmic_bytes']:.3g} B"

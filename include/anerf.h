@@ -72,7 +72,8 @@ const char* anerf_last_error(void);
 int anerf_version(void);
 
 /* which: 0 = forward image (W), 1 = backward-data image (W^T of the hidden trunk, feature and view layers),
- * 2 = input-gradient image (W^T of the encoded-input columns of pts_linears.0/.5 and views_linears.0). */
+ * 2 = input-gradient image (W^T of the encoded-input columns of pts_linears.0/.5 and views_linears.0),
+ * 3 = bf16x3 forward image (hi/lo bf16 pairs; see anerf_mlp_raw_b3). */
 int anerf_layout(const AnerfConfig* cfg, int which, AnerfLayout* out);
 /* HOST: fill table[stream_floats + aux_floats]: entry = (tensor_id << 24) | element offset, -1 = 0.0f;
  * tensor_id = index into {w[0..11], b[0..11]} (0..23).  Upload once per config. */
@@ -218,6 +219,20 @@ int anerf_gen_rays(int32_t H, int32_t W, float focal_x, float focal_y, float cen
  * rgb + (1-acc)*bg at valid_idx on exit; disp_img / acc_img [H*W] optional. */
 int anerf_assemble_frame(const float* rgb_map, const float* acc_map, const float* disp_map, const int64_t* valid_idx,
                          int32_t n_rays, float* rgb_img, float* disp_img, float* acc_img, void* stream);
+
+/* ---- bf16x3 render path (BASELINE config 5 "bf16 MFMA path", held to the fp32 parity bar) ------------------------
+ * Weight image which=3: every weight split into two bf16 (hi, lo); the kernel evaluates W x as
+ * Whi*Xhi + Whi*Xlo + Wlo*Xhi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (~2^-17 relative per product).
+ * anerf_build_pack_table(which=3) fills 2*stream_floats + aux_floats entries (one per bf16 element, then aux). */
+int anerf_pack_params_b3(const AnerfNetParams* params, const int32_t* table, int64_t stream_floats, int64_t aux_floats,
+                         float* out, void* stream);
+/* Same contract as anerf_mlp_raw, on the which=3 image. */
+int anerf_mlp_raw_b3(const AnerfConfig* cfg, const float* packed, const float* aux,
+                     const float* rays, int32_t ray_stride, const float* z_vals,
+                     const float* skts, int64_t skt_ray_stride, const float* cam_idx,
+                     const float* codes, int32_t n_codes,
+                     float tau_v, float tau_d, const float* cutoff_v, const float* cutoff_d,
+                     int32_t n_rays, int32_t n_samples, float* raw, void* stream);
 
 #ifdef __cplusplus
 }

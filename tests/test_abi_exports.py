@@ -44,6 +44,24 @@ def test_layout_and_pack_table_host_side():
             assert cnt.shape[0] == o * k and (cnt == 1).all(), n
             b = np.bincount(offs[ids == 12 + i], minlength=o)
             assert (b == 1).all(), n + ".bias"
+    # bf16x3 image: one table entry per bf16 element (hi and lo of every weight exactly once) + the fp32 aux entries
+    cfg = ops.PathConfig()
+    sf, af, nst, _ = ops.layout(cfg, 3)
+    assert (sf, nst) == ops.layout(cfg, 0)[0:3:2]
+    host = np.empty(2 * sf + af, dtype=np.int32)
+    cc = cfg.c()
+    assert lib_mod.load().anerf_build_pack_table(ctypes.byref(cc), 3, host.ctypes.data_as(ctypes.c_void_p)) == 0
+    st = host[:2 * sf]
+    used = st[st >= 0]
+    part, ids, offs = (used >> 29) & 1, (used >> 24) & 31, used & 0xFFFFFF
+    shapes = synth.net_shapes(7, 4, 0)
+    for i, n in enumerate(ops.PARAM_ORDER):
+        if i in (8, 11):
+            continue                      # alpha / rgb heads live in aux (fp32)
+        o, k = shapes[n]
+        for pp in (0, 1):
+            cnt = np.bincount(offs[(ids == i) & (part == pp)], minlength=o * k)
+            assert (cnt == 1).all(), (n, pp)
     bad = ops.PathConfig(multires=5)
     cc = bad.c()
     L = lib_mod.AnerfLayout()

@@ -30,11 +30,12 @@ def cuda_params(P):
     return {k: dev(v) for k, v in P.items()}
 
 
-def run_hip(c, extras=True, cams=None, mean_code=False):
+def run_hip(c, extras=True, cams=None, mean_code=False, precision="fp32"):
     cfg = ops.PathConfig(**c["cfg"])
     Pc, Pf = cuda_params(c["Pc"]), cuda_params(c["Pf"])
-    net_c = ops.pack_params(cfg, Pc)
-    net_f = net_c if c.get("single_net") else ops.pack_params(cfg, Pf)
+    which = 3 if precision == "bf16x3" else 0
+    net_c = ops.pack_params(cfg, Pc, which)
+    net_f = net_c if c.get("single_net") else ops.pack_params(cfg, Pf, which)
     rb = pipeline.make_ray_batch(dev(c["rays_o"]), dev(c["rays_d"]))
     kw = {k: dev(c[k]) for k in ["t_rand", "u_imp", "noise", "noise_fine"] if k in c}
     cams = c.get("cams") if cams is None else cams
@@ -46,7 +47,7 @@ def run_hip(c, extras=True, cams=None, mean_code=False):
             cams = np.zeros(c["n"], np.float32)
     return pipeline.render_rays_forward(cfg, net_c, net_f, rb, dev(c["skts"]), dev(c["cyls"]), c["S"], c["Ni"],
                                         cam_idx=None if cams is None else dev(cams), codes_c=codes_c, codes_f=codes_f,
-                                        single_net=bool(c.get("single_net")), extras=extras, **kw)
+                                        single_net=bool(c.get("single_net")), extras=extras, precision=precision, **kw)
 
 
 def run_oracle(oracle, c, cams=None, mean_code=False):
@@ -264,3 +265,35 @@ def test_gen_rays_and_frame_assembly(synth):
     dref[vi] = out["disp_map"].cpu().numpy()
     np.testing.assert_allclose(disps[0].reshape(-1), dref, atol=1e-6)
     assert rgbs.shape == (1, 64, 64, 3) and accs.shape == (1, 64, 64, 1)
+
+
+@pytest.mark.parametrize("name", ["eval_s32", "eval_hier", "train_pytest", "mixamo_train", "single_net"])
+def test_bf16x3_path_meets_the_fp32_bar(oracle, golden, name):
+    """bf16x3 render path (hi/lo-split bf16 MFMAs): same 1e-4 RGB bar as fp32, vs the reference golden vectors."""
+    g = golden(name)
+    c = build(name)
+    out = run_hip(c, precision="bf16x3")
+    keys = ["rgb_map", "acc_map", "alpha"] + (["rgb0", "alpha0"] if c["Ni"] else [])
+    for k in keys:
+        close(out[k], g[k], atol=1e-4, msg=f"bf16x3 {name}:{k}")
+    if name == "eval_s32":
+        err = np.abs(out["_extras"]["raw"].cpu().numpy() - g["raw"]).max()
+        assert err < 1e-4, err          # logits: fp32 path is ~3e-6 here; the split path a few 1e-6..1e-5
+
+
+def test_bf16x3_frame_psnr_and_fp32_agreement(oracle, synth, golden):
+    g = golden("frame64")
+    sc = synth.make_scene(0, 64, 64, 75.0)
+    n = len(sc["rays_o"])
+    cfg = ops.PathConfig()
+    P = cuda_params(synth.make_net_params(11))
+    rb = pipeline.make_ray_batch(dev(sc["rays_o"]), dev(sc["rays_d"]))
+    cyl = dev(sc["cyl"])[None].expand(n, -1).contiguous()
+    skt = dev(sc["pose"]["skts"])[None]
+    o3 = pipeline.render_rays_forward(cfg, ops.pack_params(cfg, P, 3), None, rb, skt, cyl, 32, precision="bf16x3")
+    o0 = pipeline.render_rays_forward(cfg, ops.pack_params(cfg, P, 0), None, rb, skt, cyl, 32)
+    rgb = o3["rgb_map"].cpu()
+    assert float((rgb - t(g["rgb_map"])).abs().max()) < 1e-4
+    assert float((o3["rgb_map"] - o0["rgb_map"]).abs().max()) < 5e-5
+    target = t(np.random.default_rng(7).random((n, 3)))
+    assert abs(oracle.psnr(rgb, target) - oracle.psnr(t(g["rgb_map"]), target)) < 1e-3

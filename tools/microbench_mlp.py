@@ -23,6 +23,10 @@ def timeit(f, reps=3):
 P = n * 64
 ms = timeit(lambda: ops.mlp_raw(cfg, net[0], net[1], rb, z, skt, 20.0, 20.0, cut, cut))
 out = {"lib": os.environ.get("ANERF_LIB", "default"), "fused_ms": ms, "fused_TF": P * 1.723648e6 / ms / 1e9}
+if "--b3" in sys.argv:
+    net3 = ops.pack_params(cfg, {k: dev(v) for k, v in synth.make_net_params(11).items()}, 3)
+    ms3 = timeit(lambda: ops.mlp_raw(cfg, net3[0], net3[1], rb, z, skt, 20.0, 20.0, cut, cut, precision="bf16x3"))
+    out.update(b3_ms=ms3, b3_algorithmic_TF=P * 1.723648e6 / ms3 / 1e9)
 if "--pre" in sys.argv:
     X = torch.rand(P // 4, 1080, device="cuda") - 0.5
     ms2 = timeit(lambda: ops.mlp_forward(cfg, net[0], net[1], X))
