@@ -15,6 +15,11 @@ constexpr int LDS_BONES_OFF = LDS_AUX_OFF + LDS_AUX_BYTES;        // MAX_TILE_RA
 // ------------------------------------------------------------------------------------------------
 // weight-stream pipe: global -> LDS ring (3 slots x 32 KiB), all 4 waves cooperate.  Invariant while stage s is
 // being consumed: stages s and s+1 are complete and visible to every wave; stage s+2 is in flight.
+// Tried and rejected on the bf16x3 kernel (short ~1500-cycle stages, where more lead would help):
+//   * 4 slots + counted `s_waitcnt vmcnt(8)` (keep the newest stage pending): stale fragments -- LDS-DMA
+//     completions are not ordered the way a counted wait needs; parity tests caught it;
+//   * 4 slots + per-wave-pair stage ownership (16 glds per owner): also produced stale fragments;
+//   * 4 slots with plain vmcnt(0): correct but 6 % slower than 3 slots (same one-stage lead, worse allocation).
 // ------------------------------------------------------------------------------------------------
 struct Pipe3 {
   const char* gsrc;   // per-lane source of this wave's first fragment of stage 0
