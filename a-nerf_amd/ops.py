@@ -235,3 +235,50 @@ def assemble_frame(rgb_map, acc_map, disp_map, valid_idx, rgb_img, want_acc=Fals
                                                 _p(valid_idx), n, _p(rgb_img), _p(disp_img), _p(acc_img), _stream()),
                "anerf_assemble_frame")
     return rgb_img, disp_img, acc_img
+
+
+def loss(rgb, acc, target, rgb0=None, acc0=None, bgs=None, loss_type=0, coarse_weight=1.0, want_grads=True):
+    """_compute_nerf_loss + its gradient w.r.t. the rendered maps in one pass (anerf_loss; trainer.py:353-380).
+    bgs: None (no background composite), a [3] / [1,3] colour, or per-ray [N,3].
+    Returns (out4 = [total, fine, coarse, fine mse], grads dict or None)."""
+    rgb, acc, target = _f32c(rgb, "rgb"), _f32c(acc, "acc"), _f32c(target, "target")
+    rgb0, acc0, bgs = _f32c(rgb0, "rgb0"), _f32c(acc0, "acc0"), _f32c(bgs, "bgs")
+    n, dev = rgb.shape[0], rgb.device
+    if target.shape != rgb.shape:
+        raise ValueError(f"loss: target {tuple(target.shape)} vs rgb {tuple(rgb.shape)}")
+    stride = 0
+    if bgs is not None:
+        if bgs.numel() == 3:
+            stride = 0
+        elif bgs.shape == rgb.shape:
+            stride = 3
+        else:
+            raise ValueError(f"loss: bgs must have 3 or N*3 elements, got {tuple(bgs.shape)}")
+    lib = _lib.load()
+    out = torch.zeros(4, dtype=torch.float32, device=dev)
+    part = torch.empty(4 * lib.anerf_loss_blocks(n), dtype=torch.float32, device=dev)
+    g = None
+    if want_grads:
+        g = {"rgb": torch.empty_like(rgb), "acc": torch.empty_like(acc) if bgs is not None else None,
+             "rgb0": torch.empty_like(rgb0) if rgb0 is not None else None,
+             "acc0": torch.empty_like(acc0) if (rgb0 is not None and bgs is not None) else None}
+    gp = (lambda k: _p(g[k]) if g is not None else None)
+    _lib.check(lib.anerf_loss(_p(rgb), _p(acc), _p(rgb0), _p(acc0), _p(target), _p(bgs), stride, n, int(loss_type),
+                              float(coarse_weight), _p(out), gp("rgb"), gp("acc"), gp("rgb0"), gp("acc0"), _p(part), _stream()),
+               "anerf_loss")
+    return out, g
+
+
+def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_scale=1.0, zero_grads=False,
+              n_tensors=0, norms2=None):
+    """torch.optim.Adam's update over one flat fp32 buffer (anerf_adam_step).  norms2: optional [2] tensor that
+    receives get_gradnorm's (total_norm, avg_norm)."""
+    for t, nm in ((params, "params"), (grads, "grads"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != params.numel():
+            raise ValueError(f"adam_step: {nm} must be contiguous float32 with {params.numel()} elements")
+    lib = _lib.load()
+    n = params.numel()
+    part = torch.empty(lib.anerf_adam_blocks(n), dtype=torch.float32, device=params.device) if norms2 is not None else None
+    _lib.check(lib.anerf_adam_step(_p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), n, float(lr), float(beta1), float(beta2),
+                                   float(eps), int(step), float(grad_scale), int(bool(zero_grads)), int(n_tensors), _p(part),
+                                   _p(norms2), _stream()), "anerf_adam_step")

@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--workload", default="render64", choices=["render64", "hier", "render64x64", "train"])
     ap.add_argument("--cpu-rays", type=int, default=8192, help="ray sample for the CPU baseline (0 = skip)")
     ap.add_argument("--n-rand", type=int, default=3072, help="train workload: global rays per step")
+    ap.add_argument("--torch-tail", action="store_true",
+                    help="train workload: torch loss + torch.optim.Adam + copy-bucket all-reduce instead of the fused kernels")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
                     help="render workloads: exact fp32 MFMA, or hi/lo-split bf16 MFMAs (3 per product, fp32 accumulate)")
     return ap.parse_args()
@@ -173,6 +175,7 @@ def bench_train(args, rank, world, device, dist, synth):
     raycaster = importlib.import_module("a-nerf_amd.raycaster")
     render_mod = importlib.import_module("a-nerf_amd.render")
     parallel = importlib.import_module("a-nerf_amd.parallel")
+    optim = importlib.import_module("a-nerf_amd.optim")
     N_rand, S, Ni = args.n_rand, 64, 16
     dev = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32, device=device)
     kw = dict(D=8, W=256, input_ch=360, input_ch_bones=72, input_ch_views=648, use_viewdirs=True)
@@ -186,8 +189,9 @@ def bench_train(args, rank, world, device, dist, synth):
     caster = raycaster.RayCaster(net_c, e_v, e_b, e_d, network_fine=net_f).to(device)
     caster.train()
     params = [p for p in caster.parameters() if p.requires_grad]
-    opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.999))
-    bucket = parallel.GradBucket(params)
+    fused = not args.torch_tail
+    opt = optim.FusedAdam(params, lr=5e-4, betas=(0.9, 0.999)) if fused else torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.999))
+    bucket = None if fused else parallel.GradBucket(params)
     # per-ray replicated pose batch as the reference's collate produces it (dataset.py:813-820), 8 poses
     ro, rd, kp, skts, bones, cyls, _ = synth.scene_batch(N_rand, list(range(8)), H=512, W=512, focal=600.0, ray_seed=3,
                                                          per_ray_pose=True)
@@ -205,13 +209,17 @@ def bench_train(args, rank, world, device, dist, synth):
         out = render_mod.render(512, 512, 600.0, chunk=4096, rays=rays, use_viewdirs=True, ray_caster=caster, cams=None,
                                 subject_idxs=None, N_samples=S, N_importance=Ni, perturb=1.0, raw_noise_std=1.0,
                                 preproc_kwargs=pk, **batch)
-        loss, _ = render_mod.nerf_loss(out, target, bgs=1.0)
+        loss, _ = (optim.fused_nerf_loss if fused else render_mod.nerf_loss)(out, target, bgs=1.0)
         loss.backward()
         if i is not None:
             ev[i][1].record()
-        bucket.all_reduce_mean()
-        opt.step()
-        opt.zero_grad()
+        if fused:
+            opt.all_reduce_grads()            # one RCCL all-reduce on the flat gradient buffer; 1/world folded into Adam
+            opt.step(zero_grad=True)
+        else:
+            bucket.all_reduce_mean()
+            opt.step()
+            opt.zero_grad()
         return loss
 
     def barrier():
@@ -240,7 +248,8 @@ def bench_train(args, rank, world, device, dist, synth):
                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"SURREAL-shaped training step, N_rand={N_rand}, 64+16 samples, fwd+bwd+Adam (BASELINE config 3)",
                           "rays_per_step": N_rand, "samples_per_ray": S, "n_importance": Ni,
-                          "parallelism": f"ray-sharded x{world}, 1 all-reduce/step", "loss": float(loss)},
+                          "parallelism": f"ray-sharded x{world}, 1 all-reduce/step", "loss": float(loss),
+                          "tail": "fused loss + FusedAdam (anerf_loss / anerf_adam_step)" if fused else "torch loss + torch.optim.Adam"},
                "roofline": {"bound": "mfma", "kernel": "k_mlp_fwd<train> + k_mlp_bwd + k_gemm_tn (both nets), HIP-event time of fwd+bwd",
                             "achieved": achieved / 1e12, "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
                             "frac": achieved / PEAK_FP32_MFMA, "avg_launch_ms": fb_ms, "flop_per_launch": flop_step_rank,

@@ -234,6 +234,28 @@ int anerf_mlp_raw_b3(const AnerfConfig* cfg, const float* packed, const float* a
                      float tau_v, float tau_d, const float* cutoff_v, const float* cutoff_d,
                      int32_t n_rays, int32_t n_samples, float* raw, void* stream);
 
+/* ---- loss + optimiser step ---------------------------------------------------------------------
+ * _compute_nerf_loss (core/trainer.py:353-380) for the fine and (optional) coarse head, with img2mse / img2l1
+ * (:8-60), AND its gradient w.r.t. the rendered maps in one pass:
+ *   pred = rgb + (1 - acc) * bg  (bgs != NULL; bg_stride 0 = one [3] colour, >= 3 = per ray)   else pred = rgb
+ *   loss = mean_{N x 3} (pred - target)^2   (loss_type 0)   or   mean |pred - target|   (loss_type 1)
+ * out4 = {fine + coarse_weight * coarse, fine, coarse, fine MSE (mse2psnr input)};  g_* = d(out4[0]) / d(map), any
+ * may be NULL.  partials: workspace of 4 * anerf_loss_blocks(n_rays) floats.  Deterministic (fixed-order sums). */
+int anerf_loss_blocks(int32_t n_rays);
+int anerf_loss(const float* rgb, const float* acc, const float* rgb0, const float* acc0, const float* target,
+               const float* bgs, int32_t bg_stride, int32_t n_rays, int32_t loss_type, float coarse_weight,
+               float* out4, float* g_rgb, float* g_acc, float* g_rgb0, float* g_acc0, float* partials, void* stream);
+
+/* torch.optim.Adam (no amsgrad, no weight decay: trainer.py:173-183) over ONE flat fp32 buffer of n elements
+ * (16-byte aligned), step = 1-based step count; grads are multiplied by grad_scale first (1/world after a summed
+ * all-reduce), optionally zeroed afterwards (optimizer.zero_grad()).  If norms2 != NULL it receives get_gradnorm's
+ * (total_norm, avg_norm) (trainer.py:192-203; n_tensors = tensors with a gradient) -- no host sync; partials:
+ * anerf_adam_blocks(n) floats. */
+int anerf_adam_blocks(int64_t n);
+int anerf_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                    float beta2, float eps, int32_t step, float grad_scale, int32_t zero_grads, int32_t n_tensors,
+                    float* partials, float* norms2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

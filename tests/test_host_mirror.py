@@ -99,3 +99,22 @@ def test_unsupported_configurations_fail_loudly():
     with pytest.raises(NotImplementedError):
         networks.get_embedder(7, input_dims=24, cutoff_kwargs={"cutoff": True, "cutoff_inputs": True, "cutoff_dim": 24,
                                                                "dist_inputs": False, "freq_schedule": True})[0]
+
+
+def test_fused_adam_host_contract():
+    """FusedAdam mirrors torch.optim.Adam's surface; on CPU it refuses to run (no fallback for the product path)."""
+    optim = importlib.import_module("a-nerf_amd.optim")
+    ps = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn(2), requires_grad=False)]
+    opt = optim.FusedAdam(ps, lr=5e-4, betas=(0.9, 0.999))
+    assert len(opt.param_groups[0]["params"]) == 2 and opt.param_groups[0]["lr"] == 5e-4 and opt.state == {}
+    sd = opt.state_dict()
+    assert sd["state"] == {} and sd["param_groups"][0]["params"] == [0, 1] and sd["param_groups"][0]["betas"] == (0.9, 0.999)
+    torch.optim.Adam([p for p in ps if p.requires_grad], lr=1.0).load_state_dict(sd)      # torch accepts the format
+    for p in ps[:2]:
+        p.grad = torch.ones_like(p)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        opt.step()
+    with pytest.raises(ValueError):
+        optim.FusedAdam([ps[2]])
+    with pytest.raises(NotImplementedError):
+        optim.fused_nerf_loss({"rgb_map": torch.zeros(1, 3), "acc_map": torch.zeros(1)}, torch.zeros(1, 3), loss_fn="BCE")
