@@ -42,7 +42,6 @@ int mlp_raw_entry(const AnerfConfig* cfg, const float* packed, const float* aux,
                   hipStream_t st);
 int mlp_bwd_entry(const float* packed_t, const float* aux, const float* draw, const AnerfSaved* sv, float* dz, float* df,
                   float* dzv, long long P, int nstages, hipStream_t st);
-int launch_weight_grads(GemmBatch& G, float* ws, hipStream_t st);
 int mlp_b3_entry(const AnerfConfig* cfg, const float* packed, const float* aux, const float* rays, int ray_stride,
                  const float* z, const float* skts, long long skt_stride, const float* cam, const float* codes, int n_codes,
                  float tau_v, float tau_d, const float* cut_v, const float* cut_d, long long P, int N, int S, int nstages,
@@ -411,11 +410,13 @@ int anerf_importance(const float* z_vals, const float* weights, int32_t n_rays, 
 // ---------------------------------------------------------------------------------------------------------------
 // training path
 // ---------------------------------------------------------------------------------------------------------------
-static int gemm_chunks_for(int64_t p_pad) {
-  int64_t c = p_pad / 4096;
-  if (c < 1) c = 1;
-  if (c > 32) c = 32;
-  return (int)c;
+// Number of heavy (4 x 128x128 wave tiles) and skinny (alpha / rgb heads) blocks of the weight-gradient GEMM.
+static void gemm_block_counts(const AnerfConfig* cfg, int* nheavy, int* nskinny) {
+  const int tx = (dim_x(cfg) + 127) / 128;                       // column tiles of X'
+  const int tv = 2 + (u_width(cfg) + 127) / 128;                 // views layer: feature (2 tiles) + U' tiles, M = 128
+  // M = 256 problems pair their column tiles 2 x 2:  L0 (X'), L1-4, L5 (X' and h4), L6, L7, feature
+  *nheavy = (tx + 1) / 2 + 4 + (tx + 1) / 2 + 1 + 2 + 1 + (tv + 3) / 4;
+  *nskinny = 1;
 }
 
 int anerf_train_layout(const AnerfConfig* cfg, int64_t n_points, AnerfTrainLayout* out) {
@@ -426,13 +427,15 @@ int anerf_train_layout(const AnerfConfig* cfg, int64_t n_points, AnerfTrainLayou
   if (out->p_pad == 0) out->p_pad = 128;
   out->x_width = dim_x(cfg);
   out->u_width = u_width(cfg);
-  out->gemm_chunks = gemm_chunks_for(out->p_pad);
-  const int64_t kv = 256 + u_width(cfg);
-  // sum over the 14 problems of M*N (+ M for the bias partials)
-  int64_t per_chunk = 256LL * dim_x(cfg) + 256 + 6 * (256LL * 256 + 256) + 256LL * dim_x(cfg) + 256 + 256LL * 256 +
-                      (256LL * 256 + 256) + (128LL * 256 + 128) + 128LL * u_width(cfg) + (4LL * 128 + 4) + (4LL * 256 + 4);
-  (void)kv;
-  out->gemm_ws_floats = per_chunk * out->gemm_chunks;
+  int nh, ns, rh, ch, rs, cs;
+  gemm_block_counts(cfg, &nh, &ns);
+  gemm_plan_rows(out->p_pad, nh, ns, &rh, &ch, &rs, &cs);
+  out->gemm_chunks = ch;
+  // partials: heavy problems (M*N + bias M) x chunks_h, head problems x chunks_s
+  const int64_t heavy = 256LL * dim_x(cfg) + 256 + 6 * (256LL * 256 + 256) + 256LL * dim_x(cfg) + 256 + 256LL * 256 +
+                        (256LL * 256 + 256) + (128LL * 256 + 128) + 128LL * u_width(cfg);
+  const int64_t heads = (4LL * 128 + 4) + (4LL * 256 + 4);
+  out->gemm_ws_floats = heavy * ch + heads * cs;
   return ANERF_OK;
 }
 
@@ -510,25 +513,38 @@ int anerf_weight_grads(const AnerfConfig* cfg, const AnerfSaved* sv, const float
   const long long pp = T.p_pad;
   const int DX = dim_x(cfg), UW = u_width(cfg), KV = 256 + UW;
   GemmBatch G;
+  GemmPlan P;
   memset(&G, 0, sizeof(G));
-  G.chunks = T.gemm_chunks;
-  G.p_pad = pp;
-  G.rows_per_chunk = ((pp / G.chunks) + 31) / 32 * 32;
+  memset(&P, 0, sizeof(P));
+  P.p_pad = pp;
+  gemm_block_counts(cfg, &P.nheavy, &P.nskinny);
+  gemm_plan_rows(pp, P.nheavy, P.nskinny, &P.rows_h, &P.chunks_h, &P.rows_s, &P.chunks_s);
   long long ws_pos = 0, out_pos = 0;
-  int tiles = 0, np = 0;
+  int np = 0, nmat = 0;
+  auto mat = [&](const float* ptr, int ld) {
+    for (int i = 0; i < nmat; ++i)
+      if (P.mat[i].ptr == ptr) return i;
+    P.mat[nmat].ptr = ptr; P.mat[nmat].ld = ld; P.mat[nmat].ncols = ld;
+    return nmat++;
+  };
+  struct WT { int prob, a_mat, b_mat, m0, n0; };                 // one wave tile
+  std::vector<WT> sq, wide, skinny;                              // M = 256 (2 x 2 blocks), M = 128 (1 x 4), M = 4
   auto add = [&](const float* A, int lda, int M, const float* B, int ldb, int N, float* dst, int dst_ld, int col0,
                  const int* cmap, int m_first, int m_count, float* bias, int bm_first, int bm_count) {
-    GemmProb& p = G.p[np++];
-    p.A = A; p.B = B; p.dst = dst; p.bias_dst = bias; p.colmap = cmap;
-    p.lda = lda; p.ldb = ldb; p.lda_cols = lda; p.ldb_cols = ldb; p.M = M; p.N = N;
-    p.tiles_m = (M + 127) / 128; p.tiles_n = (N + 127) / 128; p.tile_base = tiles;
-    tiles += p.tiles_m * p.tiles_n;
+    const int chunks = M == 4 ? P.chunks_s : P.chunks_h;
+    GemmProb& p = G.p[np];
+    p.dst = dst; p.bias_dst = bias; p.colmap = cmap; p.M = M; p.N = N; p.chunks = chunks;
     p.dst_ld = dst_ld; p.dst_col0 = col0; p.m_first = m_first; p.m_count = m_count;
     p.bm_first = bm_first; p.bm_count = bm_count;
-    p.part_off = ws_pos; ws_pos += (long long)G.chunks * M * N;
+    p.part_off = ws_pos; ws_pos += (long long)chunks * M * N;
     p.bias_off = -1;
-    if (bias) { p.bias_off = ws_pos; ws_pos += (long long)G.chunks * M; }
+    if (bias) { p.bias_off = ws_pos; ws_pos += (long long)chunks * M; }
     p.out_base = out_pos; out_pos += (long long)M * N + (bias ? M : 0);
+    const int am = mat(A, lda), bm = mat(B, ldb);
+    std::vector<WT>& list = M == 256 ? sq : (M == 128 ? wide : skinny);
+    for (int n0 = 0; n0 < N; n0 += 128)
+      for (int m0 = 0; m0 < M; m0 += 128) list.push_back({np, am, bm, m0, n0});
+    ++np;
   };
   auto DZ = [&](int l) { return dz + (long long)l * pp * 256; };
   auto H = [&](int l) { return sv->h + (long long)l * pp * 256; };
@@ -544,10 +560,50 @@ int anerf_weight_grads(const AnerfConfig* cfg, const AnerfSaved* sv, const float
   add(draw, 4, 4, sv->g, 128, 128, gr->w[11], 128, 0, nullptr, 0, 3, gr->b[11], 0, 3);
   add(draw, 4, 4, H(7), 256, 256, gr->w[8], 256, 0, nullptr, 3, 1, gr->b[8], 3, 1);
   G.nprob = np;
-  G.total_tiles = tiles;
   G.total_out = out_pos;
-  if (ws_pos > ws_floats) return set_error(ANERF_E_WORKSPACE, "weight_grads: workspace accounting");
-  return launch_weight_grads(G, workspace, (hipStream_t)stream);
+  if (ws_pos > ws_floats || ws_pos >= (1LL << 31)) return set_error(ANERF_E_WORKSPACE, "weight_grads: workspace accounting");
+  // ---- group the wave tiles into blocks of 4 that share LDS operand tiles
+  int nb = 0;
+  auto tile_of = [&](GemmBlock& B, int m, int col0) {
+    for (int i = 0; i < B.ntiles; ++i)
+      if (B.t[i].mat == m && B.t[i].col0 == col0) return i;
+    B.t[B.ntiles].mat = m; B.t[B.ntiles].col0 = col0;
+    return B.ntiles++;
+  };
+  auto emit = [&](const std::vector<WT>& list, size_t per_block, int skinny_flag) {
+    for (size_t i0 = 0; i0 < list.size(); i0 += per_block) {
+      GemmBlock& B = P.blk[nb++];
+      B.ntiles = 0; B.skinny = skinny_flag;
+      for (int w = 0; w < 4; ++w) B.w[w].a_tile = -1;
+      for (size_t k = 0; k < per_block && i0 + k < list.size(); ++k) {
+        const WT& t = list[i0 + k];
+        const GemmProb& p = G.p[t.prob];
+        GemmWave& W = B.w[k];
+        W.a_tile = tile_of(B, t.a_mat, t.m0);
+        W.b_tile = tile_of(B, t.b_mat, t.n0);
+        W.part_off = (int)p.part_off;
+        W.bias_off = (p.bias_off >= 0 && t.n0 == 0) ? (int)p.bias_off : -1;
+        W.M = p.M; W.N = p.N; W.m0 = t.m0; W.n0 = t.n0;
+      }
+    }
+  };
+  // M = 256: wave tiles were pushed n-major with both m tiles adjacent -> 4 consecutive = {n, n+128} x {m 0, 128}.
+  // A problem with an odd number of column tiles (X': 4 tiles -> even; defensive) must not share a block with the next.
+  {
+    std::vector<WT> run;
+    for (size_t i = 0; i <= sq.size(); ++i) {
+      if (i == sq.size() || (!run.empty() && sq[i].prob != run.back().prob)) {
+        emit(run, 4, 0);
+        run.clear();
+      }
+      if (i < sq.size()) run.push_back(sq[i]);
+    }
+  }
+  emit(wide, 4, 0);       // views layer: one A tile (dzv) x up to 4 column tiles of f / U'
+  if (nb != P.nheavy) return set_error(ANERF_E_CONFIG, "weight_grads: block plan mismatch");
+  emit(skinny, 4, 1);
+  if (nb != P.nheavy + P.nskinny || nb > 16 || nmat > 24) return set_error(ANERF_E_CONFIG, "weight_grads: block plan mismatch");
+  return launch_weight_grads(P, G, workspace, (hipStream_t)stream);
 }
 
 int anerf_input_grads(const AnerfConfig* cfg, const float* packed_i, const float* dz, const float* dzv, int64_t p_pad,

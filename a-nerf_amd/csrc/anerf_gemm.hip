@@ -1,12 +1,23 @@
 // anerf_gemm.hip -- weight gradients of the MLP as a GROUPED fp32-MFMA "TN" GEMM over the sample axis:
 //     dW[m][n] = sum_p A[p][m] * B[p][n]      A = d(pre-activation) rows, B = layer-input rows (both row-major,
 //                                             saved by k_mlp_fwd<TRAIN> / k_mlp_bwd), p = sample index.
-// One launch covers every layer of a network (13 problems): blockIdx -> (problem, 128x128 output tile, p-chunk).
-// Each workgroup reduces its p-chunk into registers (4 waves x 64x64, v_mfma_f32_32x32x2_f32, operands staged
-// through a double-buffered LDS tile pair filled with global_load_lds_dwordx4) and writes a partial tile;
-// k_reduce_dw sums the chunks in a fixed order (deterministic) and scatters into the torch-layout gradient
-// tensors (undoing the stream column order of X'/U').  Bias gradients (column sums of A) ride along.
 // Autograd of the 12 nn.Linear layers of NeRF (core/networks/nerf.py:57-88) w.r.t. weights and biases.
+//
+// One launch covers every layer of a network.  Work unit = one WAVE computing a 128x128 output tile over a chunk
+// of sample rows with v_mfma_f32_32x32x2_f32 (16 accumulator blocks = all 256 AGPRs).  Operand rows are staged
+// [16 rows][128 cols] in LDS exactly as they lie in memory (global_load_lds_dwordx4, 2 rows per wave-instruction);
+// lane (i, kk) then reads row 2s+kk, columns 4i..4i+3 with ONE ds_read_b128: the four floats are its operands for
+// the four 32-row blocks of the tile (block b <-> columns 4i+b).  That column interleave costs nothing -- block b,
+// row i' of the accumulator is simply output row 4i'+b, and on the way out four blocks' registers form a float4 of
+// four consecutive output columns -- and it makes the inner loop 2 LDS reads + 16 MFMAs (1024 MFMA cycles) with
+// NO address arithmetic.  (The fp32 MFMA does not overlap VALU on this chip, tools/probe: every VALU instruction
+// in the loop is paid for in matrix time; the previous 64x64-per-wave version spent 2.3 VALU per MFMA.)
+// A block = 4 such waves sharing operand tiles: 2x2 (two A tiles x two B tiles: a whole 256x256 layer per block,
+// each activation row read once) or 1x4 (views layer, M = 128).  The 4-row head problems (alpha / rgb, A = draw)
+// run as "skinny" waves: 4 MFMAs per row pair against one broadcast A block.
+// Blocks write partial tiles; k_reduce_dw sums the row chunks in a fixed order (deterministic) and scatters into
+// the torch-layout gradient tensors (undoing the stream column order of X'/U').  Bias gradients = column sums of
+// A, accumulated by the waves that own a problem's first column tile.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "anerf_dev.h"
@@ -14,105 +25,235 @@
 
 namespace anerf {
 
-constexpr int GT = 128;          // output tile edge
-constexpr int GP = 32;           // p rows per LDS tile
-constexpr int TILE_BYTES = GP * GT * 4;   // 16 KiB
+constexpr int GT = 128;                         // tile edge (columns of an operand tile, rows/cols of an output tile)
+constexpr int GTILE_BYTES = GEMM_ROWS * GT * 4; // 8 KiB
+constexpr int GSTAGE_BYTES = 5 * GTILE_BYTES;   // 40 KiB
+constexpr int GLDS_BYTES = 2 * GSTAGE_BYTES;    // double buffer
 
-__device__ __forceinline__ void stage_tile(const float* __restrict__ src, int ld, int col0, int ncols, long long row0,
-                                           char* lds_tile, int wave, int lane) {
-  // 32 rows x 128 cols; one wave-instruction = 2 rows (64 lanes x 16 B).  Columns past the matrix edge are
-  // clamped to the last valid float4 (their products land in output entries that are never written).
-  int c = col0 + (lane & 31) * 4;
-  const int cmax = ncols - 4;
-  c = c > cmax ? cmax : c;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = wave * 8 + i * 2 + (lane >> 5);
-    const float* g = src + (row0 + r) * ld + c;
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)g, (lds_ptr_t)(lds_tile + (wave * 8 + i * 2) * (GT * 4)), 16, 0, 0);
+// Chunking: every block (heavy or skinny) covers the same rows_h sample rows; one block per CU at a time (256 AGPRs).
+// Pick rows_h (multiple of 16) minimising  rounds(blocks over 256 CUs) x (rows + epilogue).
+void gemm_plan_rows(long long p_pad, int nheavy, int nskinny, int* rows_h, int* chunks_h, int* rows_s, int* chunks_s) {
+  const int NCU = 256;
+  long long best_cost = -1;
+  int best_r = 0;
+  const long long rmin = p_pad < 256 ? p_pad : 256;
+  for (long long r = rmin / 16 * 16; r <= p_pad; r += 16) {
+    if (r <= 0) continue;
+    const long long ch = (p_pad + r - 1) / r;
+    if (ch > 96) continue;
+    const long long blocks = (nheavy + nskinny) * ch;                // a skinny block is shorter but holds a CU too
+    const long long rounds = (blocks + NCU - 1) / NCU;
+    const long long cost = rounds * (r + 96);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_r = (int)r; }
   }
+  if (best_r == 0) best_r = (int)((p_pad + 95) / 96 + 15) / 16 * 16;
+  *rows_h = best_r;
+  *chunks_h = (int)((p_pad + best_r - 1) / best_r);
+  *rows_s = *rows_h;
+  *chunks_s = *chunks_h;
 }
 
-__global__ __launch_bounds__(256) void k_gemm_tn(const GemmBatch G, float* __restrict__ ws) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tile_id = blockIdx.x % G.total_tiles;
-  const int chunk = blockIdx.x / G.total_tiles;
-  int pi = 0;
-#pragma unroll 1
-  for (int i = 1; i < G.nprob; ++i)
-    if (tile_id >= G.p[i].tile_base) pi = i;
-  const GemmProb& pr = G.p[pi];
-  const int lt = tile_id - pr.tile_base;
-  const int tm = lt / pr.tiles_n, tn = lt - tm * pr.tiles_n;
-  const long long r0 = (long long)chunk * G.rows_per_chunk;
-  long long r1 = r0 + G.rows_per_chunk;
-  if (r1 > G.p_pad) r1 = G.p_pad;
-  const int ntile = (int)((r1 - r0) / GP);
-  const int wm = wave >> 1, wn = wave & 1;
+template <bool SKINNY>
+__device__ __forceinline__ void gemm_body(const GemmPlan& G, const GemmBlock& B, char* smem, float* __restrict__ ws,
+                                          long long r0, int nst, int chunk, int wave, int lane) {
+#ifdef ANERF_EXP_GEMM_TIMING   // debug build only: per-wave cycle stamps at ws + 64M floats
+  const long long tk0 = wall_clock64();
+#endif
   const int i = lane & 31, kk = lane >> 5;
+  const GemmWave& W = B.w[wave];
+  const bool active = W.a_tile >= 0;
+  const bool do_bias = active && W.bias_off >= 0;
 
-  f32x16 acc[2][2];
+  // ---- loader: every operand tile of a stage is 8 two-row wave-instructions; wave w issues rows {2w, 2w+1} and
+  // {2w+8, 2w+9} of each tile.  Only 5 per-lane offsets (VGPRs) live across the MFMA loop: a spilled VGPR here
+  // would put a scratch reload -- an in-order VMEM op -- behind the freshly issued operand loads and expose their
+  // full latency at every stage.
+  // Tile descriptors are copied into scalars up front: read through the plan reference they would be re-fetched with
+  // dependent s_load round trips at every stage (the asm "memory" clobber of the stage barrier forbids caching them).
+  const char* t_ptr[5];
+  int t_ld[5];
+  unsigned t_lo[5];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int tile = 0; tile < 5; ++tile) {
+    const int tt = tile < B.ntiles ? tile : 0;
+    const GemmMat& M = G.mat[B.t[tt].mat];
+    int c = B.t[tt].col0 + i * 4;
+    const int cmax = M.ncols - 4;
+    c = c > cmax ? cmax : c;   // clamp: columns past the edge repeat the last float4 (their outputs are never stored)
+    t_ld[tile] = M.ld;
+    t_ptr[tile] = reinterpret_cast<const char*>(M.ptr + (r0 + 2 * wave) * M.ld);    // wave-uniform
+    t_lo[tile] = (unsigned)(kk * M.ld + c) * 4u;                                      // per lane
+  }
+  const int ntiles = B.ntiles;
+  auto issue = [&](int stage, int slot) {
+#ifdef ANERF_EXP_GEMM_NOLOAD   // ablation build only (tools/ablate.sh): results are wrong
+    (void)stage; (void)slot; return;
+#endif
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int tile = 0; tile < 5; ++tile)
+      if (tile < ntiles) {
+        const char* rowp = t_ptr[tile] + (long long)stage * (GEMM_ROWS * 4) * t_ld[tile];
+        char* l = smem + slot * GSTAGE_BYTES + tile * GTILE_BYTES + wave * (2 * GT * 4);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(rowp + t_lo[tile]), (lds_ptr_t)l, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(rowp + (long long)t_ld[tile] * 32 + t_lo[tile]), (lds_ptr_t)(l + 8 * (GT * 4)), 16, 0, 0);
+      }
+  };
+
+  constexpr int NA = SKINNY ? 1 : 4;
+  f32x16 acc[NA][4];
+#pragma unroll
+  for (int a = 0; a < NA; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-  float asum0 = 0.f, asum1 = 0.f;
+  f32x4 asum = {0.f, 0.f, 0.f, 0.f};
 
-  // LDS: [buffer 0: A tile | B tile][buffer 1: A tile | B tile]
-  if (ntile > 0) {
-    stage_tile(pr.A, pr.lda, tm * GT, pr.lda_cols, r0, smem, wave, lane);
-    stage_tile(pr.B, pr.ldb, tn * GT, pr.ldb_cols, r0, smem + TILE_BYTES, wave, lane);
+  const unsigned a_off = W.a_tile * GTILE_BYTES + kk * (GT * 4) + (SKINNY ? (i & 3) * 4 : i * 16);
+  const unsigned b_off = W.b_tile * GTILE_BYTES + kk * (GT * 4) + i * 16;
+
+  if (nst > 0) issue(0, 0);
+  if (!active) {                                       // idle wave of a partially filled block: loads and barriers only
+    for (int t = 0; t < nst; ++t) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t + 1 < nst) issue(t + 1, (t + 1) & 1);
+    }
+    return;
   }
-  for (int t = 0; t < ntile; ++t) {
+  // The loop body below is straight-line code on purpose (the column sums are accumulated by every wave and only
+  // stored by the ones that own a bias): any branch that touches it makes the compiler shuttle the 256 accumulators
+  // between AGPRs and VGPRs at the merge points.
+  for (int t = 0; t < nst; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t + 1 < ntile) {
-      char* nxt = smem + ((t + 1) & 1) * (2 * TILE_BYTES);
-      stage_tile(pr.A, pr.lda, tm * GT, pr.lda_cols, r0 + (long long)(t + 1) * GP, nxt, wave, lane);
-      stage_tile(pr.B, pr.ldb, tn * GT, pr.ldb_cols, r0 + (long long)(t + 1) * GP, nxt + TILE_BYTES, wave, lane);
-    }
-    const char* cur = smem + (t & 1) * (2 * TILE_BYTES);
-    const float* a_s = reinterpret_cast<const float*>(cur) + wm * 64 + i;
-    const float* b_s = reinterpret_cast<const float*>(cur + TILE_BYTES) + wn * 64 + i;
+#ifndef ANERF_EXP_GEMM_NOBARRIER   // ablation build only: results are wrong
+    __syncthreads();                                   // stage t landed; everyone is done with stage t-1's slot
+#endif
+    if (t + 1 < nst) issue(t + 1, (t + 1) & 1);
+    const char* base = smem + (t & 1) * GSTAGE_BYTES;
+    if constexpr (SKINNY) {
+      f32x4 b4 = *reinterpret_cast<const f32x4*>(base + b_off);
+      float a1 = *reinterpret_cast<const float*>(base + a_off);
 #pragma unroll
-    for (int s = 0; s < GP / 2; ++s) {
-      const float a0 = a_s[(2 * s + kk) * GT], a1 = a_s[(2 * s + kk) * GT + 32];
-      const float b0 = b_s[(2 * s + kk) * GT], b1 = b_s[(2 * s + kk) * GT + 32];
-      asum0 += a0;
-      asum1 += a1;
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-    }
-  }
-  // ---- partial tile -> workspace [chunk][M][N]
-  float* part = ws + pr.part_off + (long long)chunk * pr.M * pr.N;
+      for (int s = 0; s < GEMM_ROWS / 2; ++s) {
+        f32x4 bn = b4;
+        float an = a1;
+        if (s + 1 < GEMM_ROWS / 2) {
+          bn = *reinterpret_cast<const f32x4*>(base + b_off + (s + 1) * (2 * GT * 4));
+          an = *reinterpret_cast<const float*>(base + a_off + (s + 1) * (2 * GT * 4));
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+        for (int c = 0; c < 4; ++c) acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b4[c], acc[0][c], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        asum[0] += a1;
+        a1 = an;
+        b4 = bn;
+      }
+    } else {
+      // Operands are read TWO row pairs ahead: the s_waitcnt in front of a group's MFMAs then only has to cover reads
+      // issued a full group (1024 MFMA cycles) earlier and may leave the newest pair in flight (lgkmcnt(2)).  The
+      // sched_barriers pin that order: left alone, the scheduler hoists the column-sum adds of later pairs above the
+      // MFMAs and drags a wait for the freshly issued reads in front of them.
+      constexpr int NS = GEMM_ROWS / 2;
+      f32x4 av[NS], bv[NS];
+      av[0] = *reinterpret_cast<const f32x4*>(base + a_off);
+      bv[0] = *reinterpret_cast<const f32x4*>(base + b_off);
+      av[1] = *reinterpret_cast<const f32x4*>(base + a_off + 2 * GT * 4);
+      bv[1] = *reinterpret_cast<const f32x4*>(base + b_off + 2 * GT * 4);
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int n = tn * GT + wn * 64 + b * 32 + i;
+      for (int s = 0; s < NS; ++s) {
+        if (s + 2 < NS) {
+          av[s + 2] = *reinterpret_cast<const f32x4*>(base + a_off + (s + 2) * (2 * GT * 4));
+          bv[s + 2] = *reinterpret_cast<const f32x4*>(base + b_off + (s + 2) * (2 * GT * 4));
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int mrow = tm * GT + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-        if (mrow < pr.M && n < pr.N) part[(long long)mrow * pr.N + n] = acc[a][b][r];
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][a], bv[s][c], acc[a][c], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        asum += av[s];
       }
     }
-  if (pr.bias_off >= 0 && tn == 0 && wn == 0) {
-    asum0 += __shfl_xor(asum0, 32);
-    asum1 += __shfl_xor(asum1, 32);
-    float* bp = ws + pr.bias_off + (long long)chunk * pr.M;
-    const int m0 = tm * GT + wm * 64 + i;
+  }
+#ifdef ANERF_EXP_GEMM_TIMING
+  const long long tk1 = wall_clock64();
+#endif
+  // ---- partial tile -> workspace [chunk][M][N]: accumulator block (a, c), register r, lane (i, kk) holds
+  //      output row 4*((r&3) + 8*(r>>2) + 4*kk) + a, column 4*i + c   (skinny: row (r&3), rows >= 4 are copies)
+  float* part = ws + W.part_off + (long long)chunk * W.M * W.N;
+  const int n = W.n0 + 4 * i;
+  if (n < W.N) {
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rowi = (r & 3) + 8 * (r >> 2) + 4 * kk;
+        const int m = SKINNY ? rowi : W.m0 + 4 * rowi + a;
+        if (SKINNY ? (rowi < 4 && m < W.M) : (m < W.M)) {
+          const f32x4 o = {acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
+          *reinterpret_cast<f32x4*>(part + (long long)m * W.N + n) = o;
+        }
+      }
+  }
+  if (do_bias) {
+    float* bp = ws + W.bias_off + (long long)chunk * W.M;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) asum[a] += __shfl_xor(asum[a], 32);
     if (kk == 0) {
-      if (m0 < pr.M) bp[m0] = asum0;
-      if (m0 + 32 < pr.M) bp[m0 + 32] = asum1;
+      if constexpr (SKINNY) {
+        if (i < 4 && i < W.M) bp[i] = asum[0];
+      } else {
+        const int m = W.m0 + 4 * i;
+        if (m < W.M) *reinterpret_cast<f32x4*>(bp + m) = asum;   // M is a multiple of 4 for every heavy problem
+      }
     }
   }
+#ifdef ANERF_EXP_GEMM_TIMING
+  if (lane == 0) {
+    long long* dbg = reinterpret_cast<long long*>(ws + (64LL << 20)) + ((long long)blockIdx.x * 4 + wave) * 4;
+    dbg[0] = tk0; dbg[1] = tk1; dbg[2] = wall_clock64(); dbg[3] = nst;
+  }
+#endif
+}
+
+__global__ __launch_bounds__(256) void k_gemm_tn(const GemmPlan G, float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // blockIdx -> (block job, row chunk).  Consecutive workgroup ids go round-robin over the 8 XCDs (each with its own
+  // L2): within a full group of 8 chunks, chunk c of every job gets id = 8 * job + c % 8, so the jobs that share
+  // activation rows share one L2.  No padding ids: every XCD gets the same number of blocks (an earlier version
+  // padded the chunk count to a multiple of 8 with empty blocks -- XCD 0 then ran 3 chunks while the others ran 2,
+  // and the kernel took two rounds instead of one).  Skinny blocks come last.
+  const int bid = blockIdx.x;
+  const int heavy_grid = G.chunks_h * G.nheavy;
+  const int full = (G.chunks_h / 8) * 8 * G.nheavy;          // ids covered by full groups of 8 chunks
+  int job, chunk, rows;
+  if (bid < full) {
+    const int grp = bid / (8 * G.nheavy), rem = bid - grp * (8 * G.nheavy);
+    job = rem >> 3;
+    chunk = grp * 8 + (rem & 7);
+    rows = G.rows_h;
+  } else if (bid < heavy_grid) {
+    const int m = G.chunks_h & 7, k = bid - full;
+    job = k / m;
+    chunk = (G.chunks_h / 8) * 8 + k % m;
+    rows = G.rows_h;
+  } else {
+    const int s = bid - heavy_grid;
+    job = G.nheavy + s % G.nskinny;
+    chunk = s / G.nskinny;
+    rows = G.rows_s;
+  }
+  const long long r0 = (long long)chunk * rows;
+  long long r1 = r0 + rows;
+  if (r1 > G.p_pad) r1 = G.p_pad;
+  const int nst = (int)((r1 - r0) / GEMM_ROWS);
+  const GemmBlock& B = G.blk[job];
+  if (B.skinny) gemm_body<true>(G, B, smem, ws, r0, nst, chunk, wave, lane);
+  else gemm_body<false>(G, B, smem, ws, r0, nst, chunk, wave, lane);
 }
 
 // Sum the chunk partials in index order and scatter into the gradient tensors.
@@ -130,7 +271,7 @@ __global__ void k_reduce_dw(const GemmBatch G, const float* __restrict__ ws) {
     const int mrow = (int)(e / pr.N), n = (int)(e - (long long)mrow * pr.N);
     const float* src = ws + pr.part_off + e;
     float s = 0.f;
-    for (int c = 0; c < G.chunks; ++c) s += src[(long long)c * mn];
+    for (int c = 0; c < pr.chunks; ++c) s += src[(long long)c * mn];
     if (mrow >= pr.m_first && mrow < pr.m_first + pr.m_count) {
       const int col = pr.colmap ? pr.colmap[n] : n;
       pr.dst[(long long)(mrow - pr.m_first) * pr.dst_ld + pr.dst_col0 + col] = s;
@@ -139,19 +280,19 @@ __global__ void k_reduce_dw(const GemmBatch G, const float* __restrict__ ws) {
     const int mrow = (int)(e - mn);
     const float* src = ws + pr.bias_off + mrow;
     float s = 0.f;
-    for (int c = 0; c < G.chunks; ++c) s += src[(long long)c * pr.M];
+    for (int c = 0; c < pr.chunks; ++c) s += src[(long long)c * pr.M];
     if (mrow >= pr.bm_first && mrow < pr.bm_first + pr.bm_count) pr.bias_dst[mrow - pr.bm_first] = s;
   }
 }
 
-int launch_weight_grads(GemmBatch& G, float* ws, hipStream_t st) {
-  const size_t lds = 4 * TILE_BYTES;
+int launch_weight_grads(const GemmPlan& P, const GemmBatch& G, float* ws, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_tn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_tn), hipFuncAttributeMaxDynamicSharedMemorySize, GLDS_BYTES);
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_gemm_tn, dim3((unsigned)(G.total_tiles * G.chunks)), dim3(256), lds, st, G, ws);
+  const int grid = P.chunks_h * P.nheavy + P.chunks_s * P.nskinny;
+  hipLaunchKernelGGL(k_gemm_tn, dim3((unsigned)grid), dim3(256), GLDS_BYTES, st, P, ws);
   int rc = check_launch("k_gemm_tn");
   if (rc) return rc;
   hipLaunchKernelGGL(k_reduce_dw, dim3((unsigned)((G.total_out + 255) / 256)), dim3(256), 0, st, G, (const float*)ws);
