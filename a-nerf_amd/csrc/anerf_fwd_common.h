@@ -120,6 +120,50 @@ __device__ __forceinline__ float head_dot(const f32x16* acc, const float* wrow_h
   return s + __shfl_xor(s, 32);
 }
 
+// One k-group (8 contraction indices: 4 from each lane half) against NB 32-row feature blocks.
+// kg: k-group index relative to the segment (layer) start; first: first k-group of the layer (informational);
+// last: final k-group of the segment (segments are padded to whole stages).  All three fold at compile time.
+template <int NB>
+__device__ __forceinline__ void kgroup(Pipe3& pipe, f32x16 (&acc)[NB], int kg, bool first, bool last, float b0, float b1,
+                                       float b2, float b3) {
+  constexpr int KPS = STAGE_FRAGS / NB;  // k-groups per stage
+  const int ks = kg % KPS;
+  f32x4 a[NB];
+  if (ks == 0 && kg != 0) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) a[nb] = pipe.pref[nb];
+  } else {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+      a[nb] = *reinterpret_cast<const f32x4*>(pipe.smem + pipe.cur + (ks * NB + nb) * FRAG_BYTES);
+  }
+  if (ks == KPS - 1 && !last) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) pipe.pref[nb] = *reinterpret_cast<const f32x4*>(pipe.smem + pipe.nxt + nb * FRAG_BYTES);
+  }
+  (void)first;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nb].x, b0, acc[nb], 0, 0, 0);
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nb].y, b1, acc[nb], 0, 0, 0);
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nb].z, b2, acc[nb], 0, 0, 0);
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nb].w, b3, acc[nb], 0, 0, 0);
+  if (ks == KPS - 1 || last) pipe.end_stage();
+}
+
+// 32 k-groups whose B operands are the previous layer's 256 outputs, read straight from its accumulator set
+// `prev` (bias added by the accumulator init, ReLU already applied in place): no copy, no VALU in the MFMA stream.
+template <int NB, int KG0>
+__device__ __forceinline__ void hidden_part(Pipe3& pipe, f32x16 (&acc)[NB], const f32x16 (&prev)[8], bool first,
+                                            bool last) {
+#pragma unroll
+  for (int kg = 0; kg < 32; ++kg)
+    kgroup<NB>(pipe, acc, KG0 + kg, first && kg == 0, last && kg == 31, prev[kg >> 2][4 * (kg & 3) + 0],
+               prev[kg >> 2][4 * (kg & 3) + 1], prev[kg >> 2][4 * (kg & 3) + 2], prev[kg >> 2][4 * (kg & 3) + 3]);
+}
+
 struct MlpArgs {
   const float* packed;
   const float* aux;
