@@ -1,0 +1,245 @@
+// anerf_fk.hip -- forward kinematics of the SMPL skeleton and its backward:
+//   PoseOptLayer.calculate_kinematic / get_kinematic_chain_T + unrolled_kinematic_chain (core/pose_opt.py:372-445,
+//   482-566): per pose, axis-angle bones [24,3] + pelvis [3] + rest pose [24,3]  ->  local rotations `rots`, joint-to-
+//   world matrices `l2ws`, world-to-bone matrices `skts` (= inverse(l2ws), what the ray-march kernels consume) and
+//   joint locations `kp`.  The reference runs ~40 small batched ops forward and ~100 backward per call; here it is one
+//   launch each way.  The rotation map is pytorch3d's axis_angle_to_matrix (third-party, absent from this image:
+//   pytorch3d/transforms/rotation_conversions.py, the version the reference's README installs -- py38_cu102_pyt190
+//   wheels = v0.6.x), restated from its published source:
+//     axis_angle_to_quaternion: th = |a|, q = (cos(th/2), a * k), k = sin(th/2)/th, or 0.5 - th^2/48 when th < 1e-6
+//     quaternion_to_matrix:     R = I + (2 / q.q) * B(q)
+//   Latency-bound scalar work (one thread per pose, the 24-joint chain is sequential); it exists to take ~140 tiny
+//   launches off the pose-refinement step, not to chase a roofline.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "anerf.h"
+#include "anerf_dev.h"
+
+namespace anerf {
+
+constexpr int NJ = 24;
+// SMPLSkeleton.joint_trees (core/utils/skeleton_utils.py:98-104), root_id = 0
+__device__ __constant__ int kParent[NJ] = {0, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21};
+
+struct Quat { float r, i, j, k, th, kf; };
+
+__device__ __forceinline__ Quat aa_to_quat(const float* a) {
+  Quat q;
+  q.th = sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+  const float hf = 0.5f * q.th;
+  q.kf = q.th < 1e-6f ? 0.5f - q.th * q.th / 48.f : sinf(hf) / q.th;
+  q.r = cosf(hf);
+  q.i = a[0] * q.kf;
+  q.j = a[1] * q.kf;
+  q.k = a[2] * q.kf;
+  return q;
+}
+
+__device__ __forceinline__ void quat_to_mat(const Quat& q, float* R) {
+  const float two_s = 2.0f / (q.r * q.r + q.i * q.i + q.j * q.j + q.k * q.k);
+  R[0] = 1.f - two_s * (q.j * q.j + q.k * q.k);
+  R[1] = two_s * (q.i * q.j - q.k * q.r);
+  R[2] = two_s * (q.i * q.k + q.j * q.r);
+  R[3] = two_s * (q.i * q.j + q.k * q.r);
+  R[4] = 1.f - two_s * (q.i * q.i + q.k * q.k);
+  R[5] = two_s * (q.j * q.k - q.i * q.r);
+  R[6] = two_s * (q.i * q.k - q.j * q.r);
+  R[7] = two_s * (q.j * q.k + q.i * q.r);
+  R[8] = 1.f - two_s * (q.i * q.i + q.j * q.j);
+}
+
+// d(loss)/dR -> d(loss)/d(axis-angle)
+__device__ __forceinline__ void aa_backward(const float* a, const float* dR, float* da) {
+  const Quat q = aa_to_quat(a);
+  const float n = q.r * q.r + q.i * q.i + q.j * q.j + q.k * q.k, two_s = 2.0f / n;
+  // R = I + two_s * B
+  const float B[9] = {-(q.j * q.j + q.k * q.k), q.i * q.j - q.k * q.r, q.i * q.k + q.j * q.r,
+                      q.i * q.j + q.k * q.r, -(q.i * q.i + q.k * q.k), q.j * q.k - q.i * q.r,
+                      q.i * q.k - q.j * q.r, q.j * q.k + q.i * q.r, -(q.i * q.i + q.j * q.j)};
+  float d_two_s = 0.f, dB[9];
+#pragma unroll
+  for (int e = 0; e < 9; ++e) {
+    d_two_s += dR[e] * B[e];
+    dB[e] = dR[e] * two_s;
+  }
+  float dr = -q.k * dB[1] + q.j * dB[2] + q.k * dB[3] - q.i * dB[5] - q.j * dB[6] + q.i * dB[7];
+  float di = q.j * dB[1] + q.k * dB[2] + q.j * dB[3] - 2.f * q.i * dB[4] - q.r * dB[5] + q.k * dB[6] + q.r * dB[7] - 2.f * q.i * dB[8];
+  float dj = -2.f * q.j * dB[0] + q.i * dB[1] + q.r * dB[2] + q.i * dB[3] + q.k * dB[5] - q.r * dB[6] + q.k * dB[7] - 2.f * q.j * dB[8];
+  float dk = -2.f * q.k * dB[0] - q.r * dB[1] + q.i * dB[2] + q.r * dB[3] - 2.f * q.k * dB[4] + q.j * dB[5] + q.i * dB[6] + q.j * dB[7];
+  const float dn = -2.0f / (n * n) * d_two_s;      // two_s = 2 / n
+  dr += 2.f * q.r * dn;
+  di += 2.f * q.i * dn;
+  dj += 2.f * q.j * dn;
+  dk += 2.f * q.k * dn;
+  // q = (cos(th/2), a * k(th))
+  const float hf = 0.5f * q.th;
+  float dth = -0.5f * sinf(hf) * dr;
+  const float dkf = a[0] * di + a[1] * dj + a[2] * dk;
+  const float dk_dth = q.th < 1e-6f ? -q.th / 24.f : (0.5f * cosf(hf) * q.th - sinf(hf)) / (q.th * q.th);
+  dth += dkf * dk_dth;
+  const float inv = q.th > 0.f ? 1.0f / q.th : 0.f;   // d|a|/da = a/|a| (0 at the origin, as torch.norm's backward)
+  da[0] = q.kf * di + dth * a[0] * inv;
+  da[1] = q.kf * dj + dth * a[1] * inv;
+  da[2] = q.kf * dk + dth * a[2] * inv;
+}
+
+// one thread per pose.  l2ws / skts [U,24,4,4] row-major, rots [U,24,3,3], kp [U,24,3]; any output may be NULL.
+__global__ void k_fk_fwd(const float* __restrict__ bones, const float* __restrict__ pelvis, const float* __restrict__ rest,
+                         long long rest_stride, int n, float* __restrict__ l2ws, float* __restrict__ skts,
+                         float* __restrict__ rots, float* __restrict__ kp) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n) return;
+  const float* rp = rest + (long long)u * rest_stride;
+  float pv[3] = {0.f, 0.f, 0.f};
+  if (pelvis) { pv[0] = pelvis[3 * u]; pv[1] = pelvis[3 * u + 1]; pv[2] = pelvis[3 * u + 2]; }
+  float Rg[NJ][9], tg[NJ][3];
+  for (int j = 0; j < NJ; ++j) {
+    float R[9];
+    quat_to_mat(aa_to_quat(bones + ((long long)u * NJ + j) * 3), R);
+    if (rots)
+      for (int e = 0; e < 9; ++e) rots[((long long)u * NJ + j) * 9 + e] = R[e];
+    if (j == 0) {
+      for (int e = 0; e < 9; ++e) Rg[0][e] = R[e];
+      for (int c = 0; c < 3; ++c) tg[0][c] = rp[c];
+    } else {
+      const int p = kParent[j];
+      const float o[3] = {rp[3 * j] - rp[3 * p], rp[3 * j + 1] - rp[3 * p + 1], rp[3 * j + 2] - rp[3 * p + 2]};
+      for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c)
+          Rg[j][3 * r + c] = Rg[p][3 * r] * R[c] + Rg[p][3 * r + 1] * R[3 + c] + Rg[p][3 * r + 2] * R[6 + c];
+        tg[j][r] = Rg[p][3 * r] * o[0] + Rg[p][3 * r + 1] * o[1] + Rg[p][3 * r + 2] * o[2] + tg[p][r];
+      }
+    }
+  }
+  for (int j = 0; j < NJ; ++j) {
+    const float c[3] = {tg[j][0] + pv[0], tg[j][1] + pv[1], tg[j][2] + pv[2]};
+    const long long m = ((long long)u * NJ + j) * 16;
+    if (l2ws) {
+      for (int r = 0; r < 3; ++r) {
+        l2ws[m + 4 * r] = Rg[j][3 * r]; l2ws[m + 4 * r + 1] = Rg[j][3 * r + 1]; l2ws[m + 4 * r + 2] = Rg[j][3 * r + 2];
+        l2ws[m + 4 * r + 3] = c[r];
+      }
+      l2ws[m + 12] = 0.f; l2ws[m + 13] = 0.f; l2ws[m + 14] = 0.f; l2ws[m + 15] = 1.f;
+    }
+    if (skts) {   // inverse of a rigid transform: [R^T | -R^T c]
+      for (int r = 0; r < 3; ++r) {
+        skts[m + 4 * r] = Rg[j][r]; skts[m + 4 * r + 1] = Rg[j][3 + r]; skts[m + 4 * r + 2] = Rg[j][6 + r];
+        skts[m + 4 * r + 3] = -(Rg[j][r] * c[0] + Rg[j][3 + r] * c[1] + Rg[j][6 + r] * c[2]);
+      }
+      skts[m + 12] = 0.f; skts[m + 13] = 0.f; skts[m + 14] = 0.f; skts[m + 15] = 1.f;
+    }
+    if (kp) { kp[((long long)u * NJ + j) * 3] = c[0]; kp[((long long)u * NJ + j) * 3 + 1] = c[1]; kp[((long long)u * NJ + j) * 3 + 2] = c[2]; }
+  }
+}
+
+// backward: gradients w.r.t. skts / l2ws (rows 0..2 used) / kp / rots  ->  gradients w.r.t. bones and pelvis
+__global__ void k_fk_bwd(const float* __restrict__ bones, const float* __restrict__ pelvis, const float* __restrict__ rest,
+                         long long rest_stride, int n, const float* __restrict__ g_skts, const float* __restrict__ g_l2ws,
+                         const float* __restrict__ g_kp, const float* __restrict__ g_rots, float* __restrict__ g_bones,
+                         float* __restrict__ g_pelvis) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n) return;
+  const float* rp = rest + (long long)u * rest_stride;
+  float pv[3] = {0.f, 0.f, 0.f};
+  if (pelvis) { pv[0] = pelvis[3 * u]; pv[1] = pelvis[3 * u + 1]; pv[2] = pelvis[3 * u + 2]; }
+  // recompute the chain
+  float Rl[NJ][9], Rg[NJ][9], tg[NJ][3];
+  for (int j = 0; j < NJ; ++j) {
+    quat_to_mat(aa_to_quat(bones + ((long long)u * NJ + j) * 3), Rl[j]);
+    if (j == 0) {
+      for (int e = 0; e < 9; ++e) Rg[0][e] = Rl[0][e];
+      for (int c = 0; c < 3; ++c) tg[0][c] = rp[c];
+    } else {
+      const int p = kParent[j];
+      const float o[3] = {rp[3 * j] - rp[3 * p], rp[3 * j + 1] - rp[3 * p + 1], rp[3 * j + 2] - rp[3 * p + 2]};
+      for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c)
+          Rg[j][3 * r + c] = Rg[p][3 * r] * Rl[j][c] + Rg[p][3 * r + 1] * Rl[j][3 + c] + Rg[p][3 * r + 2] * Rl[j][6 + c];
+        tg[j][r] = Rg[p][3 * r] * o[0] + Rg[p][3 * r + 1] * o[1] + Rg[p][3 * r + 2] * o[2] + tg[p][r];
+      }
+    }
+  }
+  // gradients w.r.t. the global rotation and the joint centre c = tg + pelvis of every joint
+  float dRg[NJ][9], dc[NJ][3];
+  float dpel[3] = {0.f, 0.f, 0.f};
+  for (int j = 0; j < NJ; ++j) {
+    for (int e = 0; e < 9; ++e) dRg[j][e] = 0.f;
+    dc[j][0] = dc[j][1] = dc[j][2] = 0.f;
+    const long long m = ((long long)u * NJ + j) * 16;
+    const float c[3] = {tg[j][0] + pv[0], tg[j][1] + pv[1], tg[j][2] + pv[2]};
+    if (g_l2ws)
+      for (int r = 0; r < 3; ++r) {
+        dRg[j][3 * r] += g_l2ws[m + 4 * r]; dRg[j][3 * r + 1] += g_l2ws[m + 4 * r + 1]; dRg[j][3 * r + 2] += g_l2ws[m + 4 * r + 2];
+        dc[j][r] += g_l2ws[m + 4 * r + 3];
+      }
+    if (g_skts) {   // S = Rg^T, s = -Rg^T c
+      float ds[3];
+      for (int r = 0; r < 3; ++r) {
+        ds[r] = g_skts[m + 4 * r + 3];
+        for (int k = 0; k < 3; ++k) dRg[j][3 * k + r] += g_skts[m + 4 * r + k];     // dS[r][k] -> dRg[k][r]
+      }
+      for (int k = 0; k < 3; ++k) {
+        dc[j][k] -= Rg[j][3 * k] * ds[0] + Rg[j][3 * k + 1] * ds[1] + Rg[j][3 * k + 2] * ds[2];
+        for (int r = 0; r < 3; ++r) dRg[j][3 * k + r] -= c[k] * ds[r];
+      }
+    }
+    if (g_kp)
+      for (int r = 0; r < 3; ++r) dc[j][r] += g_kp[((long long)u * NJ + j) * 3 + r];
+    for (int r = 0; r < 3; ++r) dpel[r] += dc[j][r];
+  }
+  // reverse chain: children before parents (every child index is larger than its parent's)
+  for (int j = NJ - 1; j >= 0; --j) {
+    float dRl[9];
+    if (j == 0) {
+      for (int e = 0; e < 9; ++e) dRl[e] = dRg[0][e];
+    } else {
+      const int p = kParent[j];
+      const float o[3] = {rp[3 * j] - rp[3 * p], rp[3 * j + 1] - rp[3 * p + 1], rp[3 * j + 2] - rp[3 * p + 2]};
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+          // Rg_j = Rg_p Rl_j :  dRl = Rg_p^T dRg_j ;  dRg_p += dRg_j Rl_j^T ;  tg_j = Rg_p o + tg_p : dRg_p += dtg o^T
+          dRl[3 * r + c] = Rg[p][r] * dRg[j][c] + Rg[p][3 + r] * dRg[j][3 + c] + Rg[p][6 + r] * dRg[j][6 + c];
+          dRg[p][3 * r + c] += dRg[j][3 * r] * Rl[j][3 * c] + dRg[j][3 * r + 1] * Rl[j][3 * c + 1] + dRg[j][3 * r + 2] * Rl[j][3 * c + 2] +
+                               dc[j][r] * o[c];
+        }
+      for (int r = 0; r < 3; ++r) dc[p][r] += dc[j][r];
+    }
+    if (g_rots)
+      for (int e = 0; e < 9; ++e) dRl[e] += g_rots[((long long)u * NJ + j) * 9 + e];
+    float da[3];
+    aa_backward(bones + ((long long)u * NJ + j) * 3, dRl, da);
+    g_bones[((long long)u * NJ + j) * 3] = da[0];
+    g_bones[((long long)u * NJ + j) * 3 + 1] = da[1];
+    g_bones[((long long)u * NJ + j) * 3 + 2] = da[2];
+  }
+  if (g_pelvis) { g_pelvis[3 * u] = dpel[0]; g_pelvis[3 * u + 1] = dpel[1]; g_pelvis[3 * u + 2] = dpel[2]; }
+}
+
+}  // namespace anerf
+
+using namespace anerf;
+
+extern "C" {
+
+int anerf_fk_forward(const float* bones, const float* pelvis, const float* rest_pose, int64_t rest_pose_stride,
+                     int32_t n_poses, float* l2ws, float* skts, float* rots, float* kp, void* stream) {
+  if (n_poses < 0 || (rest_pose_stride != 0 && rest_pose_stride != 72)) return set_error(ANERF_E_SHAPE, "fk_forward: n_poses >= 0, rest_pose_stride 0 or 72");
+  if (n_poses == 0) return ANERF_OK;
+  if (!bones || !rest_pose) return set_error(ANERF_E_NULL, "fk_forward: NULL pointer");
+  hipLaunchKernelGGL(k_fk_fwd, dim3((n_poses + 63) / 64), dim3(64), 0, (hipStream_t)stream, bones, pelvis, rest_pose,
+                     (long long)rest_pose_stride, (int)n_poses, l2ws, skts, rots, kp);
+  return check_launch("k_fk_fwd");
+}
+
+int anerf_fk_backward(const float* bones, const float* pelvis, const float* rest_pose, int64_t rest_pose_stride,
+                      int32_t n_poses, const float* g_skts, const float* g_l2ws, const float* g_kp, const float* g_rots,
+                      float* g_bones, float* g_pelvis, void* stream) {
+  if (n_poses < 0 || (rest_pose_stride != 0 && rest_pose_stride != 72)) return set_error(ANERF_E_SHAPE, "fk_backward: n_poses >= 0, rest_pose_stride 0 or 72");
+  if (n_poses == 0) return ANERF_OK;
+  if (!bones || !rest_pose || !g_bones) return set_error(ANERF_E_NULL, "fk_backward: NULL pointer");
+  hipLaunchKernelGGL(k_fk_bwd, dim3((n_poses + 63) / 64), dim3(64), 0, (hipStream_t)stream, bones, pelvis, rest_pose,
+                     (long long)rest_pose_stride, (int)n_poses, g_skts, g_l2ws, g_kp, g_rots, g_bones, g_pelvis);
+  return check_launch("k_fk_bwd");
+}
+
+}  // extern "C"

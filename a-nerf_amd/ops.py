@@ -282,3 +282,35 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, g
     _lib.check(lib.anerf_adam_step(_p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), n, float(lr), float(beta1), float(beta2),
                                    float(eps), int(step), float(grad_scale), int(bool(zero_grads)), int(n_tensors), _p(part),
                                    _p(norms2), _stream()), "anerf_adam_step")
+
+
+def fk_forward(bones, rest_pose, pelvis=None, want=("l2ws", "skts", "rots", "kp")):
+    """PoseOptLayer.calculate_kinematic's math (anerf_fk_forward; pose_opt.py:372-445): bones [U,24,3] axis-angle,
+    rest_pose [24,3] / [1,24,3] (shared) or [U,24,3], pelvis [U,3] or None -> dict of the requested outputs."""
+    bones, rest_pose, pelvis = _f32c(bones, "bones"), _f32c(rest_pose, "rest_pose"), _f32c(pelvis, "pelvis")
+    if bones.dim() != 3 or bones.shape[1:] != (24, 3):
+        raise ValueError(f"fk_forward: bones must be [U,24,3] axis-angle, got {tuple(bones.shape)}")
+    u, dev = bones.shape[0], bones.device
+    rest = rest_pose.reshape(-1, 24, 3)
+    if rest.shape[0] not in (1, u):
+        raise ValueError(f"fk_forward: rest_pose must have 1 or {u} poses, got {rest.shape[0]}")
+    stride = 0 if rest.shape[0] == 1 else 72
+    shapes = {"l2ws": (u, 24, 4, 4), "skts": (u, 24, 4, 4), "rots": (u, 24, 3, 3), "kp": (u, 24, 3)}
+    out = {k: torch.empty(shapes[k], dtype=torch.float32, device=dev) for k in want}
+    _lib.check(_lib.load().anerf_fk_forward(_p(bones), _p(pelvis), _p(rest), stride, u, _p(out.get("l2ws")), _p(out.get("skts")),
+                                            _p(out.get("rots")), _p(out.get("kp")), _stream()), "anerf_fk_forward")
+    return out
+
+
+def fk_backward(bones, rest_pose, pelvis, g_skts=None, g_l2ws=None, g_kp=None, g_rots=None):
+    """-> (g_bones [U,24,3], g_pelvis [U,3] or None)   (anerf_fk_backward)"""
+    bones, rest_pose, pelvis = _f32c(bones, "bones"), _f32c(rest_pose, "rest_pose"), _f32c(pelvis, "pelvis")
+    g_skts, g_l2ws, g_kp, g_rots = _f32c(g_skts, "g_skts"), _f32c(g_l2ws, "g_l2ws"), _f32c(g_kp, "g_kp"), _f32c(g_rots, "g_rots")
+    u = bones.shape[0]
+    rest = rest_pose.reshape(-1, 24, 3)
+    stride = 0 if rest.shape[0] == 1 else 72
+    gb = torch.empty_like(bones)
+    gp = torch.empty(u, 3, dtype=torch.float32, device=bones.device) if pelvis is not None else None
+    _lib.check(_lib.load().anerf_fk_backward(_p(bones), _p(pelvis), _p(rest), stride, u, _p(g_skts), _p(g_l2ws), _p(g_kp),
+                                             _p(g_rots), _p(gb), _p(gp), _stream()), "anerf_fk_backward")
+    return gb, gp

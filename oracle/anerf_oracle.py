@@ -327,3 +327,51 @@ def psnr(pred, target):
 
 def params_from_numpy(d, requires_grad=False):
     return {k: torch.tensor(np.asarray(v), dtype=torch.float32, requires_grad=requires_grad) for k, v in d.items()}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# forward kinematics of the pose-refinement layer
+# ---------------------------------------------------------------------------------------------------------------
+SMPL_PARENTS = [0, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21]   # skeleton_utils.py:98-104
+
+
+def axis_angle_to_matrix(a):
+    """pytorch3d.transforms.axis_angle_to_matrix, restated from the published source (third-party dependency of the
+    reference, absent from this image; called by core/utils/skeleton_utils.py:411-412 axisang_to_rot):
+    axis_angle_to_quaternion (half-angle, Taylor branch below 1e-6) then quaternion_to_matrix.  Cross-checked in
+    tests/golden/gen_golden_fk.py against scipy Rotation.from_rotvec, which the reference itself uses for the same map
+    (skeleton_utils.py:349)."""
+    ang = torch.norm(a, p=2, dim=-1, keepdim=True)
+    half = 0.5 * ang
+    small = ang.abs() < 1e-6
+    k = torch.where(small, 0.5 - ang * ang / 48, torch.sin(half) / torch.where(small, torch.ones_like(ang), ang))
+    q = torch.cat([torch.cos(half), a * k], -1)
+    r, i, j, kk = torch.unbind(q, -1)
+    two_s = 2.0 / (q * q).sum(-1)
+    o = torch.stack((1 - two_s * (j * j + kk * kk), two_s * (i * j - kk * r), two_s * (i * kk + j * r),
+                     two_s * (i * j + kk * r), 1 - two_s * (i * i + kk * kk), two_s * (j * kk - i * r),
+                     two_s * (i * kk - j * r), two_s * (j * kk + i * r), 1 - two_s * (i * i + j * j)), -1)
+    return o.reshape(a.shape[:-1] + (3, 3))
+
+
+def fk_chain(bones, rest_pose, pelvis=None):
+    """PoseOptLayer.calculate_kinematic (core/pose_opt.py:372-445) / get_kinematic_chain_T (:482-512), axis-angle bones
+    [U,24,3], rest_pose [24,3] or [U,24,3], pelvis [U,3] or None  ->  kp [U,24,3], skts, l2ws [U,24,4,4], rots [U,24,3,3].
+    The reference unrolls the SMPL tree by hand (unrolled_kinematic_chain :514-566); the parent loop is the same product."""
+    U = bones.shape[0]
+    rots = axis_angle_to_matrix(bones)
+    rest = rest_pose.expand(U, 24, 3)
+    bottom = torch.tensor([0., 0., 0., 1.], dtype=bones.dtype).expand(U, 1, 4)
+    l2ws = []
+    for j in range(24):
+        p = SMPL_PARENTS[j]
+        loc = rest[:, j] if j == 0 else rest[:, j] - rest[:, p]
+        T = torch.cat([torch.cat([rots[:, j], loc[..., None]], -1), bottom], -2)
+        l2ws.append(T if j == 0 else l2ws[p] @ T)
+    l2ws = torch.stack(l2ws, 1)
+    if pelvis is not None:
+        shift = torch.zeros(U, 4, 4, dtype=bones.dtype)
+        shift[:, :3, 3] = pelvis
+        l2ws = l2ws + shift[:, None]
+    skts = torch.inverse(l2ws)
+    return l2ws[..., :3, 3], skts, l2ws, rots

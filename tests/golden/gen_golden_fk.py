@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Golden vectors for the forward-kinematics row from the REFERENCE's PoseOptLayer.calculate_kinematic
+and get_kinematic_chain_T (/root/reference/core/pose_opt.py, build container only; the reference never travels).
+
+core.pose_opt imports smplx / h5py-based modules that are absent here: they are stubbed (nothing on this path uses
+them).  pytorch3d is absent too: its axis_angle_to_matrix is provided by the oracle's restatement and asserted here
+against scipy's Rotation.from_rotvec (the map the reference itself uses in get_smpl_l2ws).  Everything else -- the
+joint-to-joint transforms, the hand-unrolled SMPL chain, the pelvis shift, torch.inverse, autograd -- is the
+reference's own code.
+
+Run:  python tests/golden/gen_golden_fk.py      (writes tests/golden/fk.npz)
+"""
+import importlib, os, sys
+from unittest import mock
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+import gen_golden
+
+oracle = importlib.import_module("oracle.anerf_oracle")
+synth = importlib.import_module("a-nerf_amd.synth")
+
+
+def fk_inputs(seed, n):
+    """numpy-seeded poses, regenerated identically by the tests"""
+    rng = np.random.RandomState(seed)
+    bones = (rng.randn(n, 24, 3) * 0.4).astype(np.float32)
+    bones[0] = 0.0                       # exact rest pose: the Taylor branch of the rotation map
+    bones[1, 3] = [1e-7, -2e-7, 5e-8]    # tiny angle
+    pelvis = (rng.randn(n, 3) * 0.5).astype(np.float32)
+    rest = (synth.SMPL_REST_POSE * synth.SURREAL_SCALE).astype(np.float32)
+    w = {k: rng.randn(*s).astype(np.float32) for k, s in
+         [("skts", (n, 24, 4, 4)), ("kp", (n, 24, 3)), ("l2ws", (n, 24, 4, 4))]}
+    return bones, pelvis, rest, w
+
+
+def main():
+    gen_golden.import_reference()
+    for m in ["smplx", "h5py", "imageio", "core.process_spin", "core.load_data", "tensorboard"]:
+        sys.modules.setdefault(m, mock.MagicMock(name=m))
+    import core.utils.skeleton_utils as su
+    su.p3dr.axis_angle_to_matrix = oracle.axis_angle_to_matrix
+    import core.pose_opt as po
+    from scipy.spatial.transform import Rotation
+    bones, pelvis, rest, w = fk_inputs(21, 6)
+    ref_rot = np.stack([Rotation.from_rotvec(b).as_matrix() for b in bones.reshape(-1, 3).astype(np.float64)])
+    got = oracle.axis_angle_to_matrix(torch.tensor(bones.reshape(-1, 3), dtype=torch.float64)).numpy()
+    assert np.abs(ref_rot - got).max() < 1e-12, np.abs(ref_rot - got).max()
+
+    tb = torch.tensor(bones, requires_grad=True)
+    # (a) the free function (no pelvis)
+    kps, _, skts, l2ws, rots = po.get_kinematic_chain_T(torch.tensor(rest), tb)
+    loss = (skts * torch.tensor(w["skts"])).sum() + (kps * torch.tensor(w["kp"])).sum()
+    g_a, = torch.autograd.grad(loss, tb)
+    out = {"a_kp": kps, "a_skts": skts, "a_l2ws": l2ws, "a_rots": rots, "a_gbones": g_a}
+    # (b) the layer: pelvis parameter + unique/inverse index handling
+    layer = po.PoseOptLayer(torch.tensor(pelvis)[:, None].expand(-1, 24, 3).clone(), torch.tensor(bones), torch.tensor(rest)[None])
+    idxs = np.array([4, 1, 1, 0, 5])
+    kp, bone, skt, l2w, rot = layer(idxs)
+    loss = (skt * torch.tensor(w["skts"][:5])).sum() + (kp * torch.tensor(w["kp"][:5])).sum() + \
+           (l2w * torch.tensor(w["l2ws"][:5])).sum()
+    loss.backward()
+    out.update({"b_idxs": torch.tensor(idxs), "b_kp": kp, "b_skts": skt, "b_l2ws": l2w, "b_rots": rot,
+                "b_gbones": layer.bones.grad, "b_gpelvis": layer.pelvis.grad})
+    np.savez_compressed(os.path.join(HERE, "fk.npz"), **{k: v.detach().numpy() for k, v in out.items()})
+    print({k: tuple(v.shape) for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()
