@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="render64", choices=["render64", "hier", "render64x64", "train"])
+    ap.add_argument("--workload", default="render64", choices=["render64", "hier", "hier128", "render64x64", "train", "train_mixamo"])
     ap.add_argument("--cpu-rays", type=int, default=8192, help="ray sample for the CPU baseline (0 = skip)")
     ap.add_argument("--n-rand", type=int, default=3072, help="train workload: global rays per step")
     ap.add_argument("--torch-tail", action="store_true",
@@ -63,8 +63,8 @@ def main():
     synth = importlib.import_module("a-nerf_amd.synth")
     ops = importlib.import_module("a-nerf_amd.ops")
     pipeline = importlib.import_module("a-nerf_amd.pipeline")
-    if args.workload == "train":
-        return bench_train(args, rank, world, device, dist, synth)
+    if args.workload in ("train", "train_mixamo"):
+        return bench_train(args, rank, world, device, dist, synth, mixamo=args.workload == "train_mixamo")
 
     if args.workload == "render64x64":
         H = W = 64; focal = 75.0; S, Ni = 32, 0
@@ -72,6 +72,9 @@ def main():
     elif args.workload == "hier":
         H = W = 512; focal = 600.0; S, Ni = 64, 16
         name = "SURREAL-shaped 512x512 frame, 64+16 samples/ray (surreal.txt), forward render"
+    elif args.workload == "hier128":
+        H = W = 512; focal = 600.0; S, Ni = 64, 128
+        name = "SURREAL-shaped 512x512 frame, 64+128 samples/ray, forward render (BASELINE config 5)"
     else:
         H = W = 512; focal = 600.0; S, Ni = 64, 0
         name = "SURREAL-shaped 512x512 frame, 64 samples/ray, forward render (BASELINE config 2)"
@@ -167,10 +170,14 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_train(args, rank, world, device, dist, synth):
+def bench_train(args, rank, world, device, dist, synth, mixamo=False):
     """BASELINE config 3: SURREAL training step, N_rand = 3072 rays (global), 64 + 16 samples, fwd + bwd + Adam,
     through the reference-shaped API (RayCaster mirror + render() + loss).  Strong scaling: each rank takes
-    N_rand / world rays; gradients are averaged with one RCCL all-reduce of a flat bucket per step."""
+    N_rand / world rays; gradients are averaged with one RCCL all-reduce of a flat bucket per step.
+    mixamo=True is BASELINE config 4 (configs/mixamo/mixamo.txt:41-55): + per-frame codes (920-wide view layer), L1
+    loss, and pose refinement: skts come from the FK layer (PoseOptLayer mirror) and the hot path's dskts flow back into
+    the bone parameters, stepped by their own Adam (the reference steps them every opt_pose_step iterations; here
+    every step, which is the more expensive schedule)."""
     networks = importlib.import_module("a-nerf_amd.networks")
     raycaster = importlib.import_module("a-nerf_amd.raycaster")
     render_mod = importlib.import_module("a-nerf_amd.render")
@@ -178,10 +185,15 @@ def bench_train(args, rank, world, device, dist, synth):
     optim = importlib.import_module("a-nerf_amd.optim")
     N_rand, S, Ni = args.n_rand, 64, 16
     dev = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32, device=device)
+    n_poses = 8
     kw = dict(D=8, W=256, input_ch=360, input_ch_bones=72, input_ch_views=648, use_viewdirs=True)
+    mk = {}
+    if mixamo:
+        kw.update(use_framecode=True, framecode_ch=16, n_framecodes=n_poses)
+        mk = dict(framecode_ch=16, n_codes=n_poses)
     net_c, net_f = networks.NeRF(**kw), networks.NeRF(**kw)
-    net_c.load_state_dict({k: torch.tensor(v) for k, v in synth.make_net_params(11).items()})
-    net_f.load_state_dict({k: torch.tensor(v) for k, v in synth.make_net_params(12).items()})
+    net_c.load_state_dict({k: torch.tensor(v) for k, v in synth.make_net_params(11, **mk).items()})
+    net_f.load_state_dict({k: torch.tensor(v) for k, v in synth.make_net_params(12, **mk).items()})
     ck = {"cutoff": True, "cutoff_dist": 0.5, "cutoff_inputs": True, "cutoff_dim": 24}
     e_v, _ = networks.get_embedder(7, input_dims=24, cutoff_kwargs=dict(ck, dist_inputs=False))
     e_b, _ = networks.get_embedder(0, input_dims=72, cutoff_kwargs={"cutoff": False})
@@ -193,29 +205,50 @@ def bench_train(args, rank, world, device, dist, synth):
     opt = optim.FusedAdam(params, lr=5e-4, betas=(0.9, 0.999)) if fused else torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.999))
     bucket = None if fused else parallel.GradBucket(params)
     # per-ray replicated pose batch as the reference's collate produces it (dataset.py:813-820), 8 poses
-    ro, rd, kp, skts, bones, cyls, _ = synth.scene_batch(N_rand, list(range(8)), H=512, W=512, focal=600.0, ray_seed=3,
-                                                         per_ray_pose=True)
+    ro, rd, kp, skts, bones, cyls, pidx = synth.scene_batch(N_rand, list(range(n_poses)), H=512, W=512, focal=600.0, ray_seed=3,
+                                                            per_ray_pose=True)
     lo, hi = parallel.shard_rays(N_rand, rank, world)
     sl = slice(lo, hi)
     rays = (dev(ro[sl]), dev(rd[sl]))
     batch = dict(kp_batch=dev(kp[sl]), skts=dev(skts[sl]), cyls=dev(cyls[sl]), bones=dev(bones[sl]))
     target = dev(np.random.default_rng(1).random((N_rand, 3))[sl])
+    cams = popt = popt_opt = None
+    if mixamo:
+        pose_opt = importlib.import_module("a-nerf_amd.pose_opt")
+        poses = [synth.make_pose(k) for k in range(n_poses)]
+        popt = pose_opt.PoseOptLayer(np.stack([q["kp"] for q in poses]), np.stack([q["bones"] for q in poses]),
+                                     (synth.SMPL_REST_POSE * synth.SURREAL_SCALE)[None]).to(device)
+        popt_opt = torch.optim.Adam(popt.parameters(), lr=5e-4)
+        pose_of_ray = torch.tensor(np.asarray(pidx)[sl], device=device)
+        cams = pose_of_ray.to(torch.float32)
     pk = {"density_scale": 1.0, "density_fn": torch.nn.functional.relu}
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i=None):
         if i is not None:
             ev[i][0].record()
-        out = render_mod.render(512, 512, 600.0, chunk=4096, rays=rays, use_viewdirs=True, ray_caster=caster, cams=None,
+        b = batch
+        if mixamo:   # FK once per distinct pose, then the per-ray gather the reference's collate does (dataset.py:813-820)
+            kp_u, bones_u, skts_u, _, _ = popt(np.arange(n_poses))
+            b = dict(batch, kp_batch=kp_u[pose_of_ray], skts=skts_u[pose_of_ray], bones=bones_u[pose_of_ray])
+        out = render_mod.render(512, 512, 600.0, chunk=4096, rays=rays, use_viewdirs=True, ray_caster=caster, cams=cams,
                                 subject_idxs=None, N_samples=S, N_importance=Ni, perturb=1.0, raw_noise_std=1.0,
-                                preproc_kwargs=pk, **batch)
-        loss, _ = (optim.fused_nerf_loss if fused else render_mod.nerf_loss)(out, target, bgs=1.0)
+                                preproc_kwargs=pk, **b)
+        loss, _ = (optim.fused_nerf_loss if fused else render_mod.nerf_loss)(out, target, bgs=1.0,
+                                                                              loss_fn="L1" if mixamo else "MSE")
         loss.backward()
         if i is not None:
             ev[i][1].record()
         if fused:
             opt.all_reduce_grads()            # one RCCL all-reduce on the flat gradient buffer; 1/world folded into Adam
             opt.step(zero_grad=True)
+            if mixamo:
+                if world > 1:
+                    for q in popt.parameters():
+                        dist.all_reduce(q.grad)
+                        q.grad.div_(world)
+                popt_opt.step()
+                popt_opt.zero_grad()
         else:
             bucket.all_reduce_mean()
             opt.step()
@@ -246,9 +279,11 @@ def bench_train(args, rank, world, device, dist, synth):
         res = {"metric": "rays/sec", "value": N_rand * args.steps / dt, "unit": "rays/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": f"SURREAL-shaped training step, N_rand={N_rand}, 64+16 samples, fwd+bwd+Adam (BASELINE config 3)",
+               "config": {"workload": (f"Mixamo-shaped training step (frame codes, pose refinement through the FK layer, L1), N_rand={N_rand}, "
+                                       "64+16 samples, fwd+bwd+Adam (BASELINE config 4)") if mixamo else
+                                      f"SURREAL-shaped training step, N_rand={N_rand}, 64+16 samples, fwd+bwd+Adam (BASELINE config 3)",
                           "rays_per_step": N_rand, "samples_per_ray": S, "n_importance": Ni,
-                          "parallelism": f"ray-sharded x{world}, 1 all-reduce/step", "loss": float(loss),
+                          "parallelism": f"ray-sharded x{world}, 1 all-reduce/step", "loss": float(loss.detach()),
                           "tail": "fused loss + FusedAdam (anerf_loss / anerf_adam_step)" if fused else "torch loss + torch.optim.Adam"},
                "roofline": {"bound": "mfma", "kernel": "k_mlp_fwd<train> + k_mlp_bwd + k_gemm_tn (both nets), HIP-event time of fwd+bwd",
                             "achieved": achieved / 1e12, "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
