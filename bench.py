@@ -163,7 +163,7 @@ def main():
                 res["roofline"]["traffic_note"] = f"bytes/launch, FETCH_SIZE(x2)+WRITE_SIZE, {tr['source']}; algorithmic {tr['algorithmic_bytes']:.3g} B"
         except (OSError, ValueError):
             pass
-        if args.cpu_rays > 0:
+        if args.cpu_rays > 0 and world == 1:   # CPU baseline: rank 0 at N=1 only (bench contract)
             res["cpu_baseline"], res["parity"] = cpu_baseline(sc, S, Ni, Pc, Pf, out, lo, min(args.cpu_rays, hi - lo))
         print(json.dumps(res))
     if world > 1:
