@@ -8,8 +8,9 @@
 //   wheels = v0.6.x), restated from its published source:
 //     axis_angle_to_quaternion: th = |a|, q = (cos(th/2), a * k), k = sin(th/2)/th, or 0.5 - th^2/48 when th < 1e-6
 //     quaternion_to_matrix:     R = I + (2 / q.q) * B(q)
-//   Latency-bound scalar work (one thread per pose, the 24-joint chain is sequential); it exists to take ~140 tiny
-//   launches off the pose-refinement step, not to chase a roofline.
+//   Latency-bound scalar work: one 32-thread block per pose, thread j = joint j, the chain evaluated level by level
+//   of the SMPL tree (9 levels) through LDS; it exists to take ~140 tiny launches off the pose-refinement step, not to
+//   chase a roofline.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "anerf.h"
@@ -83,136 +84,152 @@ __device__ __forceinline__ void aa_backward(const float* a, const float* dR, flo
   da[2] = q.kf * dk + dth * a[2] * inv;
 }
 
-// one thread per pose.  l2ws / skts [U,24,4,4] row-major, rots [U,24,3,3], kp [U,24,3]; any output may be NULL.
-__global__ void k_fk_fwd(const float* __restrict__ bones, const float* __restrict__ pelvis, const float* __restrict__ rest,
-                         long long rest_stride, int n, float* __restrict__ l2ws, float* __restrict__ skts,
-                         float* __restrict__ rots, float* __restrict__ kp) {
-  const int u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= n) return;
-  const float* rp = rest + (long long)u * rest_stride;
-  float pv[3] = {0.f, 0.f, 0.f};
-  if (pelvis) { pv[0] = pelvis[3 * u]; pv[1] = pelvis[3 * u + 1]; pv[2] = pelvis[3 * u + 2]; }
-  float Rg[NJ][9], tg[NJ][3];
-  for (int j = 0; j < NJ; ++j) {
-    float R[9];
-    quat_to_mat(aa_to_quat(bones + ((long long)u * NJ + j) * 3), R);
-    if (rots)
-      for (int e = 0; e < 9; ++e) rots[((long long)u * NJ + j) * 9 + e] = R[e];
-    if (j == 0) {
-      for (int e = 0; e < 9; ++e) Rg[0][e] = R[e];
-      for (int c = 0; c < 3; ++c) tg[0][c] = rp[c];
-    } else {
-      const int p = kParent[j];
-      const float o[3] = {rp[3 * j] - rp[3 * p], rp[3 * j + 1] - rp[3 * p + 1], rp[3 * j + 2] - rp[3 * p + 2]};
-      for (int r = 0; r < 3; ++r) {
-        for (int c = 0; c < 3; ++c)
-          Rg[j][3 * r + c] = Rg[p][3 * r] * R[c] + Rg[p][3 * r + 1] * R[3 + c] + Rg[p][3 * r + 2] * R[6 + c];
-        tg[j][r] = Rg[p][3 * r] * o[0] + Rg[p][3 * r + 1] * o[1] + Rg[p][3 * r + 2] * o[2] + tg[p][r];
+// SMPL tree depth of every joint (root = 0): the chain is evaluated level by level, the joints of a level in parallel
+__device__ __constant__ int kDepth[NJ] = {0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5, 6, 6, 7, 7, 8, 8};
+constexpr int NLEVEL = 9;
+constexpr int FKT = 32;   // threads per pose (one per joint, 8 idle)
+
+struct FkShared {
+  float Rl[NJ][9], Rg[NJ][9], tg[NJ][3], dRg[NJ][9], dc[NJ][3];
+};
+
+// forward chain of one pose into shared memory: thread j = joint j
+__device__ __forceinline__ void fk_chain(FkShared& S, const float* __restrict__ bones_u, const float* __restrict__ rp, int j) {
+  if (j < NJ) quat_to_mat(aa_to_quat(bones_u + 3 * j), S.Rl[j]);
+  __syncthreads();
+  for (int lvl = 0; lvl < NLEVEL; ++lvl) {
+    if (j < NJ && kDepth[j] == lvl) {
+      if (j == 0) {
+        for (int e = 0; e < 9; ++e) S.Rg[0][e] = S.Rl[0][e];
+        for (int c = 0; c < 3; ++c) S.tg[0][c] = rp[c];
+      } else {
+        const int p = kParent[j];
+        const float o[3] = {rp[3 * j] - rp[3 * p], rp[3 * j + 1] - rp[3 * p + 1], rp[3 * j + 2] - rp[3 * p + 2]};
+        for (int r = 0; r < 3; ++r) {
+          for (int c = 0; c < 3; ++c)
+            S.Rg[j][3 * r + c] = S.Rg[p][3 * r] * S.Rl[j][c] + S.Rg[p][3 * r + 1] * S.Rl[j][3 + c] + S.Rg[p][3 * r + 2] * S.Rl[j][6 + c];
+          S.tg[j][r] = S.Rg[p][3 * r] * o[0] + S.Rg[p][3 * r + 1] * o[1] + S.Rg[p][3 * r + 2] * o[2] + S.tg[p][r];
+        }
       }
     }
-  }
-  for (int j = 0; j < NJ; ++j) {
-    const float c[3] = {tg[j][0] + pv[0], tg[j][1] + pv[1], tg[j][2] + pv[2]};
-    const long long m = ((long long)u * NJ + j) * 16;
-    if (l2ws) {
-      for (int r = 0; r < 3; ++r) {
-        l2ws[m + 4 * r] = Rg[j][3 * r]; l2ws[m + 4 * r + 1] = Rg[j][3 * r + 1]; l2ws[m + 4 * r + 2] = Rg[j][3 * r + 2];
-        l2ws[m + 4 * r + 3] = c[r];
-      }
-      l2ws[m + 12] = 0.f; l2ws[m + 13] = 0.f; l2ws[m + 14] = 0.f; l2ws[m + 15] = 1.f;
-    }
-    if (skts) {   // inverse of a rigid transform: [R^T | -R^T c]
-      for (int r = 0; r < 3; ++r) {
-        skts[m + 4 * r] = Rg[j][r]; skts[m + 4 * r + 1] = Rg[j][3 + r]; skts[m + 4 * r + 2] = Rg[j][6 + r];
-        skts[m + 4 * r + 3] = -(Rg[j][r] * c[0] + Rg[j][3 + r] * c[1] + Rg[j][6 + r] * c[2]);
-      }
-      skts[m + 12] = 0.f; skts[m + 13] = 0.f; skts[m + 14] = 0.f; skts[m + 15] = 1.f;
-    }
-    if (kp) { kp[((long long)u * NJ + j) * 3] = c[0]; kp[((long long)u * NJ + j) * 3 + 1] = c[1]; kp[((long long)u * NJ + j) * 3 + 2] = c[2]; }
+    __syncthreads();
   }
 }
 
-// backward: gradients w.r.t. skts / l2ws (rows 0..2 used) / kp / rots  ->  gradients w.r.t. bones and pelvis
-__global__ void k_fk_bwd(const float* __restrict__ bones, const float* __restrict__ pelvis, const float* __restrict__ rest,
-                         long long rest_stride, int n, const float* __restrict__ g_skts, const float* __restrict__ g_l2ws,
-                         const float* __restrict__ g_kp, const float* __restrict__ g_rots, float* __restrict__ g_bones,
-                         float* __restrict__ g_pelvis) {
-  const int u = blockIdx.x * blockDim.x + threadIdx.x;
-  if (u >= n) return;
+// one block (32 threads) per pose.  l2ws / skts [U,24,4,4] row-major, rots [U,24,3,3], kp [U,24,3]; any output may be NULL.
+__global__ __launch_bounds__(FKT) void k_fk_fwd(const float* __restrict__ bones, const float* __restrict__ pelvis,
+                                                const float* __restrict__ rest, long long rest_stride, int n,
+                                                float* __restrict__ l2ws, float* __restrict__ skts,
+                                                float* __restrict__ rots, float* __restrict__ kp) {
+  __shared__ FkShared S;
+  const int u = blockIdx.x, j = threadIdx.x;
   const float* rp = rest + (long long)u * rest_stride;
+  fk_chain(S, bones + (long long)u * NJ * 3, rp, j);
+  if (j >= NJ) return;
   float pv[3] = {0.f, 0.f, 0.f};
   if (pelvis) { pv[0] = pelvis[3 * u]; pv[1] = pelvis[3 * u + 1]; pv[2] = pelvis[3 * u + 2]; }
-  // recompute the chain
-  float Rl[NJ][9], Rg[NJ][9], tg[NJ][3];
-  for (int j = 0; j < NJ; ++j) {
-    quat_to_mat(aa_to_quat(bones + ((long long)u * NJ + j) * 3), Rl[j]);
-    if (j == 0) {
-      for (int e = 0; e < 9; ++e) Rg[0][e] = Rl[0][e];
-      for (int c = 0; c < 3; ++c) tg[0][c] = rp[c];
-    } else {
-      const int p = kParent[j];
-      const float o[3] = {rp[3 * j] - rp[3 * p], rp[3 * j + 1] - rp[3 * p + 1], rp[3 * j + 2] - rp[3 * p + 2]};
-      for (int r = 0; r < 3; ++r) {
-        for (int c = 0; c < 3; ++c)
-          Rg[j][3 * r + c] = Rg[p][3 * r] * Rl[j][c] + Rg[p][3 * r + 1] * Rl[j][3 + c] + Rg[p][3 * r + 2] * Rl[j][6 + c];
-        tg[j][r] = Rg[p][3 * r] * o[0] + Rg[p][3 * r + 1] * o[1] + Rg[p][3 * r + 2] * o[2] + tg[p][r];
-      }
+  const float* Rg = S.Rg[j];
+  const float c[3] = {S.tg[j][0] + pv[0], S.tg[j][1] + pv[1], S.tg[j][2] + pv[2]};
+  const long long m = ((long long)u * NJ + j) * 16;
+  if (rots)
+    for (int e = 0; e < 9; ++e) rots[((long long)u * NJ + j) * 9 + e] = S.Rl[j][e];
+  if (l2ws) {
+    for (int r = 0; r < 3; ++r) {
+      l2ws[m + 4 * r] = Rg[3 * r]; l2ws[m + 4 * r + 1] = Rg[3 * r + 1]; l2ws[m + 4 * r + 2] = Rg[3 * r + 2];
+      l2ws[m + 4 * r + 3] = c[r];
     }
+    l2ws[m + 12] = 0.f; l2ws[m + 13] = 0.f; l2ws[m + 14] = 0.f; l2ws[m + 15] = 1.f;
   }
+  if (skts) {   // inverse of a rigid transform: [R^T | -R^T c]
+    for (int r = 0; r < 3; ++r) {
+      skts[m + 4 * r] = Rg[r]; skts[m + 4 * r + 1] = Rg[3 + r]; skts[m + 4 * r + 2] = Rg[6 + r];
+      skts[m + 4 * r + 3] = -(Rg[r] * c[0] + Rg[3 + r] * c[1] + Rg[6 + r] * c[2]);
+    }
+    skts[m + 12] = 0.f; skts[m + 13] = 0.f; skts[m + 14] = 0.f; skts[m + 15] = 1.f;
+  }
+  if (kp) { kp[((long long)u * NJ + j) * 3] = c[0]; kp[((long long)u * NJ + j) * 3 + 1] = c[1]; kp[((long long)u * NJ + j) * 3 + 2] = c[2]; }
+}
+
+// backward: gradients w.r.t. skts / l2ws (rows 0..2 used) / kp / rots  ->  gradients w.r.t. bones and pelvis
+__global__ __launch_bounds__(FKT) void k_fk_bwd(const float* __restrict__ bones, const float* __restrict__ pelvis,
+                                                const float* __restrict__ rest, long long rest_stride, int n,
+                                                const float* __restrict__ g_skts, const float* __restrict__ g_l2ws,
+                                                const float* __restrict__ g_kp, const float* __restrict__ g_rots,
+                                                float* __restrict__ g_bones, float* __restrict__ g_pelvis) {
+  __shared__ FkShared S;
+  __shared__ float dpel[NJ][3];
+  const int u = blockIdx.x, j = threadIdx.x;
+  const float* rp = rest + (long long)u * rest_stride;
+  fk_chain(S, bones + (long long)u * NJ * 3, rp, j);     // recompute the chain
+  float pv[3] = {0.f, 0.f, 0.f};
+  if (pelvis) { pv[0] = pelvis[3 * u]; pv[1] = pelvis[3 * u + 1]; pv[2] = pelvis[3 * u + 2]; }
   // gradients w.r.t. the global rotation and the joint centre c = tg + pelvis of every joint
-  float dRg[NJ][9], dc[NJ][3];
-  float dpel[3] = {0.f, 0.f, 0.f};
-  for (int j = 0; j < NJ; ++j) {
-    for (int e = 0; e < 9; ++e) dRg[j][e] = 0.f;
-    dc[j][0] = dc[j][1] = dc[j][2] = 0.f;
+  if (j < NJ) {
+    float dRg[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dc[3] = {0.f, 0.f, 0.f};
     const long long m = ((long long)u * NJ + j) * 16;
-    const float c[3] = {tg[j][0] + pv[0], tg[j][1] + pv[1], tg[j][2] + pv[2]};
+    const float* Rg = S.Rg[j];
+    const float c[3] = {S.tg[j][0] + pv[0], S.tg[j][1] + pv[1], S.tg[j][2] + pv[2]};
     if (g_l2ws)
       for (int r = 0; r < 3; ++r) {
-        dRg[j][3 * r] += g_l2ws[m + 4 * r]; dRg[j][3 * r + 1] += g_l2ws[m + 4 * r + 1]; dRg[j][3 * r + 2] += g_l2ws[m + 4 * r + 2];
-        dc[j][r] += g_l2ws[m + 4 * r + 3];
+        dRg[3 * r] += g_l2ws[m + 4 * r]; dRg[3 * r + 1] += g_l2ws[m + 4 * r + 1]; dRg[3 * r + 2] += g_l2ws[m + 4 * r + 2];
+        dc[r] += g_l2ws[m + 4 * r + 3];
       }
     if (g_skts) {   // S = Rg^T, s = -Rg^T c
       float ds[3];
       for (int r = 0; r < 3; ++r) {
         ds[r] = g_skts[m + 4 * r + 3];
-        for (int k = 0; k < 3; ++k) dRg[j][3 * k + r] += g_skts[m + 4 * r + k];     // dS[r][k] -> dRg[k][r]
+        for (int k = 0; k < 3; ++k) dRg[3 * k + r] += g_skts[m + 4 * r + k];     // dS[r][k] -> dRg[k][r]
       }
       for (int k = 0; k < 3; ++k) {
-        dc[j][k] -= Rg[j][3 * k] * ds[0] + Rg[j][3 * k + 1] * ds[1] + Rg[j][3 * k + 2] * ds[2];
-        for (int r = 0; r < 3; ++r) dRg[j][3 * k + r] -= c[k] * ds[r];
+        dc[k] -= Rg[3 * k] * ds[0] + Rg[3 * k + 1] * ds[1] + Rg[3 * k + 2] * ds[2];
+        for (int r = 0; r < 3; ++r) dRg[3 * k + r] -= c[k] * ds[r];
       }
     }
     if (g_kp)
-      for (int r = 0; r < 3; ++r) dc[j][r] += g_kp[((long long)u * NJ + j) * 3 + r];
-    for (int r = 0; r < 3; ++r) dpel[r] += dc[j][r];
+      for (int r = 0; r < 3; ++r) dc[r] += g_kp[((long long)u * NJ + j) * 3 + r];
+    for (int e = 0; e < 9; ++e) S.dRg[j][e] = dRg[e];
+    for (int r = 0; r < 3; ++r) { S.dc[j][r] = dc[r]; dpel[j][r] = dc[r]; }
   }
-  // reverse chain: children before parents (every child index is larger than its parent's)
-  for (int j = NJ - 1; j >= 0; --j) {
-    float dRl[9];
-    if (j == 0) {
-      for (int e = 0; e < 9; ++e) dRl[e] = dRg[0][e];
-    } else {
-      const int p = kParent[j];
-      const float o[3] = {rp[3 * j] - rp[3 * p], rp[3 * j + 1] - rp[3 * p + 1], rp[3 * j + 2] - rp[3 * p + 2]};
-      for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) {
-          // Rg_j = Rg_p Rl_j :  dRl = Rg_p^T dRg_j ;  dRg_p += dRg_j Rl_j^T ;  tg_j = Rg_p o + tg_p : dRg_p += dtg o^T
-          dRl[3 * r + c] = Rg[p][r] * dRg[j][c] + Rg[p][3 + r] * dRg[j][3 + c] + Rg[p][6 + r] * dRg[j][6 + c];
-          dRg[p][3 * r + c] += dRg[j][3 * r] * Rl[j][3 * c] + dRg[j][3 * r + 1] * Rl[j][3 * c + 1] + dRg[j][3 * r + 2] * Rl[j][3 * c + 2] +
-                               dc[j][r] * o[c];
+  __syncthreads();
+  if (g_pelvis && j < 3) {     // every joint centre contains the pelvis shift; fixed summation order
+    float s = 0.f;
+    for (int q = 0; q < NJ; ++q) s += dpel[q][j];
+    g_pelvis[3 * u + j] = s;
+  }
+  // reverse chain, level by level: a parent gathers from its (already final) children
+  for (int lvl = NLEVEL - 2; lvl >= 0; --lvl) {
+    if (j < NJ && kDepth[j] == lvl) {
+      for (int ch = j + 1; ch < NJ; ++ch) {
+        if (kParent[ch] != j) continue;
+        const float o[3] = {rp[3 * ch] - rp[3 * j], rp[3 * ch + 1] - rp[3 * j + 1], rp[3 * ch + 2] - rp[3 * j + 2]};
+        // Rg_c = Rg_p Rl_c : dRg_p += dRg_c Rl_c^T ;  tg_c = Rg_p o + tg_p : dRg_p += dtg_c o^T, dtg_p += dtg_c
+        for (int r = 0; r < 3; ++r) {
+          for (int c = 0; c < 3; ++c)
+            S.dRg[j][3 * r + c] += S.dRg[ch][3 * r] * S.Rl[ch][3 * c] + S.dRg[ch][3 * r + 1] * S.Rl[ch][3 * c + 1] +
+                                   S.dRg[ch][3 * r + 2] * S.Rl[ch][3 * c + 2] + S.dc[ch][r] * o[c];
+          S.dc[j][r] += S.dc[ch][r];
         }
-      for (int r = 0; r < 3; ++r) dc[p][r] += dc[j][r];
+      }
     }
-    if (g_rots)
-      for (int e = 0; e < 9; ++e) dRl[e] += g_rots[((long long)u * NJ + j) * 9 + e];
-    float da[3];
-    aa_backward(bones + ((long long)u * NJ + j) * 3, dRl, da);
-    g_bones[((long long)u * NJ + j) * 3] = da[0];
-    g_bones[((long long)u * NJ + j) * 3 + 1] = da[1];
-    g_bones[((long long)u * NJ + j) * 3 + 2] = da[2];
+    __syncthreads();
   }
-  if (g_pelvis) { g_pelvis[3 * u] = dpel[0]; g_pelvis[3 * u + 1] = dpel[1]; g_pelvis[3 * u + 2] = dpel[2]; }
+  if (j >= NJ) return;
+  float dRl[9];
+  if (j == 0) {
+    for (int e = 0; e < 9; ++e) dRl[e] = S.dRg[0][e];
+  } else {
+    const int p = kParent[j];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c)   // dRl = Rg_p^T dRg_j
+        dRl[3 * r + c] = S.Rg[p][r] * S.dRg[j][c] + S.Rg[p][3 + r] * S.dRg[j][3 + c] + S.Rg[p][6 + r] * S.dRg[j][6 + c];
+  }
+  if (g_rots)
+    for (int e = 0; e < 9; ++e) dRl[e] += g_rots[((long long)u * NJ + j) * 9 + e];
+  float da[3];
+  aa_backward(bones + ((long long)u * NJ + j) * 3, dRl, da);
+  g_bones[((long long)u * NJ + j) * 3] = da[0];
+  g_bones[((long long)u * NJ + j) * 3 + 1] = da[1];
+  g_bones[((long long)u * NJ + j) * 3 + 2] = da[2];
 }
 
 }  // namespace anerf
@@ -226,7 +243,7 @@ int anerf_fk_forward(const float* bones, const float* pelvis, const float* rest_
   if (n_poses < 0 || (rest_pose_stride != 0 && rest_pose_stride != 72)) return set_error(ANERF_E_SHAPE, "fk_forward: n_poses >= 0, rest_pose_stride 0 or 72");
   if (n_poses == 0) return ANERF_OK;
   if (!bones || !rest_pose) return set_error(ANERF_E_NULL, "fk_forward: NULL pointer");
-  hipLaunchKernelGGL(k_fk_fwd, dim3((n_poses + 63) / 64), dim3(64), 0, (hipStream_t)stream, bones, pelvis, rest_pose,
+  hipLaunchKernelGGL(k_fk_fwd, dim3(n_poses), dim3(FKT), 0, (hipStream_t)stream, bones, pelvis, rest_pose,
                      (long long)rest_pose_stride, (int)n_poses, l2ws, skts, rots, kp);
   return check_launch("k_fk_fwd");
 }
@@ -237,7 +254,7 @@ int anerf_fk_backward(const float* bones, const float* pelvis, const float* rest
   if (n_poses < 0 || (rest_pose_stride != 0 && rest_pose_stride != 72)) return set_error(ANERF_E_SHAPE, "fk_backward: n_poses >= 0, rest_pose_stride 0 or 72");
   if (n_poses == 0) return ANERF_OK;
   if (!bones || !rest_pose || !g_bones) return set_error(ANERF_E_NULL, "fk_backward: NULL pointer");
-  hipLaunchKernelGGL(k_fk_bwd, dim3((n_poses + 63) / 64), dim3(64), 0, (hipStream_t)stream, bones, pelvis, rest_pose,
+  hipLaunchKernelGGL(k_fk_bwd, dim3(n_poses), dim3(FKT), 0, (hipStream_t)stream, bones, pelvis, rest_pose,
                      (long long)rest_pose_stride, (int)n_poses, g_skts, g_l2ws, g_kp, g_rots, g_bones, g_pelvis);
   return check_launch("k_fk_bwd");
 }
