@@ -20,6 +20,7 @@
 // A, accumulated by the waves that own a problem's first column tile.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "anerf_dev.h"
 #include "anerf_gemm.h"
 
@@ -47,6 +48,9 @@ void gemm_plan_rows(long long p_pad, int nheavy, int nskinny, int* rows_h, int* 
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_r = (int)r; }
   }
   if (best_r == 0) best_r = (int)((p_pad + 95) / 96 + 15) / 16 * 16;
+#ifdef ANERF_EXP_GEMM_ROWS   // tuning build only: ANERF_GEMM_ROWS=<rows per block>
+  if (const char* e = getenv("ANERF_GEMM_ROWS")) best_r = atoi(e) / 16 * 16;
+#endif
   *rows_h = best_r;
   *chunks_h = (int)((p_pad + best_r - 1) / best_r);
   *rows_s = *rows_h;
