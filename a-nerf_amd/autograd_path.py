@@ -24,14 +24,15 @@ def train_layout(cfg, n_points):
     return T
 
 
-def perm_tables(cfg, device):
-    k = (cfg.key(), str(device))
+def perm_tables(cfg, device, b3=False):
+    """saved-plane column -> torch input column, for the fp32 training forward or (b3) the split-bf16 one"""
+    k = (cfg.key(), str(device), bool(b3))
     if k not in _perm_cache:
         T = train_layout(cfg, 128)
         px, pu = np.empty(T.x_width, np.int32), np.empty(T.u_width, np.int32)
         cc = cfg.c()
-        _lib.check(_lib.load().anerf_build_perm_tables(C.byref(cc), px.ctypes.data_as(C.c_void_p),
-                                                       pu.ctypes.data_as(C.c_void_p)), "anerf_build_perm_tables")
+        fn = _lib.load().anerf_build_perm_tables_b3 if b3 else _lib.load().anerf_build_perm_tables
+        _lib.check(fn(C.byref(cc), px.ctypes.data_as(C.c_void_p), pu.ctypes.data_as(C.c_void_p)), "anerf_build_perm_tables")
         _perm_cache[k] = (torch.from_numpy(px).to(device), torch.from_numpy(pu).to(device))
     return _perm_cache[k]
 
@@ -61,8 +62,10 @@ class _MlpRawFn(torch.autograd.Function):
         stride = 0 if skts.shape[0] == 1 else 16 * cfg.n_joints
         codes = meta.get("codes")
         cc = cfg.c()
-        packed, aux = meta["packed"]
-        _lib.check(_lib.load().anerf_mlp_raw_train(
+        b3 = meta.get("precision", "fp32") == "bf16x3"
+        packed, aux = meta["packed_b3"] if b3 else meta["packed"]
+        fwd = _lib.load().anerf_mlp_raw_train_b3 if b3 else _lib.load().anerf_mlp_raw_train
+        _lib.check(fwd(
             C.byref(cc), _p(packed), _p(aux), _p(meta["rays"]), meta["rays"].shape[1], _p(z), _p(skts), stride,
             _p(meta.get("cam")), _p(codes), 0 if codes is None else codes.shape[0], float(meta["tau_v"]),
             float(meta["tau_d"]), _p(meta["cut_v"]), _p(meta["cut_d"]), n, s, _p(raw), C.byref(st), _stream()),
@@ -83,7 +86,7 @@ class _MlpRawFn(torch.autograd.Function):
         st = _lib.AnerfSaved(_p(sv["h"]), _p(sv["f"]), _p(sv["g"]), _p(sv["x"]), _p(sv["u"]), pp)
         cc = cfg.c()
         packed_t, _ = meta["packed_t"]
-        _, aux = meta["packed"]
+        _, aux = meta["packed_b3"] if meta.get("precision", "fp32") == "bf16x3" else meta["packed"]
         lib = _lib.load()
         _lib.check(lib.anerf_mlp_backward(C.byref(cc), _p(packed_t), _p(aux), _p(draw), C.byref(st), _p(dz), _p(df), _p(dzv),
                                           P, _stream()), "anerf_mlp_backward")
@@ -93,7 +96,7 @@ class _MlpRawFn(torch.autograd.Function):
             gs.w[i] = grads[2 * i].data_ptr()
             gs.b[i] = grads[2 * i + 1].data_ptr()
         ws = torch.empty(T.gemm_ws_floats, dtype=torch.float32, device=dev)
-        px, pu = perm_tables(cfg, dev)
+        px, pu = perm_tables(cfg, dev, b3=meta.get("precision", "fp32") == "bf16x3")
         _lib.check(lib.anerf_weight_grads(C.byref(cc), C.byref(st), _p(dz), _p(df), _p(dzv), _p(draw), P, _p(px), _p(pu),
                                           C.byref(gs), _p(ws), T.gemm_ws_floats, _stream()), "anerf_weight_grads")
         g_skts = g_codes = None
@@ -164,6 +167,9 @@ def render_rays_train(caster, kw):
     cfg, rays, skts, cyls = kw["cfg"], kw["ray_batch"], kw["skts"], kw["cyls"]
     S, Ni = kw["n_samples"], kw["n_importance"]
     net_c, net_f = caster.network, caster.network_fine
+    prec = getattr(caster, "train_precision", "fp32")
+    if prec not in ("fp32", "bf16x3"):
+        raise ValueError(f"train_precision must be 'fp32' or 'bf16x3', got {prec!r}")
     skts_c = skts.contiguous()
     with torch.no_grad():
         nf_raw, stats = ops.ray_bounds(rays, cyls)
@@ -174,7 +180,8 @@ def render_rays_train(caster, kw):
         cam = kw["cam_idx"].contiguous() if net.use_framecode else None
         meta = dict(cfg=cfg, rays=rays, z=zz, skts=skts_c.detach(), tau_v=kw["tau_v"], tau_d=kw["tau_d"],
                     cut_v=kw["cut_v"], cut_d=kw["cut_d"], cam=cam, codes=None if codes is None else codes.detach(),
-                    packed=net.packed(0), packed_t=net.packed(1), packed_i=lambda: net.packed(2))
+                    packed=net.packed(0) if prec == "fp32" else None, packed_t=net.packed(1), packed_i=lambda: net.packed(2),
+                    precision=prec, packed_b3=net.packed(3) if prec == "bf16x3" else None)
         return _MlpRawFn.apply(meta, skts_c, codes, *_net_params(net))
 
     def comp(raw, zz, noise):

@@ -45,7 +45,7 @@ int mlp_bwd_entry(const float* packed_t, const float* aux, const float* draw, co
 int mlp_b3_entry(const AnerfConfig* cfg, const float* packed, const float* aux, const float* rays, int ray_stride,
                  const float* z, const float* skts, long long skt_stride, const float* cam, const float* codes, int n_codes,
                  float tau_v, float tau_d, const float* cut_v, const float* cut_d, long long P, int N, int S, int nstages,
-                 float* raw, hipStream_t st);
+                 float* raw, const AnerfSaved* sv, hipStream_t st);
 int launch_pack_b3(const AnerfNetParams* P, const int32_t* table, long long n, void* out, hipStream_t st);
 int mlp_density_entry(const float* packed, const float* aux, const float* pts, const float* skts, float tau_v,
                       const float* cut_v, long long P, int nstages_trunk, float* sigma, hipStream_t st);
@@ -324,7 +324,7 @@ int anerf_mlp_raw_b3(const AnerfConfig* cfg, const float* packed, const float* a
   if (skt_ray_stride != 0 && skt_ray_stride != 384) return set_error(ANERF_E_SHAPE, "mlp_raw_b3: skt_ray_stride 0|384");
   if (ray_stride < 6) return set_error(ANERF_E_SHAPE, "mlp_raw_b3: ray_stride >= 6");
   return mlp_b3_entry(cfg, packed, aux, rays, ray_stride, z_vals, skts, skt_ray_stride, cam_idx, codes, n_codes, tau_v, tau_d,
-                      cutoff_v, cutoff_d, (long long)n_rays * n_samples, n_rays, n_samples, L.n_stages, raw,
+                      cutoff_v, cutoff_d, (long long)n_rays * n_samples, n_rays, n_samples, L.n_stages, raw, nullptr,
                       (hipStream_t)stream);
 }
 
@@ -476,6 +476,41 @@ int anerf_mlp_raw_train(const AnerfConfig* cfg, const float* packed, const float
   return mlp_raw_entry(cfg, packed, aux, rays, ray_stride, z_vals, skts, skt_ray_stride, cam_idx, codes, n_codes, tau_v,
                        tau_d, cutoff_v, cutoff_d, nullptr, 0, (long long)n_rays * n_samples, n_rays, n_samples,
                        L.n_stages, raw, false, saved, (hipStream_t)stream);
+}
+
+int anerf_build_perm_tables_b3(const AnerfConfig* cfg, int32_t* perm_x, int32_t* perm_u) {
+  if (!config_ok(cfg)) return set_error(ANERF_E_CONFIG, "unsupported AnerfConfig");
+  if (!perm_x || !perm_u) return set_error(ANERF_E_NULL, "perm tables NULL");
+  const std::vector<Seg> segs = fwd_segments(cfg);
+  const Seg& s0 = segs.front();
+  const Seg& sv = segs.back();
+  const int nx = dim_x(cfg) / 2, nu = u_width(cfg) / 2;            // values per lane half
+  for (int h = 0; h < 2; ++h) {
+    for (int i = 0; i < nx; ++i) perm_x[h * nx + i] = b3_col(cfg, s0, i / 8, h, i % 8);
+    for (int i = 0; i < nu; ++i) perm_u[h * nu + i] = b3_col(cfg, sv, 16 + i / 8, h, i % 8) - 256;
+  }
+  return ANERF_OK;
+}
+
+int anerf_mlp_raw_train_b3(const AnerfConfig* cfg, const float* packed, const float* aux, const float* rays,
+                           int32_t ray_stride, const float* z_vals, const float* skts, int64_t skt_ray_stride,
+                           const float* cam_idx, const float* codes, int32_t n_codes, float tau_v, float tau_d,
+                           const float* cutoff_v, const float* cutoff_d, int32_t n_rays, int32_t n_samples, float* raw,
+                           const AnerfSaved* saved, void* stream) {
+  if (n_rays == 0) return ANERF_OK;
+  AnerfLayout L;
+  const int rc = anerf_layout(cfg, 3, &L);
+  if (rc) return rc;
+  if (!packed || !aux || !rays || !z_vals || !skts || !cutoff_v || !cutoff_d || !raw)
+    return set_error(ANERF_E_NULL, "mlp_raw_train_b3: NULL pointer");
+  if (cfg->framecode_ch && (!cam_idx || !codes || n_codes < 1)) return set_error(ANERF_E_NULL, "mlp_raw_train_b3: frame codes");
+  if (n_samples < MIN_SAMPLES || n_samples > MAX_SAMPLES) return set_error(ANERF_E_SHAPE, "mlp_raw_train_b3: 8 <= samples <= 512");
+  if (skt_ray_stride != 0 && skt_ray_stride != 384) return set_error(ANERF_E_SHAPE, "mlp_raw_train_b3: skt_ray_stride 0|384");
+  if (ray_stride < 6) return set_error(ANERF_E_SHAPE, "mlp_raw_train_b3: ray_stride >= 6");
+  if (!saved_ok(saved) || saved->p_pad < (int64_t)n_rays * n_samples) return set_error(ANERF_E_WORKSPACE, "mlp_raw_train_b3: AnerfSaved");
+  return mlp_b3_entry(cfg, packed, aux, rays, ray_stride, z_vals, skts, skt_ray_stride, cam_idx, codes, n_codes, tau_v, tau_d,
+                      cutoff_v, cutoff_d, (long long)n_rays * n_samples, n_rays, n_samples, L.n_stages, raw, saved,
+                      (hipStream_t)stream);
 }
 
 int anerf_composite_backward(const AnerfConfig* cfg, const float* raw, const float* z_vals, const float* rays,

@@ -91,11 +91,28 @@ __device__ __forceinline__ void hidden_part_b3(Pipe3& pipe, f32x16 (&acc)[NB], c
   }
 }
 
-// emit N/8 k-steps from a value array (N a multiple of 8)
-template <int NB, int N>
-__device__ __forceinline__ void emit(Pipe3& pipe, f32x16 (&acc)[NB], int ks0, int ks_last, const float (&val)[N]) {
+// emit N/8 k-steps from a value array (N a multiple of 8).  save != nullptr (training forward): the lane's values are
+// also written to save[8 * (ks0 - ks_base + k) .. +7] -- its half of the saved X' / U' row, in value order (see
+// anerf_build_perm_tables_b3); only the first `nreal` values of the segment are real, the rest is zero padding.
+// SAVE is a compile-time switch and every lane stores (tail lanes of the last tile are clamped to the last valid
+// sample and rewrite its values): a per-lane `if (save)` around these stores, i.e. an exec-masked region in the middle
+// of a stage, produced stale weight fragments in the view layer (rgb off by 1e-4, run-to-run different) even when the
+// branch was never taken.
+template <int NB, int N, bool SAVE = false>
+__device__ __forceinline__ void emit(Pipe3& pipe, f32x16 (&acc)[NB], int ks0, int ks_last, const float (&val)[N],
+                                     float* __restrict__ save = nullptr, int ks_base = 0, int nreal = 1 << 30) {
 #pragma unroll
   for (int k = 0; k < N / 8; ++k) {
+    if constexpr (SAVE) {
+      // The stores are pinned in FRONT of the split of the same values: scheduled freely, the compiler sinks them to the
+      // last use of val[] and lets the next ds_read_b128 (weight fragments) land in the store's data registers right
+      // after issue -- the saved U' then carried fragment bits in a few hundred elements per launch, different ones
+      // every run.  With the split (16 VALU) between the store and the registers' reuse the data has been read.
+      const int i0 = 8 * (ks0 - ks_base + k);
+      if (i0 + 3 < nreal) *reinterpret_cast<f32x4*>(save + i0) = f32x4{val[8 * k], val[8 * k + 1], val[8 * k + 2], val[8 * k + 3]};
+      if (i0 + 7 < nreal) *reinterpret_cast<f32x4*>(save + i0 + 4) = f32x4{val[8 * k + 4], val[8 * k + 5], val[8 * k + 6], val[8 * k + 7]};
+      __builtin_amdgcn_sched_barrier(0);
+    }
     const BOp b = split8(val[8 * k], val[8 * k + 1], val[8 * k + 2], val[8 * k + 3], val[8 * k + 4], val[8 * k + 5],
                          val[8 * k + 6], val[8 * k + 7]);
     kstep<NB>(pipe, acc, ks0 + k, ks0 + k == ks_last, b);
@@ -104,9 +121,9 @@ __device__ __forceinline__ void emit(Pipe3& pipe, f32x16 (&acc)[NB], int ks0, in
 
 // The lane's 216 x-values, band-major [15 bands x 12 owned joints][36 bone-direction components], as 27 k-steps:
 // 7 band pairs (24 values = 3 k-steps each) then cos_6 (12) + directions (36) = 6 k-steps.
-template <int LV>
+template <int LV, bool SAVE = false>
 __device__ __forceinline__ void x_part_b3(Pipe3& pipe, f32x16 (&acc)[8], const float (&v)[12], const float (&wv)[12],
-                                          const float (&rh)[36], bool last) {
+                                          const float (&rh)[36], bool last, float* __restrict__ xsave = nullptr) {
   static_assert(LV == 7, "band pairing below is written for multires = 7");
   constexpr int KS_LAST = 26;
   float sb[12], cb[12];
@@ -125,17 +142,31 @@ __device__ __forceinline__ void x_part_b3(Pipe3& pipe, f32x16 (&acc)[8], const f
       }
       val[12 + a] = sb[a] * wv[a];                           // band 2p+1: sin_p
     }
-    emit<8, 24>(pipe, acc, 3 * p, last ? KS_LAST : -1, val);
+    emit<8, 24, SAVE>(pipe, acc, 3 * p, last ? KS_LAST : -1, val, xsave);
   }
   float val[48];
 #pragma unroll
   for (int a = 0; a < 12; ++a) val[a] = cb[a] * wv[a];       // band 14: cos_6
 #pragma unroll
   for (int i = 0; i < 36; ++i) val[12 + i] = rh[i];
-  emit<8, 48>(pipe, acc, 3 * LV, last ? KS_LAST : -1, val);
+  emit<8, 48, SAVE>(pipe, acc, 3 * LV, last ? KS_LAST : -1, val, xsave);
 }
 
-template <int LV, int LD, int CODE>
+// TRAIN: also save what the (fp32) backward needs -- h0..h7, f, g row-major exactly as k_mlp_fwd<TRAIN> does, and the
+// density-net / view-net inputs X', U' in THIS kernel's value order: row = [half 0's values | half 1's values]
+// (216 + 216 and NU + NU floats: same plane shapes as the fp32 path, different column permutation).
+template <int NB>
+__device__ __forceinline__ void store_rows(float* __restrict__ row_h, const f32x16 (&acc)[NB]) {
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 o = {acc[nb][4 * q], acc[nb][4 * q + 1], acc[nb][4 * q + 2], acc[nb][4 * q + 3]};
+      *reinterpret_cast<f32x4*>(row_h + 32 * nb + 8 * q) = o;
+    }
+}
+
+template <int LV, int LD, int CODE, bool TRAIN>
 __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -149,6 +180,17 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
   const long long p = (long long)blockIdx.x * TILE + wave * 32 + m;
   const bool valid = p < A.P;
   const long long pc = valid ? p : A.P - 1;
+#ifdef ANERF_EXP_B3_NOHSAVE
+  const bool save = false;
+#else
+  const bool save = TRAIN && valid;
+#endif
+#ifdef ANERF_EXP_B3_NOXSAVE
+  constexpr bool XS = false;
+#else
+  constexpr bool XS = TRAIN;
+#endif
+  auto HROW = [&](int l) { return A.save_h + ((long long)l * A.Ppad + p) * 256 + 4 * h; };
 
   float* aux_l = reinterpret_cast<float*>(smem + LDS_AUX_OFF);
   for (int i = tid; i < AUX_FLOATS / 4; i += 256)
@@ -201,17 +243,20 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
 
   // ---- layer 0
   init_bias<8>(accA, aux_h + AUX_B0);
-  x_part_b3<LV>(pipe, accA, v, wv, rh, true);
+  x_part_b3<LV, XS>(pipe, accA, v, wv, rh, true, XS ? A.save_x + pc * (24 * (1 + 2 * LV) + 72) + h * (12 * (1 + 2 * LV) + 36) : nullptr);
   relu_pass<8>(accA);
+  if (save) store_rows<8>(HROW(0), accA);
   // ---- layers 1..4
 #pragma unroll 1
   for (int L = 1; L <= 3; L += 2) {
     init_bias<8>(accB, aux_h + AUX_B0 + 256 * L);
     hidden_part_b3<8, 0>(pipe, accB, accA, true);
     relu_pass<8>(accB);
+    if (save) store_rows<8>(HROW(L), accB);
     init_bias<8>(accA, aux_h + AUX_B0 + 256 * (L + 1));
     hidden_part_b3<8, 0>(pipe, accA, accB, true);
     relu_pass<8>(accA);
+    if (save) store_rows<8>(HROW(L + 1), accA);
   }
   // ---- layer 5 (skip): x re-encoded (opaque so that the compiler does not keep layer 0's products alive)
 #pragma unroll
@@ -220,17 +265,21 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
   x_part_b3<LV>(pipe, accB, v, wv, rh, false);
   hidden_part_b3<8, KSX>(pipe, accB, accA, true);
   relu_pass<8>(accB);
+  if (save) store_rows<8>(HROW(5), accB);
   // ---- layers 6, 7
   init_bias<8>(accA, aux_h + AUX_B0 + 256 * 6);
   hidden_part_b3<8, 0>(pipe, accA, accB, true);
   relu_pass<8>(accA);
+  if (save) store_rows<8>(HROW(6), accA);
   init_bias<8>(accB, aux_h + AUX_B0 + 256 * 7);
   hidden_part_b3<8, 0>(pipe, accB, accA, true);
   relu_pass<8>(accB);
+  if (save) store_rows<8>(HROW(7), accB);
   const float sigma_raw = head_dot<8>(accB, aux_h + AUX_WA) + aux_l[AUX_BA];
   // ---- feature layer
   init_bias<8>(accA, aux_h + AUX_BF);
   hidden_part_b3<8, 0>(pipe, accA, accB, true);
+  if (save) store_rows<8>(A.save_f + p * 256 + 4 * h, accA);
   // ---- view layer: [feature (16 k-steps); D bands; code; zero padding to a multiple of 8 values per lane]
   f32x16 accv[4];
   init_bias<4>(accv, aux_h + AUX_BV);
@@ -238,6 +287,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
   constexpr int NU = 36 * (1 + 2 * LD) + CODE / 2;          // values per lane
   constexpr int NUP = (NU + 7) / 8 * 8;
   constexpr int KSV_LAST = 16 + NUP / 8 - 1;
+  float* usave = XS ? A.save_u + pc * (2 * NU) + h * NU : nullptr;
   float e[36], wd[12];
 #pragma unroll
   for (int a = 0; a < 12; ++a) {
@@ -268,7 +318,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
       }
       val[36 + i] = sbe[i] * wd[i / 3];
     }
-    emit<4, 72>(pipe, accv, 16 + 9 * pq, KSV_LAST, val);
+    emit<4, 72, XS>(pipe, accv, 16 + 9 * pq, KSV_LAST, val, usave, 16, NU);
   }
   {
     // last band (cos_{LD-1}, or the raw band when LD == 0) + frame code + zero padding
@@ -286,9 +336,10 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
     }
 #pragma unroll
     for (int i = NU - 72 * LD; i < NT; ++i) val[i] = 0.f;
-    emit<4, NT>(pipe, accv, 16 + 9 * LD, KSV_LAST, val);
+    emit<4, NT, XS>(pipe, accv, 16 + 9 * LD, KSV_LAST, val, usave, 16, NU);
   }
   relu_pass<4>(accv);
+  if (save) store_rows<4>(A.save_g + p * 128 + 4 * h, accv);
   const float c0 = head_dot<4>(accv, aux_h + AUX_WC + 0) + aux_l[AUX_BC + 0];
   const float c1 = head_dot<4>(accv, aux_h + AUX_WC + 128) + aux_l[AUX_BC + 1];
   const float c2 = head_dot<4>(accv, aux_h + AUX_WC + 256) + aux_l[AUX_BC + 2];
@@ -298,12 +349,12 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
   }
 }
 
-template <int LV, int LD, int CODE>
+template <int LV, int LD, int CODE, bool TRAIN>
 static int launch_b3(const MlpArgs& a, hipStream_t st) {
   const long long nblk = (a.P + TILE - 1) / TILE;
   if (nblk <= 0) return ANERF_OK;
   const size_t lds = LDS_BONES_OFF + MAX_TILE_RAYS * 72 * 16;
-  auto kern = k_mlp_fwd_b3<LV, LD, CODE>;
+  auto kern = k_mlp_fwd_b3<LV, LD, CODE, TRAIN>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -313,21 +364,31 @@ static int launch_b3(const MlpArgs& a, hipStream_t st) {
   return check_launch("k_mlp_fwd_b3");
 }
 
+// sv == nullptr: render (no activations saved); else the training forward (anerf_mlp_raw_train_b3)
 int mlp_b3_entry(const AnerfConfig* cfg, const float* packed, const float* aux, const float* rays, int ray_stride,
                  const float* z, const float* skts, long long skt_stride, const float* cam, const float* codes, int n_codes,
                  float tau_v, float tau_d, const float* cut_v, const float* cut_d, long long P, int N, int S, int nstages,
-                 float* raw, hipStream_t st) {
+                 float* raw, const AnerfSaved* sv, hipStream_t st) {
   MlpArgs a;
   a.packed = packed; a.aux = aux; a.rays = rays; a.z = z; a.skts = skts; a.cam = cam; a.codes = codes;
   a.cut_v = cut_v; a.cut_d = cut_d; a.x = nullptr; a.raw = raw; a.P = P; a.Ppad = P; a.skt_stride = skt_stride;
   a.S = S; a.N = N; a.ray_stride = ray_stride; a.n_codes = n_codes; a.x_width = 0; a.nstages = nstages;
   a.tau_v = tau_v; a.tau_d = tau_d;
   a.save_h = a.save_f = a.save_g = a.save_x = a.save_u = nullptr;
+  if (sv) {
+    a.save_h = sv->h; a.save_f = sv->f; a.save_g = sv->g; a.save_x = sv->x; a.save_u = sv->u; a.Ppad = sv->p_pad;
+  }
   const int ld = cfg->multires_views, cd = cfg->framecode_ch;
   if (cfg->multires != 7) return set_error(ANERF_E_CONFIG, "multires must be 7");
-  if (ld == 4 && cd == 0) return launch_b3<7, 4, 0>(a, st);
-  if (ld == 4 && cd == 16) return launch_b3<7, 4, 16>(a, st);
-  if (ld == 0 && cd == 0) return launch_b3<7, 0, 0>(a, st);
+  if (sv) {
+    if (ld == 4 && cd == 0) return launch_b3<7, 4, 0, true>(a, st);
+    if (ld == 4 && cd == 16) return launch_b3<7, 4, 16, true>(a, st);
+    if (ld == 0 && cd == 0) return launch_b3<7, 0, 0, true>(a, st);
+  } else {
+    if (ld == 4 && cd == 0) return launch_b3<7, 4, 0, false>(a, st);
+    if (ld == 4 && cd == 16) return launch_b3<7, 4, 16, false>(a, st);
+    if (ld == 0 && cd == 0) return launch_b3<7, 0, 0, false>(a, st);
+  }
   return set_error(ANERF_E_CONFIG, "unsupported (multires_views, framecode_ch); built: (4,0) (4,16) (0,0)");
 }
 

@@ -199,9 +199,15 @@ class CutoffEmbedder(Embedder):
         self.cutoff_dist = nn.Parameter(torch.ones(cutoff_dim) * cutoff_dist, requires_grad=False)
         self.init_tau = 20.
         self.register_buffer("tau", torch.tensor(self.init_tau))
+        self._tau_host = (None, None, 0.0)     # (tensor identity, version, value): host copy of the device buffer
 
     def get_tau(self):
-        return self.tau.item()
+        """tau as a host float (a kernel argument).  The device buffer is only read back when it changed
+        (load_state_dict, .to()); a plain `self.tau.item()` here was a host sync in every caster call."""
+        key = (id(self.tau), self.tau._version)
+        if self._tau_host[:2] != key:
+            self._tau_host = key + (float(self.tau.item()),)
+        return self._tau_host[2]
 
     def get_cutoff_dist(self):
         return self.cutoff_dist
@@ -211,7 +217,9 @@ class CutoffEmbedder(Embedder):
 
     def update_tau(self, global_step, step, rate):
         # cutoff_embedder.py:181-183
-        self.tau = (self.init_tau * torch.ones_like(self.tau) * rate ** (global_step / float(step * 1000))).clamp(max=2000.)
+        val = min(self.init_tau * rate ** (global_step / float(step * 1000)), 2000.)
+        self.tau = torch.full_like(self.tau, val)
+        self._tau_host = (id(self.tau), self.tau._version, float(np.float32(val)))   # what .item() of the fp32 buffer returns
 
 
 def get_embedder(multires, i=0, input_dims=3, cutoff_kwargs={"cutoff": False}, skel_type=None, kc=False):

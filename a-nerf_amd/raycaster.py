@@ -53,8 +53,11 @@ class RayCaster(nn.Module):
             self.register_buffer("joint_coords", joint_coords.reshape(-1, n_j, 3, 3))
         self.single_net = single_net
         # "fp32" (exact fp32 MFMA) or "bf16x3" (hi/lo-split bf16 MFMAs, ~5x faster, same 1e-4 RGB bar) for the
-        # no-grad render path; training always runs fp32.
+        # no-grad render path.
         self.render_precision = "fp32"
+        # Training forward: "fp32", or "bf16x3" = the split-bf16 forward kernel saving fp32 activations; the backward
+        # kernels and the weight-gradient GEMM are fp32 either way (activations differ from fp32 by ~1e-6 relative).
+        self.train_precision = "fp32"
 
     @torch.no_grad()
     def forward_eval(self, *args, **kwargs):

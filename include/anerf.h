@@ -270,6 +270,18 @@ int anerf_fk_backward(const float* bones, const float* pelvis, const float* rest
                       int32_t n_poses, const float* g_skts, const float* g_l2ws, const float* g_kp, const float* g_rots,
                       float* g_bones, float* g_pelvis, void* stream);
 
+/* ---- split-bf16 TRAINING forward: same contract as anerf_mlp_raw_train on the which=3 weight image.  Activations
+ * are saved in fp32 exactly as the fp32 forward saves them (the backward kernels and the weight-gradient GEMM stay
+ * fp32 and are unchanged); only the column order of saved->x / saved->u differs, so pass the DEVICE copies of
+ * anerf_build_perm_tables_b3 (not anerf_build_perm_tables) to anerf_weight_grads. */
+int anerf_build_perm_tables_b3(const AnerfConfig* cfg, int32_t* perm_x, int32_t* perm_u);
+int anerf_mlp_raw_train_b3(const AnerfConfig* cfg, const float* packed, const float* aux,
+                           const float* rays, int32_t ray_stride, const float* z_vals,
+                           const float* skts, int64_t skt_ray_stride, const float* cam_idx,
+                           const float* codes, int32_t n_codes,
+                           float tau_v, float tau_d, const float* cutoff_v, const float* cutoff_d,
+                           int32_t n_rays, int32_t n_samples, float* raw, const AnerfSaved* saved, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

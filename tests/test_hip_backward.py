@@ -117,6 +117,40 @@ def test_pose_and_framecode_gradients(oracle, golden, name):
                                        atol=2e-3 * np.abs(refc).max(), err_msg="framecodes")
 
 
+@pytest.mark.parametrize("name", ["train_pytest", "mixamo_train"])
+def test_bf16x3_training_forward_keeps_the_gradient_bar(golden, name):
+    """train_precision = 'bf16x3': split-bf16 forward (fp32 activations saved in its own column order) + the fp32
+    backward: outputs, loss, weight / frame-code / pose gradients against the same reference golden vectors and bars."""
+    g = golden(name)
+    c = build(name)
+    caster = make_caster(c)
+    caster.train()
+    caster.train_precision = "bf16x3"
+    n = c["n"]
+    skts = dev(c["skts"]).requires_grad_(True)
+    cams = None if "cams" not in c else dev(c["cams"])
+    out = render_mod.render(64, 64, 75.0, chunk=4096, rays=(dev(c["rays_o"]), dev(c["rays_d"])), use_viewdirs=True,
+                            ray_caster=caster, kp_batch=dev(c["kp"]), skts=skts, cyls=dev(c["cyls"]),
+                            bones=dev(c["bones"]), cams=cams, subject_idxs=None, N_samples=64, N_importance=16,
+                            perturb=1.0, raw_noise_std=1.0, pytest=True,
+                            preproc_kwargs={"density_scale": 1.0, "density_fn": torch.nn.functional.relu})
+    for k in ["rgb_map", "acc_map", "alpha", "rgb0", "alpha0"]:
+        np.testing.assert_allclose(out[k].detach().cpu().numpy(), g[k], atol=1e-4, err_msg=k)
+    target = dev(np.random.default_rng(1 if name == "train_pytest" else 2).random((n, 3)))
+    loss, _ = render_mod.nerf_loss(out, target, bgs=torch.ones(n, 3, device="cuda"), loss_fn=c.get("loss", "MSE"))
+    assert abs(float(loss.detach()) - float(g["loss"])) < 5e-6
+    loss.backward()
+    ref = g["dskts"]
+    np.testing.assert_allclose(skts.grad.cpu().numpy(), ref, rtol=5e-3, atol=2e-3 * np.abs(ref).max(), err_msg="dskts")
+    for tag, net in [("c", caster.network), ("f", caster.network_fine)]:
+        for pname, p in net.named_parameters():
+            ref_n = float(g[f"gnorm_{tag}.{pname}"])
+            assert abs(float(p.grad.norm()) - ref_n) <= 2e-3 * ref_n + 1e-9, (tag, pname)
+            key = f"gfull_{tag}.{pname}"
+            if key in g:
+                np.testing.assert_allclose(p.grad.cpu().numpy(), g[key], rtol=5e-3, atol=2e-3 * np.abs(g[key]).max(), err_msg=key)
+
+
 def test_composite_backward_vs_autograd(oracle):
     """k_composite_bwd alone against torch autograd of the oracle's composite (softplus density too)."""
     autograd_path = importlib.import_module("a-nerf_amd.autograd_path")
