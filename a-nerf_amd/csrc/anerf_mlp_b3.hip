@@ -95,19 +95,19 @@ __device__ __forceinline__ void hidden_part_b3(Pipe3& pipe, f32x16 (&acc)[NB], c
 // also written to save[8 * (ks0 - ks_base + k) .. +7] -- its half of the saved X' / U' row, in value order (see
 // anerf_build_perm_tables_b3); only the first `nreal` values of the segment are real, the rest is zero padding.
 // SAVE is a compile-time switch and every lane stores (tail lanes of the last tile are clamped to the last valid
-// sample and rewrite its values): a per-lane `if (save)` around these stores, i.e. an exec-masked region in the middle
-// of a stage, produced stale weight fragments in the view layer (rgb off by 1e-4, run-to-run different) even when the
-// branch was never taken.
+// sample and rewrite its values), so there is no exec-mask juggling in the middle of a stage.
 template <int NB, int N, bool SAVE = false>
 __device__ __forceinline__ void emit(Pipe3& pipe, f32x16 (&acc)[NB], int ks0, int ks_last, const float (&val)[N],
                                      float* __restrict__ save = nullptr, int ks_base = 0, int nreal = 1 << 30) {
 #pragma unroll
   for (int k = 0; k < N / 8; ++k) {
     if constexpr (SAVE) {
-      // The stores are pinned in FRONT of the split of the same values: scheduled freely, the compiler sinks them to the
-      // last use of val[] and lets the next ds_read_b128 (weight fragments) land in the store's data registers right
-      // after issue -- the saved U' then carried fragment bits in a few hundred elements per launch, different ones
-      // every run.  With the split (16 VALU) between the store and the registers' reuse the data has been read.
+      // HAZARD (measured, gfx950): the stores are pinned in FRONT of the split of the same values.  Scheduled freely,
+      // the compiler sinks them to the last use of val[] and the next ds_read_b128 (a weight fragment) is issued into
+      // the store's data registers right behind it: the saved U' then carried fragment bits in a few hundred elements
+      // per launch and the rgb logits were off by 1e-5..1e-4, different elements every run (first seen with a per-lane
+      // `if (save)` around the stores, still there with unconditional stores, gone with this sched_barrier).  With the
+      // split (16 VALU) between a store and the reuse of its registers the store has read its data.
       const int i0 = 8 * (ks0 - ks_base + k);
       if (i0 + 3 < nreal) *reinterpret_cast<f32x4*>(save + i0) = f32x4{val[8 * k], val[8 * k + 1], val[8 * k + 2], val[8 * k + 3]};
       if (i0 + 7 < nreal) *reinterpret_cast<f32x4*>(save + i0 + 4) = f32x4{val[8 * k + 4], val[8 * k + 5], val[8 * k + 6], val[8 * k + 7]};
