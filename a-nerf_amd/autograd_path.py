@@ -96,8 +96,9 @@ class _MlpRawFn(torch.autograd.Function):
             gs.w[i] = grads[2 * i].data_ptr()
             gs.b[i] = grads[2 * i + 1].data_ptr()
         ws = torch.empty(T.gemm_ws_floats, dtype=torch.float32, device=dev)
-        px, pu = perm_tables(cfg, dev, b3=meta.get("precision", "fp32") == "bf16x3")
-        _lib.check(lib.anerf_weight_grads(C.byref(cc), C.byref(st), _p(dz), _p(df), _p(dzv), _p(draw), P, _p(px), _p(pu),
+        b3 = meta.get("precision", "fp32") == "bf16x3"
+        px, pu = perm_tables(cfg, dev, b3=b3)
+        _lib.check((lib.anerf_weight_grads_b3 if b3 else lib.anerf_weight_grads)(C.byref(cc), C.byref(st), _p(dz), _p(df), _p(dzv), _p(draw), P, _p(px), _p(pu),
                                           C.byref(gs), _p(ws), T.gemm_ws_floats, _stream()), "anerf_weight_grads")
         g_skts = g_codes = None
         need_skts, need_codes = ctx.needs_input_grad[1], ctx.needs_input_grad[2]

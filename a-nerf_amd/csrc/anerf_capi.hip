@@ -534,9 +534,9 @@ int anerf_mlp_backward(const AnerfConfig* cfg, const float* packed_t, const floa
   return mlp_bwd_entry(packed_t, aux, draw, saved, dz, df, dzv, n_points, L.n_stages, (hipStream_t)stream);
 }
 
-int anerf_weight_grads(const AnerfConfig* cfg, const AnerfSaved* sv, const float* dz, const float* df, const float* dzv,
-                       const float* draw, int64_t n_points, const int32_t* perm_x, const int32_t* perm_u,
-                       const AnerfNetGrads* gr, float* workspace, int64_t ws_floats, void* stream) {
+static int weight_grads_impl(const AnerfConfig* cfg, const AnerfSaved* sv, const float* dz, const float* df, const float* dzv,
+                             const float* draw, int64_t n_points, const int32_t* perm_x, const int32_t* perm_u,
+                             const AnerfNetGrads* gr, float* workspace, int64_t ws_floats, bool b3, void* stream) {
   AnerfTrainLayout T;
   const int rc = anerf_train_layout(cfg, n_points, &T);
   if (rc) return rc;
@@ -638,7 +638,19 @@ int anerf_weight_grads(const AnerfConfig* cfg, const AnerfSaved* sv, const float
   if (nb != P.nheavy) return set_error(ANERF_E_CONFIG, "weight_grads: block plan mismatch");
   emit(skinny, 4, 1);
   if (nb != P.nheavy + P.nskinny || nb > 16 || nmat > 24) return set_error(ANERF_E_CONFIG, "weight_grads: block plan mismatch");
-  return launch_weight_grads(P, G, workspace, (hipStream_t)stream);
+  return launch_weight_grads(P, G, workspace, b3, (hipStream_t)stream);
+}
+
+int anerf_weight_grads(const AnerfConfig* cfg, const AnerfSaved* sv, const float* dz, const float* df, const float* dzv,
+                       const float* draw, int64_t n_points, const int32_t* perm_x, const int32_t* perm_u,
+                       const AnerfNetGrads* gr, float* workspace, int64_t ws_floats, void* stream) {
+  return weight_grads_impl(cfg, sv, dz, df, dzv, draw, n_points, perm_x, perm_u, gr, workspace, ws_floats, false, stream);
+}
+
+int anerf_weight_grads_b3(const AnerfConfig* cfg, const AnerfSaved* sv, const float* dz, const float* df, const float* dzv,
+                          const float* draw, int64_t n_points, const int32_t* perm_x, const int32_t* perm_u,
+                          const AnerfNetGrads* gr, float* workspace, int64_t ws_floats, void* stream) {
+  return weight_grads_impl(cfg, sv, dz, df, dzv, draw, n_points, perm_x, perm_u, gr, workspace, ws_floats, true, stream);
 }
 
 int anerf_input_grads(const AnerfConfig* cfg, const float* packed_i, const float* dz, const float* dzv, int64_t p_pad,

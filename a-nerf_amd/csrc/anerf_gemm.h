@@ -57,6 +57,6 @@ constexpr int GEMM_ROWS = 16;   // sample rows per LDS stage
 // rows-per-block search shared by anerf_train_layout (workspace size) and anerf_weight_grads
 void gemm_plan_rows(long long p_pad, int nheavy, int nskinny, int* rows_h, int* chunks_h, int* rows_s, int* chunks_s);
 
-int launch_weight_grads(const GemmPlan& P, const GemmBatch& G, float* ws, hipStream_t st);
+int launch_weight_grads(const GemmPlan& P, const GemmBatch& G, float* ws, bool b3, hipStream_t st);
 
 }  // namespace anerf

@@ -23,13 +23,15 @@
 #include <stdlib.h>
 #include "anerf_dev.h"
 #include "anerf_gemm.h"
+#include "anerf_split.h"
 
 namespace anerf {
 
 constexpr int GT = 128;                         // tile edge (columns of an operand tile, rows/cols of an output tile)
 constexpr int GTILE_BYTES = GEMM_ROWS * GT * 4; // 8 KiB
 constexpr int GSTAGE_BYTES = 5 * GTILE_BYTES;   // 40 KiB
-constexpr int GLDS_BYTES = 2 * GSTAGE_BYTES;    // double buffer
+constexpr int GLDS_BYTES = 2 * GSTAGE_BYTES;    // double buffer (fp32 kernel)
+constexpr int GLDS3_BYTES = 3 * GSTAGE_BYTES;   // 3-slot ring (split-bf16 kernel)
 
 // Chunking: every block (heavy or skinny) covers the same rows_h sample rows; one block per CU at a time (256 AGPRs).
 // Pick rows_h (multiple of 16) minimising  rounds(blocks over 256 CUs) x (rows + epilogue).
@@ -57,39 +59,37 @@ void gemm_plan_rows(long long p_pad, int nheavy, int nskinny, int* rows_h, int* 
   *chunks_s = *chunks_h;
 }
 
-template <bool SKINNY>
-__device__ __forceinline__ void gemm_body(const GemmPlan& G, const GemmBlock& B, char* smem, float* __restrict__ ws,
-                                          long long r0, int nst, int chunk, int wave, int lane) {
-#ifdef ANERF_EXP_GEMM_TIMING   // debug build only: per-wave cycle stamps at ws + 64M floats
-  const long long tk0 = wall_clock64();
-#endif
-  const int i = lane & 31, kk = lane >> 5;
-  const GemmWave& W = B.w[wave];
-  const bool active = W.a_tile >= 0;
-  const bool do_bias = active && W.bias_off >= 0;
-
-  // ---- loader: every operand tile of a stage is 8 two-row wave-instructions; wave w issues rows {2w, 2w+1} and
-  // {2w+8, 2w+9} of each tile.  Only 5 per-lane offsets (VGPRs) live across the MFMA loop: a spilled VGPR here
-  // would put a scratch reload -- an in-order VMEM op -- behind the freshly issued operand loads and expose their
-  // full latency at every stage.
-  // Tile descriptors are copied into scalars up front: read through the plan reference they would be re-fetched with
-  // dependent s_load round trips at every stage (the asm "memory" clobber of the stage barrier forbids caching them).
+// ---- loader: every operand tile of a stage is 8 two-row wave-instructions; wave w issues rows {2w, 2w+1} and
+// {2w+8, 2w+9} of each tile.  Only 5 per-lane offsets (VGPRs) live across the MFMA loop: a spilled VGPR here would put
+// a scratch reload -- an in-order VMEM op -- behind the freshly issued operand loads and expose their full latency at
+// every stage.  Tile descriptors are copied into scalars up front: read through the plan reference they would be
+// re-fetched with dependent s_load round trips at every stage (the asm "memory" clobber of the stage barrier forbids
+// caching them).
+struct GemmLoader {
   const char* t_ptr[5];
   int t_ld[5];
   unsigned t_lo[5];
+  int ntiles, wave;
+  char* smem;
+
+  __device__ __forceinline__ void init(const GemmPlan& G, const GemmBlock& B, char* smem_, long long r0, int wave_, int lane) {
+    const int i = lane & 31, kk = lane >> 5;
+    smem = smem_;
+    wave = wave_;
+    ntiles = B.ntiles;
 #pragma unroll
-  for (int tile = 0; tile < 5; ++tile) {
-    const int tt = tile < B.ntiles ? tile : 0;
-    const GemmMat& M = G.mat[B.t[tt].mat];
-    int c = B.t[tt].col0 + i * 4;
-    const int cmax = M.ncols - 4;
-    c = c > cmax ? cmax : c;   // clamp: columns past the edge repeat the last float4 (their outputs are never stored)
-    t_ld[tile] = M.ld;
-    t_ptr[tile] = reinterpret_cast<const char*>(M.ptr + (r0 + 2 * wave) * M.ld);    // wave-uniform
-    t_lo[tile] = (unsigned)(kk * M.ld + c) * 4u;                                      // per lane
+    for (int tile = 0; tile < 5; ++tile) {
+      const int tt = tile < B.ntiles ? tile : 0;
+      const GemmMat& M = G.mat[B.t[tt].mat];
+      int c = B.t[tt].col0 + i * 4;
+      const int cmax = M.ncols - 4;
+      c = c > cmax ? cmax : c;   // clamp: columns past the edge repeat the last float4 (their outputs are never stored)
+      t_ld[tile] = M.ld;
+      t_ptr[tile] = reinterpret_cast<const char*>(M.ptr + (r0 + 2 * wave) * M.ld);    // wave-uniform
+      t_lo[tile] = (unsigned)(kk * M.ld + c) * 4u;                                      // per lane
+    }
   }
-  const int ntiles = B.ntiles;
-  auto issue = [&](int stage, int slot) {
+  __device__ __forceinline__ void issue(int stage, int slot) const {
 #ifdef ANERF_EXP_GEMM_NOLOAD   // ablation build only (tools/ablate.sh): results are wrong
     (void)stage; (void)slot; return;
 #endif
@@ -101,7 +101,54 @@ __device__ __forceinline__ void gemm_body(const GemmPlan& G, const GemmBlock& B,
         __builtin_amdgcn_global_load_lds((glb_ptr_t)(rowp + t_lo[tile]), (lds_ptr_t)l, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((glb_ptr_t)(rowp + (long long)t_ld[tile] * 32 + t_lo[tile]), (lds_ptr_t)(l + 8 * (GT * 4)), 16, 0, 0);
       }
-  };
+  }
+};
+
+// partial tile -> workspace [chunk][M][N]: accumulator block (a, c), register r, lane (i, kk) holds output row
+// 4*((r&3) + 8*(r>>2) + 4*kk) + a, column 4*i + c   (skinny: row (r&3), rows >= 4 are copies); then the bias partials
+template <bool SKINNY, int NA>
+__device__ __forceinline__ void gemm_store(const GemmWave& W, float* __restrict__ ws, int chunk, const f32x16 (&acc)[NA][4],
+                                           f32x4 asum, bool do_bias, int i, int kk) {
+  float* part = ws + W.part_off + (long long)chunk * W.M * W.N;
+  const int n = W.n0 + 4 * i;
+  if (n < W.N) {
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rowi = (r & 3) + 8 * (r >> 2) + 4 * kk;
+        const int m = SKINNY ? rowi : W.m0 + 4 * rowi + a;
+        if (SKINNY ? (rowi < 4 && m < W.M) : (m < W.M)) {
+          const f32x4 o = {acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
+          *reinterpret_cast<f32x4*>(part + (long long)m * W.N + n) = o;
+        }
+      }
+  }
+  if (do_bias) {
+    float* bp = ws + W.bias_off + (long long)chunk * W.M;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) asum[a] += __shfl_xor(asum[a], 32);
+    if (kk == 0) {
+      if constexpr (SKINNY) {
+        if (i < 4 && i < W.M) bp[i] = asum[0];
+      } else {
+        const int m = W.m0 + 4 * i;
+        if (m < W.M) *reinterpret_cast<f32x4*>(bp + m) = asum;   // M is a multiple of 4 for every heavy problem
+      }
+    }
+  }
+}
+
+template <bool SKINNY>
+__device__ __forceinline__ void gemm_body(const GemmPlan& G, const GemmBlock& B, char* smem, float* __restrict__ ws,
+                                          long long r0, int nst, int chunk, int wave, int lane) {
+  const int i = lane & 31, kk = lane >> 5;
+  const GemmWave& W = B.w[wave];
+  const bool active = W.a_tile >= 0;
+  const bool do_bias = active && W.bias_off >= 0;
+  GemmLoader L;
+  L.init(G, B, smem, r0, wave, lane);
+  auto issue = [&](int stage, int slot) { L.issue(stage, slot); };
 
   constexpr int NA = SKINNY ? 1 : 4;
   f32x16 acc[NA][4];
@@ -181,47 +228,107 @@ __device__ __forceinline__ void gemm_body(const GemmPlan& G, const GemmBlock& B,
       }
     }
   }
-#ifdef ANERF_EXP_GEMM_TIMING
-  const long long tk1 = wall_clock64();
-#endif
-  // ---- partial tile -> workspace [chunk][M][N]: accumulator block (a, c), register r, lane (i, kk) holds
-  //      output row 4*((r&3) + 8*(r>>2) + 4*kk) + a, column 4*i + c   (skinny: row (r&3), rows >= 4 are copies)
-  float* part = ws + W.part_off + (long long)chunk * W.M * W.N;
-  const int n = W.n0 + 4 * i;
-  if (n < W.N) {
-#pragma unroll
-    for (int a = 0; a < NA; ++a)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rowi = (r & 3) + 8 * (r >> 2) + 4 * kk;
-        const int m = SKINNY ? rowi : W.m0 + 4 * rowi + a;
-        if (SKINNY ? (rowi < 4 && m < W.M) : (m < W.M)) {
-          const f32x4 o = {acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
-          *reinterpret_cast<f32x4*>(part + (long long)m * W.N + n) = o;
-        }
-      }
-  }
-  if (do_bias) {
-    float* bp = ws + W.bias_off + (long long)chunk * W.M;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) asum[a] += __shfl_xor(asum[a], 32);
-    if (kk == 0) {
-      if constexpr (SKINNY) {
-        if (i < 4 && i < W.M) bp[i] = asum[0];
-      } else {
-        const int m = W.m0 + 4 * i;
-        if (m < W.M) *reinterpret_cast<f32x4*>(bp + m) = asum;   // M is a multiple of 4 for every heavy problem
-      }
-    }
-  }
-#ifdef ANERF_EXP_GEMM_TIMING
-  if (lane == 0) {
-    long long* dbg = reinterpret_cast<long long*>(ws + (64LL << 20)) + ((long long)blockIdx.x * 4 + wave) * 4;
-    dbg[0] = tk0; dbg[1] = tk1; dbg[2] = wall_clock64(); dbg[3] = nst;
-  }
-#endif
+  gemm_store<SKINNY, NA>(W, ws, chunk, acc, asum, do_bias, i, kk);
 }
 
+// ---- split-bf16 variant of the heavy body (anerf_weight_grads_b3): the products run on v_mfma_f32_32x32x16_bf16 with
+// hi/lo-split operands (anerf_split.h).  A stage's 16 sample rows are exactly one k-step: lane (i, kh) reads rows
+// 8kh..8kh+7 of its 4-column group with 8 ds_read_b128 per operand, splits the 8 values of each of the 4 blocks into
+// (hi, lo) bf16x8 and issues 3 MFMAs per (a, c) block pair (48 per stage = 1536 matrix cycles).  To keep the matrix
+// pipe fed the stages are software-pipelined through a 3-slot ring: while stage s is multiplied, the raw operands of
+// stage s+1 (already landed -- same invariant as the forward kernel's pipe) are read and split, interleaved with the
+// MFMAs by sched_group_barriers (bf16 MFMAs, unlike fp32 ones, do run beside VALU).  Same accumulator layout, same
+// epilogue, same deterministic reduction.
+struct SplitOps {
+  BOp A[4], B[4];
+};
+
+__device__ __forceinline__ void gemm_read_raw(const char* base, unsigned a_off, unsigned b_off, f32x4 (&ar)[8], f32x4 (&br)[8]) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    ar[t] = *reinterpret_cast<const f32x4*>(base + a_off + t * (GT * 4));
+    br[t] = *reinterpret_cast<const f32x4*>(base + b_off + t * (GT * 4));
+  }
+}
+
+__device__ __forceinline__ void gemm_split(const f32x4 (&ar)[8], const f32x4 (&br)[8], SplitOps& o, f32x4& asum) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) asum += ar[t];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    o.A[q] = split8(ar[0][q], ar[1][q], ar[2][q], ar[3][q], ar[4][q], ar[5][q], ar[6][q], ar[7][q]);
+    o.B[q] = split8(br[0][q], br[1][q], br[2][q], br[3][q], br[4][q], br[5][q], br[6][q], br[7][q]);
+  }
+}
+
+__device__ __forceinline__ void gemm_body_b3(const GemmPlan& G, const GemmBlock& B, char* smem, float* __restrict__ ws,
+                                             long long r0, int nst, int chunk, int wave, int lane) {
+  const int i = lane & 31, kh = lane >> 5;
+  const GemmWave& W = B.w[wave];
+  const bool active = W.a_tile >= 0;
+  const bool do_bias = active && W.bias_off >= 0;
+  GemmLoader L;
+  L.init(G, B, smem, r0, wave, lane);
+  // ring protocol: while stage s is consumed, stages s and s+1 have landed and s+2 is in flight
+  if (nst > 0) L.issue(0, 0);
+  if (nst > 1) L.issue(1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (nst > 2) L.issue(2, 2);
+  auto end_stage = [&](int s) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stage s+2 landed (this wave's share)
+    __syncthreads();                                   // ... everybody's; nobody reads slot s % 3 any more
+    if (s + 3 < nst) L.issue(s + 3, s % 3);
+  };
+  if (!active) {
+    for (int s = 0; s < nst; ++s) end_stage(s);
+    return;
+  }
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+  f32x4 asum = {0.f, 0.f, 0.f, 0.f};
+  const unsigned a_off = W.a_tile * GTILE_BYTES + 8 * kh * (GT * 4) + i * 16;
+  const unsigned b_off = W.b_tile * GTILE_BYTES + 8 * kh * (GT * 4) + i * 16;
+
+  SplitOps cur;
+  {
+    f32x4 ar[8], br[8];
+    gemm_read_raw(smem, a_off, b_off, ar, br);
+    gemm_split(ar, br, cur, asum);
+  }
+  for (int s = 0; s < nst; ++s) {
+    SplitOps nxt = cur;
+    f32x4 ar[8], br[8];
+    const bool more = s + 1 < nst;
+    if (more) gemm_read_raw(smem + ((s + 1) % 3) * GSTAGE_BYTES, a_off, b_off, ar, br);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.A[a].lo, cur.B[c].hi, acc[a][c], 0, 0, 0);
+        acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.A[a].hi, cur.B[c].lo, acc[a][c], 0, 0, 0);
+        acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.A[a].hi, cur.B[c].hi, acc[a][c], 0, 0, 0);
+      }
+    if (more) gemm_split(ar, br, nxt, asum);
+    // interleave: one MFMA, then a few of the next stage's LDS reads / split VALU
+#pragma unroll
+    for (int k = 0; k < 48; ++k) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+      if (k < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // 4 VALU
+    }
+    end_stage(s);
+    cur = nxt;
+  }
+  gemm_store<false, 4>(W, ws, chunk, acc, asum, do_bias, i, kh);
+}
+
+template <bool B3>
 __global__ __launch_bounds__(256) void k_gemm_tn(const GemmPlan G, float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -257,6 +364,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const GemmPlan G, float* __rest
   const int nst = (int)((r1 - r0) / GEMM_ROWS);
   const GemmBlock& B = G.blk[job];
   if (B.skinny) gemm_body<true>(G, B, smem, ws, r0, nst, chunk, wave, lane);
+  else if constexpr (B3) gemm_body_b3(G, B, smem, ws, r0, nst, chunk, wave, lane);
   else gemm_body<false>(G, B, smem, ws, r0, nst, chunk, wave, lane);
 }
 
@@ -289,14 +397,16 @@ __global__ void k_reduce_dw(const GemmBatch G, const float* __restrict__ ws) {
   }
 }
 
-int launch_weight_grads(const GemmPlan& P, const GemmBatch& G, float* ws, hipStream_t st) {
+int launch_weight_grads(const GemmPlan& P, const GemmBatch& G, float* ws, bool b3, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_tn), hipFuncAttributeMaxDynamicSharedMemorySize, GLDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_tn<false>), hipFuncAttributeMaxDynamicSharedMemorySize, GLDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_tn<true>), hipFuncAttributeMaxDynamicSharedMemorySize, GLDS3_BYTES);
     attr_set = true;
   }
   const int grid = P.chunks_h * P.nheavy + P.chunks_s * P.nskinny;
-  hipLaunchKernelGGL(k_gemm_tn, dim3((unsigned)grid), dim3(256), GLDS_BYTES, st, P, ws);
+  if (b3) hipLaunchKernelGGL(k_gemm_tn<true>, dim3((unsigned)grid), dim3(256), GLDS3_BYTES, st, P, ws);
+  else hipLaunchKernelGGL(k_gemm_tn<false>, dim3((unsigned)grid), dim3(256), GLDS_BYTES, st, P, ws);
   int rc = check_launch("k_gemm_tn");
   if (rc) return rc;
   hipLaunchKernelGGL(k_reduce_dw, dim3((unsigned)((G.total_out + 255) / 256)), dim3(256), 0, st, G, (const float*)ws);

@@ -14,39 +14,9 @@
 // Reference ops replaced: identical to anerf_mlp.hip (core/encoders.py, core/cutoff_embedder.py,
 // core/networks/nerf.py:94-148).
 #include "anerf_fwd_common.h"
+#include "anerf_split.h"
 
 namespace anerf {
-
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
-typedef float f2_t __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-// (a, b) -> packed bf16 pairs hi, lo with a = hi.x + lo.x (+ 2^-18 rel.), round-to-nearest both times
-__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
-  const bf2_t h = __builtin_convertvector(f2_t{a, b}, bf2_t);
-  const f2_t hf = __builtin_convertvector(h, f2_t);
-  const bf2_t l = __builtin_convertvector(f2_t{a - hf.x, b - hf.y}, bf2_t);
-  hi = __builtin_bit_cast(unsigned, h);
-  lo = __builtin_bit_cast(unsigned, l);
-}
-
-struct BOp {
-  bf16x8 hi, lo;
-};
-
-__device__ __forceinline__ BOp split8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7) {
-  unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-  split2(v0, v1, h0, l0);
-  split2(v2, v3, h1, l1);
-  split2(v4, v5, h2, l2);
-  split2(v6, v7, h3, l3);
-  const u32x4 h = {h0, h1, h2, h3}, l = {l0, l1, l2, l3};
-  BOp o;
-  o.hi = __builtin_bit_cast(bf16x8, h);
-  o.lo = __builtin_bit_cast(bf16x8, l);
-  return o;
-}
 
 // One k-step (16 contraction indices) against NB 32-row feature blocks: per block a (hi, lo) fragment pair from
 // LDS and three MFMAs.  ks: k-step index relative to the segment start; last: final k-step of the segment.

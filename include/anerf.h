@@ -282,6 +282,13 @@ int anerf_mlp_raw_train_b3(const AnerfConfig* cfg, const float* packed, const fl
                            float tau_v, float tau_d, const float* cutoff_v, const float* cutoff_d,
                            int32_t n_rays, int32_t n_samples, float* raw, const AnerfSaved* saved, void* stream);
 
+/* anerf_weight_grads with the products on split-bf16 MFMAs (operands split hi + lo in registers, fp32 accumulate):
+ * same arguments, workspace and (deterministic) reduction; ~1e-6 relative on the gradients. */
+int anerf_weight_grads_b3(const AnerfConfig* cfg, const AnerfSaved* saved, const float* dz, const float* df,
+                          const float* dzv, const float* draw, int64_t n_points, const int32_t* perm_x,
+                          const int32_t* perm_u, const AnerfNetGrads* grads, float* workspace, int64_t ws_floats,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif
