@@ -85,10 +85,11 @@ class _MlpRawFn(torch.autograd.Function):
         dzv = _planes(pp, P, 128, 1, dev)
         st = _lib.AnerfSaved(_p(sv["h"]), _p(sv["f"]), _p(sv["g"]), _p(sv["x"]), _p(sv["u"]), pp)
         cc = cfg.c()
+        b3 = meta.get("precision", "fp32") == "bf16x3"
         packed_t, _ = meta["packed_t"]
-        _, aux = meta["packed_b3"] if meta.get("precision", "fp32") == "bf16x3" else meta["packed"]
+        _, aux = meta["packed_b3"] if b3 else meta["packed"]
         lib = _lib.load()
-        _lib.check(lib.anerf_mlp_backward(C.byref(cc), _p(packed_t), _p(aux), _p(draw), C.byref(st), _p(dz), _p(df), _p(dzv),
+        _lib.check((lib.anerf_mlp_backward_b3 if b3 else lib.anerf_mlp_backward)(C.byref(cc), _p(packed_t), _p(aux), _p(draw), C.byref(st), _p(dz), _p(df), _p(dzv),
                                           P, _stream()), "anerf_mlp_backward")
         grads = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in ctx.shapes]
         gs = _lib.AnerfNetGrads()
@@ -96,7 +97,6 @@ class _MlpRawFn(torch.autograd.Function):
             gs.w[i] = grads[2 * i].data_ptr()
             gs.b[i] = grads[2 * i + 1].data_ptr()
         ws = torch.empty(T.gemm_ws_floats, dtype=torch.float32, device=dev)
-        b3 = meta.get("precision", "fp32") == "bf16x3"
         px, pu = perm_tables(cfg, dev, b3=b3)
         _lib.check((lib.anerf_weight_grads_b3 if b3 else lib.anerf_weight_grads)(C.byref(cc), C.byref(st), _p(dz), _p(df), _p(dzv), _p(draw), P, _p(px), _p(pu),
                                           C.byref(gs), _p(ws), T.gemm_ws_floats, _stream()), "anerf_weight_grads")
@@ -181,7 +181,7 @@ def render_rays_train(caster, kw):
         cam = kw["cam_idx"].contiguous() if net.use_framecode else None
         meta = dict(cfg=cfg, rays=rays, z=zz, skts=skts_c.detach(), tau_v=kw["tau_v"], tau_d=kw["tau_d"],
                     cut_v=kw["cut_v"], cut_d=kw["cut_d"], cam=cam, codes=None if codes is None else codes.detach(),
-                    packed=net.packed(0) if prec == "fp32" else None, packed_t=net.packed(1), packed_i=lambda: net.packed(2),
+                    packed=net.packed(0) if prec == "fp32" else None, packed_t=net.packed(4 if prec == "bf16x3" else 1), packed_i=lambda: net.packed(2),
                     precision=prec, packed_b3=net.packed(3) if prec == "bf16x3" else None)
         return _MlpRawFn.apply(meta, skts_c, codes, *_net_params(net))
 

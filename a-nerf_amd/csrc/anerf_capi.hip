@@ -42,6 +42,8 @@ int mlp_raw_entry(const AnerfConfig* cfg, const float* packed, const float* aux,
                   hipStream_t st);
 int mlp_bwd_entry(const float* packed_t, const float* aux, const float* draw, const AnerfSaved* sv, float* dz, float* df,
                   float* dzv, long long P, int nstages, hipStream_t st);
+int mlp_bwd_b3_entry(const float* packed_t, const float* aux, const float* draw, const AnerfSaved* sv, float* dz, float* df,
+                     float* dzv, long long P, int nstages, hipStream_t st);
 int mlp_b3_entry(const AnerfConfig* cfg, const float* packed, const float* aux, const float* rays, int ray_stride,
                  const float* z, const float* skts, long long skt_stride, const float* cam, const float* codes, int n_codes,
                  float tau_v, float tau_d, const float* cut_v, const float* cut_d, long long P, int N, int S, int nstages,
@@ -192,7 +194,8 @@ int anerf_version(void) { return 1; }
 int anerf_layout(const AnerfConfig* cfg, int which, AnerfLayout* out) {
   if (!out) return set_error(ANERF_E_NULL, "out is NULL");
   if (!config_ok(cfg)) return set_error(ANERF_E_CONFIG, "unsupported AnerfConfig");
-  if (which < 0 || which > 3) return set_error(ANERF_E_CONFIG, "which must be 0 (W), 1 (W^T), 2 (input-gradient image) or 3 (bf16x3 W)");
+  if (which < 0 || which > 4)
+    return set_error(ANERF_E_CONFIG, "which must be 0 (W), 1 (W^T), 2 (input-gradient image), 3 (bf16x3 W) or 4 (bf16x3 W^T)");
   int stages = 0;
   if (which == 0)
     for (const Seg& s : fwd_segments(cfg)) stages += seg_stages(s);
@@ -200,6 +203,8 @@ int anerf_layout(const AnerfConfig* cfg, int which, AnerfLayout* out) {
     for (const BSeg& s : bwd_segments(cfg)) stages += bseg_stages(s);
   else if (which == 2)
     stages = 2 * (8 + 8) + ((u_width(cfg) + 255) / 256) * 4;
+  else if (which == 4)
+    for (const BSeg& s : bwd_segments(cfg)) stages += bseg_stages(s);   // same bytes per k as fp32: (hi, lo) bf16 = 4 B
   else
     for (const Seg& s : fwd_segments(cfg)) stages += b3_stages(cfg, s);
   out->n_stages = stages;
@@ -214,7 +219,7 @@ int anerf_build_pack_table(const AnerfConfig* cfg, int which, int32_t* table) {
   const int rc = anerf_layout(cfg, which, &L);
   if (rc) return rc;
   if (!table) return set_error(ANERF_E_NULL, "table is NULL");
-  const int64_t n_stream_entries = which == 3 ? 2 * L.stream_floats : L.stream_floats;   // which=3: one per bf16 element
+  const int64_t n_stream_entries = which >= 3 ? 2 * L.stream_floats : L.stream_floats;   // bf16x3 images: one per bf16 element
   for (int64_t i = 0; i < n_stream_entries + L.aux_floats; ++i) table[i] = -1;
   int64_t pos = 0;
   if (which == 3) {
@@ -231,6 +236,24 @@ int anerf_build_pack_table(const AnerfConfig* cfg, int which, int32_t* table) {
                     (part << 29) | (s.tensor << 24) | (n * s.K + col);
               }
       pos += (int64_t)b3_stages(cfg, s) * STAGE_FRAGS * 512;
+    }
+  }
+  if (which == 4) {
+    // W^T in bf16x3 fragments: k-step ks contracts 16 rows n of W, supplied in the accumulator order of the split-bf16
+    // kernels (lane half hh, element e -> n = 16 ks + (e & 3) + 8 (e >> 2) + 4 hh); block nb produces columns
+    // c0 + 32 nb + (lane & 31) of W
+    for (const BSeg& s : bwd_segments(cfg)) {
+      for (int ks = 0; ks < s.ncontract / 16; ++ks)
+        for (int nb = 0; nb < 8; ++nb)
+          for (int part = 0; part < 2; ++part)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int e = 0; e < 8; ++e) {
+                const int n = 16 * ks + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const int col = s.c0 + 32 * nb + (lane & 31);
+                table[pos + ((int64_t)((ks * 8 + nb) * 2 + part) * 64 + lane) * 8 + e] =
+                    (part << 29) | (s.tensor << 24) | (n * s.K + col);
+              }
+      pos += (int64_t)bseg_stages(s) * STAGE_FRAGS * 512;
     }
   }
   if (which == 1) {
@@ -639,6 +662,16 @@ static int weight_grads_impl(const AnerfConfig* cfg, const AnerfSaved* sv, const
   emit(skinny, 4, 1);
   if (nb != P.nheavy + P.nskinny || nb > 16 || nmat > 24) return set_error(ANERF_E_CONFIG, "weight_grads: block plan mismatch");
   return launch_weight_grads(P, G, workspace, b3, (hipStream_t)stream);
+}
+
+int anerf_mlp_backward_b3(const AnerfConfig* cfg, const float* packed_t, const float* aux, const float* draw,
+                          const AnerfSaved* saved, float* dz, float* df, float* dzv, int64_t n_points, void* stream) {
+  AnerfLayout L;
+  const int rc = anerf_layout(cfg, 4, &L);
+  if (rc) return rc;
+  if (!packed_t || !aux || !draw || !dz || !df || !dzv) return set_error(ANERF_E_NULL, "mlp_backward_b3: NULL pointer");
+  if (!saved_ok(saved) || saved->p_pad < n_points) return set_error(ANERF_E_WORKSPACE, "mlp_backward_b3: AnerfSaved");
+  return mlp_bwd_b3_entry(packed_t, aux, draw, saved, dz, df, dzv, n_points, L.n_stages, (hipStream_t)stream);
 }
 
 int anerf_weight_grads(const AnerfConfig* cfg, const AnerfSaved* sv, const float* dz, const float* df, const float* dzv,

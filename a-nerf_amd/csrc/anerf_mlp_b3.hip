@@ -363,6 +363,154 @@ int mlp_b3_entry(const AnerfConfig* cfg, const float* packed, const float* aux, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_mlp_bwd_b3 -- backward-data of the MLP on split-bf16 MFMAs (anerf_mlp_backward_b3): the structure of k_mlp_bwd
+// (anerf_mlp_bwd.hip: ping-pong accumulator sets read directly as the next layer's B operands, ReLU-mask row
+// prefetched per layer, in-place mask pass, one continuous weight segment) with the k-steps of this file: the W^T image
+// `which = 4` holds (hi, lo) fragment pairs, dz values are split in registers.  Same inputs / outputs as k_mlp_bwd.
+// ------------------------------------------------------------------------------------------------
+struct BwdArgs3 {
+  const float* packed_t;   // W^T image, which = 4
+  const float* aux;
+  const float* draw;       // [P][4]
+  const float* save_h;     // [8][Ppad][256]
+  const float* save_g;     // [Ppad][128]
+  float* dz;               // [8][Ppad][256]
+  float* df;               // [Ppad][256]
+  float* dzv;              // [Ppad][128]
+  long long P, Ppad;
+  int nstages;
+};
+
+template <int NB>
+__device__ __forceinline__ void load_mask3(f32x4 (&mk)[32], const float* __restrict__ row_h) {
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mk[4 * nb + q] = *reinterpret_cast<const f32x4*>(row_h + 32 * nb + 8 * q);
+}
+template <int NB>
+__device__ __forceinline__ void mask_pass3(f32x16 (&acc)[NB], const f32x4 (&mk)[32]) {
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc[nb][4 * q + 0] = mk[4 * nb + q].x > 0.f ? acc[nb][4 * q + 0] : 0.f;
+      acc[nb][4 * q + 1] = mk[4 * nb + q].y > 0.f ? acc[nb][4 * q + 1] : 0.f;
+      acc[nb][4 * q + 2] = mk[4 * nb + q].z > 0.f ? acc[nb][4 * q + 2] : 0.f;
+      acc[nb][4 * q + 3] = mk[4 * nb + q].w > 0.f ? acc[nb][4 * q + 3] : 0.f;
+    }
+}
+template <int NB>
+__device__ __forceinline__ void zero_acc3(f32x16 (&acc)[NB]) {
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
+}
+
+__device__ __forceinline__ void bwd_layer_b3(Pipe3& pipe, f32x16 (&out)[8], const f32x16 (&prev)[8], f32x4 (&mk)[32],
+                                             const float* __restrict__ mask_row_h, float* __restrict__ dz_row_h, bool valid,
+                                             bool last) {
+  load_mask3<8>(mk, mask_row_h);
+  zero_acc3<8>(out);
+  hidden_part_b3<8, 16>(pipe, out, prev, last);     // KS0 = 16: any non-zero multiple of the k-steps per stage
+  mask_pass3<8>(out, mk);
+  if (valid) store_rows<8>(dz_row_h, out);
+}
+
+__global__ __launch_bounds__(256) void k_mlp_bwd_b3(const BwdArgs3 A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 31, h = lane >> 5;
+  Pipe3 pipe;
+  pipe.init(A.packed_t, smem, wave, lane, A.nstages);
+  const long long p = (long long)blockIdx.x * TILE + wave * 32 + m;
+  const bool valid = p < A.P;
+  const long long pc = valid ? p : A.P - 1;
+  float* aux_l = reinterpret_cast<float*>(smem + LDS_AUX_OFF);
+  for (int i = tid; i < AUX_FLOATS / 4; i += 256)
+    reinterpret_cast<f32x4*>(aux_l)[i] = reinterpret_cast<const f32x4*>(A.aux)[i];
+  const float* aux_h = aux_l + 4 * h;
+  const f32x4 dr = *reinterpret_cast<const f32x4*>(A.draw + pc * 4);
+  f32x4 mk[32];
+  load_mask3<4>(mk, A.save_g + pc * 128 + 4 * h);
+  pipe.begin();
+
+  f32x16 accA[8], accB[8];
+  f32x16 accv[4];
+  // ---- rgb head (VALU): dg = Wc^T dc ; dzv = dg * [g > 0]
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int o = 32 * nb + 8 * q;
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(aux_h + AUX_WC + o);
+      const f32x4 w1 = *reinterpret_cast<const f32x4*>(aux_h + AUX_WC + 128 + o);
+      const f32x4 w2 = *reinterpret_cast<const f32x4*>(aux_h + AUX_WC + 256 + o);
+      accv[nb][4 * q + 0] = w0.x * dr.x + w1.x * dr.y + w2.x * dr.z;
+      accv[nb][4 * q + 1] = w0.y * dr.x + w1.y * dr.y + w2.y * dr.z;
+      accv[nb][4 * q + 2] = w0.z * dr.x + w1.z * dr.y + w2.z * dr.z;
+      accv[nb][4 * q + 3] = w0.w * dr.x + w1.w * dr.y + w2.w * dr.z;
+    }
+  mask_pass3<4>(accv, mk);
+  if (valid) store_rows<4>(A.dzv + p * 128 + 4 * h, accv);
+  // ---- view layer, feature columns: df = Wv[:, :256]^T dzv      (8 k-steps over the 128 view units)
+  load_mask3<8>(mk, A.save_h + (7 * A.Ppad + pc) * 256 + 4 * h);
+  zero_acc3<8>(accA);
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    const int nbk = ks >> 1, r0 = 8 * (ks & 1);
+    const BOp b = split8(accv[nbk][r0], accv[nbk][r0 + 1], accv[nbk][r0 + 2], accv[nbk][r0 + 3], accv[nbk][r0 + 4],
+                         accv[nbk][r0 + 5], accv[nbk][r0 + 6], accv[nbk][r0 + 7]);
+    kstep<8>(pipe, accA, ks, false, b);
+  }
+  if (valid) store_rows<8>(A.df + p * 256 + 4 * h, accA);
+  // ---- feature layer + density head: dh7 = Wf^T df + w_alpha * dsigma ; dz7 = dh7 * [h7 > 0]
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 wa = *reinterpret_cast<const f32x4*>(aux_h + AUX_WA + 32 * nb + 8 * q);
+      accB[nb][4 * q + 0] = wa.x * dr.w;
+      accB[nb][4 * q + 1] = wa.y * dr.w;
+      accB[nb][4 * q + 2] = wa.z * dr.w;
+      accB[nb][4 * q + 3] = wa.w * dr.w;
+    }
+  hidden_part_b3<8, 8>(pipe, accB, accA, false);
+  mask_pass3<8>(accB, mk);
+  if (valid) store_rows<8>(A.dz + (7 * A.Ppad + p) * 256 + 4 * h, accB);
+  // ---- trunk: dz_{l-1} = (W_l^T dz_l) * [h_{l-1} > 0],  l = 7..1   (W_5: hidden columns only)
+  const float* hrow = A.save_h + pc * 256 + 4 * h;
+  float* zrow = A.dz + p * 256 + 4 * h;
+  const long long plane = A.Ppad * 256;
+#pragma unroll 1
+  for (int L = 7; L >= 3; L -= 2) {
+    bwd_layer_b3(pipe, accA, accB, mk, hrow + (L - 1) * plane, zrow + (L - 1) * plane, valid, false);
+    bwd_layer_b3(pipe, accB, accA, mk, hrow + (L - 2) * plane, zrow + (L - 2) * plane, valid, false);
+  }
+  bwd_layer_b3(pipe, accA, accB, mk, hrow, zrow, valid, true);
+}
+
+int mlp_bwd_b3_entry(const float* packed_t, const float* aux, const float* draw, const AnerfSaved* sv, float* dz, float* df,
+                     float* dzv, long long P, int nstages, hipStream_t st) {
+  BwdArgs3 b;
+  b.packed_t = packed_t; b.aux = aux; b.draw = draw; b.save_h = sv->h; b.save_g = sv->g;
+  b.dz = dz; b.df = df; b.dzv = dzv; b.P = P; b.Ppad = sv->p_pad; b.nstages = nstages;
+  const long long nblk = (P + TILE - 1) / TILE;
+  if (nblk <= 0) return ANERF_OK;
+  const size_t lds = LDS_BONES_OFF;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_b3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_mlp_bwd_b3, dim3((unsigned)nblk), dim3(256), lds, st, b);
+  return check_launch("k_mlp_bwd_b3");
+}
+
+// ------------------------------------------------------------------------------------------------
 // parameter gather + hi/lo split into the bf16x3 weight image (which = 3).  Table entry per 16-bit element:
 // bit 29 = part (0 hi, 1 lo), bits 24..28 = tensor id, bits 0..23 = element offset; -1 = zero.
 // ------------------------------------------------------------------------------------------------

@@ -69,7 +69,7 @@ def pack_table(cfg, device, which=0):
     k = (cfg.key(), which, str(device))
     if k not in _table_cache:
         sf, af, _, _ = layout(cfg, which)
-        host = np.empty((2 * sf if which == 3 else sf) + af, dtype=np.int32)   # which=3: one entry per bf16 element
+        host = np.empty((2 * sf if which >= 3 else sf) + af, dtype=np.int32)   # bf16x3 images: one entry per bf16 element
         cc = cfg.c()
         _lib.check(_lib.load().anerf_build_pack_table(C.byref(cc), which, host.ctypes.data_as(C.c_void_p)), "anerf_build_pack_table")
         _table_cache[k] = torch.from_numpy(host).to(device)
@@ -102,7 +102,7 @@ def pack_params(cfg, params, which=0, out=None):
     if out is None:
         out = torch.empty(sf + af, dtype=torch.float32, device=dev)
     st, keep = net_params_struct(params)
-    if which == 3:
+    if which >= 3:   # 3: bf16x3 W (forward), 4: bf16x3 W^T (backward-data)
         _lib.check(_lib.load().anerf_pack_params_b3(C.byref(st), _p(table), sf, af, _p(out), _stream()), "anerf_pack_params_b3")
     else:
         _lib.check(_lib.load().anerf_pack_params(C.byref(st), _p(table), sf + af, _p(out), _stream()), "anerf_pack_params")

@@ -55,8 +55,8 @@ class RayCaster(nn.Module):
         # "fp32" (exact fp32 MFMA) or "bf16x3" (hi/lo-split bf16 MFMAs, ~5x faster, same 1e-4 RGB bar) for the
         # no-grad render path.
         self.render_precision = "fp32"
-        # Training: "fp32", or "bf16x3" = split-bf16 forward kernel (saves fp32 activations) + split-bf16 weight-gradient
-        # GEMM; backward-data stays fp32.  Outputs / gradients differ from fp32 by ~1e-6 / ~1e-5 relative.
+        # Training: "fp32", or "bf16x3" = split-bf16 forward (saves fp32 activations), backward-data and weight-gradient
+        # GEMM kernels.  Outputs / gradients differ from fp32 by ~1e-6 / ~1e-5 relative.
         self.train_precision = "fp32"
 
     @torch.no_grad()

@@ -282,6 +282,11 @@ int anerf_mlp_raw_train_b3(const AnerfConfig* cfg, const float* packed, const fl
                            float tau_v, float tau_d, const float* cutoff_v, const float* cutoff_d,
                            int32_t n_rays, int32_t n_samples, float* raw, const AnerfSaved* saved, void* stream);
 
+/* anerf_mlp_backward on split-bf16 MFMAs: packed_t = weight image which=4 (W^T as (hi, lo) bf16 fragment pairs, built
+ * with anerf_build_pack_table(which=4) + anerf_pack_params_b3), dz values split in registers; same outputs. */
+int anerf_mlp_backward_b3(const AnerfConfig* cfg, const float* packed_t, const float* aux, const float* draw,
+                          const AnerfSaved* saved, float* dz, float* df, float* dzv, int64_t n_points, void* stream);
+
 /* anerf_weight_grads with the products on split-bf16 MFMAs (operands split hi + lo in registers, fp32 accumulate):
  * same arguments, workspace and (deterministic) reduction; ~1e-6 relative on the gradients. */
 int anerf_weight_grads_b3(const AnerfConfig* cfg, const AnerfSaved* saved, const float* dz, const float* df,

@@ -62,6 +62,30 @@ def test_layout_and_pack_table_host_side():
         for pp in (0, 1):
             cnt = np.bincount(offs[(ids == i) & (part == pp)], minlength=o * k)
             assert (cnt == 1).all(), (n, pp)
+    # bf16x3 W^T image (which=4, backward-data): every hidden-side weight the backward contracts appears once as hi and once
+    # as lo: views_linears.0[:, :256], feature, pts_linears.1-4, 6, 7, and pts_linears.5[:, 432:]
+    sf4, af4, nst4, _ = ops.layout(cfg, 4)
+    assert (sf4, nst4) == ops.layout(cfg, 1)[0:3:2]
+    host = np.empty(2 * sf4 + af4, dtype=np.int32)
+    assert lib_mod.load().anerf_build_pack_table(ctypes.byref(cc), 4, host.ctypes.data_as(ctypes.c_void_p)) == 0
+    used = host[:2 * sf4][host[:2 * sf4] >= 0]
+    part, ids, offs = (used >> 29) & 1, (used >> 24) & 31, used & 0xFFFFFF
+    for i, n in enumerate(ops.PARAM_ORDER):
+        o, k = shapes[n]
+        sel = ids == i
+        if i in (1, 2, 3, 4, 6, 7, 9):
+            cols = np.arange(k)
+        elif i == 5:
+            cols = np.arange(432, k)
+        elif i == 10:
+            cols = np.arange(256)
+        else:
+            assert not sel.any(), n
+            continue
+        want = (np.arange(o)[:, None] * k + cols[None, :]).ravel()
+        for pp in (0, 1):
+            got = np.sort(offs[sel & (part == pp)])
+            assert np.array_equal(got, np.sort(want)), (n, pp)
     bad = ops.PathConfig(multires=5)
     cc = bad.c()
     L = lib_mod.AnerfLayout()
