@@ -151,6 +151,59 @@ def test_bf16x3_training_forward_keeps_the_gradient_bar(golden, name):
                 np.testing.assert_allclose(p.grad.cpu().numpy(), g[key], rtol=5e-3, atol=2e-3 * np.abs(g[key]).max(), err_msg=key)
 
 
+def test_bf16x3_training_kernels_are_bitwise_repeatable_and_save_clean_planes():
+    """Guards the two hazards found while writing the split-bf16 training forward (store data overwritten by a trailing
+    ds_read; stores inside a stage): repeated launches must agree bit for bit -- outputs AND saved planes -- and the saved
+    X' / U' must equal the fp32 forward's (same values, different column order) after undoing the permutations."""
+    import ctypes as C
+    _lib = importlib.import_module("a-nerf_amd._lib")
+    ap = importlib.import_module("a-nerf_amd.autograd_path")
+    pipeline = importlib.import_module("a-nerf_amd.pipeline")
+    c = build("mixamo_train")
+    cfg = ops.PathConfig(**c["cfg"])
+    P_ = {k: dev(v) for k, v in c["Pc"].items()}
+    codes = P_["framecodes.codes.weight"]
+    cams = dev(c["cams"])
+    rb = pipeline.make_ray_batch(dev(c["rays_o"]), dev(c["rays_d"]))
+    skts, cyl = dev(c["skts"]), dev(c["cyls"])
+    nf, st = ops.ray_bounds(rb, cyl)
+    z, _ = ops.coarse_z(nf, st, rb, 64, dev(c["t_rand"]))
+    cut = torch.full((24,), 0.5, device="cuda")
+    n, s = z.shape
+    T = ap.train_layout(cfg, n * s)
+    pp, lib, cc = T.p_pad, _lib.load(), cfg.c()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    stream = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run(which, fn):
+        packed, aux = ops.pack_params(cfg, P_, which)
+        sv = {k: torch.zeros(sh, device="cuda") for k, sh in [("h", (8, pp, 256)), ("f", (pp, 256)), ("g", (pp, 128)),
+                                                               ("x", (pp, T.x_width)), ("u", (pp, T.u_width))]}
+        stt = _lib.AnerfSaved(p(sv["h"]), p(sv["f"]), p(sv["g"]), p(sv["x"]), p(sv["u"]), pp)
+        raw = torch.empty(n, s, 4, device="cuda")
+        _lib.check(fn(C.byref(cc), p(packed), p(aux), p(rb), 11, p(z), p(skts), 384, p(cams), p(codes), codes.shape[0], 20.0, 20.0,
+                      p(cut), p(cut), n, s, p(raw), C.byref(stt), stream()), "train forward")
+        return raw, sv
+
+    raw0, sv0 = run(3, lib.anerf_mlp_raw_train_b3)
+    for _ in range(4):
+        raw1, sv1 = run(3, lib.anerf_mlp_raw_train_b3)
+        assert torch.equal(raw0, raw1)
+        for k in sv0:
+            assert torch.equal(sv0[k], sv1[k]), k
+    rawf, svf = run(0, lib.anerf_mlp_raw_train)
+    assert float((raw0 - rawf).abs().max()) < 2e-5
+    for nm, b3 in [("x", True), ("u", True)]:
+        pa = ap.perm_tables(cfg, torch.device("cuda"), b3=True)[0 if nm == "x" else 1].long()
+        pb = ap.perm_tables(cfg, torch.device("cuda"))[0 if nm == "x" else 1].long()
+        a, b = torch.zeros_like(sv0[nm]), torch.zeros_like(svf[nm])
+        a[:, pa] = sv0[nm]
+        b[:, pb] = svf[nm]
+        assert float((a - b).abs().max()) < 2e-6, nm          # same inputs to the net: no fragment bits in the planes
+    for l in range(8):
+        assert float((sv0["h"][l] - svf["h"][l]).abs().max()) < 2e-5, l
+
+
 def test_composite_backward_vs_autograd(oracle):
     """k_composite_bwd alone against torch autograd of the oracle's composite (softplus density too)."""
     autograd_path = importlib.import_module("a-nerf_amd.autograd_path")
