@@ -306,9 +306,53 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
                             "achieved": achieved / 1e12, "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
                             "frac": achieved / PEAK_FP32_MFMA, "avg_launch_ms": fb_ms, "flop_per_launch": flop_step_rank,
                             "traffic": None}}
+        if args.cpu_rays > 0 and world == 1 and not mixamo:
+            res["cpu_baseline"] = cpu_train_baseline(synth, ro, rd, skts, cyls, S, Ni, min(args.cpu_rays, 512, N_rand))
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
+
+
+def cpu_train_baseline(synth, ro, rd, skts, cyls, S, Ni, n_cpu):
+    """One training step (forward, MSE loss on both heads, backward; no optimiser) of the torch-CPU oracle on the first
+    n_cpu rays of the same batch: the reference's op sequence with autograd, best of a few thread counts."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    oracle = importlib.import_module("anerf_oracle")
+    t = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32)
+    ocfg = oracle.OracleConfig()
+    P = oracle.params_from_numpy(synth.make_net_params(11))
+    PF = oracle.params_from_numpy(synth.make_net_params(12))
+    for q in list(P.values()) + list(PF.values()):
+        q.requires_grad_(True)
+    rb = oracle.make_ray_batch(t(ro[:n_cpu]), t(rd[:n_cpu]))
+    sk, cy = t(skts[:n_cpu]), t(cyls[:n_cpu])
+    target = t(np.random.default_rng(1).random((n_cpu, 3)))
+    gen = torch.Generator().manual_seed(0)
+
+    def one():
+        out = oracle.render_rays(ocfg, P, PF, rb, sk, cy, S, Ni, t_rand=torch.rand(n_cpu, S, generator=gen),
+                                 u_imp=torch.rand(n_cpu, Ni, generator=gen), noise=torch.randn(n_cpu, S, generator=gen),
+                                 noise_fine=torch.randn(n_cpu, S + Ni, generator=gen))
+        loss, _ = oracle.nerf_loss(out, target, 1.0)
+        loss.backward()
+    ncpu = os.cpu_count() or 1
+    best, best_dt = 1, float("inf")
+    for th in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
+        torch.set_num_threads(th)
+        t0 = time.perf_counter()
+        one()
+        d = time.perf_counter() - t0
+        if d < best_dt:
+            best, best_dt = th, d
+    torch.set_num_threads(best)
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        one()
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": n_cpu / dt, "unit": "rays/s", "cores": best, "kind": "port",
+            "sample": f"first {n_cpu} rays of the same batch, {S}+{Ni} samples, forward + loss + backward (no optimiser), "
+                      f"{dt:.1f} s per step; best of 8/16/32/64 torch threads on this {ncpu}-thread host"}
 
 
 def cpu_baseline(sc, S, Ni, Pc, Pf, gpu_out, lo, n_cpu):
