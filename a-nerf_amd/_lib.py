@@ -100,6 +100,8 @@ SIGNATURES = {
                                          C.c_void_p]),
     "anerf_mlp_backward_b3": (C.c_int, [C.POINTER(AnerfConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(AnerfSaved),
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "anerf_input_grads_b3": (C.c_int, [C.POINTER(AnerfConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
     "anerf_weight_grads_b3": (C.c_int, [C.POINTER(AnerfConfig), C.POINTER(AnerfSaved), C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(AnerfNetGrads), C.c_void_p,
                                         C.c_int64, C.c_void_p]),

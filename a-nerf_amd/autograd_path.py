@@ -106,8 +106,8 @@ class _MlpRawFn(torch.autograd.Function):
             packed_i, _ = meta["packed_i"]()
             dx = torch.empty(pp, T.x_width, dtype=torch.float32, device=dev)
             du = torch.empty(pp, T.u_width, dtype=torch.float32, device=dev)
-            _lib.check(lib.anerf_input_grads(C.byref(cc), _p(packed_i), _p(dz), _p(dzv), pp, P, _p(dx), _p(du), _stream()),
-                       "anerf_input_grads")
+            _lib.check((lib.anerf_input_grads_b3 if b3 else lib.anerf_input_grads)(
+                C.byref(cc), _p(packed_i), _p(dz), _p(dzv), pp, P, _p(dx), _p(du), _stream()), "anerf_input_grads")
             z, rays, skts = meta["z"], meta["rays"], meta["skts"]
             n, s = z.shape
             if need_skts:
@@ -181,7 +181,7 @@ def render_rays_train(caster, kw):
         cam = kw["cam_idx"].contiguous() if net.use_framecode else None
         meta = dict(cfg=cfg, rays=rays, z=zz, skts=skts_c.detach(), tau_v=kw["tau_v"], tau_d=kw["tau_d"],
                     cut_v=kw["cut_v"], cut_d=kw["cut_d"], cam=cam, codes=None if codes is None else codes.detach(),
-                    packed=net.packed(0) if prec == "fp32" else None, packed_t=net.packed(4 if prec == "bf16x3" else 1), packed_i=lambda: net.packed(2),
+                    packed=net.packed(0) if prec == "fp32" else None, packed_t=net.packed(4 if prec == "bf16x3" else 1), packed_i=lambda: net.packed(5 if prec == "bf16x3" else 2),
                     precision=prec, packed_b3=net.packed(3) if prec == "bf16x3" else None)
         return _MlpRawFn.apply(meta, skts_c, codes, *_net_params(net))
 

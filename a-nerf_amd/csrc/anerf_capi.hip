@@ -42,6 +42,8 @@ int mlp_raw_entry(const AnerfConfig* cfg, const float* packed, const float* aux,
                   hipStream_t st);
 int mlp_bwd_entry(const float* packed_t, const float* aux, const float* draw, const AnerfSaved* sv, float* dz, float* df,
                   float* dzv, long long P, int nstages, hipStream_t st);
+int mlp_bwd_in_b3_entry(const float* packed_i, const float* dz, const float* dzv, float* dx, float* du, long long P,
+                        long long Ppad, int nstages, int uw, hipStream_t st);
 int mlp_bwd_b3_entry(const float* packed_t, const float* aux, const float* draw, const AnerfSaved* sv, float* dz, float* df,
                      float* dzv, long long P, int nstages, hipStream_t st);
 int mlp_b3_entry(const AnerfConfig* cfg, const float* packed, const float* aux, const float* rays, int ray_stride,
@@ -194,14 +196,15 @@ int anerf_version(void) { return 1; }
 int anerf_layout(const AnerfConfig* cfg, int which, AnerfLayout* out) {
   if (!out) return set_error(ANERF_E_NULL, "out is NULL");
   if (!config_ok(cfg)) return set_error(ANERF_E_CONFIG, "unsupported AnerfConfig");
-  if (which < 0 || which > 4)
-    return set_error(ANERF_E_CONFIG, "which must be 0 (W), 1 (W^T), 2 (input-gradient image), 3 (bf16x3 W) or 4 (bf16x3 W^T)");
+  if (which < 0 || which > 5)
+    return set_error(ANERF_E_CONFIG, "which must be 0 (W), 1 (W^T), 2 (input-gradient image), 3 (bf16x3 W), 4 (bf16x3 W^T) or "
+                                     "5 (bf16x3 input-gradient image)");
   int stages = 0;
   if (which == 0)
     for (const Seg& s : fwd_segments(cfg)) stages += seg_stages(s);
   else if (which == 1)
     for (const BSeg& s : bwd_segments(cfg)) stages += bseg_stages(s);
-  else if (which == 2)
+  else if (which == 2 || which == 5)
     stages = 2 * (8 + 8) + ((u_width(cfg) + 255) / 256) * 4;
   else if (which == 4)
     for (const BSeg& s : bwd_segments(cfg)) stages += bseg_stages(s);   // same bytes per k as fp32: (hi, lo) bf16 = 4 B
@@ -268,6 +271,31 @@ int anerf_build_pack_table(const AnerfConfig* cfg, int which, int32_t* table) {
             }
       pos += (int64_t)bseg_stages(s) * STAGE_FLOATS;
     }
+  }
+  if (which == 5) {
+    // the which=2 image as bf16x3 fragments: k-steps of 16 contraction rows in the accumulator order of the split-bf16
+    // kernels; same stream-column (perm) semantics of the produced columns, so k_encode_bwd is unchanged
+    std::vector<int32_t> px(dim_x(cfg)), pu(u_width(cfg));
+    anerf_build_perm_tables(cfg, px.data(), pu.data());
+    auto emit3 = [&](int tensor, int K, int colbase, const std::vector<int32_t>& perm, int gi, int nks) {
+      for (int ks = 0; ks < nks; ++ks)
+        for (int nb = 0; nb < 8; ++nb)
+          for (int part = 0; part < 2; ++part)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int e = 0; e < 8; ++e) {
+                const int n = 16 * ks + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const int cs = 256 * gi + 32 * nb + (lane & 31);     // stream column
+                if (cs < (int)perm.size())
+                  table[pos + ((int64_t)((ks * 8 + nb) * 2 + part) * 64 + lane) * 8 + e] =
+                      (part << 29) | (tensor << 24) | (n * K + colbase + perm[cs]);
+              }
+      pos += (int64_t)(nks * 16 / STAGE_FRAGS) * STAGE_FRAGS * 512;
+    };
+    for (int gi = 0; gi < 2; ++gi) {
+      emit3(0, dim_x(cfg), 0, px, gi, 16);
+      emit3(5, dim_x(cfg) + 256, 0, px, gi, 16);
+    }
+    for (int gi = 0; gi < (u_width(cfg) + 255) / 256; ++gi) emit3(10, 256 + u_width(cfg), 256, pu, gi, 8);
   }
   if (which == 2) {
     // [x columns 256*gi .. +255 of W0^T (32 kg) then of W5^T (32 kg)] for gi = 0,1; then [u columns of Wv^T (16 kg)]
@@ -694,6 +722,16 @@ int anerf_input_grads(const AnerfConfig* cfg, const float* packed_i, const float
   if (!packed_i || !dz || !dzv || !dx || !du) return set_error(ANERF_E_NULL, "input_grads: NULL pointer");
   if (p_pad < n_points || p_pad % 128) return set_error(ANERF_E_WORKSPACE, "input_grads: p_pad");
   return mlp_bwd_in_entry(packed_i, dz, dzv, dx, du, n_points, p_pad, L.n_stages, u_width(cfg), (hipStream_t)stream);
+}
+
+int anerf_input_grads_b3(const AnerfConfig* cfg, const float* packed_i, const float* dz, const float* dzv, int64_t p_pad,
+                         int64_t n_points, float* dx, float* du, void* stream) {
+  AnerfLayout L;
+  const int rc = anerf_layout(cfg, 5, &L);
+  if (rc) return rc;
+  if (!packed_i || !dz || !dzv || !dx || !du) return set_error(ANERF_E_NULL, "input_grads_b3: NULL pointer");
+  if (p_pad < n_points || p_pad % 128) return set_error(ANERF_E_WORKSPACE, "input_grads_b3: p_pad");
+  return mlp_bwd_in_b3_entry(packed_i, dz, dzv, dx, du, n_points, p_pad, L.n_stages, u_width(cfg), (hipStream_t)stream);
 }
 
 int anerf_encode_backward(const AnerfConfig* cfg, const float* dx, const float* du, const float* rays,

@@ -511,6 +511,106 @@ int mlp_bwd_b3_entry(const float* packed_t, const float* aux, const float* draw,
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_mlp_bwd_in_b3 -- input gradients (pose refinement / frame codes) on split-bf16 MFMAs (anerf_input_grads_b3):
+//     dX'[p][432] = W0'^T dz0 + W5x'^T dz5          dU'[p][UW] = Wvu'^T dzv        (stream column order, as k_mlp_bwd_in)
+// on the which = 5 image.  The B operands come from memory: lane (m, hh) needs, for k-step ks, the two float4
+// dz[16 ks + 4 hh ..+3] and dz[16 ks + 8 + 4 hh ..+3] of its sample's row -- the dz0 and dz5 rows (2 x 128 registers) are
+// fetched once per tile and kept for both 256-column output groups; dzv reuses dz0's registers afterwards.
+// ------------------------------------------------------------------------------------------------
+struct BwdInArgs3 {
+  const float* packed_i;
+  const float* dz;     // [8][Ppad][256]
+  const float* dzv;    // [Ppad][128]
+  float* dx;           // [Ppad][432]
+  float* du;           // [Ppad][UW]
+  long long P, Ppad;
+  int nstages, uw;
+};
+
+template <int NKS>
+__device__ __forceinline__ void load_dz_row(f32x4 (&d)[32], const float* __restrict__ row_h) {
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    d[2 * ks] = *reinterpret_cast<const f32x4*>(row_h + 16 * ks);
+    d[2 * ks + 1] = *reinterpret_cast<const f32x4*>(row_h + 16 * ks + 8);
+  }
+}
+
+template <int NKS>
+__device__ __forceinline__ void contract_row(Pipe3& pipe, f32x16 (&acc)[8], const f32x4 (&d)[32], int ks0, bool last) {
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    const BOp b = split8(d[2 * ks].x, d[2 * ks].y, d[2 * ks].z, d[2 * ks].w, d[2 * ks + 1].x, d[2 * ks + 1].y,
+                         d[2 * ks + 1].z, d[2 * ks + 1].w);
+    kstep<8>(pipe, acc, ks0 + ks, last && ks == NKS - 1, b);
+  }
+}
+
+__device__ __forceinline__ void store_cols3(float* __restrict__ row, const f32x16 (&acc)[8], int c0, int w, int h) {
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = c0 + 32 * nb + 8 * q + 4 * h;
+      if (c < w) {
+        f32x4 o = {acc[nb][4 * q], acc[nb][4 * q + 1], acc[nb][4 * q + 2], acc[nb][4 * q + 3]};
+        *reinterpret_cast<f32x4*>(row + c) = o;
+      }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_mlp_bwd_in_b3(const BwdInArgs3 A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 31, h = lane >> 5;
+  Pipe3 pipe;
+  pipe.init(A.packed_i, smem, wave, lane, A.nstages);
+  const long long p = (long long)blockIdx.x * TILE + wave * 32 + m;
+  const bool valid = p < A.P;
+  const long long pc = valid ? p : A.P - 1;
+  f32x4 d0[32], d5[32];
+  load_dz_row<16>(d0, A.dz + pc * 256 + 4 * h);
+  load_dz_row<16>(d5, A.dz + (5 * A.Ppad + pc) * 256 + 4 * h);
+  pipe.begin();
+  f32x16 acc[8];
+  const int ngu = (A.uw + 255) / 256;
+  // one continuous weight segment: k-step numbering only matters modulo the k-steps per stage (2)
+  zero_acc3<8>(acc);
+  contract_row<16>(pipe, acc, d0, 0, false);
+  contract_row<16>(pipe, acc, d5, 16, false);
+  if (valid) store_cols3(A.dx + p * 432, acc, 0, 432, h);
+  zero_acc3<8>(acc);
+  contract_row<16>(pipe, acc, d0, 16, false);
+  contract_row<16>(pipe, acc, d5, 16, false);
+  if (valid) store_cols3(A.dx + p * 432, acc, 256, 432, h);
+  load_dz_row<8>(d0, A.dzv + pc * 128 + 4 * h);
+#pragma unroll 1
+  for (int gi = 0; gi < ngu; ++gi) {
+    zero_acc3<8>(acc);
+    contract_row<8>(pipe, acc, d0, 16, gi == ngu - 1);
+    if (valid) store_cols3(A.du + p * A.uw, acc, 256 * gi, A.uw, h);
+  }
+}
+
+int mlp_bwd_in_b3_entry(const float* packed_i, const float* dz, const float* dzv, float* dx, float* du, long long P,
+                        long long Ppad, int nstages, int uw, hipStream_t st) {
+  BwdInArgs3 b;
+  b.packed_i = packed_i; b.dz = dz; b.dzv = dzv; b.dx = dx; b.du = du; b.P = P; b.Ppad = Ppad; b.nstages = nstages; b.uw = uw;
+  const long long nblk = (P + TILE - 1) / TILE;
+  if (nblk <= 0) return ANERF_OK;
+  const size_t lds = LDS_BONES_OFF;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_in_b3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_mlp_bwd_in_b3, dim3((unsigned)nblk), dim3(256), lds, st, b);
+  return check_launch("k_mlp_bwd_in_b3");
+}
+
+// ------------------------------------------------------------------------------------------------
 // parameter gather + hi/lo split into the bf16x3 weight image (which = 3).  Table entry per 16-bit element:
 // bit 29 = part (0 hi, 1 lo), bits 24..28 = tensor id, bits 0..23 = element offset; -1 = zero.
 // ------------------------------------------------------------------------------------------------

@@ -287,6 +287,11 @@ int anerf_mlp_raw_train_b3(const AnerfConfig* cfg, const float* packed, const fl
 int anerf_mlp_backward_b3(const AnerfConfig* cfg, const float* packed_t, const float* aux, const float* draw,
                           const AnerfSaved* saved, float* dz, float* df, float* dzv, int64_t n_points, void* stream);
 
+/* anerf_input_grads on split-bf16 MFMAs: packed_i = weight image which=5 (anerf_build_pack_table(which=5) +
+ * anerf_pack_params_b3); same outputs (stream column order of the fp32 path: anerf_encode_backward is unchanged). */
+int anerf_input_grads_b3(const AnerfConfig* cfg, const float* packed_i, const float* dz, const float* dzv,
+                         int64_t p_pad, int64_t n_points, float* dx, float* du, void* stream);
+
 /* anerf_weight_grads with the products on split-bf16 MFMAs (operands split hi + lo in registers, fp32 accumulate):
  * same arguments, workspace and (deterministic) reduction; ~1e-6 relative on the gradients. */
 int anerf_weight_grads_b3(const AnerfConfig* cfg, const AnerfSaved* saved, const float* dz, const float* df,
