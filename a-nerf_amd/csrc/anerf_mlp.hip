@@ -29,6 +29,9 @@
 #include "anerf_fwd_common.h"
 
 namespace anerf {
+#ifdef ANERF_EXP_TILE_TIMING
+float* g_tile_timing_buf = nullptr;   // set through anerf_debug_set_timing_buf (debug build only)
+#endif
 
 // TRAIN: row-major store of a finished layer: features 32nb+8q+4h .. +3 of `row`
 template <int NB>
@@ -121,6 +124,9 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 31, h = lane >> 5;
 
+#ifdef ANERF_EXP_TILE_TIMING   // debug build only: (start, end) wall-clock stamps of every tile in A.save_h (8 B each)
+  const unsigned long long tk0 = wall_clock64();
+#endif
   Pipe3 pipe;
   pipe.init(A.packed, smem, wave, lane, A.nstages);
 
@@ -349,6 +355,13 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
     f32x4 o = {c0, c1, c2, sigma_raw};
     *reinterpret_cast<f32x4*>(A.raw + p * 4) = o;
   }
+#ifdef ANERF_EXP_TILE_TIMING
+  if (tid == 0 && A.save_u) {
+    unsigned long long* t = reinterpret_cast<unsigned long long*>(A.save_u) + 2 * (long long)blockIdx.x;
+    t[0] = tk0;
+    t[1] = wall_clock64();
+  }
+#endif
 }
 
 template <int LV, int LD, int CODE, bool PRE, bool TRAIN>
@@ -413,6 +426,9 @@ int mlp_raw_entry(const AnerfConfig* cfg, const float* packed, const float* aux,
   a.S = S; a.N = N; a.ray_stride = ray_stride; a.n_codes = n_codes; a.x_width = x_width; a.nstages = nstages;
   a.tau_v = tau_v; a.tau_d = tau_d;
   a.save_h = a.save_f = a.save_g = a.save_x = a.save_u = nullptr;
+#ifdef ANERF_EXP_TILE_TIMING
+  a.save_u = g_tile_timing_buf;
+#endif
   a.Ppad = P;
   if (sv) {
     a.save_h = sv->h; a.save_f = sv->f; a.save_g = sv->g; a.save_x = sv->x; a.save_u = sv->u; a.Ppad = sv->p_pad;
@@ -421,3 +437,7 @@ int mlp_raw_entry(const AnerfConfig* cfg, const float* packed, const float* aux,
 }
 
 }  // namespace anerf
+
+#ifdef ANERF_EXP_TILE_TIMING
+extern "C" void anerf_debug_set_timing_buf(float* p) { anerf::g_tile_timing_buf = p; }
+#endif
