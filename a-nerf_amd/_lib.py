@@ -33,6 +33,19 @@ class AnerfSaved(C.Structure):
                 ("p_pad", C.c_int64)]
 
 
+class AnerfForwardIO(C.Structure):
+    _fields_ = [("packed_c", C.c_void_p), ("aux_c", C.c_void_p), ("packed_f", C.c_void_p), ("aux_f", C.c_void_p),
+                ("rays", C.c_void_p), ("ray_stride", C.c_int32),
+                ("skts", C.c_void_p), ("skt_ray_stride", C.c_int64),
+                ("cyls", C.c_void_p), ("cam_idx", C.c_void_p), ("codes_c", C.c_void_p), ("codes_f", C.c_void_p), ("n_codes", C.c_int32),
+                ("t_rand", C.c_void_p), ("u_imp", C.c_void_p), ("noise", C.c_void_p), ("noise_fine", C.c_void_p),
+                ("cutoff_v", C.c_void_p), ("cutoff_d", C.c_void_p), ("tau_v", C.c_float), ("tau_d", C.c_float),
+                ("n_rays", C.c_int32), ("n_samples", C.c_int32), ("n_importance", C.c_int32), ("lindisp", C.c_int32),
+                ("single_net", C.c_int32), ("precision", C.c_int32),
+                ("rgb_map", C.c_void_p), ("disp_map", C.c_void_p), ("acc_map", C.c_void_p), ("alpha", C.c_void_p),
+                ("rgb0", C.c_void_p), ("disp0", C.c_void_p), ("acc0", C.c_void_p), ("alpha0", C.c_void_p)]
+
+
 class AnerfNetGrads(C.Structure):
     _fields_ = [("w", C.c_void_p * 12), ("b", C.c_void_p * 12)]
 
@@ -105,6 +118,8 @@ SIGNATURES = {
     "anerf_weight_grads_b3": (C.c_int, [C.POINTER(AnerfConfig), C.POINTER(AnerfSaved), C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(AnerfNetGrads), C.c_void_p,
                                         C.c_int64, C.c_void_p]),
+    "anerf_workspace_size": (C.c_int64, [C.POINTER(AnerfConfig), C.c_int32, C.c_int32, C.c_int32]),
+    "anerf_forward": (C.c_int, [C.POINTER(AnerfConfig), C.POINTER(AnerfForwardIO), C.c_void_p, C.c_int64, C.c_void_p]),
     "anerf_loss_blocks": (C.c_int, [C.c_int32]),
     "anerf_loss": (C.c_int, [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_int32, C.c_float] + [C.c_void_p] * 7),
     "anerf_fk_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 5),

@@ -495,4 +495,23 @@ int launch_importance(const float* z, const float* w, int n, int S, int Ni, cons
   return check_launch("k_importance");
 }
 
+// single_net merge (raycasters.py:447-456, merge_samples :796-812): raw_f[n][k] = cat(raw_c, raw_is)[n][sorted_idx[n][k]]
+__global__ void k_gather_raw(const float* __restrict__ raw_c, const float* __restrict__ raw_is, const long long* __restrict__ idx,
+                             long long total, int S, int Ni, float* __restrict__ out) {
+  const long long g = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  const long long n = g / (S + Ni);
+  const long long j = idx[g];
+  const f32x4 v = j < S ? *reinterpret_cast<const f32x4*>(raw_c + (n * S + j) * 4)
+                        : *reinterpret_cast<const f32x4*>(raw_is + (n * Ni + (j - S)) * 4);
+  *reinterpret_cast<f32x4*>(out + g * 4) = v;
+}
+
+int launch_gather_raw(const float* raw_c, const float* raw_is, const long long* idx, int n, int S, int Ni, float* out, hipStream_t st) {
+  const long long total = (long long)n * (S + Ni);
+  if (total == 0) return ANERF_OK;
+  hipLaunchKernelGGL(k_gather_raw, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, raw_c, raw_is, idx, total, S, Ni, out);
+  return check_launch("k_gather_raw");
+}
+
 }  // namespace anerf

@@ -42,6 +42,7 @@ int mlp_raw_entry(const AnerfConfig* cfg, const float* packed, const float* aux,
                   hipStream_t st);
 int mlp_bwd_entry(const float* packed_t, const float* aux, const float* draw, const AnerfSaved* sv, float* dz, float* df,
                   float* dzv, long long P, int nstages, hipStream_t st);
+int launch_gather_raw(const float* raw_c, const float* raw_is, const long long* idx, int n, int S, int Ni, float* out, hipStream_t st);
 int mlp_bwd_in_b3_entry(const float* packed_i, const float* dz, const float* dzv, float* dx, float* du, long long P,
                         long long Ppad, int nstages, int uw, hipStream_t st);
 int mlp_bwd_b3_entry(const float* packed_t, const float* aux, const float* draw, const AnerfSaved* sv, float* dz, float* df,
@@ -787,6 +788,84 @@ int anerf_assemble_frame(const float* rgb_map, const float* acc_map, const float
   if (n_rays == 0) return ANERF_OK;
   return launch_assemble(rgb_map, acc_map, disp_map, (const long long*)valid_idx, n_rays, rgb_img, disp_img, acc_img,
                          (hipStream_t)stream);
+}
+
+// ---- one-call forward ---------------------------------------------------------------------------------------------
+namespace {
+struct FwdWs {
+  int64_t near_far, stats, z, raw, weights, zs, zm, idx, raw_is, raw_f, weights_f, total;
+};
+FwdWs fwd_ws(int64_t n, int64_t S, int64_t Ni) {
+  auto up = [](int64_t b) { return (b + 255) / 256 * 256; };
+  FwdWs w;
+  int64_t o = 0;
+  w.near_far = o; o += up(n * 2 * 4);
+  w.stats = o; o += up(16);
+  w.z = o; o += up(n * S * 4);
+  w.raw = o; o += up(n * S * 16);
+  w.weights = o; o += up(n * S * 4);
+  w.zs = o; o += up(n * Ni * 4);
+  w.zm = o; o += up(n * (S + Ni) * 4);
+  w.idx = o; o += up(n * (S + Ni) * 8);
+  w.raw_is = o; o += up(n * Ni * 16);
+  w.raw_f = o; o += up(n * (S + Ni) * 16);
+  w.weights_f = o; o += up(n * (S + Ni) * 4);
+  w.total = o;
+  return w;
+}
+}  // namespace
+
+int64_t anerf_workspace_size(const AnerfConfig* cfg, int32_t n_rays, int32_t n_samples, int32_t n_importance) {
+  if (!config_ok(cfg) || n_rays < 0 || n_samples < 1 || n_importance < 0) return set_error(ANERF_E_SHAPE, "workspace_size: bad sizes");
+  return fwd_ws(n_rays, n_samples, n_importance).total;
+}
+
+int anerf_forward(const AnerfConfig* cfg, const AnerfForwardIO* io, void* workspace, int64_t ws_bytes, void* stream) {
+  if (!config_ok(cfg)) return set_error(ANERF_E_CONFIG, "unsupported AnerfConfig");
+  if (!io) return set_error(ANERF_E_NULL, "forward: io is NULL");
+  const int n = io->n_rays, S = io->n_samples, Ni = io->n_importance;
+  if (n < 0 || Ni < 0) return set_error(ANERF_E_SHAPE, "forward: negative sizes");
+  if (n == 0) return ANERF_OK;
+  if (io->precision != 0 && io->precision != 1) return set_error(ANERF_E_CONFIG, "forward: precision must be 0 (fp32) or 1 (bf16x3)");
+  const FwdWs w = fwd_ws(n, S, Ni);
+  if (!workspace || ws_bytes < w.total || ((uintptr_t)workspace & 15)) return set_error(ANERF_E_WORKSPACE, "forward: workspace");
+  if (!io->rgb_map || !io->disp_map || !io->acc_map || !io->alpha) return set_error(ANERF_E_NULL, "forward: output maps");
+  if (Ni > 0 && !io->single_net && (!io->packed_f || !io->aux_f)) return set_error(ANERF_E_NULL, "forward: fine network image");
+  char* ws = static_cast<char*>(workspace);
+  auto F = [&](int64_t off) { return reinterpret_cast<float*>(ws + off); };
+  auto mlp = [&](const float* packed, const float* aux, const float* codes, const float* zz, int ns, float* raw) {
+    return io->precision == 1
+               ? anerf_mlp_raw_b3(cfg, packed, aux, io->rays, io->ray_stride, zz, io->skts, io->skt_ray_stride, io->cam_idx, codes,
+                                  io->n_codes, io->tau_v, io->tau_d, io->cutoff_v, io->cutoff_d, n, ns, raw, stream)
+               : anerf_mlp_raw(cfg, packed, aux, io->rays, io->ray_stride, zz, io->skts, io->skt_ray_stride, io->cam_idx, codes,
+                               io->n_codes, io->tau_v, io->tau_d, io->cutoff_v, io->cutoff_d, n, ns, raw, stream);
+  };
+  int rc = anerf_ray_bounds(io->rays, io->ray_stride, io->cyls, n, F(w.near_far), F(w.stats), stream);
+  if (rc) return rc;
+  rc = anerf_coarse_z(F(w.near_far), F(w.stats), io->rays, io->ray_stride, n, S, io->t_rand, io->lindisp, F(w.z), nullptr, stream);
+  if (rc) return rc;
+  rc = mlp(io->packed_c, io->aux_c, io->codes_c, F(w.z), S, F(w.raw));
+  if (rc) return rc;
+  const bool hier = Ni > 0;
+  float* alpha_c = hier ? io->alpha0 : io->alpha;
+  float* scratch_alpha = F(w.weights_f);            // coarse alpha lands here when the caller does not want alpha0
+  rc = anerf_composite(cfg, F(w.raw), F(w.z), io->rays, io->ray_stride, io->noise, n, S,
+                       hier ? (io->rgb0 ? io->rgb0 : io->rgb_map) : io->rgb_map, hier ? (io->disp0 ? io->disp0 : io->disp_map) : io->disp_map,
+                       hier ? (io->acc0 ? io->acc0 : io->acc_map) : io->acc_map, F(w.weights), alpha_c ? alpha_c : scratch_alpha, nullptr, stream);
+  if (rc || !hier) return rc;
+  rc = anerf_importance(F(w.z), F(w.weights), n, S, Ni, io->u_imp, io->single_net, F(w.zs), F(w.zm),
+                        reinterpret_cast<int64_t*>(ws + w.idx), stream);
+  if (rc) return rc;
+  if (io->single_net) {
+    rc = mlp(io->packed_c, io->aux_c, io->codes_c, F(w.zs), Ni, F(w.raw_is));
+    if (rc) return rc;
+    rc = launch_gather_raw(F(w.raw), F(w.raw_is), reinterpret_cast<const long long*>(ws + w.idx), n, S, Ni, F(w.raw_f), (hipStream_t)stream);
+  } else {
+    rc = mlp(io->packed_f, io->aux_f, io->codes_f, F(w.zm), S + Ni, F(w.raw_f));
+  }
+  if (rc) return rc;
+  return anerf_composite(cfg, F(w.raw_f), F(w.zm), io->rays, io->ray_stride, io->noise_fine, n, S + Ni, io->rgb_map, io->disp_map,
+                         io->acc_map, F(w.weights_f), io->alpha, nullptr, stream);
 }
 
 }  // extern "C"

@@ -314,3 +314,47 @@ def fk_backward(bones, rest_pose, pelvis, g_skts=None, g_l2ws=None, g_kp=None, g
     _lib.check(_lib.load().anerf_fk_backward(_p(bones), _p(pelvis), _p(rest), stride, u, _p(g_skts), _p(g_l2ws), _p(g_kp),
                                              _p(g_rots), _p(gb), _p(gp), _stream()), "anerf_fk_backward")
     return gb, gp
+
+
+def forward(cfg, net_c, net_f, rays, skts, cyls, n_samples, n_importance=0, tau_v=20.0, tau_d=20.0, cut_v=None, cut_d=None,
+            cam_idx=None, codes_c=None, codes_f=None, t_rand=None, u_imp=None, noise=None, noise_fine=None, lindisp=False,
+            single_net=False, precision="fp32"):
+    """RayCaster.render_rays for one caster call as ONE C call (anerf_forward): every intermediate lives in a single
+    workspace tensor; returns the reference's output dict.  net_c / net_f: (packed, aux) from pack_params (which=0 for
+    "fp32", which=3 for "bf16x3")."""
+    f = lambda t, nm: _f32c(t, nm)
+    rays, skts, cyls = f(rays, "rays"), f(skts, "skts"), f(cyls, "cyls")
+    n, dev, S, Ni = rays.shape[0], rays.device, int(n_samples), int(n_importance)
+    cut_v = torch.full((cfg.n_joints,), 0.5, device=dev) if cut_v is None else f(cut_v, "cut_v")
+    cut_d = torch.full((cfg.n_joints,), 0.5, device=dev) if cut_d is None else f(cut_d, "cut_d")
+    lib, cc = _lib.load(), cfg.c()
+    nbytes = lib.anerf_workspace_size(C.byref(cc), n, S, Ni)
+    if nbytes < 0:
+        _lib.check(int(nbytes), "anerf_workspace_size")
+    ws = torch.empty(max(int(nbytes), 16) // 4, dtype=torch.float32, device=dev)
+    E = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+    out = {"rgb_map": E(n, 3), "disp_map": E(n), "acc_map": E(n), "alpha": E(n, S + Ni)}
+    if Ni > 0:
+        out.update({"rgb0": E(n, 3), "disp0": E(n), "acc0": E(n), "alpha0": E(n, S)})
+    io = _lib.AnerfForwardIO()
+    io.packed_c, io.aux_c = net_c[0].data_ptr(), net_c[1].data_ptr()
+    if net_f is not None:
+        io.packed_f, io.aux_f = net_f[0].data_ptr(), net_f[1].data_ptr()
+    io.rays, io.ray_stride = rays.data_ptr(), rays.shape[1]
+    io.skts, io.skt_ray_stride = skts.data_ptr(), 0 if skts.shape[0] == 1 else 16 * cfg.n_joints
+    io.cyls = cyls.data_ptr()
+    keep = [rays, skts, cyls, cut_v, cut_d, ws]
+    for name, t in (("cam_idx", cam_idx), ("codes_c", codes_c), ("codes_f", codes_f), ("t_rand", t_rand), ("u_imp", u_imp),
+                    ("noise", noise), ("noise_fine", noise_fine)):
+        if t is not None:
+            t = f(t, name)
+            keep.append(t)
+            setattr(io, name, t.data_ptr())
+    io.n_codes = 0 if codes_c is None else codes_c.shape[0]
+    io.cutoff_v, io.cutoff_d, io.tau_v, io.tau_d = cut_v.data_ptr(), cut_d.data_ptr(), float(tau_v), float(tau_d)
+    io.n_rays, io.n_samples, io.n_importance = n, S, Ni
+    io.lindisp, io.single_net, io.precision = int(bool(lindisp)), int(bool(single_net)), 1 if precision == "bf16x3" else 0
+    for k, v in out.items():
+        setattr(io, k, v.data_ptr())
+    _lib.check(lib.anerf_forward(C.byref(cc), C.byref(io), _p(ws), int(nbytes), _stream()), "anerf_forward")
+    return out

@@ -4,6 +4,9 @@ HIP kernel launches on one stream, no host synchronisation in between:
   ray_bounds -> coarse_z -> [fused encode+MLP] -> composite
             (-> importance -> [fused encode+MLP on the merged depths, fine net] -> composite)
 
+Without `extras` the whole sequence is ONE C call (anerf_forward) on one workspace tensor; with `extras` the staged entry
+points are called one by one so that the intermediates can be returned (tests).
+
 The fine pass re-encodes the merged coarse+fine depths inside the fused kernel instead of
 gather-merging 1080-wide encodings (raycasters.py:679-709): same values, no [N,S,1080] tensor.
 """
@@ -19,6 +22,9 @@ def render_rays_forward(cfg, net_c, net_f, ray_batch, skts, cyls, n_samples, n_i
     """net_c / net_f: (packed, aux) images from ops.pack_params (which=0 for precision "fp32", which=3 for
     "bf16x3").  Returns the reference's output dict
     (RayCaster._collect_outputs, raycasters.py:711-724); extras adds the intermediates."""
+    if not extras:   # production path: one C call, one workspace (anerf_forward); bit-identical to the staged calls below
+        return ops.forward(cfg, net_c, net_f, ray_batch, skts, cyls, n_samples, n_importance, tau_v, tau_d, cut_v, cut_d, cam_idx,
+                           codes_c, codes_f, t_rand, u_imp, noise, noise_fine, lindisp, single_net, precision)
     dev = ray_batch.device
     if cut_v is None:
         cut_v = torch.full((cfg.n_joints,), 0.5, device=dev)

@@ -299,6 +299,29 @@ int anerf_weight_grads_b3(const AnerfConfig* cfg, const AnerfSaved* saved, const
                           const int32_t* perm_u, const AnerfNetGrads* grads, float* workspace, int64_t ws_floats,
                           void* stream);
 
+/* ---- one-call forward: RayCaster.render_rays (core/raycasters.py:361-474) for one caster call ------------------------
+ * The staged entry points above, enqueued back to back on `stream` with every intermediate (bounds, depths, raw logits,
+ * weights, importance samples, merged depths / sort indices) in ONE caller-provided workspace of
+ * anerf_workspace_size(...) bytes (16-byte aligned; nothing is allocated, nothing synchronises).
+ *   packed_c/aux_c, packed_f/aux_f: weight images of the coarse / fine network, which = 0 (precision 0, exact fp32 MFMA) or
+ *     which = 3 (precision 1, split-bf16); packed_f/aux_f may be NULL when n_importance == 0; single_net != 0 evaluates the
+ *     importance samples with the coarse image only (raycasters.py:411-456) and packed_f is ignored.
+ *   t_rand [N,S], u_imp [N,Ni], noise [N,S], noise_fine [N,S+Ni]: optional randomness, NULL = the deterministic variants.
+ *   Outputs as RayCaster._collect_outputs (:711-724): rgb_map [N,3], disp_map/acc_map [N], alpha [N,S+Ni] of the last
+ *   pass; rgb0/disp0/acc0/alpha0 of the coarse pass when n_importance > 0 (each may be NULL). */
+typedef struct AnerfForwardIO {
+  const float *packed_c, *aux_c, *packed_f, *aux_f;
+  const float *rays; int32_t ray_stride;
+  const float *skts; int64_t skt_ray_stride;
+  const float *cyls, *cam_idx, *codes_c, *codes_f; int32_t n_codes;
+  const float *t_rand, *u_imp, *noise, *noise_fine;
+  const float *cutoff_v, *cutoff_d; float tau_v, tau_d;
+  int32_t n_rays, n_samples, n_importance, lindisp, single_net, precision;
+  float *rgb_map, *disp_map, *acc_map, *alpha, *rgb0, *disp0, *acc0, *alpha0;
+} AnerfForwardIO;
+int64_t anerf_workspace_size(const AnerfConfig* cfg, int32_t n_rays, int32_t n_samples, int32_t n_importance);
+int anerf_forward(const AnerfConfig* cfg, const AnerfForwardIO* io, void* workspace, int64_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

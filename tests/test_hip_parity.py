@@ -189,6 +189,31 @@ def test_full_size_properties(synth):
     assert float(full["alpha"].min()) >= 0.0 and float(full["alpha"].max()) <= 1.0
 
 
+@pytest.mark.parametrize("name,precision", [("eval_s32", "fp32"), ("eval_hier", "fp32"), ("single_net", "fp32"),
+                                            ("mixamo_train", "fp32"), ("eval_hier", "bf16x3")])
+def test_one_call_forward_equals_the_staged_pipeline(name, precision):
+    """anerf_forward (one C call, one workspace) must be bit-identical to the staged entry points it composes."""
+    c = build(name)
+    cfg = ops.PathConfig(**c["cfg"])
+    staged = run_hip(c, precision=precision)
+    Pc, Pf = cuda_params(c["Pc"]), cuda_params(c["Pf"])
+    which = 3 if precision == "bf16x3" else 0
+    net_c = ops.pack_params(cfg, Pc, which)
+    net_f = None if c.get("single_net") else ops.pack_params(cfg, Pf, which)
+    rb = pipeline.make_ray_batch(dev(c["rays_o"]), dev(c["rays_d"]))
+    kw = {k: dev(c[k]) for k in ["t_rand", "u_imp", "noise", "noise_fine"] if k in c}
+    codes_c = codes_f = cams = None
+    if cfg.framecode_ch:
+        codes_c, codes_f, cams = Pc["framecodes.codes.weight"], Pf["framecodes.codes.weight"], dev(c["cams"])
+    one = ops.forward(cfg, net_c, net_f, rb, dev(c["skts"]), dev(c["cyls"]), c["S"], c["Ni"], cam_idx=cams, codes_c=codes_c,
+                      codes_f=codes_f, single_net=bool(c.get("single_net")), precision=precision, **kw)
+    assert set(one) == {k for k in staged if k != "_extras"}
+    for k, v in one.items():
+        assert torch.equal(v, staged[k]), k
+    with pytest.raises(importlib.import_module("a-nerf_amd._lib").AnerfError):
+        ops.forward(cfg, net_c, None, rb, dev(c["skts"]), dev(c["cyls"]), 16, 8)          # fine image missing
+
+
 def test_error_codes():
     lib_mod = importlib.import_module("a-nerf_amd._lib")
     cfg = ops.PathConfig(multires_views=2)
