@@ -61,12 +61,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # ANERF_BENCH_BACKEND=gloo: smoke-test the multi-rank control flow with all ranks on ONE GPU (RCCL refuses duplicate
+    # devices); the driver's multi-GPU runs use the default, nccl (= RCCL), one rank per GPU
+    backend = os.environ.get("ANERF_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     synth = importlib.import_module("a-nerf_amd.synth")
     ops = importlib.import_module("a-nerf_amd.ops")
@@ -121,7 +128,10 @@ def main():
         if world > 1:
             mine = torch.zeros(per, 5, device=device)
             mine[:hi - lo, 0:3] = co["rgb_map"]; mine[:hi - lo, 3] = co["acc_map"]; mine[:hi - lo, 4] = co["disp_map"]
-            dist.all_gather_into_tensor(gather_buf, mine)
+            if backend == "nccl":
+                dist.all_gather_into_tensor(gather_buf, mine)
+            else:
+                dist.all_gather(list(gather_buf.view(world, per, 5).unbind(0)), mine)
         return co
 
     def barrier():
