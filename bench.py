@@ -263,8 +263,8 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
         popt = pose_opt.PoseOptLayer(np.stack([q["kp"] for q in poses]), np.stack([q["bones"] for q in poses]),
                                      (synth.SMPL_REST_POSE * synth.SURREAL_SCALE)[None]).to(device)
         popt_opt = torch.optim.Adam(popt.parameters(), lr=5e-4)
-        pose_of_ray = torch.tensor(np.asarray(pidx)[sl], device=device)
-        cams = pose_of_ray.to(torch.float32)
+        pose_idx_host = np.asarray(pidx)[sl]
+        cams = torch.tensor(pose_idx_host, device=device).to(torch.float32)
     pk = {"density_scale": 1.0, "density_fn": torch.nn.functional.relu}
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
@@ -272,9 +272,9 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
         if i is not None:
             ev[i][0].record()
         b = batch
-        if mixamo:   # FK once per distinct pose, then the per-ray gather the reference's collate does (dataset.py:813-820)
-            kp_u, bones_u, skts_u, _, _ = popt(np.arange(n_poses))
-            b = dict(batch, kp_batch=kp_u[pose_of_ray], skts=skts_u[pose_of_ray], bones=bones_u[pose_of_ray])
+        if mixamo:   # per-ray pose indices, as the reference calls its layer (kp_idx of the batch): FK once per distinct pose
+            kp_r, bones_r, skts_r, _, _ = popt(pose_idx_host)
+            b = dict(batch, kp_batch=kp_r, skts=skts_r, bones=bones_r)
         out = render_mod.render(512, 512, 600.0, chunk=4096, rays=rays, use_viewdirs=True, ray_caster=caster, cams=cams,
                                 subject_idxs=None, N_samples=S, N_importance=Ni, perturb=1.0, raw_noise_std=1.0,
                                 preproc_kwargs=pk, **b)

@@ -90,6 +90,19 @@ def test_hip_fk_matches_reference_golden_and_oracle(oracle, golden):
     loss.backward()
     np.testing.assert_allclose(layer.bones.grad.cpu().numpy(), g["b_gbones"], atol=5e-5, rtol=2e-5)
     np.testing.assert_allclose(layer.pelvis.grad.cpu().numpy(), g["b_gpelvis"], atol=5e-5, rtol=2e-5)
+    # (b2) structured index patterns take the reshaped-sum backward: same values and gradients as plain indexing
+    for pattern in (np.repeat(np.arange(6), 4), np.tile(np.arange(6), 4), np.array([0, 2, 1, 3, 5, 4] * 4)):
+        lay = po.PoseOptLayer(np.repeat(pelvis[:, None], 24, 1), bones, rest[None]).cuda()
+        kp_r, _, skt_r, _, _ = lay(pattern)
+        wk, wsk = torch.randn(kp_r.shape, device="cuda"), torch.randn(skt_r.shape, device="cuda")
+        ((kp_r * wk).sum() + (skt_r * wsk).sum()).backward()
+        ref = po.PoseOptLayer(np.repeat(pelvis[:, None], 24, 1), bones, rest[None]).cuda()
+        kp_u, _, skt_u, _, _ = ref(np.arange(6))
+        idx = torch.tensor(pattern, device="cuda")
+        ((kp_u[idx] * wk).sum() + (skt_u[idx] * wsk).sum()).backward()
+        assert torch.equal(kp_r, kp_u[idx]) and torch.equal(skt_r, skt_u[idx])
+        np.testing.assert_allclose(lay.bones.grad.cpu().numpy(), ref.bones.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(lay.pelvis.grad.cpu().numpy(), ref.pelvis.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
     # (c) larger random batch incl. per-pose rest poses and the rots gradient, vs the oracle's autograd
     rng = np.random.RandomState(5)
     U = 300
