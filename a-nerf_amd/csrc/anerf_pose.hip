@@ -12,6 +12,10 @@
 
 namespace anerf {
 
+// One thread per (sample, lane half h, joint quad G): it owns joints j = 8G + 4h + t (t = 0..3), i.e. k-group column t of
+// k-groups g == G (mod 3) of the x part and direction components 12G..12G+11 of the lane half -- a third of what one
+// lane of the forward kernel encodes.  (One thread per sample-half held 12 joints' worth of state: 256 VGPRs + 210
+// AGPRs of spill space, one wave per SIMD, every strided gradient load exposed; the quad version needs < 128 registers.)
 template <int LD>
 __global__ __launch_bounds__(256) void k_encode_bwd(const float* __restrict__ dx, const float* __restrict__ du, int uw,
                                                     const float* __restrict__ rays, int ray_stride,
@@ -21,8 +25,9 @@ __global__ __launch_bounds__(256) void k_encode_bwd(const float* __restrict__ dx
                                                     long long P, int S, float* __restrict__ dY, float* __restrict__ dQ) {
   constexpr int LV = 7;
   const long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  const long long p = gid >> 1;
-  const int h = (int)(gid & 1);
+  const long long p = gid / 6;
+  const int sub = (int)(gid - p * 6);
+  const int h = sub & 1, G = sub >> 1;
   if (p >= P) return;
   const long long ray = p / S;
   const float* rp = rays + ray * ray_stride;
@@ -30,10 +35,10 @@ __global__ __launch_bounds__(256) void k_encode_bwd(const float* __restrict__ dx
   const float d0 = rp[3], d1 = rp[4], d2 = rp[5];
   const float x0 = fmaf(d0, zz, rp[0]), x1 = fmaf(d1, zz, rp[1]), x2 = fmaf(d2, zz, rp[2]);
   const float* sk = skts + ray * skt_stride;
-  float v[12], wv[12], wvp[12], wd[12], wdp[12], rh[36], e[36], qn[12], dv[12], dr[36], de[36];
+  float v[4], wv[4], wvp[4], wd[4], wdp[4], rh[12], e[12], qn[4], dv[4], dr[12], de[12];
 #pragma unroll
-  for (int a = 0; a < 12; ++a) {
-    const int j = 8 * (a >> 2) + 4 * h + (a & 3);
+  for (int t = 0; t < 4; ++t) {
+    const int j = 8 * G + 4 * h + t;
     const f32x4 r0 = *reinterpret_cast<const f32x4*>(sk + j * 16), r1 = *reinterpret_cast<const f32x4*>(sk + j * 16 + 4),
                 r2 = *reinterpret_cast<const f32x4*>(sk + j * 16 + 8);
     const float y0 = r0.x * x0 + r0.y * x1 + r0.z * x2 + r0.w;
@@ -41,58 +46,55 @@ __global__ __launch_bounds__(256) void k_encode_bwd(const float* __restrict__ dx
     const float y2 = r2.x * x0 + r2.y * x1 + r2.z * x2 + r2.w;
     const float n = sqrtf(y0 * y0 + y1 * y1 + y2 * y2);
     const float inv = 1.f / fmaxf(n, 1e-12f);
-    v[a] = n;
-    rh[3 * a] = y0 * inv; rh[3 * a + 1] = y1 * inv; rh[3 * a + 2] = y2 * inv;
+    v[t] = n;
+    rh[3 * t] = y0 * inv; rh[3 * t + 1] = y1 * inv; rh[3 * t + 2] = y2 * inv;
     const float q0 = r0.x * d0 + r0.y * d1 + r0.z * d2, q1 = r1.x * d0 + r1.y * d1 + r1.z * d2,
                 q2 = r2.x * d0 + r2.y * d1 + r2.z * d2;
     const float qq = sqrtf(q0 * q0 + q1 * q1 + q2 * q2);
     const float qi = 1.f / fmaxf(qq, 1e-12f);
-    qn[a] = qq;
-    e[3 * a] = q0 * qi; e[3 * a + 1] = q1 * qi; e[3 * a + 2] = q2 * qi;
-    wv[a] = cutoff_gate(tau_v, n, cut_v[j]);
-    wvp[a] = -tau_v * wv[a] * (1.f - wv[a]);
-    wd[a] = cutoff_gate(tau_d, n, cut_d[j]);
-    wdp[a] = -tau_d * wd[a] * (1.f - wd[a]);
-    dv[a] = 0.f;
+    qn[t] = qq;
+    e[3 * t] = q0 * qi; e[3 * t + 1] = q1 * qi; e[3 * t + 2] = q2 * qi;
+    wv[t] = cutoff_gate(tau_v, n, cut_v[j]);
+    wvp[t] = -tau_v * wv[t] * (1.f - wv[t]);
+    wd[t] = cutoff_gate(tau_d, n, cut_d[j]);
+    wdp[t] = -tau_d * wd[t] * (1.f - wd[t]);
+    dv[t] = 0.f;
   }
 #pragma unroll
-  for (int i = 0; i < 36; ++i) { dr[i] = 0.f; de[i] = 0.f; }
-  // ---- x part: 3 raw + 42 sin/cos + 9 bone-direction k-groups
+  for (int i = 0; i < 12; ++i) de[i] = 0.f;
+  // ---- x part (stream order: k-group kg holds joints 8 (kg % 3) + 4 h + t): raw, then sin / cos per band, then directions
   const float* gx = dx + p * 432 + 4 * h;
+  {
+    const f32x4 Gr = *reinterpret_cast<const f32x4*>(gx + 8 * G);
+    const float Gt[4] = {Gr.x, Gr.y, Gr.z, Gr.w};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dv[t] += Gt[t] * (wv[t] + v[t] * wvp[t]);
+  }
+#pragma unroll
+  for (int f = 0; f < LV; ++f) {
+    const f32x4 Gs = *reinterpret_cast<const f32x4*>(gx + 8 * (3 + 6 * f + G));
+    const f32x4 Gc = *reinterpret_cast<const f32x4*>(gx + 8 * (6 + 6 * f + G));
+    const float gs[4] = {Gs.x, Gs.y, Gs.z, Gs.w}, gc[4] = {Gc.x, Gc.y, Gc.z, Gc.w};
+    const float F = (float)(1 << f);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float s, c;
+      sincos_f32(v[t] * F, s, c);
+      dv[t] += gs[t] * (F * c * wv[t] + s * wvp[t]) + gc[t] * (-F * s * wv[t] + c * wvp[t]);
+    }
+  }
+  // bone-direction components 12 G .. 12 G + 11 of this half = k-groups 45 + 3 G .. + 2
 #pragma unroll
   for (int g = 0; g < 3; ++g) {
-    const f32x4 G = *reinterpret_cast<const f32x4*>(gx + 8 * g);
-    const float Gt[4] = {G.x, G.y, G.z, G.w};
-#pragma unroll
-    for (int t = 0; t < 4; ++t) dv[4 * g + t] += Gt[t] * (wv[4 * g + t] + v[4 * g + t] * wvp[4 * g + t]);
+    const f32x4 Gd = *reinterpret_cast<const f32x4*>(gx + 8 * (45 + 3 * G + g));
+    dr[4 * g] = Gd.x; dr[4 * g + 1] = Gd.y; dr[4 * g + 2] = Gd.z; dr[4 * g + 3] = Gd.w;
   }
-#pragma unroll
-  for (int f = 0; f < LV; ++f)
-#pragma unroll
-    for (int g = 0; g < 3; ++g) {
-      const f32x4 Gs = *reinterpret_cast<const f32x4*>(gx + 8 * (3 + 6 * f + g));
-      const f32x4 Gc = *reinterpret_cast<const f32x4*>(gx + 8 * (6 + 6 * f + g));
-      const float gs[4] = {Gs.x, Gs.y, Gs.z, Gs.w}, gc[4] = {Gc.x, Gc.y, Gc.z, Gc.w};
-      const float F = (float)(1 << f);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int a = 4 * g + t;
-        float s, c;
-        sincos_f32(v[a] * F, s, c);
-        dv[a] += gs[t] * (F * c * wv[a] + s * wvp[a]) + gc[t] * (-F * s * wv[a] + c * wvp[a]);
-      }
-    }
-#pragma unroll
-  for (int g = 0; g < 9; ++g) {
-    const f32x4 G = *reinterpret_cast<const f32x4*>(gx + 8 * (45 + g));
-    dr[4 * g] = G.x; dr[4 * g + 1] = G.y; dr[4 * g + 2] = G.z; dr[4 * g + 3] = G.w;
-  }
-  // ---- view part: raw + LD sin/cos bands of the 36 owned direction components, gated by wd(v)
+  // ---- view part: raw + LD sin/cos bands of the 12 owned direction components, gated by wd(v)
   const float* gu = du + p * uw + 4 * h;
 #pragma unroll
-  for (int g = 0; g < 9; ++g) {
-    const f32x4 G = *reinterpret_cast<const f32x4*>(gu + 8 * g);
-    const float Gt[4] = {G.x, G.y, G.z, G.w};
+  for (int g = 0; g < 3; ++g) {
+    const f32x4 Gr = *reinterpret_cast<const f32x4*>(gu + 8 * (3 * G + g));
+    const float Gt[4] = {Gr.x, Gr.y, Gr.z, Gr.w};
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int i = 4 * g + t, a = i / 3;
@@ -103,9 +105,9 @@ __global__ __launch_bounds__(256) void k_encode_bwd(const float* __restrict__ dx
 #pragma unroll
   for (int f = 0; f < LD; ++f)
 #pragma unroll
-    for (int g = 0; g < 9; ++g) {
-      const f32x4 Gs = *reinterpret_cast<const f32x4*>(gu + 8 * (9 * (1 + 2 * f) + g));
-      const f32x4 Gc = *reinterpret_cast<const f32x4*>(gu + 8 * (9 * (2 + 2 * f) + g));
+    for (int g = 0; g < 3; ++g) {
+      const f32x4 Gs = *reinterpret_cast<const f32x4*>(gu + 8 * (9 * (1 + 2 * f) + 3 * G + g));
+      const f32x4 Gc = *reinterpret_cast<const f32x4*>(gu + 8 * (9 * (2 + 2 * f) + 3 * G + g));
       const float gs[4] = {Gs.x, Gs.y, Gs.z, Gs.w}, gc[4] = {Gc.x, Gc.y, Gc.z, Gc.w};
       const float F = (float)(1 << f);
 #pragma unroll
@@ -119,16 +121,16 @@ __global__ __launch_bounds__(256) void k_encode_bwd(const float* __restrict__ dx
     }
   // ---- through the norms: y -> (v, r),  q -> e
 #pragma unroll
-  for (int a = 0; a < 12; ++a) {
-    const int j = 8 * (a >> 2) + 4 * h + (a & 3);
-    const float dot = dr[3 * a] * rh[3 * a] + dr[3 * a + 1] * rh[3 * a + 1] + dr[3 * a + 2] * rh[3 * a + 2];
-    const float iv = 1.f / fmaxf(v[a], 1e-12f);
-    const float dote = de[3 * a] * e[3 * a] + de[3 * a + 1] * e[3 * a + 1] + de[3 * a + 2] * e[3 * a + 2];
-    const float iq = 1.f / fmaxf(qn[a], 1e-12f);
+  for (int t = 0; t < 4; ++t) {
+    const int j = 8 * G + 4 * h + t;
+    const float dot = dr[3 * t] * rh[3 * t] + dr[3 * t + 1] * rh[3 * t + 1] + dr[3 * t + 2] * rh[3 * t + 2];
+    const float iv = 1.f / fmaxf(v[t], 1e-12f);
+    const float dote = de[3 * t] * e[3 * t] + de[3 * t + 1] * e[3 * t + 1] + de[3 * t + 2] * e[3 * t + 2];
+    const float iq = 1.f / fmaxf(qn[t], 1e-12f);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      dY[p * 72 + 3 * j + c] = dv[a] * rh[3 * a + c] + (dr[3 * a + c] - dot * rh[3 * a + c]) * iv;
-      dQ[p * 72 + 3 * j + c] = (de[3 * a + c] - dote * e[3 * a + c]) * iq;
+      dY[p * 72 + 3 * j + c] = dv[t] * rh[3 * t + c] + (dr[3 * t + c] - dot * rh[3 * t + c]) * iv;
+      dQ[p * 72 + 3 * j + c] = (de[3 * t + c] - dote * e[3 * t + c]) * iq;
     }
   }
 }
@@ -177,7 +179,7 @@ int launch_encode_bwd(int ld, const float* dx, const float* du, int uw, const fl
                       const float* skts, long long skt_stride, float tau_v, float tau_d, const float* cut_v,
                       const float* cut_d, int n, int S, float* dY, float* dQ, float* dskts, hipStream_t st) {
   const long long P = (long long)n * S;
-  const unsigned blocks = (unsigned)((2 * P + 255) / 256);
+  const unsigned blocks = (unsigned)((6 * P + 255) / 256);
   if (ld == 4)
     hipLaunchKernelGGL(k_encode_bwd<4>, dim3(blocks), dim3(256), 0, st, dx, du, uw, rays, ray_stride, z, skts, skt_stride,
                        tau_v, tau_d, cut_v, cut_d, P, S, dY, dQ);
