@@ -204,6 +204,64 @@ def test_bf16x3_training_kernels_are_bitwise_repeatable_and_save_clean_planes():
         assert float((sv0["h"][l] - svf["h"][l]).abs().max()) < 2e-5, l
 
 
+def test_backward_kernels_are_bitwise_repeatable_and_precisions_agree():
+    """k_mlp_bwd / k_mlp_bwd_b3, k_mlp_bwd_in / _b3 and both weight-gradient GEMMs on random (fixed-seed) activations:
+    every kernel must reproduce its own output bit for bit (no store / register-reuse races), and the split-bf16 twin
+    must agree with the fp32 kernel to ~1e-5 relative."""
+    import ctypes as C
+    _lib = importlib.import_module("a-nerf_amd._lib")
+    ap = importlib.import_module("a-nerf_amd.autograd_path")
+    cfg = ops.PathConfig(framecode_ch=16)
+    lib, cc = _lib.load(), cfg.c()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    r = lambda *sh: torch.randn(*sh, device="cuda", generator=g)
+    P = 5000                                   # ragged: 39 full tiles + 8 samples
+    T = ap.train_layout(cfg, P)
+    pp = T.p_pad
+    shapes = synth_shapes = importlib.import_module("a-nerf_amd.synth").net_shapes(7, 4, 16)
+    params = {}
+    for name, (o, k) in shapes.items():
+        params[name + ".weight"] = r(o, k) * (1.0 / k ** 0.5)
+        params[name + ".bias"] = r(o) * 0.1
+    params["framecodes.codes.weight"] = r(4, 16)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    zpad = lambda t: torch.cat([t, torch.zeros((pp - P,) + t.shape[1:], device="cuda")], 0)
+    sv = {"h": torch.stack([zpad(torch.relu(r(P, 256))) for _ in range(8)]), "f": zpad(r(P, 256)), "g": zpad(torch.relu(r(P, 128))),
+          "x": zpad(r(P, T.x_width)), "u": zpad(r(P, T.u_width))}
+    stt = _lib.AnerfSaved(p(sv["h"]), p(sv["f"]), p(sv["g"]), p(sv["x"]), p(sv["u"]), pp)
+    draw = zpad(r(P, 4))
+    outs = {}
+    for tag, which_t, which_i, f_bwd, f_in, f_wg in [("fp32", 1, 2, lib.anerf_mlp_backward, lib.anerf_input_grads, lib.anerf_weight_grads),
+                                                     ("b3", 4, 5, lib.anerf_mlp_backward_b3, lib.anerf_input_grads_b3, lib.anerf_weight_grads_b3)]:
+        pt, _ = ops.pack_params(cfg, params, which_t)
+        pi, _ = ops.pack_params(cfg, params, which_i)
+        _, aux = ops.pack_params(cfg, params, 0)
+        runs = []
+        for _ in range(3):
+            dz, df, dzv = torch.zeros(8, pp, 256, device="cuda"), torch.zeros(pp, 256, device="cuda"), torch.zeros(pp, 128, device="cuda")
+            _lib.check(f_bwd(C.byref(cc), p(pt), p(aux), p(draw), C.byref(stt), p(dz), p(df), p(dzv), P, st()), "bwd")
+            dx, du = torch.zeros(pp, T.x_width, device="cuda"), torch.zeros(pp, T.u_width, device="cuda")
+            _lib.check(f_in(C.byref(cc), p(pi), p(dz), p(dzv), pp, P, p(dx), p(du), st()), "in")
+            grads = [torch.zeros(sh, device="cuda") for n_ in ops.PARAM_ORDER for sh in (params[n_ + ".weight"].shape, params[n_ + ".bias"].shape)]
+            gs = _lib.AnerfNetGrads()
+            for i in range(12):
+                gs.w[i], gs.b[i] = grads[2 * i].data_ptr(), grads[2 * i + 1].data_ptr()
+            ws = torch.empty(T.gemm_ws_floats, device="cuda")
+            px, pu = ap.perm_tables(cfg, torch.device("cuda"))
+            _lib.check(f_wg(C.byref(cc), C.byref(stt), p(dz), p(df), p(dzv), p(draw), P, p(px), p(pu), C.byref(gs), p(ws),
+                            T.gemm_ws_floats, st()), "wg")
+            runs.append([dz, df, dzv, dx, du] + grads)
+        for a, b in zip(runs[0], runs[1]):
+            assert torch.equal(a, b)
+        for a, b in zip(runs[0], runs[2]):
+            assert torch.equal(a, b)
+        outs[tag] = runs[0]
+    for k, (a, b) in enumerate(zip(outs["fp32"], outs["b3"])):
+        scale = float(a.abs().max())
+        assert float((a - b).abs().max()) <= 3e-5 * scale + 1e-12, (k, float((a - b).abs().max()), scale)
+
+
 def test_composite_backward_vs_autograd(oracle):
     """k_composite_bwd alone against torch autograd of the oracle's composite (softplus density too)."""
     autograd_path = importlib.import_module("a-nerf_amd.autograd_path")
