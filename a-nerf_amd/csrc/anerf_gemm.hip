@@ -237,8 +237,10 @@ __device__ __forceinline__ void gemm_body(const GemmPlan& G, const GemmBlock& B,
 // (hi, lo) bf16x8 and issues 3 MFMAs per (a, c) block pair (48 per stage = 1536 matrix cycles).  To keep the matrix
 // pipe fed the stages are software-pipelined through a 3-slot ring: while stage s is multiplied, the raw operands of
 // stage s+1 (already landed -- same invariant as the forward kernel's pipe) are read and split, interleaved with the
-// MFMAs by sched_group_barriers (bf16 MFMAs, unlike fp32 ones, do run beside VALU).  Same accumulator layout, same
-// epilogue, same deterministic reduction.
+// MFMAs by sched_group_barriers (bf16 MFMAs, unlike fp32 ones, do run beside VALU) -- a request the compiler does not
+// honour today: the ISA is 16 reads, 48 MFMAs, then ~300 split VALU in a row (~5100 cycles per stage, 30 % matrix duty);
+// the 3-slot pipeline therefore only matches the plain 2-slot version.  Same accumulator layout, same epilogue, same
+// deterministic reduction.
 struct SplitOps {
   BOp A[4], B[4];
 };
