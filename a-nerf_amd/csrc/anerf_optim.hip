@@ -1,7 +1,7 @@
 // anerf_optim.hip -- the scalar tail of a training step as three launches instead of ~120 tiny ones:
-//   k_loss (+ k_loss_final): background composite + MSE/L1 against the target colours for the fine and coarse
+//   k_loss (+ k_loss_final): background composite + MSE/L1/Huber against the target colours for the fine and coarse
 //       heads, the PSNR numerator, AND the gradient w.r.t. the rendered maps in the same pass
-//       (core/trainer.py:353-380 _compute_nerf_loss, :8-60 img2mse / img2l1 / mse2psnr);
+//       (core/trainer.py:353-380 _compute_nerf_loss, :8-60 img2mse / img2l1 / img2huber / mse2psnr);
 //   k_adam: torch.optim.Adam's update (no amsgrad / weight decay, as trainer.py:173-183 builds it) over ONE flat
 //       fp32 parameter buffer, fused with zero_grad and with the sum of squared gradients that
 //       get_gradnorm (trainer.py:192-203) otherwise collects with 48 .item() syncs;
@@ -30,11 +30,21 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 __global__ __launch_bounds__(RB) void k_loss(const float* __restrict__ rgb, const float* __restrict__ acc,
                                              const float* __restrict__ rgb0, const float* __restrict__ acc0,
                                              const float* __restrict__ target, const float* __restrict__ bgs, int bg_stride,
-                                             int n, int l1, float coarse_w, float* __restrict__ g_rgb,
+                                             int n, int kind, float beta, float coarse_w, float* __restrict__ g_rgb,
                                              float* __restrict__ g_acc, float* __restrict__ g_rgb0,
                                              float* __restrict__ g_acc0, float* __restrict__ partial) {
   __shared__ float sh[4];
   const float inv = 1.0f / (3.0f * (float)n);
+  // kind 0: d^2   1: |d|   2: smooth-L1 / Huber (F.smooth_l1_loss, trainer.py:57): |d| < beta ? d^2 / (2 beta) : |d| - beta/2
+  auto term = [&](float d) {
+    const float a = fabsf(d);
+    return kind == 0 ? d * d : (kind == 1 || a >= beta) ? a - (kind == 2 ? 0.5f * beta : 0.f) : 0.5f * d * d / beta;
+  };
+  auto dterm = [&](float d) {
+    const float a = fabsf(d);
+    return kind == 0 ? 2.0f * d * inv
+                     : (kind == 1 || a >= beta) ? (d > 0.f ? inv : (d < 0.f ? -inv : 0.f)) : d / beta * inv;
+  };
   float lf = 0.f, lc = 0.f, se = 0.f;
   for (int r = blockIdx.x * RB + threadIdx.x; r < n; r += gridDim.x * RB) {
     float bg[3] = {0.f, 0.f, 0.f};
@@ -52,8 +62,8 @@ __global__ __launch_bounds__(RB) void k_loss(const float* __restrict__ rgb, cons
       for (int c = 0; c < 3; ++c) {
         const float d = rgb[3 * r + c] + om * bg[c] - tt[c];
         se += d * d;
-        lf += l1 ? fabsf(d) : d * d;
-        const float g = l1 ? (d > 0.f ? inv : (d < 0.f ? -inv : 0.f)) : 2.0f * d * inv;
+        lf += term(d);
+        const float g = dterm(d);
         if (g_rgb) g_rgb[3 * r + c] = g;
         ga -= g * bg[c];
       }
@@ -65,8 +75,8 @@ __global__ __launch_bounds__(RB) void k_loss(const float* __restrict__ rgb, cons
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const float d = rgb0[3 * r + c] + om * bg[c] - tt[c];
-        lc += l1 ? fabsf(d) : d * d;
-        const float g = coarse_w * (l1 ? (d > 0.f ? inv : (d < 0.f ? -inv : 0.f)) : 2.0f * d * inv);
+        lc += term(d);
+        const float g = coarse_w * dterm(d);
         if (g_rgb0) g_rgb0[3 * r + c] = g;
         ga -= g * bg[c];
       }
@@ -177,9 +187,11 @@ int anerf_loss_blocks(int32_t n_rays) {
 }
 
 int anerf_loss(const float* rgb, const float* acc, const float* rgb0, const float* acc0, const float* target,
-               const float* bgs, int32_t bg_stride, int32_t n_rays, int32_t loss_type, float coarse_weight,
-               float* out4, float* g_rgb, float* g_acc, float* g_rgb0, float* g_acc0, float* partials, void* stream) {
-  if (loss_type != 0 && loss_type != 1) return set_error(ANERF_E_CONFIG, "loss: loss_type must be 0 (MSE) or 1 (L1)");
+               const float* bgs, int32_t bg_stride, int32_t n_rays, int32_t loss_type, float huber_beta,
+               float coarse_weight, float* out4, float* g_rgb, float* g_acc, float* g_rgb0, float* g_acc0,
+               float* partials, void* stream) {
+  if (loss_type < 0 || loss_type > 2) return set_error(ANERF_E_CONFIG, "loss: loss_type must be 0 (MSE), 1 (L1) or 2 (Huber)");
+  if (loss_type == 2 && !(huber_beta >= 0.f)) return set_error(ANERF_E_CONFIG, "loss: huber_beta must be >= 0");
   if (n_rays < 0 || (bgs && bg_stride != 0 && bg_stride < 3)) return set_error(ANERF_E_SHAPE, "loss: n_rays >= 0, bg_stride 0 or >= 3");
   if (n_rays == 0) return ANERF_OK;
   if (!rgb || !target || !out4 || !partials || (bgs && !acc) || (rgb0 && bgs && !acc0))
@@ -187,7 +199,7 @@ int anerf_loss(const float* rgb, const float* acc, const float* rgb0, const floa
   const int nblk = anerf_loss_blocks(n_rays);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_loss, dim3(nblk), dim3(RB), 0, st, rgb, acc, rgb0, acc0, target, bgs, (int)bg_stride, (int)n_rays,
-                     (int)loss_type, coarse_weight, g_rgb, g_acc, g_rgb0, g_acc0, partials);
+                     (int)loss_type, huber_beta, coarse_weight, g_rgb, g_acc, g_rgb0, g_acc0, partials);
   int rc = check_launch("k_loss");
   if (rc) return rc;
   hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(RB), 0, st, (const float*)partials, nblk, (int)n_rays,

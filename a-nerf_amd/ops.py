@@ -237,9 +237,10 @@ def assemble_frame(rgb_map, acc_map, disp_map, valid_idx, rgb_img, want_acc=Fals
     return rgb_img, disp_img, acc_img
 
 
-def loss(rgb, acc, target, rgb0=None, acc0=None, bgs=None, loss_type=0, coarse_weight=1.0, want_grads=True):
+def loss(rgb, acc, target, rgb0=None, acc0=None, bgs=None, loss_type=0, coarse_weight=1.0, want_grads=True, beta=0.1):
     """_compute_nerf_loss + its gradient w.r.t. the rendered maps in one pass (anerf_loss; trainer.py:353-380).
     bgs: None (no background composite), a [3] / [1,3] colour, or per-ray [N,3].
+    loss_type 0 MSE, 1 L1, 2 Huber (smooth-L1 with `beta`, trainer.py:57).
     Returns (out4 = [total, fine, coarse, fine mse], grads dict or None)."""
     rgb, acc, target = _f32c(rgb, "rgb"), _f32c(acc, "acc"), _f32c(target, "target")
     rgb0, acc0, bgs = _f32c(rgb0, "rgb0"), _f32c(acc0, "acc0"), _f32c(bgs, "bgs")
@@ -264,7 +265,7 @@ def loss(rgb, acc, target, rgb0=None, acc0=None, bgs=None, loss_type=0, coarse_w
              "acc0": torch.empty_like(acc0) if (rgb0 is not None and bgs is not None) else None}
     gp = (lambda k: _p(g[k]) if g is not None else None)
     _lib.check(lib.anerf_loss(_p(rgb), _p(acc), _p(rgb0), _p(acc0), _p(target), _p(bgs), stride, n, int(loss_type),
-                              float(coarse_weight), _p(out), gp("rgb"), gp("acc"), gp("rgb0"), gp("acc0"), _p(part), _stream()),
+                              float(beta), float(coarse_weight), _p(out), gp("rgb"), gp("acc"), gp("rgb0"), gp("acc0"), _p(part), _stream()),
                "anerf_loss")
     return out, g
 

@@ -1,7 +1,7 @@
 """Loss + optimiser step of the training loop as three kernel launches.
 
 Mirrors, with the same names and meaning where the reference has them:
-  * `_compute_nerf_loss` (core/trainer.py:353-380) -> `fused_nerf_loss`: background composite + MSE/L1 of the
+  * `_compute_nerf_loss` (core/trainer.py:353-380) -> `fused_nerf_loss`: background composite + MSE/L1/Huber of the
     fine and coarse heads + the PSNR numerator + the gradients w.r.t. the rendered maps, one kernel;
   * `torch.optim.Adam(params=grad_vars, lr=lrate, betas=(0.9, 0.999))` (trainer.py:173-183) -> `FusedAdam`: all
     parameters live in ONE flat fp32 buffer (each `p.data` / `p.grad` is a view of it), one kernel per step,
@@ -144,9 +144,9 @@ class FusedAdam:
 
 class _LossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rgb, acc, rgb0, acc0, target, bgs, loss_type, coarse_weight):
+    def forward(ctx, rgb, acc, rgb0, acc0, target, bgs, loss_type, coarse_weight, beta):
         need = any(t is not None and t.requires_grad for t in (rgb, acc, rgb0, acc0))
-        out, g = ops.loss(rgb, acc, target, rgb0, acc0, bgs, loss_type, coarse_weight, want_grads=need)
+        out, g = ops.loss(rgb, acc, target, rgb0, acc0, bgs, loss_type, coarse_weight, want_grads=need, beta=beta)
         ctx.g = g
         ctx.mark_non_differentiable(out)
         return out[0], out
@@ -155,13 +155,14 @@ class _LossFn(torch.autograd.Function):
     def backward(ctx, go, _):
         g = ctx.g
         sc = lambda t: None if t is None else t * go
-        return sc(g["rgb"]), sc(g["acc"]), sc(g["rgb0"]), sc(g["acc0"]), None, None, None, None
+        return sc(g["rgb"]), sc(g["acc"]), sc(g["rgb0"]), sc(g["acc0"]), None, None, None, None, None
 
 
-def fused_nerf_loss(preds, target, bgs=1.0, loss_fn="MSE", coarse_weight=1.0, use_background=True):
+def fused_nerf_loss(preds, target, bgs=1.0, loss_fn="MSE", coarse_weight=1.0, use_background=True, beta=0.1):
     """render.nerf_loss (= _compute_nerf_loss, trainer.py:353-380) as one kernel.
     Returns (loss, stats) with stats = [total, fine, coarse, fine_mse] on the device (PSNR = mse2psnr(stats[3]))."""
-    if loss_fn not in ("MSE", "L1"):
+    kinds = {"MSE": 0, "L1": 1, "Huber": 2}          # get_loss_fn, trainer.py:146-156
+    if loss_fn not in kinds:
         raise NotImplementedError(loss_fn)
     rgb = preds["rgb_map"]
     if not use_background:
@@ -173,5 +174,5 @@ def fused_nerf_loss(preds, target, bgs=1.0, loss_fn="MSE", coarse_weight=1.0, us
     else:
         bg = torch.full((3,), float(bgs), dtype=torch.float32, device=rgb.device)
     loss, stats = _LossFn.apply(rgb, preds["acc_map"], preds.get("rgb0"), preds.get("acc0"), target, bg,
-                                0 if loss_fn == "MSE" else 1, coarse_weight)
+                                kinds[loss_fn], coarse_weight, beta)
     return loss, stats

@@ -235,16 +235,18 @@ int anerf_mlp_raw_b3(const AnerfConfig* cfg, const float* packed, const float* a
                      int32_t n_rays, int32_t n_samples, float* raw, void* stream);
 
 /* ---- loss + optimiser step ---------------------------------------------------------------------
- * _compute_nerf_loss (core/trainer.py:353-380) for the fine and (optional) coarse head, with img2mse / img2l1
+ * _compute_nerf_loss (core/trainer.py:353-380) for the fine and (optional) coarse head, with img2mse / img2l1 / img2huber
  * (:8-60), AND its gradient w.r.t. the rendered maps in one pass:
  *   pred = rgb + (1 - acc) * bg  (bgs != NULL; bg_stride 0 = one [3] colour, >= 3 = per ray)   else pred = rgb
- *   loss = mean_{N x 3} (pred - target)^2   (loss_type 0)   or   mean |pred - target|   (loss_type 1)
+ *   loss = mean_{N x 3} (pred - target)^2   (loss_type 0),   mean |pred - target|   (loss_type 1)   or
+ *          img2huber = F.smooth_l1_loss(beta = huber_beta) (loss_type 2; trainer.py:57,152; huber_beta 0 = L1)
  * out4 = {fine + coarse_weight * coarse, fine, coarse, fine MSE (mse2psnr input)};  g_* = d(out4[0]) / d(map), any
  * may be NULL.  partials: workspace of 4 * anerf_loss_blocks(n_rays) floats.  Deterministic (fixed-order sums). */
 int anerf_loss_blocks(int32_t n_rays);
 int anerf_loss(const float* rgb, const float* acc, const float* rgb0, const float* acc0, const float* target,
-               const float* bgs, int32_t bg_stride, int32_t n_rays, int32_t loss_type, float coarse_weight,
-               float* out4, float* g_rgb, float* g_acc, float* g_rgb0, float* g_acc0, float* partials, void* stream);
+               const float* bgs, int32_t bg_stride, int32_t n_rays, int32_t loss_type, float huber_beta,
+               float coarse_weight, float* out4, float* g_rgb, float* g_acc, float* g_rgb0, float* g_acc0,
+               float* partials, void* stream);
 
 /* torch.optim.Adam (no amsgrad, no weight decay: trainer.py:173-183) over ONE flat fp32 buffer of n elements
  * (16-byte aligned), step = 1-based step count; grads are multiplied by grad_scale first (1/world after a summed
