@@ -122,8 +122,8 @@ SIGNATURES = {
     "anerf_forward": (C.c_int, [C.POINTER(AnerfConfig), C.POINTER(AnerfForwardIO), C.c_void_p, C.c_int64, C.c_void_p]),
     "anerf_loss_blocks": (C.c_int, [C.c_int32]),
     "anerf_loss": (C.c_int, [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float] + [C.c_void_p] * 7),
-    "anerf_fk_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 5),
-    "anerf_fk_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 7),
+    "anerf_fk_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 5),
+    "anerf_fk_backward": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 7),
     "anerf_adam_blocks": (C.c_int, [C.c_int64]),
     "anerf_adam_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
                                   C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -1,6 +1,6 @@
 // anerf_fk.hip -- forward kinematics of the SMPL skeleton and its backward:
 //   PoseOptLayer.calculate_kinematic / get_kinematic_chain_T + unrolled_kinematic_chain (core/pose_opt.py:372-445,
-//   482-566): per pose, axis-angle bones [24,3] + pelvis [3] + rest pose [24,3]  ->  local rotations `rots`, joint-to-
+//   482-566): per pose, axis-angle [24,3] or 6D-rotation [24,6] bones + pelvis [3] + rest pose [24,3]  ->  local rotations `rots`, joint-to-
 //   world matrices `l2ws`, world-to-bone matrices `skts` (= inverse(l2ws), what the ray-march kernels consume) and
 //   joint locations `kp`.  The reference runs ~40 small batched ops forward and ~100 backward per call; here it is one
 //   launch each way.  The rotation map is pytorch3d's axis_angle_to_matrix (third-party, absent from this image:
@@ -84,6 +84,61 @@ __device__ __forceinline__ void aa_backward(const float* a, const float* dR, flo
   da[2] = q.kf * dk + dth * a[2] * inv;
 }
 
+// 6D rotation parameters (opt_rot6d, 6 of the reference's 8 configs; Zhou et al. 2019): rot6d_to_rotmat
+// (core/utils/skeleton_utils.py:420-436).  x = R[:, :2] row-major: a1 = (x0,x2,x4), a2 = (x1,x3,x5);
+// b1 = a1/max(|a1|,1e-12) (F.normalize), b2 = normalize(a2 - (b1.a2) b1), b3 = b1 x b2, R = [b1 b2 b3] (columns).
+struct Rot6 { float b1[3], b2[3], a2[3], n1, n2, d; };
+
+__device__ __forceinline__ Rot6 rot6d_frame(const float* x) {
+  Rot6 f;
+  const float a1[3] = {x[0], x[2], x[4]};
+  f.a2[0] = x[1]; f.a2[1] = x[3]; f.a2[2] = x[5];
+  f.n1 = fmaxf(sqrtf(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]), 1e-12f);
+  for (int c = 0; c < 3; ++c) f.b1[c] = a1[c] / f.n1;
+  f.d = f.b1[0] * f.a2[0] + f.b1[1] * f.a2[1] + f.b1[2] * f.a2[2];
+  float v[3];
+  for (int c = 0; c < 3; ++c) v[c] = f.a2[c] - f.d * f.b1[c];
+  f.n2 = fmaxf(sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), 1e-12f);
+  for (int c = 0; c < 3; ++c) f.b2[c] = v[c] / f.n2;
+  return f;
+}
+
+__device__ __forceinline__ void rot6d_to_mat(const float* x, float* R) {
+  const Rot6 f = rot6d_frame(x);
+  const float b3[3] = {f.b1[1] * f.b2[2] - f.b1[2] * f.b2[1], f.b1[2] * f.b2[0] - f.b1[0] * f.b2[2],
+                       f.b1[0] * f.b2[1] - f.b1[1] * f.b2[0]};
+  for (int r = 0; r < 3; ++r) { R[3 * r] = f.b1[r]; R[3 * r + 1] = f.b2[r]; R[3 * r + 2] = b3[r]; }
+}
+
+// d(loss)/dR -> d(loss)/d(6D parameters)
+__device__ __forceinline__ void rot6d_backward(const float* x, const float* dR, float* dx) {
+  const Rot6 f = rot6d_frame(x);
+  float db1[3], db2[3];
+  const float db3[3] = {dR[2], dR[5], dR[8]};
+  for (int r = 0; r < 3; ++r) { db1[r] = dR[3 * r]; db2[r] = dR[3 * r + 1]; }
+  // b3 = b1 x b2 :  db1 += b2 x db3,  db2 += db3 x b1
+  db1[0] += f.b2[1] * db3[2] - f.b2[2] * db3[1];
+  db1[1] += f.b2[2] * db3[0] - f.b2[0] * db3[2];
+  db1[2] += f.b2[0] * db3[1] - f.b2[1] * db3[0];
+  db2[0] += db3[1] * f.b1[2] - db3[2] * f.b1[1];
+  db2[1] += db3[2] * f.b1[0] - db3[0] * f.b1[2];
+  db2[2] += db3[0] * f.b1[1] - db3[1] * f.b1[0];
+  // b2 = v / |v|
+  const float p2 = f.b2[0] * db2[0] + f.b2[1] * db2[1] + f.b2[2] * db2[2];
+  float dv[3], da2[3], da1[3];
+  for (int c = 0; c < 3; ++c) dv[c] = (db2[c] - (f.n2 > 1e-12f ? f.b2[c] * p2 : 0.f)) / f.n2;
+  // v = a2 - d b1,  d = b1 . a2
+  const float dd = -(dv[0] * f.b1[0] + dv[1] * f.b1[1] + dv[2] * f.b1[2]);
+  for (int c = 0; c < 3; ++c) {
+    da2[c] = dv[c] + dd * f.b1[c];
+    db1[c] += -f.d * dv[c] + dd * f.a2[c];
+  }
+  // b1 = a1 / |a1|
+  const float p1 = f.b1[0] * db1[0] + f.b1[1] * db1[1] + f.b1[2] * db1[2];
+  for (int c = 0; c < 3; ++c) da1[c] = (db1[c] - (f.n1 > 1e-12f ? f.b1[c] * p1 : 0.f)) / f.n1;
+  for (int c = 0; c < 3; ++c) { dx[2 * c] = da1[c]; dx[2 * c + 1] = da2[c]; }
+}
+
 // SMPL tree depth of every joint (root = 0): the chain is evaluated level by level, the joints of a level in parallel
 __device__ __constant__ int kDepth[NJ] = {0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5, 6, 6, 7, 7, 8, 8};
 constexpr int NLEVEL = 9;
@@ -94,8 +149,12 @@ struct FkShared {
 };
 
 // forward chain of one pose into shared memory: thread j = joint j
-__device__ __forceinline__ void fk_chain(FkShared& S, const float* __restrict__ bones_u, const float* __restrict__ rp, int j) {
-  if (j < NJ) quat_to_mat(aa_to_quat(bones_u + 3 * j), S.Rl[j]);
+__device__ __forceinline__ void fk_chain(FkShared& S, const float* __restrict__ bones_u, int rd,
+                                         const float* __restrict__ rp, int j) {
+  if (j < NJ) {
+    if (rd == 6) rot6d_to_mat(bones_u + 6 * j, S.Rl[j]);
+    else quat_to_mat(aa_to_quat(bones_u + 3 * j), S.Rl[j]);
+  }
   __syncthreads();
   for (int lvl = 0; lvl < NLEVEL; ++lvl) {
     if (j < NJ && kDepth[j] == lvl) {
@@ -117,14 +176,14 @@ __device__ __forceinline__ void fk_chain(FkShared& S, const float* __restrict__ 
 }
 
 // one block (32 threads) per pose.  l2ws / skts [U,24,4,4] row-major, rots [U,24,3,3], kp [U,24,3]; any output may be NULL.
-__global__ __launch_bounds__(FKT) void k_fk_fwd(const float* __restrict__ bones, const float* __restrict__ pelvis,
+__global__ __launch_bounds__(FKT) void k_fk_fwd(const float* __restrict__ bones, int rd, const float* __restrict__ pelvis,
                                                 const float* __restrict__ rest, long long rest_stride, int n,
                                                 float* __restrict__ l2ws, float* __restrict__ skts,
                                                 float* __restrict__ rots, float* __restrict__ kp) {
   __shared__ FkShared S;
   const int u = blockIdx.x, j = threadIdx.x;
   const float* rp = rest + (long long)u * rest_stride;
-  fk_chain(S, bones + (long long)u * NJ * 3, rp, j);
+  fk_chain(S, bones + (long long)u * NJ * rd, rd, rp, j);
   if (j >= NJ) return;
   float pv[3] = {0.f, 0.f, 0.f};
   if (pelvis) { pv[0] = pelvis[3 * u]; pv[1] = pelvis[3 * u + 1]; pv[2] = pelvis[3 * u + 2]; }
@@ -151,7 +210,7 @@ __global__ __launch_bounds__(FKT) void k_fk_fwd(const float* __restrict__ bones,
 }
 
 // backward: gradients w.r.t. skts / l2ws (rows 0..2 used) / kp / rots  ->  gradients w.r.t. bones and pelvis
-__global__ __launch_bounds__(FKT) void k_fk_bwd(const float* __restrict__ bones, const float* __restrict__ pelvis,
+__global__ __launch_bounds__(FKT) void k_fk_bwd(const float* __restrict__ bones, int rd, const float* __restrict__ pelvis,
                                                 const float* __restrict__ rest, long long rest_stride, int n,
                                                 const float* __restrict__ g_skts, const float* __restrict__ g_l2ws,
                                                 const float* __restrict__ g_kp, const float* __restrict__ g_rots,
@@ -160,7 +219,7 @@ __global__ __launch_bounds__(FKT) void k_fk_bwd(const float* __restrict__ bones,
   __shared__ float dpel[NJ][3];
   const int u = blockIdx.x, j = threadIdx.x;
   const float* rp = rest + (long long)u * rest_stride;
-  fk_chain(S, bones + (long long)u * NJ * 3, rp, j);     // recompute the chain
+  fk_chain(S, bones + (long long)u * NJ * rd, rd, rp, j);     // recompute the chain
   float pv[3] = {0.f, 0.f, 0.f};
   if (pelvis) { pv[0] = pelvis[3 * u]; pv[1] = pelvis[3 * u + 1]; pv[2] = pelvis[3 * u + 2]; }
   // gradients w.r.t. the global rotation and the joint centre c = tg + pelvis of every joint
@@ -225,11 +284,10 @@ __global__ __launch_bounds__(FKT) void k_fk_bwd(const float* __restrict__ bones,
   }
   if (g_rots)
     for (int e = 0; e < 9; ++e) dRl[e] += g_rots[((long long)u * NJ + j) * 9 + e];
-  float da[3];
-  aa_backward(bones + ((long long)u * NJ + j) * 3, dRl, da);
-  g_bones[((long long)u * NJ + j) * 3] = da[0];
-  g_bones[((long long)u * NJ + j) * 3 + 1] = da[1];
-  g_bones[((long long)u * NJ + j) * 3 + 2] = da[2];
+  float da[6];
+  if (rd == 6) rot6d_backward(bones + ((long long)u * NJ + j) * 6, dRl, da);
+  else aa_backward(bones + ((long long)u * NJ + j) * 3, dRl, da);
+  for (int e = 0; e < rd; ++e) g_bones[((long long)u * NJ + j) * rd + e] = da[e];
 }
 
 }  // namespace anerf
@@ -238,24 +296,27 @@ using namespace anerf;
 
 extern "C" {
 
-int anerf_fk_forward(const float* bones, const float* pelvis, const float* rest_pose, int64_t rest_pose_stride,
-                     int32_t n_poses, float* l2ws, float* skts, float* rots, float* kp, void* stream) {
+int anerf_fk_forward(const float* bones, int32_t rot_dim, const float* pelvis, const float* rest_pose,
+                     int64_t rest_pose_stride, int32_t n_poses, float* l2ws, float* skts, float* rots, float* kp,
+                     void* stream) {
+  if (rot_dim != 3 && rot_dim != 6) return set_error(ANERF_E_CONFIG, "fk_forward: rot_dim must be 3 (axis-angle) or 6 (rot6d)");
   if (n_poses < 0 || (rest_pose_stride != 0 && rest_pose_stride != 72)) return set_error(ANERF_E_SHAPE, "fk_forward: n_poses >= 0, rest_pose_stride 0 or 72");
   if (n_poses == 0) return ANERF_OK;
   if (!bones || !rest_pose) return set_error(ANERF_E_NULL, "fk_forward: NULL pointer");
-  hipLaunchKernelGGL(k_fk_fwd, dim3(n_poses), dim3(FKT), 0, (hipStream_t)stream, bones, pelvis, rest_pose,
-                     (long long)rest_pose_stride, (int)n_poses, l2ws, skts, rots, kp);
+  hipLaunchKernelGGL(k_fk_fwd, dim3(n_poses), dim3(FKT), 0, (hipStream_t)stream, bones, (int)rot_dim, pelvis,
+                     rest_pose, (long long)rest_pose_stride, (int)n_poses, l2ws, skts, rots, kp);
   return check_launch("k_fk_fwd");
 }
 
-int anerf_fk_backward(const float* bones, const float* pelvis, const float* rest_pose, int64_t rest_pose_stride,
-                      int32_t n_poses, const float* g_skts, const float* g_l2ws, const float* g_kp, const float* g_rots,
-                      float* g_bones, float* g_pelvis, void* stream) {
+int anerf_fk_backward(const float* bones, int32_t rot_dim, const float* pelvis, const float* rest_pose,
+                      int64_t rest_pose_stride, int32_t n_poses, const float* g_skts, const float* g_l2ws,
+                      const float* g_kp, const float* g_rots, float* g_bones, float* g_pelvis, void* stream) {
+  if (rot_dim != 3 && rot_dim != 6) return set_error(ANERF_E_CONFIG, "fk_backward: rot_dim must be 3 (axis-angle) or 6 (rot6d)");
   if (n_poses < 0 || (rest_pose_stride != 0 && rest_pose_stride != 72)) return set_error(ANERF_E_SHAPE, "fk_backward: n_poses >= 0, rest_pose_stride 0 or 72");
   if (n_poses == 0) return ANERF_OK;
   if (!bones || !rest_pose || !g_bones) return set_error(ANERF_E_NULL, "fk_backward: NULL pointer");
-  hipLaunchKernelGGL(k_fk_bwd, dim3(n_poses), dim3(FKT), 0, (hipStream_t)stream, bones, pelvis, rest_pose,
-                     (long long)rest_pose_stride, (int)n_poses, g_skts, g_l2ws, g_kp, g_rots, g_bones, g_pelvis);
+  hipLaunchKernelGGL(k_fk_bwd, dim3(n_poses), dim3(FKT), 0, (hipStream_t)stream, bones, (int)rot_dim, pelvis,
+                     rest_pose, (long long)rest_pose_stride, (int)n_poses, g_skts, g_l2ws, g_kp, g_rots, g_bones, g_pelvis);
   return check_launch("k_fk_bwd");
 }
 

@@ -286,11 +286,12 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, g
 
 
 def fk_forward(bones, rest_pose, pelvis=None, want=("l2ws", "skts", "rots", "kp")):
-    """PoseOptLayer.calculate_kinematic's math (anerf_fk_forward; pose_opt.py:372-445): bones [U,24,3] axis-angle,
+    """PoseOptLayer.calculate_kinematic's math (anerf_fk_forward; pose_opt.py:372-445): bones [U,24,3] axis-angle or
+    [U,24,6] 6D rotations (opt_rot6d),
     rest_pose [24,3] / [1,24,3] (shared) or [U,24,3], pelvis [U,3] or None -> dict of the requested outputs."""
     bones, rest_pose, pelvis = _f32c(bones, "bones"), _f32c(rest_pose, "rest_pose"), _f32c(pelvis, "pelvis")
-    if bones.dim() != 3 or bones.shape[1:] != (24, 3):
-        raise ValueError(f"fk_forward: bones must be [U,24,3] axis-angle, got {tuple(bones.shape)}")
+    if bones.dim() != 3 or bones.shape[1] != 24 or bones.shape[2] not in (3, 6):
+        raise ValueError(f"fk_forward: bones must be [U,24,3] axis-angle or [U,24,6] rot6d, got {tuple(bones.shape)}")
     u, dev = bones.shape[0], bones.device
     rest = rest_pose.reshape(-1, 24, 3)
     if rest.shape[0] not in (1, u):
@@ -298,13 +299,13 @@ def fk_forward(bones, rest_pose, pelvis=None, want=("l2ws", "skts", "rots", "kp"
     stride = 0 if rest.shape[0] == 1 else 72
     shapes = {"l2ws": (u, 24, 4, 4), "skts": (u, 24, 4, 4), "rots": (u, 24, 3, 3), "kp": (u, 24, 3)}
     out = {k: torch.empty(shapes[k], dtype=torch.float32, device=dev) for k in want}
-    _lib.check(_lib.load().anerf_fk_forward(_p(bones), _p(pelvis), _p(rest), stride, u, _p(out.get("l2ws")), _p(out.get("skts")),
+    _lib.check(_lib.load().anerf_fk_forward(_p(bones), bones.shape[2], _p(pelvis), _p(rest), stride, u, _p(out.get("l2ws")), _p(out.get("skts")),
                                             _p(out.get("rots")), _p(out.get("kp")), _stream()), "anerf_fk_forward")
     return out
 
 
 def fk_backward(bones, rest_pose, pelvis, g_skts=None, g_l2ws=None, g_kp=None, g_rots=None):
-    """-> (g_bones [U,24,3], g_pelvis [U,3] or None)   (anerf_fk_backward)"""
+    """-> (g_bones [U,24,3|6], g_pelvis [U,3] or None)   (anerf_fk_backward)"""
     bones, rest_pose, pelvis = _f32c(bones, "bones"), _f32c(rest_pose, "rest_pose"), _f32c(pelvis, "pelvis")
     g_skts, g_l2ws, g_kp, g_rots = _f32c(g_skts, "g_skts"), _f32c(g_l2ws, "g_l2ws"), _f32c(g_kp, "g_kp"), _f32c(g_rots, "g_rots")
     u = bones.shape[0]
@@ -312,7 +313,7 @@ def fk_backward(bones, rest_pose, pelvis, g_skts=None, g_l2ws=None, g_kp=None, g
     stride = 0 if rest.shape[0] == 1 else 72
     gb = torch.empty_like(bones)
     gp = torch.empty(u, 3, dtype=torch.float32, device=bones.device) if pelvis is not None else None
-    _lib.check(_lib.load().anerf_fk_backward(_p(bones), _p(pelvis), _p(rest), stride, u, _p(g_skts), _p(g_l2ws), _p(g_kp),
+    _lib.check(_lib.load().anerf_fk_backward(_p(bones), bones.shape[2], _p(pelvis), _p(rest), stride, u, _p(g_skts), _p(g_l2ws), _p(g_kp),
                                              _p(g_rots), _p(gb), _p(gp), _stream()), "anerf_fk_backward")
     return gb, gp
 

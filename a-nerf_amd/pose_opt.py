@@ -4,8 +4,9 @@ fused forward-kinematics kernels (anerf_fk.hip).
 Same constructor arguments, parameters (`pelvis`, `bones`), buffers (`rest_pose`), `forward(idxs)` 5-tuple
 `(kp, bones, skts, l2ws, rots)`, `calculate_kinematic`, `update_cache`, so `poseopt_layer_state_dict` checkpoints
 (core/trainer.py:498-505, pose_opt.py:211-240) load unchanged.  Supported set = what the shipped configs use: SMPL
-skeleton, axis-angle bones, one rest pose shared by all poses or one per pose; `use_rot6d` and the multi-view `kp_map`
-variant raise NotImplementedError at construction.
+skeleton; axis-angle bones or `use_rot6d` 6D rotations (opt_rot6d = True in the mixamo / h36m / perfcap configs); one
+rest pose shared by all poses or one per pose; the multi-view `kp_map` variant (h36m: per-view root rotation +
+shared body bones, pose_opt.py:293-296,318-331).
 `skts` returned here feed RayCaster.render_rays(skts=...); their gradient (the hot path's dskts) flows back to
 `bones` / `pelvis` through one backward kernel.  No CPU fallback.
 """
@@ -64,33 +65,100 @@ def expand_poses(x_u, inverse_idxs):
 
 
 def calculate_kinematic(bones, pelvis, rest_pose):
-    """(kp, skts, l2ws, rots) of axis-angle `bones` [U,24,3] (+ `pelvis` [U,3]); differentiable w.r.t. both."""
+    """(kp, skts, l2ws, rots) of axis-angle `bones` [U,24,3] or rot6d `bones` [U,24,6] (+ `pelvis` [U,3]);
+    differentiable w.r.t. both."""
     return _FkFn.apply(bones, pelvis, rest_pose)
+
+
+# ---- host-side rotation conversions: parameter initialisation and pose export only (never on the per-step path, which
+# is the FK kernel).  pytorch3d (absent here) is what the reference calls; restated from its published formulae.
+def axisang_to_rot(a):
+    """skeleton_utils.py:411 axisang_to_rot = pytorch3d axis_angle_to_matrix: [...,3] -> [...,3,3] (same map as anerf_fk.hip)."""
+    th = torch.linalg.norm(a, dim=-1, keepdim=True)
+    half = 0.5 * th
+    small = th.abs() < 1e-6
+    k = torch.where(small, 0.5 - th * th / 48.0, torch.sin(half) / torch.where(small, torch.ones_like(th), th))
+    r, (i, j, kk) = torch.cos(half)[..., 0], (a * k).unbind(-1)
+    two_s = 2.0 / (r * r + i * i + j * j + kk * kk)
+    o = torch.stack([1 - two_s * (j * j + kk * kk), two_s * (i * j - kk * r), two_s * (i * kk + j * r),
+                     two_s * (i * j + kk * r), 1 - two_s * (i * i + kk * kk), two_s * (j * kk - i * r),
+                     two_s * (i * kk - j * r), two_s * (j * kk + i * r), 1 - two_s * (i * i + j * j)], -1)
+    return o.reshape(a.shape[:-1] + (3, 3))
+
+
+def rot6d_to_rotmat(x):
+    """skeleton_utils.py:420-436 (Zhou et al. 2019): [...,6] -> [...,3,3]; x = the first two columns of R, row-major."""
+    sh = x.shape[:-1]
+    x = x.reshape(-1, 3, 2)
+    b1 = torch.nn.functional.normalize(x[:, :, 0], dim=-1)
+    a2 = x[:, :, 1]
+    b2 = torch.nn.functional.normalize(a2 - (b1 * a2).sum(-1, keepdim=True) * b1, dim=-1)
+    b3 = torch.linalg.cross(b1, b2, dim=-1)
+    return torch.stack((b1, b2, b3), dim=-1).reshape(*sh, 3, 3)
+
+
+def rot_to_rot6d(rot):
+    """skeleton_utils.py:408"""
+    return rot[..., :3, :2].flatten(start_dim=-2)
+
+
+def rot_to_axisang(rot):
+    """skeleton_utils.py:405 rot_to_axisang = pytorch3d matrix_to_axis_angle: [...,3,3] -> [...,3], angle in [0, pi].
+    Through the best-conditioned of the four quaternion candidates (Shepperd), as pytorch3d's matrix_to_quaternion."""
+    m = rot[..., :3, :3]
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = [m[..., r, c] for r in range(3) for c in range(3)]
+    q_abs = torch.sqrt(torch.clamp(torch.stack([1 + m00 + m11 + m22, 1 + m00 - m11 - m22, 1 - m00 + m11 - m22,
+                                                1 - m00 - m11 + m22], -1), min=0.0))
+    cand = torch.stack([torch.stack([q_abs[..., 0] ** 2, m21 - m12, m02 - m20, m10 - m01], -1),
+                        torch.stack([m21 - m12, q_abs[..., 1] ** 2, m10 + m01, m02 + m20], -1),
+                        torch.stack([m02 - m20, m10 + m01, q_abs[..., 2] ** 2, m12 + m21], -1),
+                        torch.stack([m10 - m01, m20 + m02, m21 + m12, q_abs[..., 3] ** 2], -1)], -2)
+    cand = cand / (2.0 * q_abs[..., None].clamp(min=0.1))
+    best = q_abs.argmax(-1)
+    q = torch.gather(cand, -2, best[..., None, None].expand(best.shape + (1, 4)))[..., 0, :]
+    q = torch.where(q[..., :1] < 0, -q, q)                                  # real part >= 0: angle in [0, pi]
+    n = torch.linalg.norm(q[..., 1:], dim=-1, keepdim=True)
+    half = torch.atan2(n, q[..., :1])
+    ang = 2.0 * half
+    small = ang.abs() < 1e-6
+    sin_half_over_ang = torch.where(small, 0.5 - ang * ang / 48.0, torch.sin(half) / torch.where(small, torch.ones_like(ang), ang))
+    return q[..., 1:] / sin_half_over_ang
+
+
+def rot6d_to_axisang(x):
+    """skeleton_utils.py:417"""
+    return rot_to_axisang(rot6d_to_rotmat(x))
 
 
 class PoseOptLayer(nn.Module):
     def __init__(self, kps, bones, rest_pose, skel_type=None, kp_map=None, kp_uidxs=None, use_cache=False, use_rot6d=False,
                  beta=None, rest_pose_idxs=None):
         super().__init__()
-        if use_rot6d:
-            raise NotImplementedError("rot6d bones: not in the fused FK set (axis-angle only)")
-        if kp_map is not None or kp_uidxs is not None:
-            raise NotImplementedError("multi-view kp_map: not in the fused FK set")
         if skel_type is not None and getattr(skel_type, "root_id", 0) != 0:
             raise NotImplementedError("only the SMPL skeleton (root_id 0) is supported")
         kps, bones = torch.as_tensor(kps, dtype=torch.float32), torch.as_tensor(bones, dtype=torch.float32)
         if bones.dim() != 3 or bones.shape[1:] != (24, 3):
             raise NotImplementedError(f"bones must be [N,24,3] axis-angle, got {tuple(bones.shape)}")
         self.use_cache = use_cache
-        self.use_rot6d = False
+        self.use_rot6d = bool(use_rot6d)
         self.unroll_kinematic_chain = True
         self.root_id = 0
-        self.kp_map = self.kp_uidxs = None
         self.rest_pose_idxs = rest_pose_idxs
+        if kp_map is not None:                                       # multi-view (pose_opt.py:259-263)
+            self.register_buffer("kp_map", torch.as_tensor(np.asarray(kp_map)).long())
+            self.register_buffer("kp_uidxs", torch.as_tensor(np.asarray(kp_uidxs)).long())
+        else:
+            self.kp_map = self.kp_uidxs = None
         self.beta = torch.as_tensor(beta) if beta is not None else None
         self.register_buffer("rest_pose", torch.as_tensor(rest_pose, dtype=torch.float32).reshape(-1, 24, 3).clone())
         self.register_parameter("pelvis", nn.Parameter(kps[:, 0].clone()))
-        self.register_parameter("bones", nn.Parameter(bones.clone()))
+        if self.use_rot6d:                                           # pose_opt.py:284-289: first two columns of R
+            bones = rot_to_rot6d(axisang_to_rot(bones))
+        if self.kp_map is None:
+            self.register_parameter("bones", nn.Parameter(bones.clone()))
+        else:                                                        # per-view root rotation, body bones shared by the views
+            self.register_parameter("root_bones", nn.Parameter(bones[:, 0].clone()))
+            self.register_parameter("bones", nn.Parameter(bones[self.kp_uidxs.to(bones.device), 1:].clone()))
         self.N_kps = self.pelvis.shape[0]
         if use_cache:
             self.update_cache()
@@ -102,11 +170,26 @@ class PoseOptLayer(nn.Module):
             return self.rest_pose[rest_pose_idxs]
         return self.rest_pose[self.rest_pose_idxs[kp_idxs]]
 
-    def get_pelvis(self):
-        return self.pelvis
-
     def idx_to_params(self, idx):
-        return self.pelvis[idx], self.bones[idx]
+        """pose_opt.py:318-331"""
+        idx = torch.as_tensor(np.asarray(idx), device=self.pelvis.device).long().reshape(-1)
+        if self.kp_map is None:
+            return self.pelvis[idx], self.bones[idx]
+        return self.pelvis[idx], torch.cat([self.root_bones[idx, None, :], self.bones[self.kp_map[idx]]], dim=1)
+
+    def get_pelvis(self, idx=None):
+        return self.idx_to_params(np.arange(self.N_kps) if idx is None else idx)[0]
+
+    def get_beta(self):
+        return self.beta
+
+    def get_bones(self, idx=None):
+        """axis-angle bones of the (refined) poses, whatever the parametrisation (pose_opt.py:342-350)"""
+        bones = self.idx_to_params(np.arange(self.N_kps) if idx is None else idx)[1]
+        return rot6d_to_axisang(bones) if self.use_rot6d else bones
+
+    def to_bones3d(self, bones):
+        return bones if bones.shape[-1] == 3 else rot6d_to_axisang(bones)
 
     def calculate_kinematic(self, idxs, rest_pose_idxs=None):
         if idxs is None:
@@ -132,9 +215,17 @@ class PoseOptLayer(nn.Module):
 def load_poseopt_from_state_dict(state_dict):
     """pose_opt.py:211-240: rebuild the layer from a checkpoint's `poseopt_layer_state_dict`."""
     sd = state_dict["poseopt_layer_state_dict"]
-    if "kp_map" in sd or sd["bones"].shape[-1] != 3:
-        raise NotImplementedError("multi-view / rot6d pose checkpoints are outside the fused FK set")
+    kp_map = kp_uidxs = None
+    if "kp_map" in sd:                                                # multi-view: root bone stored separately
+        kp_map, kp_uidxs = sd["kp_map"].cpu().numpy(), sd["kp_uidxs"].cpu().numpy()
     n = sd["pelvis"].shape[0]
-    layer = PoseOptLayer(torch.zeros(n, 24, 3), torch.zeros(n, 24, 3), torch.zeros(sd["rest_pose"].shape))
+    layer = PoseOptLayer(torch.zeros(n, 24, 3), torch.zeros(n, 24, 3), torch.zeros(sd["rest_pose"].shape),
+                         use_rot6d=sd["bones"].shape[-1] == 6, kp_map=kp_map, kp_uidxs=kp_uidxs)
     layer.load_state_dict(sd)
     return layer
+
+
+def load_bones_from_state_dict(state_dict, device="cpu"):
+    """pose_opt.py:195-202: the checkpoint's bones as axis-angle"""
+    bones = state_dict["poseopt_layer_state_dict"]["bones"]
+    return (rot6d_to_axisang(bones) if bones.shape[-1] == 6 else bones).to(device)

@@ -260,17 +260,20 @@ int anerf_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_
 
 /* ---- PoseOptLayer forward kinematics ------------------------------------------------------------
  * PoseOptLayer.calculate_kinematic / get_kinematic_chain_T + unrolled_kinematic_chain (core/pose_opt.py:372-445,
- * 482-566) for the SMPL tree (skeleton_utils.py:98-105), axis-angle bones:
- *   bones [U,24,3], pelvis [U,3] or NULL, rest_pose [24,3] (rest_pose_stride 0) or [U,24,3] (stride 72)
- *   -> l2ws [U,24,4,4], skts [U,24,4,4] = inverse(l2ws), rots [U,24,3,3] (local), kp [U,24,3]; any output may be NULL.
- * Rotation map = pytorch3d.transforms.axis_angle_to_matrix (restated; see anerf_fk.hip). */
-int anerf_fk_forward(const float* bones, const float* pelvis, const float* rest_pose, int64_t rest_pose_stride,
-                     int32_t n_poses, float* l2ws, float* skts, float* rots, float* kp, void* stream);
-/* Gradients w.r.t. the FK outputs (any may be NULL; only rows 0..2 of the 4x4 matrices are read) -> g_bones [U,24,3],
- * g_pelvis [U,3] (may be NULL).  With g_skts = the hot path's dskts this closes the pose-refinement loop. */
-int anerf_fk_backward(const float* bones, const float* pelvis, const float* rest_pose, int64_t rest_pose_stride,
-                      int32_t n_poses, const float* g_skts, const float* g_l2ws, const float* g_kp, const float* g_rots,
-                      float* g_bones, float* g_pelvis, void* stream);
+ * 482-566) for the SMPL tree (skeleton_utils.py:98-105):
+ *   bones [U,24,rot_dim]: rot_dim 3 = axis-angle (pytorch3d.transforms.axis_angle_to_matrix, restated; see anerf_fk.hip),
+ *                         rot_dim 6 = 6D rotation, the first two columns of R row-major (opt_rot6d: pose_opt.py:284-289,
+ *                         391-392; rot6d_to_rotmat skeleton_utils.py:420-436),
+ *   pelvis [U,3] or NULL, rest_pose [24,3] (rest_pose_stride 0) or [U,24,3] (stride 72)
+ *   -> l2ws [U,24,4,4], skts [U,24,4,4] = inverse(l2ws), rots [U,24,3,3] (local), kp [U,24,3]; any output may be NULL. */
+int anerf_fk_forward(const float* bones, int32_t rot_dim, const float* pelvis, const float* rest_pose,
+                     int64_t rest_pose_stride, int32_t n_poses, float* l2ws, float* skts, float* rots, float* kp,
+                     void* stream);
+/* Gradients w.r.t. the FK outputs (any may be NULL; only rows 0..2 of the 4x4 matrices are read) -> g_bones
+ * [U,24,rot_dim], g_pelvis [U,3] (may be NULL).  With g_skts = the hot path's dskts this closes the pose-refinement loop. */
+int anerf_fk_backward(const float* bones, int32_t rot_dim, const float* pelvis, const float* rest_pose,
+                      int64_t rest_pose_stride, int32_t n_poses, const float* g_skts, const float* g_l2ws,
+                      const float* g_kp, const float* g_rots, float* g_bones, float* g_pelvis, void* stream);
 
 /* ---- split-bf16 TRAINING forward: same contract as anerf_mlp_raw_train on the which=3 weight image.  Activations
  * are saved in fp32 exactly as the fp32 forward saves them (the backward kernels and the weight-gradient GEMM stay

@@ -354,12 +354,26 @@ def axis_angle_to_matrix(a):
     return o.reshape(a.shape[:-1] + (3, 3))
 
 
+def rot6d_to_rotmat(x):
+    """core/utils/skeleton_utils.py:420-436: 6D rotation (first two columns of R, row-major) -> R by Gram-Schmidt."""
+    sh = x.shape[:-1]
+    x = x.reshape(-1, 3, 2)
+    a1, a2 = x[:, :, 0], x[:, :, 1]
+    b1 = a1 / a1.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    v = a2 - (b1 * a2).sum(-1, keepdim=True) * b1
+    b2 = v / v.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    b3 = torch.stack([b1[:, 1] * b2[:, 2] - b1[:, 2] * b2[:, 1], b1[:, 2] * b2[:, 0] - b1[:, 0] * b2[:, 2],
+                      b1[:, 0] * b2[:, 1] - b1[:, 1] * b2[:, 0]], -1)
+    return torch.stack((b1, b2, b3), dim=-1).reshape(*sh, 3, 3)
+
+
 def fk_chain(bones, rest_pose, pelvis=None):
     """PoseOptLayer.calculate_kinematic (core/pose_opt.py:372-445) / get_kinematic_chain_T (:482-512), axis-angle bones
-    [U,24,3], rest_pose [24,3] or [U,24,3], pelvis [U,3] or None  ->  kp [U,24,3], skts, l2ws [U,24,4,4], rots [U,24,3,3].
+    [U,24,3] or 6D-rotation bones [U,24,6] (use_rot6d, :391-392), rest_pose [24,3] or [U,24,3], pelvis [U,3] or None
+    ->  kp [U,24,3], skts, l2ws [U,24,4,4], rots [U,24,3,3].
     The reference unrolls the SMPL tree by hand (unrolled_kinematic_chain :514-566); the parent loop is the same product."""
     U = bones.shape[0]
-    rots = axis_angle_to_matrix(bones)
+    rots = rot6d_to_rotmat(bones) if bones.shape[-1] == 6 else axis_angle_to_matrix(bones)
     rest = rest_pose.expand(U, 24, 3)
     bottom = torch.tensor([0., 0., 0., 1.], dtype=bones.dtype).expand(U, 1, 4)
     l2ws = []

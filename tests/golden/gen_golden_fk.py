@@ -66,6 +66,33 @@ def main():
     loss.backward()
     out.update({"b_idxs": torch.tensor(idxs), "b_kp": kp, "b_skts": skt, "b_l2ws": l2w, "b_rots": rot,
                 "b_gbones": layer.bones.grad, "b_gpelvis": layer.pelvis.grad})
+    # (c) opt_rot6d (mixamo / h36m / perfcap configs): 6D-rotation parameters, perturbed off the rotation manifold the
+    # way optimisation steps leave them (columns neither unit nor orthogonal), so Gram-Schmidt and its backward matter
+    rng = np.random.RandomState(22)
+    layer6 = po.PoseOptLayer(torch.tensor(pelvis)[:, None].expand(-1, 24, 3).clone(), torch.tensor(bones),
+                             torch.tensor(rest)[None], use_rot6d=True)
+    init6 = layer6.bones.detach().clone()
+    with torch.no_grad():
+        layer6.bones.add_(torch.tensor((rng.randn(*init6.shape) * 0.1).astype(np.float32)))
+    w_rots = rng.randn(5, 24, 3, 3).astype(np.float32)
+    kp, bone, skt, l2w, rot = layer6(idxs)
+    loss = (skt * torch.tensor(w["skts"][:5])).sum() + (kp * torch.tensor(w["kp"][:5])).sum() + \
+           (l2w * torch.tensor(w["l2ws"][:5])).sum() + (rot * torch.tensor(w_rots)).sum()
+    loss.backward()
+    out.update({"c_init6": init6, "c_bones6": layer6.bones.detach().clone(), "c_wrots": torch.tensor(w_rots), "c_kp": kp,
+                "c_bone": bone, "c_skts": skt, "c_l2ws": l2w, "c_rots": rot, "c_gbones": layer6.bones.grad,
+                "c_gpelvis": layer6.pelvis.grad})
+    # (d) multi-view (h36m): per-view pelvis + root rotation, body bones shared between the views of a pose; rot6d
+    kp_map, kp_uidxs = np.array([0, 0, 1, 1, 2, 2]), np.array([0, 2, 4])
+    layerm = po.PoseOptLayer(torch.tensor(pelvis)[:, None].expand(-1, 24, 3).clone(), torch.tensor(bones),
+                             torch.tensor(rest)[None], use_rot6d=True, kp_map=kp_map, kp_uidxs=kp_uidxs)
+    midxs = np.array([5, 0, 1, 4, 4])
+    kp, bone, skt, l2w, rot = layerm(midxs)
+    loss = (skt * torch.tensor(w["skts"][:5])).sum() + (kp * torch.tensor(w["kp"][:5])).sum()
+    loss.backward()
+    out.update({"d_kp_map": torch.tensor(kp_map), "d_kp_uidxs": torch.tensor(kp_uidxs), "d_idxs": torch.tensor(midxs),
+                "d_kp": kp, "d_bone": bone, "d_skts": skt, "d_groot": layerm.root_bones.grad, "d_gbones": layerm.bones.grad,
+                "d_gpelvis": layerm.pelvis.grad})
     np.savez_compressed(os.path.join(HERE, "fk.npz"), **{k: v.detach().numpy() for k, v in out.items()})
     print({k: tuple(v.shape) for k, v in out.items()})
 
