@@ -191,7 +191,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": name, "rays_per_step": n_total, "samples_per_ray": S, "n_importance": Ni,
                        "parallelism": f"ray-sharded x{world}", "weights": "numpy-seeded random init (alpha bias +1)"},
-            "roofline": {"bound": "mfma", "kernel": "k_mlp_fwd_b3<7,4,0>" if b3 else "k_mlp_fwd<7,4,0,false,false>",
+            "roofline": {"bound": "mfma", "kernel": "k_mlp_fwd_b3<7,4,0>" if b3 else "k_mlp_fwd<7,4,0,false,false,0>",
                          "achieved": (3 if b3 else 1) * achieved / 1e12, "algorithmic": achieved / 1e12,
                          "peak": peak / 1e12, "unit": "TFLOP/s", "frac": (3 if b3 else 1) * achieved / peak,
                          "avg_launch_ms": mlp_ms, "flop_per_launch": flops_launch, "traffic": None},
