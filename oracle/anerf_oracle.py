@@ -12,7 +12,6 @@ as tests/golden/*.npz; tests/test_oracle_golden.py checks this file against thos
 
 All tensors fp32, differentiable (autograd gives the gradient oracle for the backward kernels).
 """
-import math
 import numpy as np
 import torch
 import torch.nn.functional as F

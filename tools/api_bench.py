@@ -1,4 +1,4 @@
-import importlib, sys, time, numpy as np, torch
+import importlib, sys, time, torch
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 synth = importlib.import_module("a-nerf_amd.synth"); render_mod = importlib.import_module("a-nerf_amd.render")
 import test_hip_backward as T

@@ -1,6 +1,6 @@
 """Debug aid: where do bf16x3 and fp32 logits differ on a small golden case? (run on the GPU box)"""
 import os, sys
-import numpy as np, torch
+import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import test_hip_parity as T

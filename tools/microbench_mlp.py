@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time the fused MLP kernel alone: fused-encode path vs pre-encoded path (ANERF_LIB selects an ablation build)."""
-import importlib, os, sys, time
+import importlib, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 synth = importlib.import_module("a-nerf_amd.synth"); ops = importlib.import_module("a-nerf_amd.ops")
