@@ -50,6 +50,15 @@ class AnerfNetGrads(C.Structure):
     _fields_ = [("w", C.c_void_p * 12), ("b", C.c_void_p * 12)]
 
 
+class AnerfBackwardIO(C.Structure):
+    _fields_ = [("g_rgb", C.c_void_p), ("g_disp", C.c_void_p), ("g_acc", C.c_void_p), ("g_alpha", C.c_void_p),
+                ("g_rgb0", C.c_void_p), ("g_disp0", C.c_void_p), ("g_acc0", C.c_void_p), ("g_alpha0", C.c_void_p),
+                ("packed_t_c", C.c_void_p), ("packed_t_f", C.c_void_p), ("packed_i_c", C.c_void_p), ("packed_i_f", C.c_void_p),
+                ("perm_x", C.c_void_p), ("perm_u", C.c_void_p),
+                ("grads_c", AnerfNetGrads), ("grads_f", AnerfNetGrads),
+                ("g_skts", C.c_void_p), ("g_codes_c", C.c_void_p), ("g_codes_f", C.c_void_p), ("accumulate", C.c_int32)]
+
+
 class AnerfTrainLayout(C.Structure):
     _fields_ = [("p_pad", C.c_int64), ("x_width", C.c_int32), ("u_width", C.c_int32), ("gemm_chunks", C.c_int32),
                 ("gemm_ws_floats", C.c_int64)]
@@ -124,6 +133,11 @@ SIGNATURES = {
     "anerf_loss": (C.c_int, [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float] + [C.c_void_p] * 7),
     "anerf_fk_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 5),
     "anerf_fk_backward": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 7),
+    "anerf_train_workspace_size": (C.c_int64, [C.POINTER(AnerfConfig), C.c_int32, C.c_int32, C.c_int32]),
+    "anerf_backward_scratch_size": (C.c_int64, [C.POINTER(AnerfConfig), C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "anerf_train_forward": (C.c_int, [C.POINTER(AnerfConfig), C.POINTER(AnerfForwardIO), C.c_void_p, C.c_int64, C.c_void_p]),
+    "anerf_backward": (C.c_int, [C.POINTER(AnerfConfig), C.POINTER(AnerfForwardIO), C.POINTER(AnerfBackwardIO), C.c_void_p,
+                                 C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "anerf_adam_blocks": (C.c_int, [C.c_int64]),
     "anerf_adam_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
                                   C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -1,10 +1,14 @@
 """Training path: the same kernel pipeline as pipeline.py, bridged into torch.autograd so that the reference's
 trainer (`loss.backward()` -> Adam, core/trainer.py:451-483) drives it unchanged.
 
-Two autograd Functions wrap HIP launches only (no torch math inside):
+Two-network configurations run as ONE autograd node, one C call each way:
+  _RenderRaysFn parameters (+ skts, frame codes) -> the output dict      fwd: anerf_train_forward   bwd: anerf_backward
+single_net (one shared network evaluated twice + a gather-merge of the raw outputs) composes the staged nodes, which wrap
+HIP launches only (no torch math inside):
   _MlpRawFn     parameters -> raw [N,S,4]   fwd: k_mlp_fwd<TRAIN> (saves activations)
                                             bwd: k_mlp_bwd + grouped k_gemm_tn/k_reduce_dw (weight gradients)
   _CompositeFn  raw -> rgb/disp/acc/alpha/weights      fwd: k_composite   bwd: k_composite_bwd
+Both routes enqueue the same kernels in the same order and give bit-identical results (tests/test_hip_backward.py).
 """
 import ctypes as C
 
@@ -155,6 +159,75 @@ class _CompositeFn(torch.autograd.Function):
         return None, draw
 
 
+_OUT_KEYS = ("rgb_map", "disp_map", "acc_map", "alpha", "rgb0", "disp0", "acc0", "alpha0")
+
+
+class _RenderRaysFn(torch.autograd.Function):
+    """RayCaster.render_rays (raycasters.py:361-474) as one autograd node over anerf_train_forward / anerf_backward."""
+
+    @staticmethod
+    def forward(ctx, meta, skts, codes_c, codes_f, *params):
+        kw = meta["kw"]
+        out, state = ops.train_forward(
+            kw["cfg"], meta["net_c"], meta["net_f"], kw["ray_batch"], skts, kw["cyls"], kw["n_samples"], kw["n_importance"],
+            kw["tau_v"], kw["tau_d"], kw["cut_v"], kw["cut_d"], meta["cam"], codes_c, codes_f, kw["t_rand"], kw["u_imp"],
+            kw["noise"], kw["noise_fine"], kw["lindisp"], meta["precision"])
+        ctx.state, ctx.meta = state, meta
+        ctx.keys = _OUT_KEYS if kw["n_importance"] > 0 else _OUT_KEYS[:4]
+        ctx.shapes = [tuple(p.shape) for p in params]
+        ctx.set_materialize_grads(False)
+        return tuple(out[k] for k in ctx.keys)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        meta, state = ctx.meta, ctx.state
+        if state is None:
+            raise RuntimeError("render_rays: backward called twice (the saved activations are released after the first)")
+        b3 = meta["precision"] == "bf16x3"
+        hier = len(ctx.keys) == 8
+        want_skts, want_cc, want_cf = ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.needs_input_grad[3] and hier
+        if want_skts and state["io"].skt_ray_stride == 0:
+            raise NotImplementedError("skts.requires_grad needs per-ray skts [N,24,4,4]")
+        want_in = want_skts or want_cc or want_cf
+        pi = meta["packed_i"]() if want_in else (None, None)
+        # Parameters whose .grad is a view of FusedAdam's flat gradient bucket (it marks them): the reduction kernel adds
+        # into the bucket directly -- what AccumulateGrad would otherwise do with 48 extra launches per step -- and this
+        # node reports no parameter gradients to autograd.  Anything else (torch optimisers, torch.autograd.grad) gets
+        # fresh gradient tensors through autograd as usual.
+        dev = state["ws"].device
+        into = [p.grad for p in meta["params"]]
+        direct = all(getattr(p, "_anerf_flat_grad", False) and p.requires_grad for p in meta["params"]) and \
+            all(t is not None and t.dtype == torch.float32 and t.is_contiguous() and t.device == dev for t in into)
+        grads_c, grads_f, g_skts, g_cc, g_cf = ops.backward(
+            state, dict(zip(ctx.keys, gs)), meta["packed_t_c"], meta["packed_t_f"], perm_tables(meta["kw"]["cfg"], dev, b3=b3),
+            ctx.shapes[:24], ctx.shapes[24:], pi[0], pi[1], want_skts, want_cc, want_cf,
+            accumulate_into=(into[:24], into[24:]) if direct else None)
+        ctx.state = None
+        if direct:
+            return (None, g_skts, g_cc, g_cf) + (None,) * len(ctx.shapes)
+        if not hier:
+            grads_f = [None] * (len(ctx.shapes) - 24)
+        return (None, g_skts, g_cc, g_cf, *grads_c, *grads_f)
+
+
+def _render_rays_one_node(caster, kw, prec):
+    net_c, net_f = caster.network, caster.network_fine
+    hier = kw["n_importance"] > 0
+    b3 = prec == "bf16x3"
+    cam = kw["cam_idx"].contiguous() if net_c.use_framecode else None
+    codes_c = net_c.framecodes.codes.weight if net_c.use_framecode else None
+    codes_f = net_f.framecodes.codes.weight if (hier and net_f.use_framecode) else None
+    nets = [net_c] + ([net_f] if hier else [])
+    meta = dict(kw=kw, precision=prec, cam=cam,
+                net_c=net_c.packed(3 if b3 else 0), net_f=net_f.packed(3 if b3 else 0) if hier else None,
+                packed_t_c=net_c.packed(4 if b3 else 1)[0], packed_t_f=net_f.packed(4 if b3 else 1)[0] if hier else None,
+                packed_i=lambda: tuple(n.packed(5 if b3 else 2)[0] for n in nets) + ((None,) if not hier else ()))
+    params = [p for n in nets for p in _net_params(n)]
+    meta["params"] = params
+    out = _RenderRaysFn.apply(meta, kw["skts"].contiguous(), codes_c, codes_f, *params)
+    return dict(zip(_OUT_KEYS, out))
+
+
 def _net_params(net):
     P = net.named_path_params()
     out = []
@@ -171,6 +244,8 @@ def render_rays_train(caster, kw):
     prec = getattr(caster, "train_precision", "fp32")
     if prec not in ("fp32", "bf16x3"):
         raise ValueError(f"train_precision must be 'fp32' or 'bf16x3', got {prec!r}")
+    if not kw["single_net"] and getattr(caster, "train_route", "one_call") == "one_call":
+        return _render_rays_one_node(caster, kw, prec)
     skts_c = skts.contiguous()
     with torch.no_grad():
         nf_raw, stats = ops.ray_bounds(rays, cyls)

@@ -62,7 +62,7 @@ int mlp_bwd_in_entry(const float* packed_i, const float* dz, const float* dzv, f
                      long long Ppad, int nstages, int uw, hipStream_t st);
 int launch_encode_bwd(int ld, const float* dx, const float* du, int uw, const float* rays, int ray_stride, const float* z,
                       const float* skts, long long skt_stride, float tau_v, float tau_d, const float* cut_v,
-                      const float* cut_d, int n, int S, float* dY, float* dQ, float* dskts, hipStream_t st);
+                      const float* cut_d, int n, int S, float* dY, float* dQ, float* dskts, bool accumulate, hipStream_t st);
 int launch_code_reduce(const float* du, int uw, const float* cam, int n, int S, int n_codes, float* dcodes, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------------
@@ -588,7 +588,8 @@ int anerf_mlp_backward(const AnerfConfig* cfg, const float* packed_t, const floa
 
 static int weight_grads_impl(const AnerfConfig* cfg, const AnerfSaved* sv, const float* dz, const float* df, const float* dzv,
                              const float* draw, int64_t n_points, const int32_t* perm_x, const int32_t* perm_u,
-                             const AnerfNetGrads* gr, float* workspace, int64_t ws_floats, bool b3, void* stream) {
+                             const AnerfNetGrads* gr, float* workspace, int64_t ws_floats, bool b3, bool accumulate,
+                             void* stream) {
   AnerfTrainLayout T;
   const int rc = anerf_train_layout(cfg, n_points, &T);
   if (rc) return rc;
@@ -647,6 +648,7 @@ static int weight_grads_impl(const AnerfConfig* cfg, const AnerfSaved* sv, const
   add(draw, 4, 4, sv->g, 128, 128, gr->w[11], 128, 0, nullptr, 0, 3, gr->b[11], 0, 3);
   add(draw, 4, 4, H(7), 256, 256, gr->w[8], 256, 0, nullptr, 3, 1, gr->b[8], 3, 1);
   G.nprob = np;
+  G.accumulate = accumulate ? 1 : 0;
   G.total_out = out_pos;
   if (ws_pos > ws_floats || ws_pos >= (1LL << 31)) return set_error(ANERF_E_WORKSPACE, "weight_grads: workspace accounting");
   // ---- group the wave tiles into blocks of 4 that share LDS operand tiles
@@ -706,13 +708,13 @@ int anerf_mlp_backward_b3(const AnerfConfig* cfg, const float* packed_t, const f
 int anerf_weight_grads(const AnerfConfig* cfg, const AnerfSaved* sv, const float* dz, const float* df, const float* dzv,
                        const float* draw, int64_t n_points, const int32_t* perm_x, const int32_t* perm_u,
                        const AnerfNetGrads* gr, float* workspace, int64_t ws_floats, void* stream) {
-  return weight_grads_impl(cfg, sv, dz, df, dzv, draw, n_points, perm_x, perm_u, gr, workspace, ws_floats, false, stream);
+  return weight_grads_impl(cfg, sv, dz, df, dzv, draw, n_points, perm_x, perm_u, gr, workspace, ws_floats, false, false, stream);
 }
 
 int anerf_weight_grads_b3(const AnerfConfig* cfg, const AnerfSaved* sv, const float* dz, const float* df, const float* dzv,
                           const float* draw, int64_t n_points, const int32_t* perm_x, const int32_t* perm_u,
                           const AnerfNetGrads* gr, float* workspace, int64_t ws_floats, void* stream) {
-  return weight_grads_impl(cfg, sv, dz, df, dzv, draw, n_points, perm_x, perm_u, gr, workspace, ws_floats, true, stream);
+  return weight_grads_impl(cfg, sv, dz, df, dzv, draw, n_points, perm_x, perm_u, gr, workspace, ws_floats, true, false, stream);
 }
 
 int anerf_input_grads(const AnerfConfig* cfg, const float* packed_i, const float* dz, const float* dzv, int64_t p_pad,
@@ -745,7 +747,7 @@ int anerf_encode_backward(const AnerfConfig* cfg, const float* dx, const float* 
   if (skt_ray_stride != 384) return set_error(ANERF_E_SHAPE, "encode_backward: skts must be per ray (stride 384)");
   if (n_rays == 0) return ANERF_OK;
   return launch_encode_bwd(cfg->multires_views, dx, du, u_width(cfg), rays, ray_stride, z_vals, skts, skt_ray_stride, tau_v,
-                           tau_d, cutoff_v, cutoff_d, n_rays, n_samples, dy_ws, dq_ws, dskts, (hipStream_t)stream);
+                           tau_d, cutoff_v, cutoff_d, n_rays, n_samples, dy_ws, dq_ws, dskts, false, (hipStream_t)stream);
 }
 
 int anerf_code_grads(const AnerfConfig* cfg, const float* du, const float* cam_idx, int32_t n_rays, int32_t n_samples,
@@ -820,31 +822,80 @@ int64_t anerf_workspace_size(const AnerfConfig* cfg, int32_t n_rays, int32_t n_s
   return fwd_ws(n_rays, n_samples, n_importance).total;
 }
 
-int anerf_forward(const AnerfConfig* cfg, const AnerfForwardIO* io, void* workspace, int64_t ws_bytes, void* stream) {
+namespace {
+// saved-activation planes of one network pass inside the training workspace
+struct SavedWs { int64_t h, f, g, x, u, bytes, p_pad; };
+SavedWs saved_ws(const AnerfConfig* cfg, int64_t n_points) {
+  AnerfTrainLayout T;
+  anerf_train_layout(cfg, n_points > 0 ? n_points : 1, &T);
+  SavedWs s;
+  int64_t o = 0;
+  const int64_t pp = T.p_pad;
+  s.p_pad = pp;
+  s.h = o; o += 8 * pp * 256 * 4;
+  s.f = o; o += pp * 256 * 4;
+  s.g = o; o += pp * 128 * 4;
+  s.x = o; o += pp * T.x_width * 4;
+  s.u = o; o += pp * T.u_width * 4;
+  s.bytes = o;
+  return s;
+}
+AnerfSaved saved_at(char* base, const SavedWs& s) {
+  AnerfSaved a;
+  a.h = reinterpret_cast<float*>(base + s.h);
+  a.f = reinterpret_cast<float*>(base + s.f);
+  a.g = reinterpret_cast<float*>(base + s.g);
+  a.x = reinterpret_cast<float*>(base + s.x);
+  a.u = reinterpret_cast<float*>(base + s.u);
+  a.p_pad = s.p_pad;
+  return a;
+}
+// rows [P, p_pad) of `planes` row-major [p_pad][width] planes := 0 (the weight-gradient GEMM reads them)
+int zero_pad_rows(float* base, int planes, int64_t p_pad, int64_t P, int width, hipStream_t st) {
+  if (p_pad <= P) return ANERF_OK;
+  const hipError_t e = hipMemset2DAsync(base + P * width, (size_t)p_pad * width * 4, 0, (size_t)(p_pad - P) * width * 4, planes, st);
+  return e == hipSuccess ? ANERF_OK : set_error(ANERF_E_LAUNCH, "zero_pad_rows: hipMemset2DAsync failed");
+}
+int zero_saved_pads(const AnerfConfig* cfg, const AnerfSaved& a, int64_t P, hipStream_t st) {
+  int rc = zero_pad_rows(a.h, 8, a.p_pad, P, 256, st);
+  if (!rc) rc = zero_pad_rows(a.f, 1, a.p_pad, P, 256, st);
+  if (!rc) rc = zero_pad_rows(a.g, 1, a.p_pad, P, 128, st);
+  if (!rc) rc = zero_pad_rows(a.x, 1, a.p_pad, P, dim_x(cfg), st);
+  if (!rc) rc = zero_pad_rows(a.u, 1, a.p_pad, P, u_width(cfg), st);
+  return rc;
+}
+
+int forward_check(const AnerfConfig* cfg, const AnerfForwardIO* io, const char* who) {
   if (!config_ok(cfg)) return set_error(ANERF_E_CONFIG, "unsupported AnerfConfig");
   if (!io) return set_error(ANERF_E_NULL, "forward: io is NULL");
-  const int n = io->n_rays, S = io->n_samples, Ni = io->n_importance;
-  if (n < 0 || Ni < 0) return set_error(ANERF_E_SHAPE, "forward: negative sizes");
-  if (n == 0) return ANERF_OK;
+  if (io->n_rays < 0 || io->n_importance < 0) return set_error(ANERF_E_SHAPE, "forward: negative sizes");
   if (io->precision != 0 && io->precision != 1) return set_error(ANERF_E_CONFIG, "forward: precision must be 0 (fp32) or 1 (bf16x3)");
-  const FwdWs w = fwd_ws(n, S, Ni);
-  if (!workspace || ws_bytes < w.total || ((uintptr_t)workspace & 15)) return set_error(ANERF_E_WORKSPACE, "forward: workspace");
+  (void)who;
+  return ANERF_OK;
+}
+
+// RayCaster.render_rays for one caster call; sv_c / sv_f != NULL selects the training kernels (activations saved)
+int forward_impl(const AnerfConfig* cfg, const AnerfForwardIO* io, char* ws, const FwdWs& w, const AnerfSaved* sv_c,
+                 const AnerfSaved* sv_f, void* stream) {
+  const int n = io->n_rays, S = io->n_samples, Ni = io->n_importance;
   if (!io->rgb_map || !io->disp_map || !io->acc_map || !io->alpha) return set_error(ANERF_E_NULL, "forward: output maps");
   if (Ni > 0 && !io->single_net && (!io->packed_f || !io->aux_f)) return set_error(ANERF_E_NULL, "forward: fine network image");
-  char* ws = static_cast<char*>(workspace);
   auto F = [&](int64_t off) { return reinterpret_cast<float*>(ws + off); };
-  auto mlp = [&](const float* packed, const float* aux, const float* codes, const float* zz, int ns, float* raw) {
-    return io->precision == 1
-               ? anerf_mlp_raw_b3(cfg, packed, aux, io->rays, io->ray_stride, zz, io->skts, io->skt_ray_stride, io->cam_idx, codes,
-                                  io->n_codes, io->tau_v, io->tau_d, io->cutoff_v, io->cutoff_d, n, ns, raw, stream)
-               : anerf_mlp_raw(cfg, packed, aux, io->rays, io->ray_stride, zz, io->skts, io->skt_ray_stride, io->cam_idx, codes,
-                               io->n_codes, io->tau_v, io->tau_d, io->cutoff_v, io->cutoff_d, n, ns, raw, stream);
+  auto mlp = [&](const float* packed, const float* aux, const float* codes, const float* zz, int ns, float* raw,
+                 const AnerfSaved* sv) {
+    if (sv)
+      return (io->precision == 1 ? anerf_mlp_raw_train_b3 : anerf_mlp_raw_train)(
+          cfg, packed, aux, io->rays, io->ray_stride, zz, io->skts, io->skt_ray_stride, io->cam_idx, codes, io->n_codes,
+          io->tau_v, io->tau_d, io->cutoff_v, io->cutoff_d, n, ns, raw, sv, stream);
+    return (io->precision == 1 ? anerf_mlp_raw_b3 : anerf_mlp_raw)(
+        cfg, packed, aux, io->rays, io->ray_stride, zz, io->skts, io->skt_ray_stride, io->cam_idx, codes, io->n_codes,
+        io->tau_v, io->tau_d, io->cutoff_v, io->cutoff_d, n, ns, raw, stream);
   };
   int rc = anerf_ray_bounds(io->rays, io->ray_stride, io->cyls, n, F(w.near_far), F(w.stats), stream);
   if (rc) return rc;
   rc = anerf_coarse_z(F(w.near_far), F(w.stats), io->rays, io->ray_stride, n, S, io->t_rand, io->lindisp, F(w.z), nullptr, stream);
   if (rc) return rc;
-  rc = mlp(io->packed_c, io->aux_c, io->codes_c, F(w.z), S, F(w.raw));
+  rc = mlp(io->packed_c, io->aux_c, io->codes_c, F(w.z), S, F(w.raw), sv_c);
   if (rc) return rc;
   const bool hier = Ni > 0;
   float* alpha_c = hier ? io->alpha0 : io->alpha;
@@ -857,15 +908,165 @@ int anerf_forward(const AnerfConfig* cfg, const AnerfForwardIO* io, void* worksp
                         reinterpret_cast<int64_t*>(ws + w.idx), stream);
   if (rc) return rc;
   if (io->single_net) {
-    rc = mlp(io->packed_c, io->aux_c, io->codes_c, F(w.zs), Ni, F(w.raw_is));
+    rc = mlp(io->packed_c, io->aux_c, io->codes_c, F(w.zs), Ni, F(w.raw_is), nullptr);
     if (rc) return rc;
     rc = launch_gather_raw(F(w.raw), F(w.raw_is), reinterpret_cast<const long long*>(ws + w.idx), n, S, Ni, F(w.raw_f), (hipStream_t)stream);
   } else {
-    rc = mlp(io->packed_f, io->aux_f, io->codes_f, F(w.zm), S + Ni, F(w.raw_f));
+    rc = mlp(io->packed_f, io->aux_f, io->codes_f, F(w.zm), S + Ni, F(w.raw_f), sv_f);
   }
   if (rc) return rc;
   return anerf_composite(cfg, F(w.raw_f), F(w.zm), io->rays, io->ray_stride, io->noise_fine, n, S + Ni, io->rgb_map, io->disp_map,
                          io->acc_map, F(w.weights_f), io->alpha, nullptr, stream);
+}
+
+// training workspace = forward workspace + saved planes of the coarse pass (+ of the fine pass)
+struct TrainWs { FwdWs fwd; SavedWs sc, sf; int64_t off_c, off_f, total; };
+TrainWs train_ws(const AnerfConfig* cfg, int64_t n, int64_t S, int64_t Ni) {
+  TrainWs t;
+  t.fwd = fwd_ws(n, S, Ni);
+  t.sc = saved_ws(cfg, n * S);
+  t.off_c = t.fwd.total;
+  t.off_f = t.off_c + t.sc.bytes;
+  t.sf = saved_ws(cfg, Ni > 0 ? n * (S + Ni) : 0);
+  t.total = t.off_f + (Ni > 0 ? t.sf.bytes : 0);
+  return t;
+}
+
+// backward scratch of ONE network pass over P points (reused by the second pass)
+struct BwdWs { int64_t draw, dz, df, dzv, gemm, dx, du, dy, dq, total; };
+BwdWs bwd_ws(const AnerfConfig* cfg, int64_t P, bool input_grads) {
+  auto up = [](int64_t b) { return (b + 255) / 256 * 256; };
+  AnerfTrainLayout T;
+  anerf_train_layout(cfg, P > 0 ? P : 1, &T);
+  const int64_t pp = T.p_pad;
+  BwdWs b;
+  int64_t o = 0;
+  b.draw = o; o += up(pp * 16);
+  b.dz = o; o += up(8 * pp * 256 * 4);
+  b.df = o; o += up(pp * 256 * 4);
+  b.dzv = o; o += up(pp * 128 * 4);
+  b.gemm = o; o += up(T.gemm_ws_floats * 4);
+  b.dx = b.du = b.dy = b.dq = o;
+  if (input_grads) {
+    b.dx = o; o += up(pp * T.x_width * 4);
+    b.du = o; o += up(pp * T.u_width * 4);
+    b.dy = o; o += up(P * 72 * 4);
+    b.dq = o; o += up(P * 72 * 4);
+  }
+  b.total = o;
+  return b;
+}
+}  // namespace
+
+int anerf_forward(const AnerfConfig* cfg, const AnerfForwardIO* io, void* workspace, int64_t ws_bytes, void* stream) {
+  const int rc = forward_check(cfg, io, "forward");
+  if (rc) return rc;
+  if (io->n_rays == 0) return ANERF_OK;
+  const FwdWs w = fwd_ws(io->n_rays, io->n_samples, io->n_importance);
+  if (!workspace || ws_bytes < w.total || ((uintptr_t)workspace & 15)) return set_error(ANERF_E_WORKSPACE, "forward: workspace");
+  return forward_impl(cfg, io, static_cast<char*>(workspace), w, nullptr, nullptr, stream);
+}
+
+int64_t anerf_train_workspace_size(const AnerfConfig* cfg, int32_t n_rays, int32_t n_samples, int32_t n_importance) {
+  if (!config_ok(cfg) || n_rays < 0 || n_samples < 1 || n_importance < 0) return set_error(ANERF_E_SHAPE, "train_workspace_size: bad sizes");
+  return train_ws(cfg, n_rays, n_samples, n_importance).total;
+}
+
+int64_t anerf_backward_scratch_size(const AnerfConfig* cfg, int32_t n_rays, int32_t n_samples, int32_t n_importance,
+                                    int32_t input_grads) {
+  if (!config_ok(cfg) || n_rays < 0 || n_samples < 1 || n_importance < 0) return set_error(ANERF_E_SHAPE, "backward_scratch_size: bad sizes");
+  return bwd_ws(cfg, (int64_t)n_rays * (n_samples + n_importance), input_grads != 0).total;
+}
+
+int anerf_train_forward(const AnerfConfig* cfg, const AnerfForwardIO* io, void* workspace, int64_t ws_bytes, void* stream) {
+  int rc = forward_check(cfg, io, "train_forward");
+  if (rc) return rc;
+  if (io->single_net) return set_error(ANERF_E_CONFIG, "train_forward: single_net trains through the staged entry points");
+  if (io->n_rays == 0) return ANERF_OK;
+  const int64_t n = io->n_rays, S = io->n_samples, Ni = io->n_importance;
+  const TrainWs t = train_ws(cfg, n, S, Ni);
+  if (!workspace || ws_bytes < t.total || ((uintptr_t)workspace & 15)) return set_error(ANERF_E_WORKSPACE, "train_forward: workspace");
+  char* ws = static_cast<char*>(workspace);
+  const AnerfSaved sc = saved_at(ws + t.off_c, t.sc), sf = saved_at(ws + t.off_f, t.sf);
+  rc = zero_saved_pads(cfg, sc, n * S, (hipStream_t)stream);
+  if (!rc && Ni > 0) rc = zero_saved_pads(cfg, sf, n * (S + Ni), (hipStream_t)stream);
+  if (rc) return rc;
+  return forward_impl(cfg, io, ws, t.fwd, &sc, Ni > 0 ? &sf : nullptr, stream);
+}
+
+int anerf_backward(const AnerfConfig* cfg, const AnerfForwardIO* io, const AnerfBackwardIO* b, void* workspace,
+                   int64_t ws_bytes, void* scratch, int64_t scratch_bytes, void* stream) {
+  int rc = forward_check(cfg, io, "backward");
+  if (rc) return rc;
+  if (!b) return set_error(ANERF_E_NULL, "backward: AnerfBackwardIO is NULL");
+  if (io->single_net) return set_error(ANERF_E_CONFIG, "backward: single_net trains through the staged entry points");
+  if (io->n_rays == 0) return ANERF_OK;
+  const int64_t n = io->n_rays, S = io->n_samples, Ni = io->n_importance;
+  const bool hier = Ni > 0, b3 = io->precision == 1;
+  const bool want_in = b->g_skts || b->g_codes_c || b->g_codes_f;
+  const TrainWs t = train_ws(cfg, n, S, Ni);
+  if (!workspace || ws_bytes < t.total || ((uintptr_t)workspace & 15)) return set_error(ANERF_E_WORKSPACE, "backward: workspace");
+  if (!scratch || ((uintptr_t)scratch & 15) || scratch_bytes < bwd_ws(cfg, n * (S + Ni), want_in).total)
+    return set_error(ANERF_E_WORKSPACE, "backward: scratch");
+  if (!b->g_rgb || !b->perm_x || !b->perm_u || !b->packed_t_c || (hier && (!b->packed_t_f || !b->g_rgb0)))
+    return set_error(ANERF_E_NULL, "backward: NULL pointer");
+  if (want_in && (!b->packed_i_c || (hier && !b->packed_i_f))) return set_error(ANERF_E_NULL, "backward: input-gradient weight image");
+  if (b->g_skts && io->skt_ray_stride != 384) return set_error(ANERF_E_SHAPE, "backward: g_skts needs per-ray skts (stride 384)");
+  char* ws = static_cast<char*>(workspace);
+  char* sb = static_cast<char*>(scratch);
+  hipStream_t st = (hipStream_t)stream;
+  auto F = [&](int64_t off) { return reinterpret_cast<float*>(ws + off); };
+  const int uw = u_width(cfg);
+  if (b->g_skts && hipMemsetAsync(b->g_skts, 0, (size_t)n * 24 * 16 * 4, st) != hipSuccess)
+    return set_error(ANERF_E_LAUNCH, "backward: hipMemsetAsync");
+  bool skts_written = false;
+  // one network pass: composite backward -> dz chain -> weight gradients (-> input gradients -> pose / code gradients)
+  auto pass = [&](const AnerfSaved& sv, const float* raw, const float* zz, int ns, const float* noise, const float* g_rgb,
+                  const float* g_acc, const float* g_disp, const float* g_alpha, const float* packed_t, const float* aux,
+                  const float* packed_i, const AnerfNetGrads* gr, float* g_codes) {
+    const int64_t P = n * ns;
+    const BwdWs w = bwd_ws(cfg, P, want_in);
+    auto B = [&](int64_t off) { return reinterpret_cast<float*>(sb + off); };
+    const int64_t pp = sv.p_pad;
+    int r = zero_pad_rows(B(w.draw), 1, pp, P, 4, st);
+    if (!r) r = zero_pad_rows(B(w.dz), 8, pp, P, 256, st);
+    if (!r) r = zero_pad_rows(B(w.df), 1, pp, P, 256, st);
+    if (!r) r = zero_pad_rows(B(w.dzv), 1, pp, P, 128, st);
+    if (r) return r;
+    r = anerf_composite_backward(cfg, raw, zz, io->rays, io->ray_stride, noise, (int)n, ns, g_rgb, g_acc, g_disp, g_alpha, nullptr,
+                                 B(w.draw), stream);
+    if (r) return r;
+    r = (b3 ? anerf_mlp_backward_b3 : anerf_mlp_backward)(cfg, packed_t, aux, B(w.draw), &sv, B(w.dz), B(w.df), B(w.dzv), P, stream);
+    if (r) return r;
+    AnerfTrainLayout T;
+    anerf_train_layout(cfg, P, &T);
+    r = weight_grads_impl(cfg, &sv, B(w.dz), B(w.df), B(w.dzv), B(w.draw), P, b->perm_x, b->perm_u, gr, B(w.gemm),
+                          T.gemm_ws_floats, b3, b->accumulate != 0, stream);
+    if (r || !want_in) return r;
+    r = (b3 ? anerf_input_grads_b3 : anerf_input_grads)(cfg, packed_i, B(w.dz), B(w.dzv), pp, P, B(w.dx), B(w.du), stream);
+    if (r) return r;
+    if (b->g_skts) {
+      r = launch_encode_bwd(cfg->multires_views, B(w.dx), B(w.du), uw, io->rays, io->ray_stride, zz, io->skts, io->skt_ray_stride,
+                            io->tau_v, io->tau_d, io->cutoff_v, io->cutoff_d, (int)n, ns, B(w.dy), B(w.dq), b->g_skts, skts_written, st);
+      if (r) return r;
+      skts_written = true;
+    }
+    if (g_codes) {
+      if (hipMemsetAsync(g_codes, 0, (size_t)io->n_codes * 16 * 4, st) != hipSuccess) return set_error(ANERF_E_LAUNCH, "backward: hipMemsetAsync");
+      r = anerf_code_grads(cfg, B(w.du), io->cam_idx, (int)n, ns, g_codes, io->n_codes, stream);
+    }
+    return r;
+  };
+  if (hier) {   // the fine pass first, as autograd runs it
+    const AnerfSaved sf = saved_at(ws + t.off_f, t.sf);
+    rc = pass(sf, F(t.fwd.raw_f), F(t.fwd.zm), (int)(S + Ni), io->noise_fine, b->g_rgb, b->g_acc, b->g_disp, b->g_alpha,
+              b->packed_t_f, io->aux_f, b->packed_i_f, &b->grads_f, b->g_codes_f);
+    if (rc) return rc;
+  }
+  const AnerfSaved sc = saved_at(ws + t.off_c, t.sc);
+  return pass(sc, F(t.fwd.raw), F(t.fwd.z), (int)S, io->noise, hier ? b->g_rgb0 : b->g_rgb, hier ? b->g_acc0 : b->g_acc,
+              hier ? b->g_disp0 : b->g_disp, hier ? b->g_alpha0 : b->g_alpha, b->packed_t_c, io->aux_c, b->packed_i_c, &b->grads_c,
+              b->g_codes_c);
 }
 
 }  // extern "C"

@@ -20,6 +20,7 @@ struct GemmProb {
 struct GemmBatch {
   GemmProb p[16];
   int nprob;
+  int accumulate;        // 0: gradients written; 1: added to what dst holds (p.grad accumulated in place)
   long long total_out;
 };
 

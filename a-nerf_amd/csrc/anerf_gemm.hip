@@ -388,14 +388,18 @@ __global__ void k_reduce_dw(const GemmBatch G, const float* __restrict__ ws) {
     for (int c = 0; c < pr.chunks; ++c) s += src[(long long)c * mn];
     if (mrow >= pr.m_first && mrow < pr.m_first + pr.m_count) {
       const int col = pr.colmap ? pr.colmap[n] : n;
-      pr.dst[(long long)(mrow - pr.m_first) * pr.dst_ld + pr.dst_col0 + col] = s;
+      float* d = pr.dst + (long long)(mrow - pr.m_first) * pr.dst_ld + pr.dst_col0 + col;
+      *d = G.accumulate ? *d + s : s;
     }
   } else {
     const int mrow = (int)(e - mn);
     const float* src = ws + pr.bias_off + mrow;
     float s = 0.f;
     for (int c = 0; c < pr.chunks; ++c) s += src[(long long)c * pr.M];
-    if (mrow >= pr.bm_first && mrow < pr.bm_first + pr.bm_count) pr.bias_dst[mrow - pr.bm_first] = s;
+    if (mrow >= pr.bm_first && mrow < pr.bm_first + pr.bm_count) {
+      float* d = pr.bias_dst + (mrow - pr.bm_first);
+      *d = G.accumulate ? *d + s : s;
+    }
   }
 }
 

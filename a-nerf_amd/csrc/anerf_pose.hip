@@ -138,7 +138,8 @@ __global__ __launch_bounds__(256) void k_encode_bwd(const float* __restrict__ dx
 // one thread per (ray, joint, row r<3); 128 threads per ray, 72 active
 __global__ __launch_bounds__(128) void k_pose_reduce(const float* __restrict__ dY, const float* __restrict__ dQ,
                                                      const float* __restrict__ rays, int ray_stride,
-                                                     const float* __restrict__ z, int n, int S, float* __restrict__ dskts) {
+                                                     const float* __restrict__ z, int n, int S, int accumulate,
+                                                     float* __restrict__ dskts) {
   const int ray = blockIdx.x, l = threadIdx.x;
   if (ray >= n || l >= 72) return;
   const float* rp = rays + (long long)ray * ray_stride;
@@ -156,10 +157,12 @@ __global__ __launch_bounds__(128) void k_pose_reduce(const float* __restrict__ d
   }
   const int j = l / 3, r = l - 3 * j;
   float* o = dskts + ((long long)ray * 24 + j) * 16 + r * 4;
-  o[0] = fmaf(Q, d0, R0);
-  o[1] = fmaf(Q, d1, R1);
-  o[2] = fmaf(Q, d2, R2);
-  o[3] = T;
+  const float g0 = fmaf(Q, d0, R0), g1 = fmaf(Q, d1, R1), g2 = fmaf(Q, d2, R2);
+  if (accumulate) {   // second network pass of a step (anerf_backward): same sum autograd forms from two overwriting calls
+    o[0] += g0; o[1] += g1; o[2] += g2; o[3] += T;
+  } else {
+    o[0] = g0; o[1] = g1; o[2] = g2; o[3] = T;
+  }
 }
 
 // one wave per ray: lanes 0..15 sum the code columns over the ray's samples, then one atomic per lane
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(256) void k_code_reduce(const float* __restrict__ d
 
 int launch_encode_bwd(int ld, const float* dx, const float* du, int uw, const float* rays, int ray_stride, const float* z,
                       const float* skts, long long skt_stride, float tau_v, float tau_d, const float* cut_v,
-                      const float* cut_d, int n, int S, float* dY, float* dQ, float* dskts, hipStream_t st) {
+                      const float* cut_d, int n, int S, float* dY, float* dQ, float* dskts, bool accumulate, hipStream_t st) {
   const long long P = (long long)n * S;
   const unsigned blocks = (unsigned)((6 * P + 255) / 256);
   if (ld == 4)
@@ -189,7 +192,7 @@ int launch_encode_bwd(int ld, const float* dx, const float* du, int uw, const fl
   int rc = check_launch("k_encode_bwd");
   if (rc) return rc;
   hipLaunchKernelGGL(k_pose_reduce, dim3(n), dim3(128), 0, st, (const float*)dY, (const float*)dQ, rays, ray_stride, z, n, S,
-                     dskts);
+                     accumulate ? 1 : 0, dskts);
   return check_launch("k_pose_reduce");
 }
 

@@ -318,22 +318,14 @@ def fk_backward(bones, rest_pose, pelvis, g_skts=None, g_l2ws=None, g_kp=None, g
     return gb, gp
 
 
-def forward(cfg, net_c, net_f, rays, skts, cyls, n_samples, n_importance=0, tau_v=20.0, tau_d=20.0, cut_v=None, cut_d=None,
-            cam_idx=None, codes_c=None, codes_f=None, t_rand=None, u_imp=None, noise=None, noise_fine=None, lindisp=False,
-            single_net=False, precision="fp32"):
-    """RayCaster.render_rays for one caster call as ONE C call (anerf_forward): every intermediate lives in a single
-    workspace tensor; returns the reference's output dict.  net_c / net_f: (packed, aux) from pack_params (which=0 for
-    "fp32", which=3 for "bf16x3")."""
+def _forward_io(cfg, net_c, net_f, rays, skts, cyls, n_samples, n_importance, tau_v, tau_d, cut_v, cut_d, cam_idx, codes_c,
+                codes_f, t_rand, u_imp, noise, noise_fine, lindisp, single_net, precision):
+    """AnerfForwardIO of one caster call + the output dict + the tensors whose pointers it holds"""
     f = lambda t, nm: _f32c(t, nm)
     rays, skts, cyls = f(rays, "rays"), f(skts, "skts"), f(cyls, "cyls")
     n, dev, S, Ni = rays.shape[0], rays.device, int(n_samples), int(n_importance)
     cut_v = torch.full((cfg.n_joints,), 0.5, device=dev) if cut_v is None else f(cut_v, "cut_v")
     cut_d = torch.full((cfg.n_joints,), 0.5, device=dev) if cut_d is None else f(cut_d, "cut_d")
-    lib, cc = _lib.load(), cfg.c()
-    nbytes = lib.anerf_workspace_size(C.byref(cc), n, S, Ni)
-    if nbytes < 0:
-        _lib.check(int(nbytes), "anerf_workspace_size")
-    ws = torch.empty(max(int(nbytes), 16) // 4, dtype=torch.float32, device=dev)
     E = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
     out = {"rgb_map": E(n, 3), "disp_map": E(n), "acc_map": E(n), "alpha": E(n, S + Ni)}
     if Ni > 0:
@@ -345,7 +337,7 @@ def forward(cfg, net_c, net_f, rays, skts, cyls, n_samples, n_importance=0, tau_
     io.rays, io.ray_stride = rays.data_ptr(), rays.shape[1]
     io.skts, io.skt_ray_stride = skts.data_ptr(), 0 if skts.shape[0] == 1 else 16 * cfg.n_joints
     io.cyls = cyls.data_ptr()
-    keep = [rays, skts, cyls, cut_v, cut_d, ws]
+    keep = [rays, skts, cyls, cut_v, cut_d, net_c, net_f]
     for name, t in (("cam_idx", cam_idx), ("codes_c", codes_c), ("codes_f", codes_f), ("t_rand", t_rand), ("u_imp", u_imp),
                     ("noise", noise), ("noise_fine", noise_fine)):
         if t is not None:
@@ -358,5 +350,97 @@ def forward(cfg, net_c, net_f, rays, skts, cyls, n_samples, n_importance=0, tau_
     io.lindisp, io.single_net, io.precision = int(bool(lindisp)), int(bool(single_net)), 1 if precision == "bf16x3" else 0
     for k, v in out.items():
         setattr(io, k, v.data_ptr())
-    _lib.check(lib.anerf_forward(C.byref(cc), C.byref(io), _p(ws), int(nbytes), _stream()), "anerf_forward")
+    return io, out, keep
+
+
+def _workspace(fn, name, dev, *args):
+    nbytes = fn(*args)
+    if nbytes < 0:
+        _lib.check(int(nbytes), name)
+    return torch.empty(max(int(nbytes), 16) // 4, dtype=torch.float32, device=dev), int(nbytes)
+
+
+def forward(cfg, net_c, net_f, rays, skts, cyls, n_samples, n_importance=0, tau_v=20.0, tau_d=20.0, cut_v=None, cut_d=None,
+            cam_idx=None, codes_c=None, codes_f=None, t_rand=None, u_imp=None, noise=None, noise_fine=None, lindisp=False,
+            single_net=False, precision="fp32"):
+    """RayCaster.render_rays for one caster call as ONE C call (anerf_forward): every intermediate lives in a single
+    workspace tensor; returns the reference's output dict.  net_c / net_f: (packed, aux) from pack_params (which=0 for
+    "fp32", which=3 for "bf16x3")."""
+    io, out, keep = _forward_io(cfg, net_c, net_f, rays, skts, cyls, n_samples, n_importance, tau_v, tau_d, cut_v, cut_d,
+                                cam_idx, codes_c, codes_f, t_rand, u_imp, noise, noise_fine, lindisp, single_net, precision)
+    lib, cc = _lib.load(), cfg.c()
+    ws, nbytes = _workspace(lib.anerf_workspace_size, "anerf_workspace_size", rays.device, C.byref(cc), io.n_rays,
+                            io.n_samples, io.n_importance)
+    _lib.check(lib.anerf_forward(C.byref(cc), C.byref(io), _p(ws), nbytes, _stream()), "anerf_forward")
     return out
+
+
+def train_forward(cfg, net_c, net_f, rays, skts, cyls, n_samples, n_importance=0, tau_v=20.0, tau_d=20.0, cut_v=None,
+                  cut_d=None, cam_idx=None, codes_c=None, codes_f=None, t_rand=None, u_imp=None, noise=None, noise_fine=None,
+                  lindisp=False, precision="fp32"):
+    """anerf_train_forward: `forward` with the training kernels.  Returns (output dict, state); `state` owns the workspace
+    with the saved activations and every input the backward re-reads -- hand it to `backward` unchanged."""
+    io, out, keep = _forward_io(cfg, net_c, net_f, rays, skts, cyls, n_samples, n_importance, tau_v, tau_d, cut_v, cut_d,
+                                cam_idx, codes_c, codes_f, t_rand, u_imp, noise, noise_fine, lindisp, False, precision)
+    lib, cc = _lib.load(), cfg.c()
+    ws, nbytes = _workspace(lib.anerf_train_workspace_size, "anerf_train_workspace_size", rays.device, C.byref(cc), io.n_rays,
+                            io.n_samples, io.n_importance)
+    _lib.check(lib.anerf_train_forward(C.byref(cc), C.byref(io), _p(ws), nbytes, _stream()), "anerf_train_forward")
+    return out, {"cfg": cfg, "io": io, "keep": keep, "ws": ws, "ws_bytes": nbytes, "out": out}
+
+
+def backward(state, g, packed_t_c, packed_t_f, perm, shapes_c, shapes_f, packed_i_c=None, packed_i_f=None, want_skts=False,
+             want_codes_c=False, want_codes_f=False, accumulate_into=None):
+    """anerf_backward.  g: dict of gradients of the rendered maps (keys as the output dict; rgb_map and, when hierarchical,
+    rgb0 are required -- missing ones are taken as zero).  shapes_*: parameter shapes in AnerfNetGrads order (w0, b0, ...).
+    accumulate_into: optional (list_c, list_f) of existing gradient tensors the parameter gradients are ADDED to in place
+    (then returned as they are) instead of being written to fresh tensors.
+    Returns (grads_c, grads_f, g_skts, g_codes_c, g_codes_f)."""
+    cfg, io = state["cfg"], state["io"]
+    n, S, Ni = io.n_rays, io.n_samples, io.n_importance
+    dev = state["ws"].device
+    hier = Ni > 0
+    b = _lib.AnerfBackwardIO()
+    keep = []
+
+    def gp(key, shape, required):
+        t = g.get(key)
+        if t is None:
+            if not required:
+                return None
+            t = torch.zeros(shape, dtype=torch.float32, device=dev)
+        t = _f32c(t, key)
+        keep.append(t)
+        return t.data_ptr()
+
+    b.g_rgb, b.g_disp, b.g_acc, b.g_alpha = gp("rgb_map", (n, 3), True), gp("disp_map", (n,), False), gp("acc_map", (n,), False), \
+        gp("alpha", (n, S + Ni), False)
+    if hier:
+        b.g_rgb0, b.g_disp0, b.g_acc0, b.g_alpha0 = gp("rgb0", (n, 3), True), gp("disp0", (n,), False), gp("acc0", (n,), False), \
+            gp("alpha0", (n, S), False)
+    b.packed_t_c = packed_t_c.data_ptr()
+    b.packed_t_f = packed_t_f.data_ptr() if packed_t_f is not None else None
+    b.packed_i_c = packed_i_c.data_ptr() if packed_i_c is not None else None
+    b.packed_i_f = packed_i_f.data_ptr() if packed_i_f is not None else None
+    b.perm_x, b.perm_u = perm[0].data_ptr(), perm[1].data_ptr()
+    E = lambda sh: torch.empty(sh, dtype=torch.float32, device=dev)
+    if accumulate_into is not None:
+        grads_c, grads_f = accumulate_into
+        b.accumulate = 1
+    else:
+        grads_c = [E(sh) for sh in shapes_c]
+        grads_f = [E(sh) for sh in shapes_f] if hier else []
+    for i in range(12):
+        b.grads_c.w[i], b.grads_c.b[i] = grads_c[2 * i].data_ptr(), grads_c[2 * i + 1].data_ptr()
+        if hier:
+            b.grads_f.w[i], b.grads_f.b[i] = grads_f[2 * i].data_ptr(), grads_f[2 * i + 1].data_ptr()
+    g_skts = E((n, cfg.n_joints, 4, 4)) if want_skts else None
+    g_codes_c = E((io.n_codes, 16)) if want_codes_c else None
+    g_codes_f = E((io.n_codes, 16)) if (want_codes_f and hier) else None
+    b.g_skts, b.g_codes_c, b.g_codes_f = _p(g_skts), _p(g_codes_c), _p(g_codes_f)
+    lib, cc = _lib.load(), cfg.c()
+    want_in = int(want_skts or want_codes_c or want_codes_f)
+    scratch, sbytes = _workspace(lib.anerf_backward_scratch_size, "anerf_backward_scratch_size", dev, C.byref(cc), n, S, Ni, want_in)
+    _lib.check(lib.anerf_backward(C.byref(cc), C.byref(io), C.byref(b), _p(state["ws"]), state["ws_bytes"], _p(scratch), sbytes,
+                                  _stream()), "anerf_backward")
+    return grads_c, grads_f, g_skts, g_codes_c, g_codes_f

@@ -63,6 +63,7 @@ class FusedAdam:
                     g.copy_(p.grad)
                 p.data = v
                 p.grad = g
+                p._anerf_flat_grad = True        # autograd_path: gradients may be accumulated into the bucket in place
         if self._pending is not None:
             sd, self._pending = self._pending, None
             self.load_state_dict(sd)
@@ -91,7 +92,8 @@ class FusedAdam:
         self.materialize()
         for p, g in zip(self.params, self._views(self.flat_grad)):
             if p.grad is None:
-                p.grad = g                                   # someone called zero_grad(set_to_none=True) elsewhere
+                g.zero_()                                    # someone called zero_grad(set_to_none=True) elsewhere:
+                p.grad = g                                   # no gradient this step; the view goes back for the next
             elif p.grad.data_ptr() != g.data_ptr():
                 g.copy_(p.grad)                              # foreign gradient tensor: adopt its value
                 p.grad = g

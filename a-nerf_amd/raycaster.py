@@ -58,6 +58,7 @@ class RayCaster(nn.Module):
         # Training: "fp32", or "bf16x3" = split-bf16 forward (saves fp32 activations), backward-data and weight-gradient
         # GEMM kernels.  Outputs / gradients differ from fp32 by ~1e-6 / ~1e-5 relative.
         self.train_precision = "fp32"
+        self.train_route = "one_call"          # "staged": compose the per-stage autograd nodes instead (same kernels; tests)
 
     @torch.no_grad()
     def forward_eval(self, *args, **kwargs):

@@ -327,6 +327,37 @@ typedef struct AnerfForwardIO {
 int64_t anerf_workspace_size(const AnerfConfig* cfg, int32_t n_rays, int32_t n_samples, int32_t n_importance);
 int anerf_forward(const AnerfConfig* cfg, const AnerfForwardIO* io, void* workspace, int64_t ws_bytes, void* stream);
 
+/* ---- one-call training step: the anerf_forward / anerf_backward pair of the boundary -----------------
+ * anerf_train_forward = anerf_forward with the training kernels: same io (t_rand / u_imp / noise as the trainer draws
+ * them: perturb = 1, raw_noise_std = 1), and a workspace of anerf_train_workspace_size(...) bytes that additionally holds
+ * the saved activations of both network passes.  The caller keeps io's buffers and the workspace untouched until
+ * anerf_backward has been enqueued (autograd's saved-tensor contract).  Two-network configurations only; single_net
+ * trains through the staged entry points above.
+ * anerf_backward: gradients of the rendered maps (of the last pass: g_rgb [N,3] required, g_disp / g_acc [N], g_alpha
+ * [N,S+Ni] optional; of the coarse pass when n_importance > 0: g_rgb0 required, others optional) -> every parameter
+ * gradient of both networks (written, torch layout), and optionally d(loss)/d(skts) [N,24,4,4] (per-ray skts; zero-filled
+ * inside, both passes summed) and d(loss)/d(frame codes) [n_codes,16] per network (zero-filled inside).
+ * packed_t_*: which = 1 (fp32) / 4 (bf16x3) images; packed_i_*: which = 2 / 5, only read when g_skts or g_codes_* is
+ * given; perm_x / perm_u: DEVICE copies of anerf_build_perm_tables (fp32) / anerf_build_perm_tables_b3 (bf16x3).
+ * scratch: anerf_backward_scratch_size(...) bytes (input_grads != 0 when g_skts / g_codes_* will be requested), free
+ * to reuse after the call is enqueued and executed.  Same kernels, same order, same results as the staged sequence
+ * composite_backward -> mlp_backward -> weight_grads (-> input_grads -> encode_backward / code_grads) per pass. */
+typedef struct AnerfBackwardIO {
+  const float *g_rgb, *g_disp, *g_acc, *g_alpha;
+  const float *g_rgb0, *g_disp0, *g_acc0, *g_alpha0;
+  const float *packed_t_c, *packed_t_f, *packed_i_c, *packed_i_f;
+  const int32_t *perm_x, *perm_u;
+  AnerfNetGrads grads_c, grads_f;
+  float *g_skts, *g_codes_c, *g_codes_f;
+  int32_t accumulate;   /* 0: grads_c / grads_f are written; 1: added to their current contents (param.grad in place) */
+} AnerfBackwardIO;
+int64_t anerf_train_workspace_size(const AnerfConfig* cfg, int32_t n_rays, int32_t n_samples, int32_t n_importance);
+int64_t anerf_backward_scratch_size(const AnerfConfig* cfg, int32_t n_rays, int32_t n_samples, int32_t n_importance,
+                                    int32_t input_grads);
+int anerf_train_forward(const AnerfConfig* cfg, const AnerfForwardIO* io, void* workspace, int64_t ws_bytes, void* stream);
+int anerf_backward(const AnerfConfig* cfg, const AnerfForwardIO* io, const AnerfBackwardIO* b, void* workspace,
+                   int64_t ws_bytes, void* scratch, int64_t scratch_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -168,6 +168,52 @@ def test_pose_and_framecode_gradients(oracle, golden, name):
                                        atol=2e-3 * np.abs(refc).max(), err_msg="framecodes")
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("name,n,S,Ni", [("train_pytest", None, 64, 16), ("mixamo_train", None, 64, 16),
+                                          ("mixamo_train", 37, 24, 8), ("train_pytest", 41, 40, 0)])
+def test_one_call_training_step_equals_the_staged_nodes(name, n, S, Ni, precision):
+    """anerf_train_forward / anerf_backward (one autograd node, one C call each way) vs the staged per-kernel autograd nodes:
+    same kernels in the same order, so outputs, all parameter gradients and dskts are bit-identical; ragged sizes exercise
+    the zeroed pad rows of the saved planes (P not a multiple of 128) and N_importance = 0 the single-pass form."""
+    c = build(name)
+    n = c["n"] if n is None else n
+    res = {}
+    for route in ("one_call", "staged", "one_call_flat"):
+        caster = make_caster(c)
+        caster.train()
+        caster.train_precision, caster.train_route = precision, route.replace("_flat", "")
+        if route == "one_call_flat":      # FusedAdam-managed parameters: gradients are accumulated into its flat bucket in place
+            opt = importlib.import_module("a-nerf_amd.optim").FusedAdam([p for p in caster.parameters() if p.requires_grad])
+            opt.materialize()
+            assert float(opt.flat_grad.abs().max()) == 0.0
+        skts = dev(c["skts"][:n]).requires_grad_(True)
+        cams = None if "cams" not in c else dev(c["cams"][:n])
+        out = render_mod.render(64, 64, 75.0, chunk=4096, rays=(dev(c["rays_o"][:n]), dev(c["rays_d"][:n])), use_viewdirs=True,
+                                ray_caster=caster, kp_batch=dev(c["kp"][:n]), skts=skts, cyls=dev(c["cyls"][:n]),
+                                bones=dev(c["bones"][:n]), cams=cams, subject_idxs=None, N_samples=S, N_importance=Ni,
+                                perturb=1.0, raw_noise_std=1.0, pytest=True,
+                                preproc_kwargs={"density_scale": 1.0, "density_fn": torch.nn.functional.relu})
+        target = dev(np.random.default_rng(3).random((n, 3)))
+        loss, _ = render_mod.nerf_loss(out, target, bgs=torch.ones(n, 3, device="cuda"), loss_fn=c.get("loss", "MSE"))
+        (loss + 0.1 * out["disp_map"].mean() + 0.05 * out["alpha"].mean()).backward()     # every output gets a gradient
+        nets = [("c", caster.network)] + ([("f", caster.network_fine)] if Ni > 0 else [])
+        res[route] = ({k: v.detach().clone() for k, v in out.items()}, skts.grad.clone(),
+                      {f"{tag}.{k}": p.grad.clone() for tag, net in nets for k, p in net.named_parameters()})
+    o2, s2, g2 = res["staged"]
+    for route in ("one_call", "one_call_flat"):
+        o1, s1, g1 = res[route]
+        assert set(o1) == set(o2) and set(g1) == set(g2)
+        for k in o1:
+            assert torch.equal(o1[k], o2[k]), (route, k)
+        assert torch.equal(s1, s2) and float(s1.abs().max()) > 0
+        for k in g1:
+            if "framecodes" in k:      # k_code_reduce sums rays with float atomics: order-dependent in the last bits
+                np.testing.assert_allclose(g1[k].cpu().numpy(), g2[k].cpu().numpy(), rtol=1e-4, atol=1e-7 * float(g2[k].abs().max()) + 1e-12)
+            else:
+                assert torch.equal(g1[k], g2[k]), (route, k)
+        assert all(float(v.abs().max()) > 0 for k, v in g1.items())
+
+
 @pytest.mark.parametrize("name", ["train_pytest", "mixamo_train"])
 def test_bf16x3_training_forward_keeps_the_gradient_bar(golden, name):
     """train_precision = 'bf16x3': split-bf16 forward (fp32 activations saved in its own column order) + the fp32
