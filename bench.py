@@ -74,6 +74,12 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+        # prime the communicator (RCCL builds its rings on the first collective) outside any timed region, whatever --warmup is
+        prime = torch.zeros(4 * world, device=device)
+        dist.all_reduce(prime)
+        if backend == "nccl":
+            dist.all_gather_into_tensor(prime, prime[:4].clone())
+        torch.cuda.synchronize()
 
     synth = importlib.import_module("a-nerf_amd.synth")
     ops = importlib.import_module("a-nerf_amd.ops")
