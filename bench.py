@@ -47,8 +47,37 @@ def parse():
     return ap.parse_args()
 
 
+_JSON_FD = None
+
+
+def _flush_c_stdio():
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
+def emit(res):
+    """The ONE JSON line of the bench contract, written to the process's original stdout."""
+    _flush_c_stdio()
+    line = (json.dumps(res) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, line)
+
+
 def main():
     args = parse()
+    # stdout carries exactly one line, the JSON record.  Libraries write there too -- RCCL prints a five-line version
+    # banner through C stdio on communicator creation, gloo its connection notes -- and, being buffered, would land AFTER
+    # the record at process exit.  So: keep the original stdout for the record only and point fd 1 at stderr for the run.
+    global _JSON_FD
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
     # Host hygiene for millisecond-scale steps: a full (generation-2) pass of Python's cycle collector over the ~10^6
     # objects that `import torch` leaves behind takes ~40 ms and was landing inside the timed window of the small-batch
     # training runs (2.8 -> 4.7 ms/step).  gc.freeze() after set-up moves those long-lived objects out of the
@@ -68,7 +97,11 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    # ANERF_BENCH_FORCE_DIST=1: initialise the process group and run every collective even with ONE rank -- exercises the
+    # RCCL code path (init with device_id, all_gather_into_tensor, all_reduce) on a single-GPU box
+    if world > 1 or os.environ.get("ANERF_BENCH_FORCE_DIST") == "1":
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
@@ -80,6 +113,7 @@ def main():
         if backend == "nccl":
             dist.all_gather_into_tensor(prime, prime[:4].clone())
         torch.cuda.synchronize()
+        _flush_c_stdio()          # the communicator banner leaves the C buffers now, not at exit behind the record
 
     synth = importlib.import_module("a-nerf_amd.synth")
     ops = importlib.import_module("a-nerf_amd.ops")
@@ -115,7 +149,7 @@ def main():
     cyl = dev(sc["cyl"])[None].expand(hi - lo, -1).contiguous()
     skt = dev(sc["pose"]["skts"])[None]          # one pose per frame: shared (stride-0) bone matrices
     cut = torch.full((24,), 0.5, device=device)
-    gather_buf = torch.empty(world * per, 5, device=device) if world > 1 else None
+    gather_buf = torch.empty(world * per, 5, device=device) if dist is not None else None
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i=None):
@@ -131,7 +165,7 @@ def main():
             zs, zm, _ = ops.importance(z, co["weights"], Ni, want_idx=False)
             raw_f = ops.mlp_raw(cfg, net_f[0], net_f[1], rb, zm, skt, 20.0, 20.0, cut, cut, precision=args.precision)
             co = ops.composite(cfg, raw_f, zm, rb)
-        if world > 1:
+        if dist is not None:
             mine = torch.zeros(per, 5, device=device)
             mine[:hi - lo, 0:3] = co["rgb_map"]; mine[:hi - lo, 3] = co["acc_map"]; mine[:hi - lo, 4] = co["disp_map"]
             if backend == "nccl":
@@ -141,7 +175,7 @@ def main():
         return co
 
     def barrier():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -154,7 +188,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], device=device)
-    if world > 1:
+    if dist is not None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     mlp_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
@@ -175,7 +209,7 @@ def main():
             out3 = step()
         barrier()
         d3 = torch.tensor([time.perf_counter() - t1], device=device)
-        if world > 1:
+        if dist is not None:
             dist.all_reduce(d3, op=dist.ReduceOp.MAX)
         net_c, net_f, args.precision = saved
         alt = {"precision": "bf16x3 (hi/lo-split bf16 MFMA operands, f32 accumulate)", "value": n_total * args.steps / float(d3.item()),
@@ -214,8 +248,8 @@ def main():
             res["alt_precision"] = alt
         if args.cpu_rays > 0 and world == 1:   # CPU baseline: rank 0 at N=1 only (bench contract)
             res["cpu_baseline"], res["parity"] = cpu_baseline(sc, S, Ni, Pc, Pf, out, lo, min(args.cpu_rays, hi - lo))
-        print(json.dumps(res))
-    if world > 1:
+        emit(res)
+    if dist is not None:
         dist.destroy_process_group()
 
 
@@ -297,7 +331,7 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
             opt.all_reduce_grads()            # one RCCL all-reduce on the flat gradient buffer; 1/world folded into Adam
             opt.step(zero_grad=True)
             if mixamo:
-                if world > 1:
+                if dist is not None:
                     for q in popt.parameters():
                         dist.all_reduce(q.grad)
                         q.grad.div_(world)
@@ -310,7 +344,7 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
         return loss
 
     def barrier():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -329,7 +363,7 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
     barrier()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], device=device)
-    if world > 1:
+    if dist is not None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     fb_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
@@ -356,8 +390,8 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
                             "avg_launch_ms": fb_ms, "flop_per_launch": flop_step_rank, "traffic": None}}
         if args.cpu_rays > 0 and world == 1 and not mixamo:
             res["cpu_baseline"] = cpu_train_baseline(synth, ro, rd, skts, cyls, S, Ni, min(args.cpu_rays, 512, N_rand))
-        print(json.dumps(res))
-    if world > 1:
+        emit(res)
+    if dist is not None:
         dist.destroy_process_group()
 
 
