@@ -335,7 +335,9 @@ def _forward_io(cfg, net_c, net_f, rays, skts, cyls, n_samples, n_importance, ta
     if net_f is not None:
         io.packed_f, io.aux_f = net_f[0].data_ptr(), net_f[1].data_ptr()
     io.rays, io.ray_stride = rays.data_ptr(), rays.shape[1]
-    io.skts, io.skt_ray_stride = skts.data_ptr(), 0 if skts.shape[0] == 1 else 16 * cfg.n_joints
+    if skts.shape[0] not in (1, n):
+        raise ValueError(f"skts must hold one pose or one per ray, got {tuple(skts.shape)} for {n} rays")
+    io.skts, io.skt_ray_stride = skts.data_ptr(), 16 * cfg.n_joints if skts.shape[0] == n else 0
     io.cyls = cyls.data_ptr()
     keep = [rays, skts, cyls, cut_v, cut_d, net_c, net_f]
     for name, t in (("cam_idx", cam_idx), ("codes_c", codes_c), ("codes_f", codes_f), ("t_rand", t_rand), ("u_imp", u_imp),

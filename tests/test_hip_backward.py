@@ -170,7 +170,8 @@ def test_pose_and_framecode_gradients(oracle, golden, name):
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("name,n,S,Ni", [("train_pytest", None, 64, 16), ("mixamo_train", None, 64, 16),
-                                          ("mixamo_train", 37, 24, 8), ("train_pytest", 41, 40, 0)])
+                                          ("mixamo_train", 37, 24, 8), ("train_pytest", 41, 40, 0),
+                                          ("mixamo_train", 1, 8, 1), ("train_pytest", 3, 300, 212)])
 def test_one_call_training_step_equals_the_staged_nodes(name, n, S, Ni, precision):
     """anerf_train_forward / anerf_backward (one autograd node, one C call each way) vs the staged per-kernel autograd nodes:
     same kernels in the same order, so outputs, all parameter gradients and dskts are bit-identical; ragged sizes exercise
