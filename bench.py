@@ -388,6 +388,13 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
                             "peak": (PEAK_BF16_MFMA if b3 else PEAK_FP32_MFMA) / 1e12, "unit": "TFLOP/s",
                             "frac": (3 * achieved / PEAK_BF16_MFMA) if b3 else achieved / PEAK_FP32_MFMA,
                             "avg_launch_ms": fb_ms, "flop_per_launch": flop_step_rank, "traffic": None}}
+        try:   # HBM bytes per step from the rocprofv3 --pmc passes committed under profiles/ (fp32, N_rand 3072 only)
+            tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("train")
+            if tr and world == 1 and not mixamo and not b3 and N_rand == 3072:
+                res["roofline"]["traffic"] = tr["hbm_bytes"]
+                res["roofline"]["traffic_note"] = f"bytes/step, FETCH_SIZE(x2)+WRITE_SIZE of the three MFMA kernels, {tr['source']}; algorithmic {tr['algorithmic_bytes']:.3g} B"
+        except (OSError, ValueError):
+            pass
         if args.cpu_rays > 0 and world == 1 and not mixamo:
             res["cpu_baseline"] = cpu_train_baseline(synth, ro, rd, skts, cyls, S, Ni, min(args.cpu_rays, 512, N_rand))
         emit(res)
