@@ -49,15 +49,97 @@ __device__ __forceinline__ void kstep(Pipe3& pipe, f32x16 (&acc)[NB], int ks, bo
   if (kk == KPS - 1 || last) pipe.end_stage();
 }
 
+// One whole stage (2 k-steps x 8 feature blocks) with the fragment reads software-pipelined by hand: the 32 fragments
+// are consumed in four groups of 4 blocks (8 reads, 12 MFMAs = 384 matrix cycles); while a group's MFMAs run, the next
+// group's reads are in flight into the other of two 32-register buffers.  Left to itself the compiler issues "2 reads,
+// s_waitcnt lgkmcnt(0), 3 MFMAs" per block with a single 8-register buffer (the kernel is at the register limit), which
+// exposes the LDS latency behind every block.  sched_barrier fences keep the program order; the hardware does the rest.
+// first: the stage is the first of its weight segment (its leading group is read from LDS, not taken from pipe.pref).
+__device__ __forceinline__ void stage8_b3(Pipe3& pipe, f32x16 (&acc)[8], const BOp& b0, const BOp& b1, bool first, bool last) {
+  bf16x8 F[2][8];
+  auto frag = [&](int kk, int nb, int lo) {
+    return *reinterpret_cast<const bf16x8*>(pipe.smem + pipe.cur + ((kk * 8 + nb) * 2 + lo) * FRAG_BYTES);
+  };
+  auto read_group = [&](bf16x8 (&f)[8], int kk, int nb0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f[2 * i] = frag(kk, nb0 + i, 0);
+      f[2 * i + 1] = frag(kk, nb0 + i, 1);
+    }
+  };
+  // a group's 12 MFMAs in two parts: the next group's reads are issued BETWEEN them, so that the s_waitcnt lgkmcnt(0)
+  // the compiler puts in front of a group's first MFMA only ever waits for reads that had 8 MFMAs (256 cycles) to land
+  auto mfma_head = [&](const bf16x8 (&f)[8], int nb0, const BOp& b) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[nb0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[2 * i + 1], b.hi, acc[nb0 + i], 0, 0, 0);
+  };
+  auto mfma_tail = [&](const bf16x8 (&f)[8], int nb0, const BOp& b) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[nb0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[2 * i], b.lo, acc[nb0 + i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[nb0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[2 * i], b.hi, acc[nb0 + i], 0, 0, 0);
+  };
+  if (first) {
+    read_group(F[0], 0, 0);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) F[0][i] = __builtin_bit_cast(bf16x8, pipe.pref[i]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_head(F[0], 0, b0);
+  __builtin_amdgcn_sched_barrier(0);
+  read_group(F[1], 0, 4);
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_tail(F[0], 0, b0);
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_head(F[1], 4, b0);
+  __builtin_amdgcn_sched_barrier(0);
+  read_group(F[0], 1, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_tail(F[1], 4, b0);
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_head(F[0], 0, b1);
+  __builtin_amdgcn_sched_barrier(0);
+  read_group(F[1], 1, 4);
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_tail(F[0], 0, b1);
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_head(F[1], 4, b1);
+  __builtin_amdgcn_sched_barrier(0);
+  if (!last) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pipe.pref[i] = *reinterpret_cast<const f32x4*>(pipe.smem + pipe.nxt + i * FRAG_BYTES);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_tail(F[1], 4, b1);
+  pipe.end_stage();
+}
+
 // 16 k-steps whose operands are the previous layer's 256 outputs (bias inside, ReLU already applied in place)
 template <int NB, int KS0>
 __device__ __forceinline__ void hidden_part_b3(Pipe3& pipe, f32x16 (&acc)[NB], const f32x16 (&prev)[8], bool last) {
-#pragma unroll
-  for (int ks = 0; ks < 16; ++ks) {
+  auto bop = [&](int ks) {
     const int nbk = ks >> 1, r0 = 8 * (ks & 1);
-    const BOp b = split8(prev[nbk][r0], prev[nbk][r0 + 1], prev[nbk][r0 + 2], prev[nbk][r0 + 3], prev[nbk][r0 + 4],
-                         prev[nbk][r0 + 5], prev[nbk][r0 + 6], prev[nbk][r0 + 7]);
-    kstep<NB>(pipe, acc, KS0 + ks, last && ks == 15, b);
+    return split8(prev[nbk][r0], prev[nbk][r0 + 1], prev[nbk][r0 + 2], prev[nbk][r0 + 3], prev[nbk][r0 + 4],
+                  prev[nbk][r0 + 5], prev[nbk][r0 + 6], prev[nbk][r0 + 7]);
+  };
+  if constexpr (NB == 8 && (KS0 % 2) == 0) {           // stage-aligned: 8 hand-pipelined stages
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      const BOp b0 = bop(2 * st), b1 = bop(2 * st + 1);
+      stage8_b3(pipe, acc, b0, b1, KS0 == 0 && st == 0, last && st == 7);
+    }
+  } else if constexpr (NB == 8) {                        // starts on a stage's second k-step (after the 27-k-step x part)
+    kstep<NB>(pipe, acc, KS0, false, bop(0));
+#pragma unroll
+    for (int st = 0; st < 7; ++st) {
+      const BOp b0 = bop(2 * st + 1), b1 = bop(2 * st + 2);
+      stage8_b3(pipe, acc, b0, b1, false, false);
+    }
+    kstep<NB>(pipe, acc, KS0 + 15, last, bop(15));
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) kstep<NB>(pipe, acc, KS0 + ks, last && ks == 15, bop(ks));
   }
 }
 
@@ -167,7 +249,6 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
     reinterpret_cast<f32x4*>(aux_l)[i] = reinterpret_cast<const f32x4*>(A.aux)[i];
   const float* aux_h = aux_l + 4 * h;
 
-  float v[12], wv[12], rh[36];
   float dray[3];
   const f32x4* bones4 = reinterpret_cast<const f32x4*>(smem + LDS_BONES_OFF);
   const long long tile_p0 = (long long)blockIdx.x * TILE;
@@ -189,23 +270,29 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
   dray[0] = rp[3];
   dray[1] = rp[4];
   dray[2] = rp[5];
-  const float x0 = fmaf(dray[0], z, rp[0]), x1 = fmaf(dray[1], z, rp[1]), x2 = fmaf(dray[2], z, rp[2]);
+  float x0 = fmaf(dray[0], z, rp[0]), x1 = fmaf(dray[1], z, rp[1]), x2 = fmaf(dray[2], z, rp[2]);
   pipe.begin();
+  // Skeleton-relative features of the sample for the lane half's 12 joints.  Evaluated THREE times (layer 0, the skip
+  // layer, the view layer's gates) from the 3 position registers + the bone matrices in LDS instead of keeping 60 values
+  // alive across the hidden layers: ~400 VALU per re-evaluation against 16 k-steps x 24 MFMAs per layer, and the
+  // registers go to the weight-fragment reads in flight (the kernel sits at the 512-register limit).
+  auto encode_x = [&](float (&v)[12], float (&wv)[12], float (&rh)[36]) {
 #pragma unroll
-  for (int a = 0; a < 12; ++a) {
-    const int j = 8 * (a >> 2) + 4 * h + (a & 3);
-    const f32x4 r0 = bones4[(lr * 24 + j) * 3 + 0], r1 = bones4[(lr * 24 + j) * 3 + 1], r2 = bones4[(lr * 24 + j) * 3 + 2];
-    const float y0 = r0.x * x0 + r0.y * x1 + r0.z * x2 + r0.w;
-    const float y1 = r1.x * x0 + r1.y * x1 + r1.z * x2 + r1.w;
-    const float y2 = r2.x * x0 + r2.y * x1 + r2.z * x2 + r2.w;
-    const float n = sqrtf(y0 * y0 + y1 * y1 + y2 * y2);
-    const float inv = 1.0f / fmaxf(n, 1e-12f);
-    v[a] = n;
-    rh[3 * a + 0] = y0 * inv;
-    rh[3 * a + 1] = y1 * inv;
-    rh[3 * a + 2] = y2 * inv;
-    wv[a] = cutoff_gate(A.tau_v, n, A.cut_v[j]);
-  }
+    for (int a = 0; a < 12; ++a) {
+      const int j = 8 * (a >> 2) + 4 * h + (a & 3);
+      const f32x4 r0 = bones4[(lr * 24 + j) * 3 + 0], r1 = bones4[(lr * 24 + j) * 3 + 1], r2 = bones4[(lr * 24 + j) * 3 + 2];
+      const float y0 = r0.x * x0 + r0.y * x1 + r0.z * x2 + r0.w;
+      const float y1 = r1.x * x0 + r1.y * x1 + r1.z * x2 + r1.w;
+      const float y2 = r2.x * x0 + r2.y * x1 + r2.z * x2 + r2.w;
+      const float n = sqrtf(y0 * y0 + y1 * y1 + y2 * y2);
+      const float inv = 1.0f / fmaxf(n, 1e-12f);
+      v[a] = n;
+      rh[3 * a + 0] = y0 * inv;
+      rh[3 * a + 1] = y1 * inv;
+      rh[3 * a + 2] = y2 * inv;
+      wv[a] = cutoff_gate(A.tau_v, n, A.cut_v[j]);
+    }
+  };
 
   constexpr int DIMD = 72 * (1 + 2 * LD);
   constexpr int KSX = 27;   // k-steps of the x part
@@ -213,7 +300,11 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
 
   // ---- layer 0
   init_bias<8>(accA, aux_h + AUX_B0);
-  x_part_b3<LV, XS>(pipe, accA, v, wv, rh, true, XS ? A.save_x + pc * (24 * (1 + 2 * LV) + 72) + h * (12 * (1 + 2 * LV) + 36) : nullptr);
+  {
+    float v[12], wv[12], rh[36];
+    encode_x(v, wv, rh);
+    x_part_b3<LV, XS>(pipe, accA, v, wv, rh, true, XS ? A.save_x + pc * (24 * (1 + 2 * LV) + 72) + h * (12 * (1 + 2 * LV) + 36) : nullptr);
+  }
   relu_pass<8>(accA);
   if (save) store_rows<8>(HROW(0), accA);
   // ---- layers 1..4
@@ -228,11 +319,14 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
     relu_pass<8>(accA);
     if (save) store_rows<8>(HROW(L + 1), accA);
   }
-  // ---- layer 5 (skip): x re-encoded (opaque so that the compiler does not keep layer 0's products alive)
-#pragma unroll
-  for (int a = 0; a < 12; ++a) asm volatile("" : "+v"(v[a]), "+v"(wv[a]));
+  // ---- layer 5 (skip): x re-encoded from the position (opaque so that the compiler does not keep layer 0's values alive)
+  asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2));
   init_bias<8>(accB, aux_h + AUX_B0 + 256 * 5);
-  x_part_b3<LV>(pipe, accB, v, wv, rh, false);
+  {
+    float v[12], wv[12], rh[36];
+    encode_x(v, wv, rh);
+    x_part_b3<LV>(pipe, accB, v, wv, rh, false);
+  }
   hidden_part_b3<8, KSX>(pipe, accB, accA, true);
   relu_pass<8>(accB);
   if (save) store_rows<8>(HROW(5), accB);
@@ -259,10 +353,15 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
   constexpr int KSV_LAST = 16 + NUP / 8 - 1;
   float* usave = XS ? A.save_u + pc * (2 * NU) + h * NU : nullptr;
   float e[36], wd[12];
+  asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2));
 #pragma unroll
   for (int a = 0; a < 12; ++a) {
     const int j = 8 * (a >> 2) + 4 * h + (a & 3);
     const f32x4 r0 = bones4[(lr * 24 + j) * 3 + 0], r1 = bones4[(lr * 24 + j) * 3 + 1], r2 = bones4[(lr * 24 + j) * 3 + 2];
+    const float p0 = r0.x * x0 + r0.y * x1 + r0.z * x2 + r0.w;            // joint distance again (gate of the directions)
+    const float p1 = r1.x * x0 + r1.y * x1 + r1.z * x2 + r1.w;
+    const float p2 = r2.x * x0 + r2.y * x1 + r2.z * x2 + r2.w;
+    const float vn = sqrtf(p0 * p0 + p1 * p1 + p2 * p2);
     const float y0 = r0.x * dray[0] + r0.y * dray[1] + r0.z * dray[2];
     const float y1 = r1.x * dray[0] + r1.y * dray[1] + r1.z * dray[2];
     const float y2 = r2.x * dray[0] + r2.y * dray[1] + r2.z * dray[2];
@@ -270,7 +369,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
     e[3 * a + 0] = y0 * inv;
     e[3 * a + 1] = y1 * inv;
     e[3 * a + 2] = y2 * inv;
-    wd[a] = cutoff_gate(A.tau_d, v[a], A.cut_d[j]);
+    wd[a] = cutoff_gate(A.tau_d, vn, A.cut_d[j]);
   }
   float sbe[36], cbe[36];
 #pragma unroll
