@@ -54,7 +54,7 @@ def test_train_step_gradients_vs_golden_and_oracle(oracle, golden):
         np.testing.assert_allclose(out[k].detach().cpu().numpy(), g[k], atol=1e-4, err_msg=k)
     target = dev(np.random.default_rng(1).random((n, 3)))
     loss, _ = render_mod.nerf_loss(out, target, bgs=torch.ones(n, 3, device="cuda"))
-    assert abs(float(loss) - float(g["loss"])) < 2e-6
+    assert abs(float(loss.detach()) - float(g["loss"])) < 2e-6
     loss.backward()
     # reference golden: per-tensor norms, leading slices, a few full tensors
     for tag, net in [("c", caster.network), ("f", caster.network_fine)]:

@@ -95,7 +95,7 @@ def test_train_mode_and_grads(oracle, golden, name):
     seed = 1 if name == "train_pytest" else 2
     target = t(np.random.default_rng(seed).random((c["n"], 3)))
     loss, _ = oracle.nerf_loss(out, target, torch.ones(c["n"], 3), loss=c.get("loss", "MSE"))
-    assert abs(float(loss) - float(g["loss"])) < 1e-6
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-6
     loss.backward()
     np.testing.assert_allclose(skts.grad.numpy(), g["dskts"], rtol=2e-3, atol=2e-8)
     for tag, P in [("c", Pc), ("f", Pf)]:
