@@ -141,7 +141,7 @@ def test_training_steps_fused_tail_equals_torch_tail():
                 loss.backward()
                 opt.step()
                 opt.zero_grad()
-            ls.append(float(loss))
+            ls.append(float(loss.detach()))
         casters.append(caster)
         losses.append(ls)
     np.testing.assert_allclose(losses[1], losses[0], rtol=2e-5)
