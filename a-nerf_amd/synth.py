@@ -125,11 +125,12 @@ def camera_rays(H, W, focal, c2w):
     return rays_o, rays_d
 
 
-def cylinder_bbox(cyl, H, W, focal, c2w):
+def cylinder_bbox(cyl, H, W, focal, c2w, center=None):
     """2-D pixel bbox (tl, br) of the projected cylinder caps.
 
     Restates cylinder_to_box_2d (core/utils/skeleton_utils.py:607-690) + nerf_c2w_to_extrinsic
     (:442): 50 points per cap, OpenCV-style extrinsic = inv(c2w with y,z columns negated).
+    focal: scalar or (fx, fy) (focal_to_intrinsic_np); center: principal point (x, y) or None = image centre.
     """
     rads = np.linspace(0.0, 2 * np.pi, 50)
     x = cyl[0] + np.cos(rads) * cyl[2]
@@ -139,11 +140,13 @@ def cylinder_bbox(cyl, H, W, focal, c2w):
     sw = np.concatenate([c2w[:, 0:1], -c2w[:, 1:2], -c2w[:, 2:3], c2w[:, 3:]], -1)
     w2c = np.linalg.inv(sw)
     cam = pts @ w2c.T
-    K = np.array([[focal, 0, 0], [0, focal, 0], [0, 0, 1]], dtype=np.float64)
+    fx, fy = (focal, focal) if np.ndim(focal) == 0 else (focal[0], focal[1])
+    K = np.array([[fx, 0, 0], [0, fy, 0], [0, 0, 1]], dtype=np.float64)
     proj = cam[:, :3] @ K.T
     p2 = proj[:, :2] / proj[:, 2:3]
-    tl = np.floor(p2.min(0)).astype(np.int32) + np.array([int(W * .5), int(H * .5)])
-    br = np.ceil(p2.max(0)).astype(np.int32) + np.array([int(W * .5), int(H * .5)])
+    off = np.array([int(W * .5), int(H * .5)]) if center is None else np.array([int(center[0]), int(center[1])])
+    tl = np.floor(p2.min(0)).astype(np.int32) + off
+    br = np.ceil(p2.max(0)).astype(np.int32) + off
     tl = np.array([np.clip(tl[0], 0, W - 1), np.clip(tl[1], 0, H - 1)])
     br = np.array([np.clip(br[0], 0, W - 1), np.clip(br[1], 0, H - 1)])
     return tl, br

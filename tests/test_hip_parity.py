@@ -4,6 +4,8 @@ Tolerances: north_star asks 1e-4 on RGB and 1e-3 dB PSNR; stage-level checks are
 the arithmetic allows.  fp32 everywhere (fp32 MFMA is an exact fmaf chain).
 """
 import importlib
+import os
+import sys
 
 import numpy as np
 import pytest
@@ -254,7 +256,7 @@ def test_density_and_mesh_query_path(oracle, synth, golden):
     close(mesh, g["mesh"], atol=3e-5, msg="mesh")
 
 
-def test_gen_rays_and_frame_assembly(synth):
+def test_gen_rays_and_frame_assembly(synth, golden):
     """device ray generation + render_path composite/scatter vs the numpy restatement that is pinned
     against the reference's get_rays / kp_to_valid_rays (tests/golden/synth_pins.npz)."""
     render_mod = importlib.import_module("a-nerf_amd.render")
@@ -275,10 +277,11 @@ def test_gen_rays_and_frame_assembly(synth):
         def __call__(self, rays, kp_batch=None, skts=None, cyls=None, bones=None, cams=None, subject_idxs=None, **kw):
             return pipeline.render_rays_forward(cfg, net, None, rays, skts, cyls, 32)
     bg = np.random.default_rng(4).random((64, 64, 3)).astype(np.float32)
-    rgbs, disps, accs = render_mod.render_path([c2w[:3, :4]], (64, 64, 75.0), 4096, {"ray_caster": Caster()},
-                                               kp=dev(sc["pose"]["kp"])[None], skts=dev(sc["pose"]["skts"])[None],
-                                               cyls=dev(sc["cyl"])[None], bones=dev(sc["pose"]["bones"])[None],
-                                               bg_imgs=[bg], ret_acc=True)
+    rgbs, disps, accs, vidxs, bboxes = render_mod.render_path(      # the reference's 5-tuple (run_nerf.py:145)
+        [c2w[:3, :4]], (64, 64, 75.0), 4096, {"ray_caster": Caster()}, kp=dev(sc["pose"]["kp"])[None],
+        skts=dev(sc["pose"]["skts"])[None], cyls=dev(sc["cyl"])[None], bones=dev(sc["pose"]["bones"])[None], bg_imgs=[bg],
+        ret_acc=True, ext_scale=0.001)
+    assert np.array_equal(vidxs[0].cpu().numpy(), sc["valid_idx"]) and np.array_equal(bboxes[0][0], tl) and np.array_equal(bboxes[0][1], br)
     n = len(sc["rays_o"])
     out = pipeline.render_rays_forward(cfg, net, None, rb, dev(sc["pose"]["skts"])[None],
                                        dev(sc["cyl"])[None].expand(n, -1).contiguous(), 32)
@@ -290,6 +293,27 @@ def test_gen_rays_and_frame_assembly(synth):
     dref[vi] = out["disp_map"].cpu().numpy()
     np.testing.assert_allclose(disps[0].reshape(-1), dref, atol=1e-6)
     assert rgbs.shape == (1, 64, 64, 3) and accs.shape == (1, 64, 64, 1)
+    # per-frame image sizes, (fx, fy) focal pairs, principal points (h36m / perfcap cameras): rays and pixel sets vs the
+    # reference's kp_to_valid_rays pins; then two frames of different size through render_path
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from gen_golden_frame import frame_inputs
+    g = golden("frame_pins")
+    pose, c2w2, H2, W2, focal2, centers2 = frame_inputs()
+    cyl2 = synth.bounding_cylinder(pose["kp"])
+    for i in range(2):
+        tl2, br2 = synth.cylinder_bbox(cyl2, int(H2[i]), int(W2[i]), focal2[i], c2w2, center=centers2[i])
+        rb2, idx2 = ops.gen_rays(int(H2[i]), int(W2[i]), focal2[i], dev(c2w2), (tl2[0], tl2[1], br2[0], br2[1]), center=centers2[i])
+        assert np.array_equal(idx2.cpu().numpy(), g[f"valid_idx_{i}"])
+        close(rb2[:, 0:3], g[f"rays_o_{i}"], atol=0)
+        close(rb2[:, 3:6], g[f"rays_d_{i}"], atol=2e-7)
+    # per-frame arrays through render_path (frames of one call share a size, as np.stack in the reference requires)
+    sel = np.array([0, 0])
+    out5 = render_mod.render_path([c2w2[:3, :4], c2w2[:3, :4]], (H2[sel], W2[sel], focal2[sel]), 4096, {"ray_caster": Caster()},
+                                  centers=centers2[sel], kp=dev(pose["kp"])[None], skts=dev(pose["skts"])[None],
+                                  bones=dev(pose["bones"])[None], ext_scale=0.001, render_factor=0)
+    assert out5[2] == [] and len(out5[3]) == 2 and out5[0].shape == (2, 48, 72, 3)
+    assert np.array_equal(out5[3][1].cpu().numpy(), g["valid_idx_0"]) and np.array_equal(out5[4][0][0], g["tl_0"])
+    assert np.array_equal(out5[0][0], out5[0][1]) and float(np.abs(out5[0]).max()) > 0
 
 
 @pytest.mark.parametrize("name", ["eval_s32", "eval_hier", "train_pytest", "mixamo_train", "single_net"])

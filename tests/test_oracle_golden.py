@@ -45,6 +45,24 @@ def test_synth_matches_reference_helpers(synth, golden):
     np.testing.assert_array_equal(idx512[-8:], g["valid_idx_512_tail"])
 
 
+def test_frame_helpers_with_per_frame_cameras(synth, golden):
+    """cylinder bbox with (fx, fy) focal pairs, explicit principal points and per-frame image sizes (h36m / perfcap style
+    cameras) against the reference's kp_to_valid_rays / cylinder_to_box_2d pins (tests/golden/gen_golden_frame.py)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from gen_golden_frame import frame_inputs
+    g = golden("frame_pins")
+    pose, c2w, H, W, focal, centers = frame_inputs()
+    cyl = synth.bounding_cylinder(pose["kp"])
+    np.testing.assert_allclose(cyl, g["cyl"][0], rtol=1e-6, atol=1e-7)
+    for i in range(2):
+        tl, br = synth.cylinder_bbox(cyl, int(H[i]), int(W[i]), focal[i], c2w, center=centers[i])
+        np.testing.assert_array_equal(tl, g[f"tl_{i}"])
+        np.testing.assert_array_equal(br, g[f"br_{i}"])
+        hh, ww = np.meshgrid(np.arange(tl[1], br[1]), np.arange(tl[0], br[0]), indexing="ij")
+        np.testing.assert_array_equal((hh * int(W[i]) + ww).reshape(-1), g[f"valid_idx_{i}"])
+
+
 def test_eval_s32_stages(oracle, golden):
     g = golden("eval_s32")
     out, *_ = run_case(oracle, build("eval_s32"))
