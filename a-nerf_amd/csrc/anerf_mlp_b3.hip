@@ -18,10 +18,10 @@
 
 namespace anerf {
 
-// One k-step (16 contraction indices) against NB 32-row feature blocks: per block a (hi, lo) fragment pair from
-// LDS and three MFMAs.  ks: k-step index relative to the segment start; last: final k-step of the segment.
+// Compiler-scheduled k-step (training forward and the backward kernels: with their extra live state -- saved-row
+// stores, 128 ReLU-mask values -- the two fragment buffers of the pipelined form below cost more in spills than they gain).
 template <int NB>
-__device__ __forceinline__ void kstep(Pipe3& pipe, f32x16 (&acc)[NB], int ks, bool last, const BOp& b) {
+__device__ __forceinline__ void kstep_plain(Pipe3& pipe, f32x16 (&acc)[NB], int ks, bool last, const BOp& b) {
   constexpr int KPS = STAGE_FRAGS / (2 * NB);   // k-steps per 32-fragment stage
   constexpr int NPF = NB < 4 ? NB : 4;          // blocks whose fragments are prefetched across the stage barrier
   const int kk = ks % KPS;
@@ -49,97 +49,87 @@ __device__ __forceinline__ void kstep(Pipe3& pipe, f32x16 (&acc)[NB], int ks, bo
   if (kk == KPS - 1 || last) pipe.end_stage();
 }
 
-// One whole stage (2 k-steps x 8 feature blocks) with the fragment reads software-pipelined by hand: the 32 fragments
-// are consumed in four groups of 4 blocks (8 reads, 12 MFMAs = 384 matrix cycles); while a group's MFMAs run, the next
-// group's reads are in flight into the other of two 32-register buffers.  Left to itself the compiler issues "2 reads,
-// s_waitcnt lgkmcnt(0), 3 MFMAs" per block with a single 8-register buffer (the kernel is at the register limit), which
-// exposes the LDS latency behind every block.  sched_barrier fences keep the program order; the hardware does the rest.
-// first: the stage is the first of its weight segment (its leading group is read from LDS, not taken from pipe.pref).
-__device__ __forceinline__ void stage8_b3(Pipe3& pipe, f32x16 (&acc)[8], const BOp& b0, const BOp& b1, bool first, bool last) {
-  bf16x8 F[2][8];
-  auto frag = [&](int kk, int nb, int lo) {
-    return *reinterpret_cast<const bf16x8*>(pipe.smem + pipe.cur + ((kk * 8 + nb) * 2 + lo) * FRAG_BYTES);
-  };
-  auto read_group = [&](bf16x8 (&f)[8], int kk, int nb0) {
+// One k-step (16 contraction indices) against NB 32-row feature blocks: per block a (hi, lo) fragment pair from
+// LDS and three MFMAs.  ks: k-step index relative to the segment start; last: final k-step of the segment.
+//
+// The fragment reads are software-pipelined by hand.  Blocks are consumed in groups of 4 (8 fragments = 32 registers,
+// 12 MFMAs = 384 matrix cycles); pipe.pref always holds the FIRST group of the NEXT k-step (same stage, or -- before the
+// stage barrier -- the first fragments of the next ring slot), and a group's 8 ds_read_b128 are issued between the head
+// (4 MFMAs) and the tail (8 MFMAs) of the group before it, so the s_waitcnt lgkmcnt(0) the compiler puts in front of a
+// group's first MFMA only ever waits for reads that had 256 matrix cycles to land.  Left to itself the compiler emits
+// "2 reads, s_waitcnt lgkmcnt(0), 3 MFMAs" per block through one 8-register buffer (the kernel is at the register
+// limit), which exposes the LDS latency behind every block.  The sched_barrier fences pin the order of MFMA and DS
+// instructions only (mask 0x6: VALU / SALU -- the next operand split, the encoding -- may move across them).
+template <int NB, bool PIPE = false>
+__device__ __forceinline__ void kstep(Pipe3& pipe, f32x16 (&acc)[NB], int ks, bool last, const BOp& b) {
+  if constexpr (!PIPE) {
+    kstep_plain<NB>(pipe, acc, ks, last, b);
+    return;
+  }
+  static_assert(NB == 8 || NB == 4, "groups of 4 feature blocks");
+  constexpr int KPS = STAGE_FRAGS / (2 * NB);   // k-steps per 32-fragment stage
+  const int kk = ks % KPS;
+  auto read_group = [&](bf16x8 (&f)[8], unsigned slot_off, int kq, int nb0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      f[2 * i] = frag(kk, nb0 + i, 0);
-      f[2 * i + 1] = frag(kk, nb0 + i, 1);
-    }
+    for (int i = 0; i < 8; ++i)
+      f[i] = *reinterpret_cast<const bf16x8*>(pipe.smem + slot_off + ((kq * NB + nb0) * 2 + i) * FRAG_BYTES);
   };
-  // a group's 12 MFMAs in two parts: the next group's reads are issued BETWEEN them, so that the s_waitcnt lgkmcnt(0)
-  // the compiler puts in front of a group's first MFMA only ever waits for reads that had 8 MFMAs (256 cycles) to land
-  auto mfma_head = [&](const bf16x8 (&f)[8], int nb0, const BOp& b) {
+  auto head = [&](const bf16x8 (&f)[8], int nb0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[nb0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[2 * i + 1], b.hi, acc[nb0 + i], 0, 0, 0);
   };
-  auto mfma_tail = [&](const bf16x8 (&f)[8], int nb0, const BOp& b) {
+  auto tail = [&](const bf16x8 (&f)[8], int nb0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[nb0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[2 * i], b.lo, acc[nb0 + i], 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[nb0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[2 * i], b.hi, acc[nb0 + i], 0, 0, 0);
   };
-  if (first) {
-    read_group(F[0], 0, 0);
+  auto lookahead = [&]() {   // first group of the next k-step -> pipe.pref
+    if (last) return;
+    bf16x8 n[8];
+    if (kk == KPS - 1) read_group(n, pipe.nxt, 0, 0);
+    else read_group(n, pipe.cur, kk + 1, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pipe.pref[i] = __builtin_bit_cast(f32x4, n[i]);
+  };
+  bf16x8 ga[8];
+  if (ks == 0) {            // segment start: nothing was looked ahead
+    read_group(ga, pipe.cur, 0, 0);
   } else {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) F[0][i] = __builtin_bit_cast(bf16x8, pipe.pref[i]);
+    for (int i = 0; i < 8; ++i) ga[i] = __builtin_bit_cast(bf16x8, pipe.pref[i]);
   }
-  __builtin_amdgcn_sched_barrier(0);
-  mfma_head(F[0], 0, b0);
-  __builtin_amdgcn_sched_barrier(0);
-  read_group(F[1], 0, 4);
-  __builtin_amdgcn_sched_barrier(0);
-  mfma_tail(F[0], 0, b0);
-  __builtin_amdgcn_sched_barrier(0);
-  mfma_head(F[1], 4, b0);
-  __builtin_amdgcn_sched_barrier(0);
-  read_group(F[0], 1, 0);
-  __builtin_amdgcn_sched_barrier(0);
-  mfma_tail(F[1], 4, b0);
-  __builtin_amdgcn_sched_barrier(0);
-  mfma_head(F[0], 0, b1);
-  __builtin_amdgcn_sched_barrier(0);
-  read_group(F[1], 1, 4);
-  __builtin_amdgcn_sched_barrier(0);
-  mfma_tail(F[0], 0, b1);
-  __builtin_amdgcn_sched_barrier(0);
-  mfma_head(F[1], 4, b1);
-  __builtin_amdgcn_sched_barrier(0);
-  if (!last) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) pipe.pref[i] = *reinterpret_cast<const f32x4*>(pipe.smem + pipe.nxt + i * FRAG_BYTES);
+  __builtin_amdgcn_sched_barrier(0x6);
+  head(ga, 0);
+  __builtin_amdgcn_sched_barrier(0x6);
+  if constexpr (NB == 8) {
+    bf16x8 gb[8];
+    read_group(gb, pipe.cur, kk, 4);
+    __builtin_amdgcn_sched_barrier(0x6);
+    tail(ga, 0);
+    __builtin_amdgcn_sched_barrier(0x6);
+    head(gb, 4);
+    __builtin_amdgcn_sched_barrier(0x6);
+    lookahead();
+    __builtin_amdgcn_sched_barrier(0x6);
+    tail(gb, 4);
+  } else {
+    lookahead();
+    __builtin_amdgcn_sched_barrier(0x6);
+    tail(ga, 0);
   }
-  __builtin_amdgcn_sched_barrier(0);
-  mfma_tail(F[1], 4, b1);
-  pipe.end_stage();
+  if (kk == KPS - 1 || last) pipe.end_stage();
 }
 
 // 16 k-steps whose operands are the previous layer's 256 outputs (bias inside, ReLU already applied in place)
-template <int NB, int KS0>
+template <int NB, int KS0, bool PIPE = false>
 __device__ __forceinline__ void hidden_part_b3(Pipe3& pipe, f32x16 (&acc)[NB], const f32x16 (&prev)[8], bool last) {
-  auto bop = [&](int ks) {
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
     const int nbk = ks >> 1, r0 = 8 * (ks & 1);
-    return split8(prev[nbk][r0], prev[nbk][r0 + 1], prev[nbk][r0 + 2], prev[nbk][r0 + 3], prev[nbk][r0 + 4],
-                  prev[nbk][r0 + 5], prev[nbk][r0 + 6], prev[nbk][r0 + 7]);
-  };
-  if constexpr (NB == 8 && (KS0 % 2) == 0) {           // stage-aligned: 8 hand-pipelined stages
-#pragma unroll
-    for (int st = 0; st < 8; ++st) {
-      const BOp b0 = bop(2 * st), b1 = bop(2 * st + 1);
-      stage8_b3(pipe, acc, b0, b1, KS0 == 0 && st == 0, last && st == 7);
-    }
-  } else if constexpr (NB == 8) {                        // starts on a stage's second k-step (after the 27-k-step x part)
-    kstep<NB>(pipe, acc, KS0, false, bop(0));
-#pragma unroll
-    for (int st = 0; st < 7; ++st) {
-      const BOp b0 = bop(2 * st + 1), b1 = bop(2 * st + 2);
-      stage8_b3(pipe, acc, b0, b1, false, false);
-    }
-    kstep<NB>(pipe, acc, KS0 + 15, last, bop(15));
-  } else {
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) kstep<NB>(pipe, acc, KS0 + ks, last && ks == 15, bop(ks));
+    const BOp b = split8(prev[nbk][r0], prev[nbk][r0 + 1], prev[nbk][r0 + 2], prev[nbk][r0 + 3], prev[nbk][r0 + 4],
+                         prev[nbk][r0 + 5], prev[nbk][r0 + 6], prev[nbk][r0 + 7]);
+    kstep<NB, PIPE>(pipe, acc, KS0 + ks, last && ks == 15, b);
   }
 }
 
@@ -148,7 +138,7 @@ __device__ __forceinline__ void hidden_part_b3(Pipe3& pipe, f32x16 (&acc)[NB], c
 // anerf_build_perm_tables_b3); only the first `nreal` values of the segment are real, the rest is zero padding.
 // SAVE is a compile-time switch and every lane stores (tail lanes of the last tile are clamped to the last valid
 // sample and rewrite its values), so there is no exec-mask juggling in the middle of a stage.
-template <int NB, int N, bool SAVE = false>
+template <int NB, int N, bool SAVE = false, bool PIPE = false>
 __device__ __forceinline__ void emit(Pipe3& pipe, f32x16 (&acc)[NB], int ks0, int ks_last, const float (&val)[N],
                                      float* __restrict__ save = nullptr, int ks_base = 0, int nreal = 1 << 30) {
 #pragma unroll
@@ -167,13 +157,13 @@ __device__ __forceinline__ void emit(Pipe3& pipe, f32x16 (&acc)[NB], int ks0, in
     }
     const BOp b = split8(val[8 * k], val[8 * k + 1], val[8 * k + 2], val[8 * k + 3], val[8 * k + 4], val[8 * k + 5],
                          val[8 * k + 6], val[8 * k + 7]);
-    kstep<NB>(pipe, acc, ks0 + k, ks0 + k == ks_last, b);
+    kstep<NB, PIPE>(pipe, acc, ks0 + k, ks0 + k == ks_last, b);
   }
 }
 
 // The lane's 216 x-values, band-major [15 bands x 12 owned joints][36 bone-direction components], as 27 k-steps:
 // 7 band pairs (24 values = 3 k-steps each) then cos_6 (12) + directions (36) = 6 k-steps.
-template <int LV, bool SAVE = false>
+template <int LV, bool SAVE = false, bool PIPE = false>
 __device__ __forceinline__ void x_part_b3(Pipe3& pipe, f32x16 (&acc)[8], const float (&v)[12], const float (&wv)[12],
                                           const float (&rh)[36], bool last, float* __restrict__ xsave = nullptr) {
   static_assert(LV == 7, "band pairing below is written for multires = 7");
@@ -194,14 +184,14 @@ __device__ __forceinline__ void x_part_b3(Pipe3& pipe, f32x16 (&acc)[8], const f
       }
       val[12 + a] = sb[a] * wv[a];                           // band 2p+1: sin_p
     }
-    emit<8, 24, SAVE>(pipe, acc, 3 * p, last ? KS_LAST : -1, val, xsave);
+    emit<8, 24, SAVE, PIPE>(pipe, acc, 3 * p, last ? KS_LAST : -1, val, xsave);
   }
   float val[48];
 #pragma unroll
   for (int a = 0; a < 12; ++a) val[a] = cb[a] * wv[a];       // band 14: cos_6
 #pragma unroll
   for (int i = 0; i < 36; ++i) val[12 + i] = rh[i];
-  emit<8, 48, SAVE>(pipe, acc, 3 * LV, last ? KS_LAST : -1, val, xsave);
+  emit<8, 48, SAVE, PIPE>(pipe, acc, 3 * LV, last ? KS_LAST : -1, val, xsave);
 }
 
 // TRAIN: also save what the (fp32) backward needs -- h0..h7, f, g row-major exactly as k_mlp_fwd<TRAIN> does, and the
@@ -296,6 +286,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
 
   constexpr int DIMD = 72 * (1 + 2 * LD);
   constexpr int KSX = 27;   // k-steps of the x part
+  constexpr bool PP = !TRAIN;  // hand-pipelined k-steps in the render kernel only (see kstep)
   f32x16 accA[8], accB[8];
 
   // ---- layer 0
@@ -303,7 +294,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
   {
     float v[12], wv[12], rh[36];
     encode_x(v, wv, rh);
-    x_part_b3<LV, XS>(pipe, accA, v, wv, rh, true, XS ? A.save_x + pc * (24 * (1 + 2 * LV) + 72) + h * (12 * (1 + 2 * LV) + 36) : nullptr);
+    x_part_b3<LV, XS, PP>(pipe, accA, v, wv, rh, true, XS ? A.save_x + pc * (24 * (1 + 2 * LV) + 72) + h * (12 * (1 + 2 * LV) + 36) : nullptr);
   }
   relu_pass<8>(accA);
   if (save) store_rows<8>(HROW(0), accA);
@@ -311,11 +302,11 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
 #pragma unroll 1
   for (int L = 1; L <= 3; L += 2) {
     init_bias<8>(accB, aux_h + AUX_B0 + 256 * L);
-    hidden_part_b3<8, 0>(pipe, accB, accA, true);
+    hidden_part_b3<8, 0, PP>(pipe, accB, accA, true);
     relu_pass<8>(accB);
     if (save) store_rows<8>(HROW(L), accB);
     init_bias<8>(accA, aux_h + AUX_B0 + 256 * (L + 1));
-    hidden_part_b3<8, 0>(pipe, accA, accB, true);
+    hidden_part_b3<8, 0, PP>(pipe, accA, accB, true);
     relu_pass<8>(accA);
     if (save) store_rows<8>(HROW(L + 1), accA);
   }
@@ -325,29 +316,29 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
   {
     float v[12], wv[12], rh[36];
     encode_x(v, wv, rh);
-    x_part_b3<LV>(pipe, accB, v, wv, rh, false);
+    x_part_b3<LV, false, PP>(pipe, accB, v, wv, rh, false);
   }
-  hidden_part_b3<8, KSX>(pipe, accB, accA, true);
+  hidden_part_b3<8, KSX, PP>(pipe, accB, accA, true);
   relu_pass<8>(accB);
   if (save) store_rows<8>(HROW(5), accB);
   // ---- layers 6, 7
   init_bias<8>(accA, aux_h + AUX_B0 + 256 * 6);
-  hidden_part_b3<8, 0>(pipe, accA, accB, true);
+  hidden_part_b3<8, 0, PP>(pipe, accA, accB, true);
   relu_pass<8>(accA);
   if (save) store_rows<8>(HROW(6), accA);
   init_bias<8>(accB, aux_h + AUX_B0 + 256 * 7);
-  hidden_part_b3<8, 0>(pipe, accB, accA, true);
+  hidden_part_b3<8, 0, PP>(pipe, accB, accA, true);
   relu_pass<8>(accB);
   if (save) store_rows<8>(HROW(7), accB);
   const float sigma_raw = head_dot<8>(accB, aux_h + AUX_WA) + aux_l[AUX_BA];
   // ---- feature layer
   init_bias<8>(accA, aux_h + AUX_BF);
-  hidden_part_b3<8, 0>(pipe, accA, accB, true);
+  hidden_part_b3<8, 0, PP>(pipe, accA, accB, true);
   if (save) store_rows<8>(A.save_f + p * 256 + 4 * h, accA);
   // ---- view layer: [feature (16 k-steps); D bands; code; zero padding to a multiple of 8 values per lane]
   f32x16 accv[4];
   init_bias<4>(accv, aux_h + AUX_BV);
-  hidden_part_b3<4, 0>(pipe, accv, accA, false);
+  hidden_part_b3<4, 0, PP>(pipe, accv, accA, false);
   constexpr int NU = 36 * (1 + 2 * LD) + CODE / 2;          // values per lane
   constexpr int NUP = (NU + 7) / 8 * 8;
   constexpr int KSV_LAST = 16 + NUP / 8 - 1;
@@ -387,7 +378,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
       }
       val[36 + i] = sbe[i] * wd[i / 3];
     }
-    emit<4, 72, XS>(pipe, accv, 16 + 9 * pq, KSV_LAST, val, usave, 16, NU);
+    emit<4, 72, XS, PP>(pipe, accv, 16 + 9 * pq, KSV_LAST, val, usave, 16, NU);
   }
   {
     // last band (cos_{LD-1}, or the raw band when LD == 0) + frame code + zero padding
@@ -405,7 +396,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
     }
 #pragma unroll
     for (int i = NU - 72 * LD; i < NT; ++i) val[i] = 0.f;
-    emit<4, NT, XS>(pipe, accv, 16 + 9 * LD, KSV_LAST, val, usave, 16, NU);
+    emit<4, NT, XS, PP>(pipe, accv, 16 + 9 * LD, KSV_LAST, val, usave, 16, NU);
   }
   relu_pass<4>(accv);
   if (save) store_rows<4>(A.save_g + p * 128 + 4 * h, accv);
