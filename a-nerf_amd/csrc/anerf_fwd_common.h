@@ -128,6 +128,10 @@ __device__ __forceinline__ void kgroup(Pipe3& pipe, f32x16 (&acc)[NB], int kg, b
                                        float b2, float b3) {
   constexpr int KPS = STAGE_FRAGS / NB;  // k-groups per stage
   const int ks = kg % KPS;
+  // The compiler schedules this as "NB ds_read_b128, s_waitcnt lgkmcnt(0), 4 NB MFMAs".  Hand-pipelining the reads one
+  // k-group ahead (as kstep<NB, true> does in anerf_mlp_b3.hip, where it gains 6 %) was measured here too (tools/ab_f32.sh,
+  // same box): +0.7 % on the render kernel, +1.2 % on the training step -- slower.  With 64-cycle fp32 MFMAs the read
+  // latency already hides behind the MFMAs still queued, and the second fragment buffer only adds register pressure.
   f32x4 a[NB];
   if (ks == 0 && kg != 0) {
 #pragma unroll
