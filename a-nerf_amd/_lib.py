@@ -104,7 +104,7 @@ SIGNATURES = {
                                         C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int32,
                                         C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "anerf_code_grads": (C.c_int, [C.POINTER(AnerfConfig), C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
-                                   C.c_int32, C.c_void_p]),
+                                   C.c_int32, C.c_void_p, C.c_void_p]),
     "anerf_density": (C.c_int, [C.POINTER(AnerfConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                                 C.c_int64, C.c_void_p, C.c_void_p]),
     "anerf_gen_rays": (C.c_int, [C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int32,

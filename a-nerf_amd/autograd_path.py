@@ -127,8 +127,9 @@ class _MlpRawFn(torch.autograd.Function):
             if need_codes:
                 codes = meta["codes"]
                 g_codes = torch.zeros_like(codes)
+                rowsum = torch.empty(n, 16, dtype=torch.float32, device=dev)
                 _lib.check(lib.anerf_code_grads(C.byref(cc), _p(du), _p(meta["cam"]), n, s, _p(g_codes), codes.shape[0],
-                                                _stream()), "anerf_code_grads")
+                                                _p(rowsum), _stream()), "anerf_code_grads")
         ctx.sv = None
         return (None, g_skts, g_codes, *grads)
 

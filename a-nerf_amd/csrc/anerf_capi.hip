@@ -63,7 +63,8 @@ int mlp_bwd_in_entry(const float* packed_i, const float* dz, const float* dzv, f
 int launch_encode_bwd(int ld, const float* dx, const float* du, int uw, const float* rays, int ray_stride, const float* z,
                       const float* skts, long long skt_stride, float tau_v, float tau_d, const float* cut_v,
                       const float* cut_d, int n, int S, float* dY, float* dQ, float* dskts, bool accumulate, hipStream_t st);
-int launch_code_reduce(const float* du, int uw, const float* cam, int n, int S, int n_codes, float* dcodes, hipStream_t st);
+int launch_code_reduce(const float* du, int uw, const float* cam, int n, int S, int n_codes, float* rowsum, float* dcodes,
+                       hipStream_t st);
 
 // ------------------------------------------------------------------------------------------------
 // weight-stream layout.  A segment = one Linear layer; its k-groups (8 input columns: 4 per lane half) are laid
@@ -751,11 +752,11 @@ int anerf_encode_backward(const AnerfConfig* cfg, const float* dx, const float* 
 }
 
 int anerf_code_grads(const AnerfConfig* cfg, const float* du, const float* cam_idx, int32_t n_rays, int32_t n_samples,
-                     float* dcodes, int32_t n_codes, void* stream) {
+                     float* dcodes, int32_t n_codes, float* rowsum_ws, void* stream) {
   if (!config_ok(cfg) || cfg->framecode_ch != 16) return set_error(ANERF_E_CONFIG, "code_grads: framecode_ch must be 16");
-  if (!du || !cam_idx || !dcodes || n_codes < 1) return set_error(ANERF_E_NULL, "code_grads: NULL pointer");
+  if (!du || !cam_idx || !dcodes || !rowsum_ws || n_codes < 1) return set_error(ANERF_E_NULL, "code_grads: NULL pointer");
   if (n_rays == 0) return ANERF_OK;
-  return launch_code_reduce(du, u_width(cfg), cam_idx, n_rays, n_samples, n_codes, dcodes, (hipStream_t)stream);
+  return launch_code_reduce(du, u_width(cfg), cam_idx, n_rays, n_samples, n_codes, rowsum_ws, dcodes, (hipStream_t)stream);
 }
 
 int anerf_density(const AnerfConfig* cfg, const float* packed, const float* aux, const float* pts, const float* skts,
@@ -933,7 +934,7 @@ TrainWs train_ws(const AnerfConfig* cfg, int64_t n, int64_t S, int64_t Ni) {
 }
 
 // backward scratch of ONE network pass over P points (reused by the second pass)
-struct BwdWs { int64_t draw, dz, df, dzv, gemm, dx, du, dy, dq, total; };
+struct BwdWs { int64_t draw, dz, df, dzv, gemm, dx, du, dy, dq, rowsum, total; };
 BwdWs bwd_ws(const AnerfConfig* cfg, int64_t P, bool input_grads) {
   auto up = [](int64_t b) { return (b + 255) / 256 * 256; };
   AnerfTrainLayout T;
@@ -946,8 +947,9 @@ BwdWs bwd_ws(const AnerfConfig* cfg, int64_t P, bool input_grads) {
   b.df = o; o += up(pp * 256 * 4);
   b.dzv = o; o += up(pp * 128 * 4);
   b.gemm = o; o += up(T.gemm_ws_floats * 4);
-  b.dx = b.du = b.dy = b.dq = o;
+  b.dx = b.du = b.dy = b.dq = b.rowsum = o;
   if (input_grads) {
+    b.rowsum = o; o += up((P / 8 + 1) * 16 * 4);     // [N][16], N <= P / 8 (MIN_SAMPLES)
     b.dx = o; o += up(pp * T.x_width * 4);
     b.du = o; o += up(pp * T.u_width * 4);
     b.dy = o; o += up(P * 72 * 4);
@@ -1053,7 +1055,7 @@ int anerf_backward(const AnerfConfig* cfg, const AnerfForwardIO* io, const Anerf
     }
     if (g_codes) {
       if (hipMemsetAsync(g_codes, 0, (size_t)io->n_codes * 16 * 4, st) != hipSuccess) return set_error(ANERF_E_LAUNCH, "backward: hipMemsetAsync");
-      r = anerf_code_grads(cfg, B(w.du), io->cam_idx, (int)n, ns, g_codes, io->n_codes, stream);
+      r = anerf_code_grads(cfg, B(w.du), io->cam_idx, (int)n, ns, g_codes, io->n_codes, B(w.rowsum), stream);
     }
     return r;
   };

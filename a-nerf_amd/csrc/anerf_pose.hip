@@ -4,7 +4,7 @@
 //                  181-193 + core/cutoff_embedder.py:111-174 restated by hand
 //   k_pose_reduce  sum over the samples of a ray: d skts[n][j][r][:] = (sum dy_r x^T + (sum dq_r) d^T | sum dy_r)
 //                  (deterministic: one thread per (ray, joint, row), no atomics)
-//   k_code_reduce  d codes[cam_idx[ray]] += sum over the ray's samples of dU'[code columns]
+//   k_code_rowsum / k_code_reduce  d codes[c] += sum over the rays with cam_idx = c and their samples of dU'[code columns]
 // VALU / HBM-bound helpers; only run when skts or frame codes require gradients (Mixamo config).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -165,17 +165,50 @@ __global__ __launch_bounds__(128) void k_pose_reduce(const float* __restrict__ d
   }
 }
 
-// one wave per ray: lanes 0..15 sum the code columns over the ray's samples, then one atomic per lane
-__global__ __launch_bounds__(256) void k_code_reduce(const float* __restrict__ du, int uw, const float* __restrict__ cam,
-                                                     int n, int S, int n_codes, float* __restrict__ dcodes) {
-  const int lane = threadIdx.x & 63;
+// Frame-code gradients in two fixed-order stages (bit-reproducible; an earlier version added per-ray sums with float
+// atomics, the only run-to-run nondeterminism of the training step):
+//   k_code_rowsum  one wave per ray, 4 sample groups x 16 columns: rowsum[ray][lane] = sum over the ray's samples of
+//                  dU'[code column lane] (each group sums samples k = g mod 4, groups combined by two fixed shuffles)
+//   k_code_reduce  one block per frame code c (exits at once when no ray of the batch carries c): thread (slot, lane)
+//                  adds rowsum[r][lane] of the rays r = slot, slot + 64, ... with cam_idx = c, the 64 slot sums are then
+//                  added in slot order; one writer per element of dcodes.
+__global__ __launch_bounds__(256) void k_code_rowsum(const float* __restrict__ du, int uw, int n, int S,
+                                                     float* __restrict__ rowsum) {
+  const int l64 = threadIdx.x & 63, lane = l64 & 15, grp = l64 >> 4;      // 4 sample groups x 16 code columns
   const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (ray >= n || lane >= 16) return;
+  if (ray >= n) return;
   float s = 0.f;
-  for (int k = 0; k < S; ++k) s += du[((long long)ray * S + k) * uw + (uw - 16) + lane];
-  int ci = (int)cam[ray];
-  ci = ci < 0 ? 0 : (ci >= n_codes ? n_codes - 1 : ci);
-  atomicAdd(dcodes + ci * 16 + lane, s);
+  for (int k = grp; k < S; k += 4) s += du[((long long)ray * S + k) * uw + (uw - 16) + lane];
+  s += __shfl_xor(s, 16);      // (g0 + g1), (g2 + g3): fixed pairing, same result in both lanes of a pair
+  s += __shfl_xor(s, 32);
+  if (grp == 0) rowsum[ray * 16 + lane] = s;
+}
+
+__device__ __forceinline__ int code_of(const float* __restrict__ cam, int r, int n_codes) {
+  const int ci = (int)cam[r];
+  return ci < 0 ? 0 : (ci >= n_codes ? n_codes - 1 : ci);
+}
+
+constexpr int CODE_SLOTS = 64;
+__global__ __launch_bounds__(16 * CODE_SLOTS) void k_code_reduce(const float* __restrict__ rowsum, const float* __restrict__ cam,
+                                                                 int n, int n_codes, float* __restrict__ dcodes) {
+  __shared__ float sh[CODE_SLOTS][16];
+  const int c = blockIdx.x, lane = threadIdx.x & 15, slot = threadIdx.x >> 4;
+  int any = 0;
+  for (int r = threadIdx.x; r < n; r += 16 * CODE_SLOTS) any |= code_of(cam, r, n_codes) == c;
+  if (!__syncthreads_or(any)) return;
+  float s = 0.f;
+  for (int r = slot; r < n; r += CODE_SLOTS) {
+    const float v = rowsum[r * 16 + lane];
+    s += code_of(cam, r, n_codes) == c ? v : 0.f;
+  }
+  sh[slot][lane] = s;
+  __syncthreads();
+  if (slot == 0) {
+    float t = 0.f;
+    for (int q = 0; q < CODE_SLOTS; ++q) t += sh[q][lane];
+    dcodes[c * 16 + lane] += t;
+  }
 }
 
 int launch_encode_bwd(int ld, const float* dx, const float* du, int uw, const float* rays, int ray_stride, const float* z,
@@ -196,8 +229,12 @@ int launch_encode_bwd(int ld, const float* dx, const float* du, int uw, const fl
   return check_launch("k_pose_reduce");
 }
 
-int launch_code_reduce(const float* du, int uw, const float* cam, int n, int S, int n_codes, float* dcodes, hipStream_t st) {
-  hipLaunchKernelGGL(k_code_reduce, dim3((n + 3) / 4), dim3(256), 0, st, du, uw, cam, n, S, n_codes, dcodes);
+int launch_code_reduce(const float* du, int uw, const float* cam, int n, int S, int n_codes, float* rowsum, float* dcodes,
+                       hipStream_t st) {
+  hipLaunchKernelGGL(k_code_rowsum, dim3((n + 3) / 4), dim3(256), 0, st, du, uw, n, S, rowsum);
+  int rc = check_launch("k_code_rowsum");
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_code_reduce, dim3(n_codes), dim3(16 * CODE_SLOTS), 0, st, (const float*)rowsum, cam, n, n_codes, dcodes);
   return check_launch("k_code_reduce");
 }
 

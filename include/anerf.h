@@ -198,9 +198,10 @@ int anerf_encode_backward(const AnerfConfig* cfg, const float* dx, const float* 
                           float tau_v, float tau_d, const float* cutoff_v, const float* cutoff_d,
                           int32_t n_rays, int32_t n_samples, float* dy_ws, float* dq_ws, float* dskts, void* stream);
 
-/* dcodes [n_codes,16] += per-ray sums of du's code columns, indexed by cam_idx (caller zero-fills dcodes). */
+/* dcodes [n_codes,16] += sums of du's code columns over the rays of each cam_idx and their samples (caller zero-fills
+ * dcodes).  Two fixed-order stages (per-ray sums into rowsum_ws [N,16], then one block per code): bit-reproducible. */
 int anerf_code_grads(const AnerfConfig* cfg, const float* du, const float* cam_idx, int32_t n_rays, int32_t n_samples,
-                     float* dcodes, int32_t n_codes, void* stream);
+                     float* dcodes, int32_t n_codes, float* rowsum_ws, void* stream);
 
 /* ---- next rows of SURVEY 8(f) ----------------------------------------------------------------------------------- */
 

@@ -207,11 +207,8 @@ def test_one_call_training_step_equals_the_staged_nodes(name, n, S, Ni, precisio
         for k in o1:
             assert torch.equal(o1[k], o2[k]), (route, k)
         assert torch.equal(s1, s2) and float(s1.abs().max()) > 0
-        for k in g1:
-            if "framecodes" in k:      # k_code_reduce sums rays with float atomics: order-dependent in the last bits
-                np.testing.assert_allclose(g1[k].cpu().numpy(), g2[k].cpu().numpy(), rtol=1e-4, atol=1e-7 * float(g2[k].abs().max()) + 1e-12)
-            else:
-                assert torch.equal(g1[k], g2[k]), (route, k)
+        for k in g1:          # incl. the frame-code tables: k_code_reduce is a fixed-order reduction (no atomics)
+            assert torch.equal(g1[k], g2[k]), (route, k)
         assert all(float(v.abs().max()) > 0 for k, v in g1.items())
 
 
