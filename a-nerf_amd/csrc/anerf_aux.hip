@@ -35,9 +35,12 @@ __global__ void k_pack(AnerfNetParams P, const int32_t* __restrict__ table, long
 }
 
 // ------------------------------------------------------------------------------------------------
-// A2.  One thread per ray.  stats = {sum_near, sum_far, cnt_near, cnt_far} over non-NaN rows (for the fallback).
+// A2.  One thread per ray.  stats = {sum_near, sum_far, cnt_near, cnt_far} over non-NaN rows (for the fallback), as four
+// 64-bit integers: the sums in 2^-32 fixed point, so that the cross-wave accumulation (integer atomics) is exact and
+// order-independent -- the fallback value, and with it every z of a missed ray, is bit-reproducible.
+constexpr double STATS_FIX = 4294967296.0;   // 2^32
 __global__ void k_ray_bounds(const float* __restrict__ rays, int ray_stride, const float* __restrict__ cyls, int n,
-                             float* __restrict__ near_far, float* __restrict__ stats) {
+                             float* __restrict__ near_far, unsigned long long* __restrict__ stats) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   float sn = 0.f, sf = 0.f, cn = 0.f, cf = 0.f;
   if (i < n) {
@@ -62,7 +65,7 @@ __global__ void k_ray_bounds(const float* __restrict__ rays, int ray_stride, con
     if (nn == nn) { sn = nn; cn = 1.f; }
     if (ff == ff) { sf = ff; cf = 1.f; }
   }
-  // wave reduce, one atomic per wave
+  // wave reduce (fixed shuffle tree), one integer atomic per wave and statistic
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     sn += __shfl_xor(sn, o);
@@ -71,15 +74,15 @@ __global__ void k_ray_bounds(const float* __restrict__ rays, int ray_stride, con
     cf += __shfl_xor(cf, o);
   }
   if ((threadIdx.x & 63) == 0 && (cn + cf) > 0.f) {
-    atomicAdd(stats + 0, sn);
-    atomicAdd(stats + 1, sf);
-    atomicAdd(stats + 2, cn);
-    atomicAdd(stats + 3, cf);
+    atomicAdd(stats + 0, (unsigned long long)__double2ll_rn((double)sn * STATS_FIX));   // two's complement: signed sums work
+    atomicAdd(stats + 1, (unsigned long long)__double2ll_rn((double)sf * STATS_FIX));
+    atomicAdd(stats + 2, (unsigned long long)cn);
+    atomicAdd(stats + 3, (unsigned long long)cf);
   }
 }
 
 // A3.  One thread per sample; applies the NaN fallback (mean of the call's valid rows, else the placeholder).
-__global__ void k_coarse_z(const float* __restrict__ near_far, const float* __restrict__ stats,
+__global__ void k_coarse_z(const float* __restrict__ near_far, const unsigned long long* __restrict__ stats,
                            const float* __restrict__ rays, int ray_stride, int n, int S,
                            const float* __restrict__ t_rand, int lindisp, float* __restrict__ z_out,
                            float* __restrict__ near_far_fixed) {
@@ -90,8 +93,8 @@ __global__ void k_coarse_z(const float* __restrict__ near_far, const float* __re
   if (!(nn == nn) || !(ff == ff)) {
     // torch.where(isnan(Q)) rows: both replaced (ray_utils.py:331-342)
     const float* r = rays + (long long)ray * ray_stride;
-    nn = stats[2] > 0.f ? stats[0] / stats[2] : r[6];
-    ff = stats[3] > 0.f ? stats[1] / stats[3] : r[7];
+    nn = stats[2] > 0 ? (float)((double)(long long)stats[0] / STATS_FIX / (double)stats[2]) : r[6];
+    ff = stats[3] > 0 ? (float)((double)(long long)stats[1] / STATS_FIX / (double)stats[3]) : r[7];
   }
   if (s == 0 && near_far_fixed) {
     near_far_fixed[2 * ray] = nn;
@@ -442,16 +445,17 @@ int launch_pack(const AnerfNetParams* P, const int32_t* table, long long n, floa
 
 int launch_ray_bounds(const float* rays, int ray_stride, const float* cyls, int n, float* near_far, float* stats,
                       hipStream_t st) {
-  if (hipMemsetAsync(stats, 0, 4 * sizeof(float), st) != hipSuccess) return set_error(ANERF_E_LAUNCH, "memset stats");
-  hipLaunchKernelGGL(k_ray_bounds, dim3((n + 255) / 256), dim3(256), 0, st, rays, ray_stride, cyls, n, near_far, stats);
+  if (hipMemsetAsync(stats, 0, 4 * sizeof(unsigned long long), st) != hipSuccess) return set_error(ANERF_E_LAUNCH, "memset stats");
+  hipLaunchKernelGGL(k_ray_bounds, dim3((n + 255) / 256), dim3(256), 0, st, rays, ray_stride, cyls, n, near_far,
+                     reinterpret_cast<unsigned long long*>(stats));
   return check_launch("k_ray_bounds");
 }
 
 int launch_coarse_z(const float* near_far, const float* stats, const float* rays, int ray_stride, int n, int S,
                     const float* t_rand, int lindisp, float* z, float* nf_fixed, hipStream_t st) {
   const long long tot = (long long)n * S;
-  hipLaunchKernelGGL(k_coarse_z, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, near_far, stats, rays,
-                     ray_stride, n, S, t_rand, lindisp, z, nf_fixed);
+  hipLaunchKernelGGL(k_coarse_z, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, near_far,
+                     reinterpret_cast<const unsigned long long*>(stats), rays, ray_stride, n, S, t_rand, lindisp, z, nf_fixed);
   return check_launch("k_coarse_z");
 }
 

@@ -385,6 +385,7 @@ int anerf_ray_bounds(const float* rays, int32_t ray_stride, const float* cyls, i
                      float* stats_ws, void* stream) {
   if (n_rays == 0) return ANERF_OK;   /* empty batch: nothing to enqueue, pointers may be NULL */
   if (!rays || !cyls || !near_far || !stats_ws) return set_error(ANERF_E_NULL, "ray_bounds: NULL pointer");
+  if ((uintptr_t)stats_ws & 7) return set_error(ANERF_E_WORKSPACE, "ray_bounds: stats_ws must be 8-byte aligned");
   if (ray_stride < 8 || n_rays < 0) return set_error(ANERF_E_SHAPE, "ray_bounds: ray_stride >= 8 required");
   if (n_rays == 0) return ANERF_OK;
   return launch_ray_bounds(rays, ray_stride, cyls, n_rays, near_far, stats_ws, (hipStream_t)stream);
@@ -803,7 +804,7 @@ FwdWs fwd_ws(int64_t n, int64_t S, int64_t Ni) {
   FwdWs w;
   int64_t o = 0;
   w.near_far = o; o += up(n * 2 * 4);
-  w.stats = o; o += up(16);
+  w.stats = o; o += up(32);
   w.z = o; o += up(n * S * 4);
   w.raw = o; o += up(n * S * 16);
   w.weights = o; o += up(n * S * 4);

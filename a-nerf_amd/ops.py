@@ -110,11 +110,11 @@ def pack_params(cfg, params, which=0, out=None):
 
 
 def ray_bounds(rays, cyls):
-    """get_near_far_in_cylinder (ray_utils.py:292): rays [N,>=8], cyls [N,5] -> (near_far [N,2] raw, stats [4])."""
+    """get_near_far_in_cylinder (ray_utils.py:292): rays [N,>=8], cyls [N,5] -> (near_far [N,2] raw, stats: 32 bytes of scratch for coarse_z)."""
     rays, cyls = _f32c(rays, "rays"), _f32c(cyls, "cyls")
     n = rays.shape[0]
     nf = torch.empty(n, 2, dtype=torch.float32, device=rays.device)
-    stats = torch.empty(4, dtype=torch.float32, device=rays.device)
+    stats = torch.empty(4, dtype=torch.int64, device=rays.device)
     _lib.check(_lib.load().anerf_ray_bounds(_p(rays), rays.shape[1], _p(cyls), n, _p(nf), _p(stats), _stream()), "anerf_ray_bounds")
     return nf, stats
 

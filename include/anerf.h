@@ -82,8 +82,8 @@ int anerf_build_pack_table(const AnerfConfig* cfg, int which, int32_t* host_tabl
 int anerf_pack_params(const AnerfNetParams* params, const int32_t* table, int64_t n, float* out, void* stream);
 
 /* A2: get_near_far_in_cylinder (ray_utils.py:292-344).  rays [N, ray_stride] = (o3,d3,near,far,...),
- * cyls [N,5].  near_far [N,2]; stats_ws: 4 floats of scratch (sum_near, sum_far, cnt_near, cnt_far),
- * zeroed by this call.  Rows whose ray misses the circle take the nan-mean of this call's rays. */
+ * cyls [N,5].  near_far [N,2]; stats_ws: 32 bytes of 8-byte-aligned scratch (sum_near, sum_far in 2^-32 fixed point,
+ * cnt_near, cnt_far as four 64-bit integers: exact, order-independent accumulation), zeroed by this call.  Rows whose ray misses the circle take the nan-mean of this call's rays. */
 int anerf_ray_bounds(const float* rays, int32_t ray_stride, const float* cyls, int32_t n_rays,
                      float* near_far, float* stats_ws, void* stream);
 /* A3: sample_from_lineseg (ray_utils.py:204-251) on the bounds of anerf_ray_bounds, NaN rows patched with the
