@@ -34,6 +34,18 @@ constexpr int AUX_FLOATS = 3080;
 int set_error(int code, const char* msg);
 int check_launch(const char* what);
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): the attribute is per device, and a host that
+// drives several GPUs from one process (one thread per GPU, as nn.DataParallel does) reaches every launcher on each of them.
+// `done` is the launcher's own static bit mask (bit = device ordinal).
+inline void ensure_dynamic_lds(const void* kernel, int bytes, unsigned long long* done) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (__atomic_load_n(done, __ATOMIC_RELAXED) & bit) return;
+  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  __atomic_fetch_or(done, bit, __ATOMIC_RELAXED);
+}
+
 #if defined(__HIPCC__)
 // sin and cos of x for |x| < ~1e4: Cody-Waite reduction by pi/2 (3 constants, exact products for |k| < 2^16)
 // + cephes-style minimax polynomials on [-pi/4, pi/4]; max abs error ~1e-7 (covers 2^6 * distance, 2^3 * unit dir).

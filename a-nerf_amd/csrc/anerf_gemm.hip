@@ -404,12 +404,9 @@ __global__ void k_reduce_dw(const GemmBatch G, const float* __restrict__ ws) {
 }
 
 int launch_weight_grads(const GemmPlan& P, const GemmBatch& G, float* ws, bool b3, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_tn<false>), hipFuncAttributeMaxDynamicSharedMemorySize, GLDS_BYTES);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_tn<true>), hipFuncAttributeMaxDynamicSharedMemorySize, GLDS3_BYTES);
-    attr_set = true;
-  }
+  static unsigned long long lds_set[2] = {};   // per-device bits, see ensure_dynamic_lds
+  ensure_dynamic_lds(reinterpret_cast<const void*>(k_gemm_tn<false>), GLDS_BYTES, &lds_set[0]);
+  ensure_dynamic_lds(reinterpret_cast<const void*>(k_gemm_tn<true>), GLDS3_BYTES, &lds_set[1]);
   const int grid = P.chunks_h * P.nheavy + P.chunks_s * P.nskinny;
   if (b3) hipLaunchKernelGGL(k_gemm_tn<true>, dim3((unsigned)grid), dim3(256), GLDS3_BYTES, st, P, ws);
   else hipLaunchKernelGGL(k_gemm_tn<false>, dim3((unsigned)grid), dim3(256), GLDS_BYTES, st, P, ws);

@@ -370,11 +370,8 @@ static int launch(const MlpArgs& a, hipStream_t st) {
   if (nblk <= 0) return ANERF_OK;
   const size_t lds = LDS_BONES_OFF + (PRE ? 0 : MAX_TILE_RAYS * 72 * 16);
   auto kern = k_mlp_fwd<LV, LD, CODE, PRE, TRAIN>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static unsigned long long lds_set = 0;   // per-device bits, see ensure_dynamic_lds
+  ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, &lds_set);
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, a);
   return check_launch("k_mlp_fwd");
 }
@@ -406,11 +403,8 @@ int mlp_density_entry(const float* packed, const float* aux, const float* pts, c
   if (nblk <= 0) return ANERF_OK;
   const size_t lds = LDS_BONES_OFF + MAX_TILE_RAYS * 72 * 16;
   auto kern = k_mlp_fwd<7, 0, 0, false, false, 1>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static unsigned long long lds_set = 0;   // per-device bits, see ensure_dynamic_lds
+  ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, &lds_set);
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, a);
   return check_launch("k_mlp_fwd<density>");
 }

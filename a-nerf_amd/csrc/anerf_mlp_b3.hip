@@ -415,11 +415,8 @@ static int launch_b3(const MlpArgs& a, hipStream_t st) {
   if (nblk <= 0) return ANERF_OK;
   const size_t lds = LDS_BONES_OFF + MAX_TILE_RAYS * 72 * 16;
   auto kern = k_mlp_fwd_b3<LV, LD, CODE, TRAIN>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static unsigned long long lds_set = 0;   // per-device bits, see ensure_dynamic_lds
+  ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)lds, &lds_set);
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, a);
   return check_launch("k_mlp_fwd_b3");
 }
@@ -591,11 +588,8 @@ int mlp_bwd_b3_entry(const float* packed_t, const float* aux, const float* draw,
   const long long nblk = (P + TILE - 1) / TILE;
   if (nblk <= 0) return ANERF_OK;
   const size_t lds = LDS_BONES_OFF;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_b3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static unsigned long long lds_set = 0;   // per-device bits, see ensure_dynamic_lds
+  ensure_dynamic_lds(reinterpret_cast<const void*>(k_mlp_bwd_b3), (int)lds, &lds_set);
   hipLaunchKernelGGL(k_mlp_bwd_b3, dim3((unsigned)nblk), dim3(256), lds, st, b);
   return check_launch("k_mlp_bwd_b3");
 }
@@ -691,11 +685,8 @@ int mlp_bwd_in_b3_entry(const float* packed_i, const float* dz, const float* dzv
   const long long nblk = (P + TILE - 1) / TILE;
   if (nblk <= 0) return ANERF_OK;
   const size_t lds = LDS_BONES_OFF;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_in_b3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static unsigned long long lds_set = 0;   // per-device bits, see ensure_dynamic_lds
+  ensure_dynamic_lds(reinterpret_cast<const void*>(k_mlp_bwd_in_b3), (int)lds, &lds_set);
   hipLaunchKernelGGL(k_mlp_bwd_in_b3, dim3((unsigned)nblk), dim3(256), lds, st, b);
   return check_launch("k_mlp_bwd_in_b3");
 }

@@ -245,11 +245,8 @@ int mlp_bwd_in_entry(const float* packed_i, const float* dz, const float* dzv, f
   const long long nblk = (P + TILE - 1) / TILE;
   if (nblk <= 0) return ANERF_OK;
   const size_t lds = 2 * STAGE_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd_in), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static unsigned long long lds_set = 0;   // per-device bits, see ensure_dynamic_lds
+  ensure_dynamic_lds(reinterpret_cast<const void*>(k_mlp_bwd_in), (int)lds, &lds_set);
   hipLaunchKernelGGL(k_mlp_bwd_in, dim3((unsigned)nblk), dim3(256), lds, st, b);
   return check_launch("k_mlp_bwd_in");
 }
@@ -262,11 +259,8 @@ int mlp_bwd_entry(const float* packed_t, const float* aux, const float* draw, co
   const long long nblk = (P + TILE - 1) / TILE;
   if (nblk <= 0) return ANERF_OK;
   const size_t lds = LDS_BONES_OFF;   // 3-slot weight ring + the aux copy (no bone staging in the backward)
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_mlp_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static unsigned long long lds_set = 0;   // per-device bits, see ensure_dynamic_lds
+  ensure_dynamic_lds(reinterpret_cast<const void*>(k_mlp_bwd), (int)lds, &lds_set);
   hipLaunchKernelGGL(k_mlp_bwd, dim3((unsigned)nblk), dim3(256), lds, st, b);
   return check_launch("k_mlp_bwd");
 }
