@@ -47,7 +47,7 @@ def test_fused_loss_value_and_gradients(loss_fn, bg, coarse):
             # atol: d = pred - target carries ~6e-8 of rounding (fma vs mul+add); Huber's quadratic zone divides it by beta
             np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-6, atol=1e-9, err_msg=k)
     pred = p["rgb_map"] + (1 - p["acc_map"])[:, None] * bgs if use_bg else p["rgb_map"]
-    mse = float(((pred - target) ** 2).mean())
+    mse = float(((pred - target) ** 2).mean().detach())
     assert abs(float(stats[3]) - mse) < 2e-7
     assert abs(float(render_mod.mse2psnr(stats[3])) - float(render_mod.mse2psnr(torch.tensor(mse)))) < 1e-3   # dB bar
 
