@@ -216,6 +216,14 @@ class RayParallel(nn.Module):
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
 
+    def sync_gradients(self, group=None):
+        """Average the gradients of every trainable parameter over the ranks with ONE all-reduce of a flat fp32 bucket
+        (parallel.GradBucket); call after loss.backward().  No-op in a single process."""
+        if getattr(self, "_bucket", None) is None:
+            from .parallel import GradBucket
+            self._bucket = GradBucket([p for p in self.module.parameters() if p.requires_grad])
+        return self._bucket.all_reduce_mean(group)
+
 
 def get_grad_vars(args, ray_caster):
     network, network_fine = ray_caster.get_networks()

@@ -44,6 +44,7 @@ def test_create_raycaster_tuple_and_checkpoint_layout():
     assert rk_test["perturb"] is False and rk_test["raw_noise_std"] == 0.0
     caster = rk_test["ray_caster"]
     assert rk_train["ray_caster"].module is caster           # trainer.py:265,270,504 reach through .module
+    assert rk_train["ray_caster"].sync_gradients() is None    # single process: nothing to reduce
     sd = caster.state_dict()
     assert set(sd) == {"network_fn_state_dict", "network_fine_state_dict", "embed_state_dict", "embedbones_state_dict",
                        "embeddirs_state_dict"}
