@@ -191,14 +191,16 @@ class _RenderRaysFn(torch.autograd.Function):
             raise NotImplementedError("skts.requires_grad needs per-ray skts [N,24,4,4]")
         want_in = want_skts or want_cc or want_cf
         pi = meta["packed_i"]() if want_in else (None, None)
-        # Parameters whose .grad is a view of FusedAdam's flat gradient bucket (it marks them): the reduction kernel adds
-        # into the bucket directly -- what AccumulateGrad would otherwise do with 48 extra launches per step -- and this
-        # node reports no parameter gradients to autograd.  Anything else (torch optimisers, torch.autograd.grad) gets
-        # fresh gradient tensors through autograd as usual.
+        # In-place gradient accumulation is an explicit opt-in: `FusedAdam.attach(caster)` registers the optimiser as the
+        # caster's gradient sink.  Only then -- and only while every parameter's .grad really is a view into that optimiser's
+        # flat bucket -- does the reduction kernel add into the bucket directly (what AccumulateGrad would otherwise do with
+        # 48 extra launches per step) and this node reports no parameter gradients to autograd.  Everything else (torch
+        # optimisers, an un-attached FusedAdam, torch.autograd.grad, hooks, DDP-style reducers) gets fresh gradient tensors
+        # through autograd as usual.
         dev = state["ws"].device
+        sink = meta.get("grad_sink")
         into = [p.grad for p in meta["params"]]
-        direct = all(getattr(p, "_anerf_flat_grad", False) and p.requires_grad for p in meta["params"]) and \
-            all(t is not None and t.dtype == torch.float32 and t.is_contiguous() and t.device == dev for t in into)
+        direct = sink is not None and sink.owns_grads(meta["params"], dev)
         grads_c, grads_f, g_skts, g_cc, g_cf = ops.backward(
             state, dict(zip(ctx.keys, gs)), meta["packed_t_c"], meta["packed_t_f"], perm_tables(meta["kw"]["cfg"], dev, b3=b3),
             ctx.shapes[:24], ctx.shapes[24:], pi[0], pi[1], want_skts, want_cc, want_cf,
@@ -225,6 +227,8 @@ def _render_rays_one_node(caster, kw, prec):
                 packed_i=lambda: tuple(n.packed(5 if b3 else 2)[0] for n in nets) + ((None,) if not hier else ()))
     params = [p for n in nets for p in _net_params(n)]
     meta["params"] = params
+    sink = getattr(caster, "_anerf_grad_sink", None)
+    meta["grad_sink"] = sink() if sink is not None else None        # weakref to an attached FusedAdam, or nothing
     out = _RenderRaysFn.apply(meta, kw["skts"].contiguous(), codes_c, codes_f, *params)
     return dict(zip(_OUT_KEYS, out))
 

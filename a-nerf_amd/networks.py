@@ -49,10 +49,20 @@ class Optcodes(nn.Module):
             nn.init.constant_(self.codes.weight, mean)
 
     def table_for(self, idx, training):
-        """(table, idx) the kernel should use: eval with all idx < 0 -> the mean code (embedding.py:21-22)."""
-        if (not training) and idx is not None and bool((idx.max() < 0)):
-            return self.codes.weight.mean(0, keepdim=True), torch.zeros_like(idx)
-        return self.codes.weight, idx
+        """(table, idx) the kernel should use.  Eval with idx < 0 -> the mean code (embedding.py:21-22: the reference
+        switches the whole call to the mean code when `idx.max() < 0`; any other negative index would crash its
+        nn.Embedding).  Here the rule is applied per ray ON THE DEVICE -- the table gets the mean code as one extra row
+        and negative indices are pointed at it -- so no host read of `idx` (a stream sync per caster call) is needed and the
+        result is the reference's wherever the reference is defined."""
+        if training or idx is None:
+            return self.codes.weight, idx
+        w = self.codes.weight
+        key = (w.data_ptr(), w._version)
+        if getattr(self, "_eval_table_key", None) != key:
+            with torch.no_grad():
+                self._eval_table = torch.cat([w.detach(), w.detach().mean(0, keepdim=True)], 0)
+            self._eval_table_key = key
+        return self._eval_table, torch.where(idx < 0, torch.full_like(idx, float(self.n_codes)), idx)
 
 
 class NeRF(nn.Module):
@@ -128,10 +138,8 @@ class NeRF(nn.Module):
         stream, aux = self.packed()
         codes = self.framecodes.codes.weight if self.use_framecode else None
         if self.use_framecode and not self.training:
-            idx = x[..., -1]
-            if bool(idx.max() < 0):
-                codes = codes.mean(0, keepdim=True)
-                x = torch.cat([x[..., :-1], torch.zeros_like(x[..., -1:])], -1)
+            codes, idx = self.framecodes.table_for(x[..., -1], False)
+            x = torch.cat([x[..., :-1], idx[..., None]], -1)
         return ops.mlp_forward(self.path_cfg, stream, aux, x, codes)
 
     def forward_batchify(self, inputs, chunk=1024 * 64, **kwargs):

@@ -10,6 +10,8 @@ Mirrors, with the same names and meaning where the reference has them:
 The flat gradient buffer is also the DP bucket: `all_reduce_grads()` is one RCCL all-reduce on it, the 1/world
 scale is folded into the Adam kernel.  No CPU fallback: the kernels come from libanerf_hip.so.
 """
+import weakref
+
 import torch
 import torch.distributed as dist
 
@@ -17,28 +19,78 @@ from . import ops
 
 
 class FusedAdam:
-    """Adam over a flat parameter buffer.  Interface subset of torch.optim.Adam: `param_groups`, `state`,
-    `step()`, `zero_grad()`, `state_dict()` / `load_state_dict()` in torch's format (so the reference's
-    checkpoint key `optimizer_state_dict`, trainer.py:498-505, round-trips)."""
+    """Adam over ONE flat fp32 buffer that holds every parameter of every group.
+
+    Interface of torch.optim.Adam (`param_groups`, `state`, `step()`, `zero_grad()`, `add_param_group()`,
+    `state_dict()` / `load_state_dict()` in torch's format, so the reference's checkpoint keys `optimizer_state_dict`
+    / `pose_optimizer_state_dict`, trainer.py:498-505, round-trip), plus what the ray-sharded DP step needs:
+
+    * groups are consecutive SEGMENTS of the flat parameter / gradient / moment buffers (each padded to 16 bytes), so the
+      gradient bucket of a step is one contiguous range and `all_reduce_grads()` is ONE collective whatever is in it;
+    * a group may carry `step_every = k`: it is stepped (and its gradients all-reduced and cleared) only on iterations
+      with `i % k == 0` and accumulates local gradients in between -- the reference's pose-optimiser cadence
+      (`if i % args.opt_pose_step == 0: pose_optimizer.step()`, trainer.py:476-478; opt_pose_step = 20 in mixamo.txt:48).
+      Summing the ranks' ACCUMULATED gradients once per k iterations equals all-reducing them every iteration (linearity);
+    * `group_optimizer(g)` is a view with the torch optimiser surface over one group -- what a trainer holds as its
+      `pose_optimizer` (own lr decay through `param_groups`, own `state_dict`).
+
+    Difference from torch.optim.Adam: a parameter whose `.grad` is None at `step()` is treated as having a zero gradient
+    (its moments decay and it moves along its first moment) -- torch skips it and keeps its own step count; one flat
+    buffer has one step count per group.  No shipped training path leaves a trainable parameter without a gradient."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
-        self.params = [p for p in params if p.requires_grad]
-        if not self.params:
-            raise ValueError("FusedAdam: no parameters")
-        self.param_groups = [{"params": self.params, "lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": 0,
-                              "amsgrad": False}]
-        self._step = 0
-        self._grad_scale = 1.0
+        params = list(params)
+        self.param_groups = []
+        self._steps = []                  # Adam step count per group
+        self._grad_scale = []             # 1/world after an all-reduce, consumed by the next step of that group
         self.flat = self.flat_grad = self.exp_avg = self.exp_avg_sq = None
         self.norms = None
-        self._pending = None          # optimizer state loaded before the buffers exist
+        self._pending = None              # optimizer state loaded before the buffers exist
+        self._defaults = {"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": 0, "amsgrad": False, "step_every": 1}
+        if params and isinstance(params[0], dict):
+            for g in params:
+                self.add_param_group(g)
+        else:
+            self.add_param_group({"params": params})
+
+    def add_param_group(self, group):
+        """torch.optim.Optimizer.add_param_group; extra key `step_every` (default 1).  Call before the first step."""
+        if self.flat is not None:
+            raise RuntimeError("FusedAdam.add_param_group: the flat buffers already exist; add groups before the first step")
+        g = dict(self._defaults)
+        g.update({k: v for k, v in group.items() if k != "params"})
+        g["betas"] = tuple(g["betas"])
+        g["params"] = [p for p in group["params"] if p.requires_grad]
+        if not g["params"]:
+            raise ValueError("FusedAdam: no parameters")
+        if g["weight_decay"] or g["amsgrad"]:
+            raise NotImplementedError("FusedAdam implements plain Adam (weight_decay 0, no amsgrad), as the reference uses it")
+        self.param_groups.append(g)
+        self._steps.append(0)
+        self._grad_scale.append(1.0)
+
+    @property
+    def params(self):
+        return [p for g in self.param_groups for p in g["params"]]
 
     # ---- flat storage ---------------------------------------------------------------------------------------
-    def _views(self, flat):
+    def _segments(self):
+        """[(offset, padded length)] of every group inside the flat buffers"""
         out, o = [], 0
-        for p in self.params:
-            out.append(flat[o:o + p.numel()].view(p.shape))
-            o += p.numel()
+        for g in self.param_groups:
+            n = sum(p.numel() for p in g["params"])
+            npad = (n + 3) // 4 * 4
+            out.append((o, npad))
+            o += npad
+        return out
+
+    def _views(self, flat, group=None):
+        out = []
+        for gi, (g, (o, _)) in enumerate(zip(self.param_groups, self._segments())):
+            for p in g["params"]:
+                if group is None or group == gi:
+                    out.append(flat[o:o + p.numel()].view(p.shape))
+                o += p.numel()
         return out
 
     def materialize(self):
@@ -48,13 +100,13 @@ class FusedAdam:
             return
         if dev.type != "cuda":
             raise RuntimeError("FusedAdam runs on the GPU only (no CPU fallback); move the model first")
-        n = sum(p.numel() for p in self.params)
-        self.numel = n
-        npad = (n + 3) // 4 * 4
-        self.flat = torch.zeros(npad, dtype=torch.float32, device=dev)
-        self.flat_grad = torch.zeros(npad, dtype=torch.float32, device=dev)
-        self.exp_avg = torch.zeros(npad, dtype=torch.float32, device=dev)
-        self.exp_avg_sq = torch.zeros(npad, dtype=torch.float32, device=dev)
+        seg = self._segments()
+        self.numel = sum(p.numel() for p in self.params)
+        ntot = seg[-1][0] + seg[-1][1]
+        self.flat = torch.zeros(ntot, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(ntot, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(ntot, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(ntot, dtype=torch.float32, device=dev)
         self.norms = torch.zeros(2, dtype=torch.float32, device=dev)
         with torch.no_grad():
             for p, v, g in zip(self.params, self._views(self.flat), self._views(self.flat_grad)):
@@ -63,85 +115,217 @@ class FusedAdam:
                     g.copy_(p.grad)
                 p.data = v
                 p.grad = g
-                p._anerf_flat_grad = True        # autograd_path: gradients may be accumulated into the bucket in place
         if self._pending is not None:
             sd, self._pending = self._pending, None
             self.load_state_dict(sd)
 
+    # ---- in-place gradient accumulation (opt-in) --------------------------------------------------------------
+    def attach(self, caster):
+        """Opt in to in-place gradient accumulation: the caster's one-call backward adds the parameter gradients straight
+        into this optimiser's flat bucket and reports none to autograd (no 48 AccumulateGrad launches per step).  While
+        attached, `torch.autograd.grad(loss, params)` on these parameters yields None -- call `detach()` (or never attach)
+        when the gradients are wanted as autograd results.  `caster` may be the RayParallel wrapper."""
+        caster = getattr(caster, "module", caster)
+        caster._anerf_grad_sink = weakref.ref(self)
+        self._attached = weakref.ref(caster)
+        return self
+
+    def detach(self):
+        caster = self._attached() if getattr(self, "_attached", None) is not None else None
+        if caster is not None and getattr(caster, "_anerf_grad_sink", None) is not None and caster._anerf_grad_sink() is self:
+            caster._anerf_grad_sink = None
+        self._attached = None
+
+    def __del__(self):
+        try:
+            self.detach()
+        except Exception:
+            pass
+
+    def owns_grads(self, params, device):
+        """True when every parameter's .grad is (still) a contiguous fp32 view into this optimiser's flat gradient bucket."""
+        fg = self.flat_grad
+        if fg is None or fg.device != device:
+            return False
+        lo, hi = fg.data_ptr(), fg.data_ptr() + fg.numel() * 4
+        for p in params:
+            g = p.grad
+            if g is None or not p.requires_grad or g.dtype != torch.float32 or not g.is_contiguous() or g.device != device:
+                return False
+            if not (lo <= g.data_ptr() and g.data_ptr() + g.numel() * 4 <= hi):
+                return False
+        return True
+
     @property
     def state(self):
         """torch-style per-parameter state (read-only views; `state[p]['step']` is what decay_optimizer_lrate reads)."""
-        if self.flat is None or self._step == 0:
+        return self._state_of(None)
+
+    def _state_of(self, group):
+        if self.flat is None:
             return {}
-        ea, es = self._views(self.exp_avg), self._views(self.exp_avg_sq)
-        return {p: {"step": self._step, "exp_avg": a, "exp_avg_sq": s} for p, a, s in zip(self.params, ea, es)}
+        out = {}
+        for gi, g in enumerate(self.param_groups):
+            if (group is not None and group != gi) or self._steps[gi] == 0:
+                continue
+            ea, es = self._views(self.exp_avg, gi), self._views(self.exp_avg_sq, gi)
+            out.update({p: {"step": self._steps[gi], "exp_avg": a, "exp_avg_sq": s} for p, a, s in zip(g["params"], ea, es)})
+        return out
 
     # ---- step -----------------------------------------------------------------------------------------------
-    def all_reduce_grads(self, group=None):
-        """Sum the flat gradient bucket over ranks (one collective); the 1/world scale is applied inside step()."""
+    def _due(self, i, only=None):
+        """indices of the groups that step on iteration `i` (None: all of them)"""
+        return [gi for gi, g in enumerate(self.param_groups)
+                if (only is None or gi == only) and (i is None or g["step_every"] <= 1 or i % g["step_every"] == 0)]
+
+    def all_reduce_grads(self, group=None, i=None, weight=None):
+        """Sum the gradient bucket over ranks; the 1/world scale is applied inside step().  ONE collective over the
+        contiguous range of the groups due on iteration `i` (see class doc; i=None: every group).
+        weight: multiply the local gradients first -- `parallel.shard_weight()` for ragged ray shards, so that the reduced
+        gradient is the global-batch mean gradient even when the ranks own different numbers of rays."""
         self.materialize()
         world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        if world > 1:
-            dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=group)
-            self._grad_scale = 1.0 / world
+        if world <= 1:
+            return
+        due = self._due(i)
+        seg = self._segments()
+        runs = []                                     # maximal runs of consecutive due groups -> one collective each
+        for gi in due:
+            if runs and runs[-1][-1] == gi - 1:
+                runs[-1].append(gi)
+            else:
+                runs.append([gi])
+        for run in runs:
+            lo, hi = seg[run[0]][0], seg[run[-1]][0] + seg[run[-1]][1]
+            buf = self.flat_grad[lo:hi]
+            if weight is not None and float(weight) != 1.0:
+                buf.mul_(float(weight))
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        for gi in due:
+            self._grad_scale[gi] = 1.0 / world
 
     @torch.no_grad()
-    def step(self, zero_grad=False, want_norms=False):
-        """One Adam update.  zero_grad: also clear the gradients (= the reference's `_optim_step`).  want_norms:
-        returns a [2] device tensor (total_norm, avg_norm) of this step's gradients -- read it when convenient."""
+    def step(self, zero_grad=False, want_norms=False, i=None, only_group=None):
+        """One Adam update of every group due on iteration `i` (None: all groups).  zero_grad: also clear the gradients of
+        the groups that stepped (= the reference's `_optim_step`; groups that are not due keep accumulating).
+        want_norms: returns a [2] device tensor (total_norm, avg_norm) of group 0's gradients at this step
+        (`get_gradnorm(ray_caster)`, trainer.py:192-203) -- read it when convenient."""
         self.materialize()
-        for p, g in zip(self.params, self._views(self.flat_grad)):
-            if p.grad is None:
-                g.zero_()                                    # someone called zero_grad(set_to_none=True) elsewhere:
-                p.grad = g                                   # no gradient this step; the view goes back for the next
-            elif p.grad.data_ptr() != g.data_ptr():
-                g.copy_(p.grad)                              # foreign gradient tensor: adopt its value
-                p.grad = g
-        grp = self.param_groups[0]
-        self._step += 1
-        ops.adam_step(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, grp["lr"], grp["betas"][0], grp["betas"][1],
-                      grp["eps"], self._step, self._grad_scale, zero_grad, len(self.params),
-                      self.norms if want_norms else None)
-        self._grad_scale = 1.0
-        for p in self.params:
-            torch.autograd.graph.increment_version(p)        # parameters changed behind torch's back
+        seg = self._segments()
+        for gi in self._due(i, only_group):
+            grp = self.param_groups[gi]
+            for p, g in zip(grp["params"], self._views(self.flat_grad, gi)):
+                if p.grad is None:
+                    g.zero_()                                    # someone called zero_grad(set_to_none=True) elsewhere:
+                    p.grad = g                                   # no gradient this step; the view goes back for the next
+                elif p.grad.data_ptr() != g.data_ptr():
+                    g.copy_(p.grad)                              # foreign gradient tensor: adopt its value
+                    p.grad = g
+            self._steps[gi] += 1
+            o, n = seg[gi]
+            norms = self.norms if (want_norms and gi == 0) else None
+            ops.adam_step(self.flat[o:o + n], self.flat_grad[o:o + n], self.exp_avg[o:o + n], self.exp_avg_sq[o:o + n],
+                          grp["lr"], grp["betas"][0], grp["betas"][1], grp["eps"], self._steps[gi], self._grad_scale[gi],
+                          zero_grad, len(grp["params"]), norms)
+            self._grad_scale[gi] = 1.0
+            for p in grp["params"]:
+                torch.autograd.graph.increment_version(p)        # parameters changed behind torch's back
         return self.norms if want_norms else None
 
-    def zero_grad(self, set_to_none=False):
+    def zero_grad(self, set_to_none=False, only_group=None):
         if self.flat_grad is not None:
-            self.flat_grad.zero_()
+            if only_group is None:
+                self.flat_grad.zero_()
+            else:
+                o, n = self._segments()[only_group]
+                self.flat_grad[o:o + n].zero_()
         else:
-            for p in self.params:
-                p.grad = None
+            for gi, g in enumerate(self.param_groups):
+                if only_group is None or only_group == gi:
+                    for p in g["params"]:
+                        p.grad = None
+
+    def group_optimizer(self, gi):
+        """torch-optimiser-shaped view of ONE group (a trainer's `pose_optimizer`)."""
+        return _GroupView(self, gi)
 
     # ---- checkpoint (torch.optim.Adam format) ------------------------------------------------------------------
+    def state_dict(self, group=None):
+        """torch.optim.Adam.state_dict() layout.  group=None: all groups (parameter indices run on across groups, as torch
+        numbers them); group=g: that group alone, numbered from 0 -- what a separate torch optimiser over it would save."""
+        st, groups, base = {}, [], 0
+        for gi, g in enumerate(self.param_groups):
+            if group is not None and group != gi:
+                continue
+            q = {k: v for k, v in g.items() if k != "params"}
+            q["params"] = list(range(base, base + len(g["params"])))
+            groups.append(q)
+            if self.flat is not None and self._steps[gi] > 0:
+                for j, (a, s) in enumerate(zip(self._views(self.exp_avg, gi), self._views(self.exp_avg_sq, gi))):
+                    st[base + j] = {"step": torch.tensor(float(self._steps[gi])), "exp_avg": a.clone(), "exp_avg_sq": s.clone()}
+            base += len(g["params"])
+        if self._pending is not None and group is None:      # a loaded state that has not reached the device buffers yet
+            st = self._pending["state"]
+        return {"state": st, "param_groups": groups}
+
+    def load_state_dict(self, sd, group=None):
+        """Inverse of state_dict(group); accepts what torch.optim.Adam saved for the same parameter lists."""
+        targets = list(range(len(self.param_groups))) if group is None else [group]
+        if len(sd["param_groups"]) != len(targets):
+            raise ValueError(f"FusedAdam.load_state_dict: {len(sd['param_groups'])} saved groups for {len(targets)} groups")
+        for gi, grp in zip(targets, sd["param_groups"]):
+            for k in ("lr", "betas", "eps", "step_every"):
+                if k in grp:
+                    self.param_groups[gi][k] = tuple(grp[k]) if k == "betas" else grp[k]
+        if self.flat is None and self.params[0].is_cuda:
+            self.materialize()
+        if self.flat is None:                      # model still on the host: keep the state until materialize()
+            if group is not None:
+                raise RuntimeError("FusedAdam.load_state_dict(group=...) needs the model on the GPU first")
+            self._pending = sd
+            return
+        state = {int(k): v for k, v in sd["state"].items()}
+        base = 0
+        with torch.no_grad():
+            for gi in targets:
+                n = len(self.param_groups[gi]["params"])
+                steps = {int(state[j]["step"]) for j in range(base, base + n) if j in state}
+                if len(steps) > 1:
+                    raise ValueError("FusedAdam: per-parameter step counts differ inside a group; a flat segment has one step count")
+                self._steps[gi] = steps.pop() if steps else 0
+                for j, (a, s) in enumerate(zip(self._views(self.exp_avg, gi), self._views(self.exp_avg_sq, gi))):
+                    if base + j in state:
+                        a.copy_(state[base + j]["exp_avg"])
+                        s.copy_(state[base + j]["exp_avg_sq"])
+                base += n
+
+
+class _GroupView:
+    """One group of a FusedAdam behind torch.optim.Optimizer's surface (param_groups / state / step / zero_grad /
+    state_dict / load_state_dict): the trainer's `pose_optimizer` when the pose parameters share the flat DP bucket."""
+
+    def __init__(self, opt, gi):
+        self.opt, self.gi = opt, gi
+
+    @property
+    def param_groups(self):
+        return [self.opt.param_groups[self.gi]]
+
+    @property
+    def state(self):
+        return self.opt._state_of(self.gi)
+
+    def step(self, zero_grad=False):
+        return self.opt.step(zero_grad=zero_grad, only_group=self.gi)
+
+    def zero_grad(self, set_to_none=False):
+        self.opt.zero_grad(only_group=self.gi)
+
     def state_dict(self):
-        grp = {k: v for k, v in self.param_groups[0].items() if k != "params"}
-        grp["params"] = list(range(len(self.params)))
-        st = {}
-        if self.flat is not None and self._step > 0:
-            for i, (a, s) in enumerate(zip(self._views(self.exp_avg), self._views(self.exp_avg_sq))):
-                st[i] = {"step": torch.tensor(float(self._step)), "exp_avg": a.clone(), "exp_avg_sq": s.clone()}
-        return {"state": st, "param_groups": [grp]}
+        return self.opt.state_dict(group=self.gi)
 
     def load_state_dict(self, sd):
-        if self.flat is None:
-            self._pending = sd
-        grp = sd["param_groups"][0]
-        for k in ("lr", "betas", "eps"):
-            if k in grp:
-                self.param_groups[0][k] = tuple(grp[k]) if k == "betas" else grp[k]
-        if self.flat is None:
-            return
-        steps = {int(v["step"]) for v in sd["state"].values()}
-        if len(steps) > 1:
-            raise ValueError("FusedAdam: per-parameter step counts differ; one flat buffer has one step count")
-        self._step = steps.pop() if steps else 0
-        with torch.no_grad():
-            for i, (a, s) in enumerate(zip(self._views(self.exp_avg), self._views(self.exp_avg_sq))):
-                if i in sd["state"]:
-                    a.copy_(sd["state"][i]["exp_avg"])
-                    s.copy_(sd["state"][i]["exp_avg_sq"])
+        self.opt.load_state_dict(sd, group=self.gi)
 
 
 class _LossFn(torch.autograd.Function):

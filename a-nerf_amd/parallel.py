@@ -28,8 +28,9 @@ class GradBucket:
                 self.views.append(self.flat[o:o + p.numel()].view_as(p))
                 o += p.numel()
 
-    def all_reduce_mean(self, group=None):
-        """Sum gradients over ranks, divide by world size, write back into p.grad.  Returns the flat bucket."""
+    def all_reduce_mean(self, group=None, weight=None):
+        """Sum gradients over ranks, divide by world size, write back into p.grad.  Returns the flat bucket.
+        weight: factor applied to this rank's gradients first (`shard_weight()` when the ray shards are ragged)."""
         if not self.params:
             return None
         world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
@@ -41,6 +42,8 @@ class GradBucket:
                 p.grad = torch.zeros_like(p)
         grads = [p.grad for p in self.params]
         torch._foreach_copy_(self.views, grads)          # one multi-tensor launch each way
+        if weight is not None and float(weight) != 1.0:
+            self.flat.mul_(float(weight))
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
         self.flat.div_(world)
         torch._foreach_copy_(grads, self.views)
@@ -55,6 +58,16 @@ def shard_rays(n_rays, rank=None, world=None):
         world = dist.get_world_size() if dist.is_initialized() else 1
     per = (n_rays + world - 1) // world
     return min(n_rays, rank * per), min(n_rays, (rank + 1) * per)
+
+
+def shard_weight(n_rays, rank=None, world=None):
+    """Factor that turns "mean over ranks of per-rank MEAN-loss gradients" into the global-batch mean gradient when the
+    shards are ragged: local_n * world / n_rays (1.0 for an even split).  Each rank's loss is a mean over ITS rays
+    (trainer.py:21), so a short last shard would otherwise be over-weighted by the plain 1/world average."""
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    lo, hi = shard_rays(n_rays, rank, world)
+    return (hi - lo) * world / float(n_rays)
 
 
 def gather_rays(local, n_total, group=None):

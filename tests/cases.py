@@ -19,6 +19,8 @@ CASES = {
     # name: (n_rays, pose_seeds, ray_seed, per_ray_pose, S, Ni, seeds(coarse, fine), cfg kwargs)
     "eval_s32": dict(n=96, poses=[0], ray_seed=1, per_ray=False, S=32, Ni=0, seeds=(11, 12), cfg={}),
     "eval_hier": dict(n=64, poses=[1], ray_seed=2, per_ray=False, S=64, Ni=16, seeds=(11, 12), cfg={}),
+    # BASELINE config 5's sample counts (64 coarse + 128 importance): 192-sample merged pass, two networks
+    "eval_hier128": dict(n=96, poses=[12], ray_seed=9, per_ray=False, S=64, Ni=128, seeds=(11, 12), cfg={}),
     "nan_fallback": dict(n=64, poses=[2], ray_seed=3, per_ray=False, S=16, Ni=0, seeds=(11, 12), cfg={}, cyl_scale=0.45),
     "train_pytest": dict(n=48, poses=[4, 5, 6], ray_seed=4, per_ray=True, S=64, Ni=16, seeds=(11, 12), cfg={}, train=True),
     "mixamo_train": dict(n=40, poses=[7, 8], ray_seed=5, per_ray=True, S=64, Ni=16, seeds=(21, 22),

@@ -1,0 +1,120 @@
+"""CPU: the reference's on-disk checkpoint format (core/trainer.py:485-517).
+
+(1) everywhere: a checkpoint written by a-nerf_amd.checkpoint.save_nerf has exactly the key / shape / dtype layout of the
+    file the reference's own Trainer.save_nerf writes (tests/golden/ckpt_manifest_*.json, dumped from such a file by
+    tests/golden/gen_golden_ckpt.py) and round-trips through load_nerf;
+(2) in the build container (where /root/reference exists): a `.tar` is written AT TEST TIME by the reference's unmodified
+    save_nerf and loaded by load_nerf (networks, embedder state, optimizer moments, pose layer, pose optimizer, anchors),
+    and the file our save_nerf writes is loaded back by the reference's modules and optimizers.
+"""
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from test_reference_args import ref_args, data_attrs
+
+raycaster = importlib.import_module("a-nerf_amd.raycaster")
+checkpoint = importlib.import_module("a-nerf_amd.checkpoint")
+pose_opt = importlib.import_module("a-nerf_amd.pose_opt")
+synth = importlib.import_module("a-nerf_amd.synth")
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+N_POSES = 5
+
+
+def ours(config, seed=0):
+    """our mirrors for `config` (CPU) after one torch-Adam step with synthetic gradients"""
+    args = ref_args(config)
+    rk_train, rk_test, _, grad_vars, optimizer, _ = raycaster.create_raycaster(args, data_attrs(N_POSES), device="cpu")
+    g = torch.Generator().manual_seed(seed)
+    for p in grad_vars:
+        p.grad = torch.randn(p.shape, generator=g) * 1e-3
+    optimizer.step()
+    optimizer.zero_grad()
+    popt = popt_optim = anchors = None
+    if args.opt_pose:
+        poses = [synth.make_pose(30 + k) for k in range(N_POSES)]
+        kps, bones = np.stack([q["kp"] for q in poses]), np.stack([q["bones"] for q in poses])
+        popt = pose_opt.PoseOptLayer(kps, bones, (synth.SMPL_REST_POSE * synth.SURREAL_SCALE)[None], use_rot6d=args.opt_rot6d)
+        popt_optim = torch.optim.Adam(list(popt.parameters()), lr=args.opt_pose_lrate, betas=(0.9, 0.999))
+        for p in popt.parameters():
+            p.grad = torch.randn(p.shape, generator=g) * 1e-3
+        popt_optim.step()
+        popt_optim.zero_grad()
+        anchors = {"kps": torch.tensor(kps), "bones": torch.tensor(bones),
+                   "rots": pose_opt.axisang_to_rot(torch.tensor(bones)), "beta": None}
+    return args, rk_train, rk_test["ray_caster"], optimizer, popt, popt_optim, anchors
+
+
+@pytest.mark.parametrize("config", ["mixamo", "surreal"])
+def test_saved_checkpoint_has_the_reference_layout_and_round_trips(tmp_path, config):
+    want = json.load(open(os.path.join(GOLDEN, f"ckpt_manifest_{config}.json")))
+    args, rk_train, caster, optimizer, popt, popt_optim, anchors = ours(config)
+    path = str(tmp_path / "000123.tar")
+    checkpoint.save_nerf(path, 123, rk_train["ray_caster"], optimizer, popt, popt_optim, anchors)
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    got = json.loads(json.dumps(checkpoint.manifest(ck)))
+    assert sorted(got) == sorted(want)
+    for k in want:
+        assert got[k] == want[k], k
+    # round trip into fresh modules
+    args2, rk2, caster2, opt2, popt2, popt_optim2, _ = ours(config, seed=7)
+    r = checkpoint.load_nerf(path, rk2["ray_caster"], opt2, popt2, popt_optim2)
+    assert r["global_step"] == 123
+    for (n1, p1), (n2, p2) in zip(caster.named_parameters(), caster2.named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2), n1
+    s1, s2 = optimizer.state_dict()["state"], opt2.state_dict()["state"]
+    assert all(torch.equal(s1[i]["exp_avg_sq"], s2[i]["exp_avg_sq"]) and float(s1[i]["step"]) == float(s2[i]["step"]) for i in s1)
+    if popt is not None:
+        assert torch.equal(popt.bones, popt2.bones) and torch.equal(popt.pelvis, popt2.pelvis)
+        assert torch.equal(popt_optim.state_dict()["state"][1]["exp_avg"], popt_optim2.state_dict()["state"][1]["exp_avg"])
+        assert torch.equal(r["poseopt_anchors"]["rots"], anchors["rots"])
+    else:
+        assert ck["poseopt_layer_state_dict"] is None and ck["pose_optimizer_state_dict"] is None and r["poseopt_anchors"] is None
+    assert checkpoint.load_nerf(path, rk2["ray_caster"], opt2, finetune=True)["global_step"] == 0      # raycasters.py:141-143
+    with pytest.raises(KeyError):
+        checkpoint.load_nerf({"foo": 1}, caster2)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/core"), reason="needs the reference source (build container only)")
+def test_reference_written_checkpoint_loads_and_ours_loads_in_the_reference(tmp_path):
+    sys.path.insert(0, GOLDEN)
+    import gen_golden_ckpt as gg
+    ref_path = str(tmp_path / "ref.tar")
+    rargs, rcaster, roptim, rpopt, rpopt_optim, ranchors = gg.reference_checkpoint(ref_path, "mixamo", global_step=4321)
+    args, rk_train, caster, optimizer, popt, popt_optim, _ = ours("mixamo", seed=3)
+    r = checkpoint.load_nerf(ref_path, rk_train["ray_caster"], optimizer, popt, popt_optim)
+    assert r["global_step"] == 4321
+    ref_sd = rcaster.state_dict()
+    our_sd = caster.state_dict()
+    assert set(ref_sd) == set(our_sd)
+    for k in ref_sd:
+        assert set(ref_sd[k]) == set(our_sd[k]), k
+        for n in ref_sd[k]:
+            assert torch.equal(ref_sd[k][n], our_sd[k][n]), (k, n)
+    rs, os_ = roptim.state_dict(), optimizer.state_dict()
+    assert rs["param_groups"][0]["lr"] == os_["param_groups"][0]["lr"] and len(rs["state"]) == len(os_["state"]) == 50
+    for i in rs["state"]:
+        for f in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(rs["state"][i][f], os_["state"][i][f]), (i, f)
+    assert torch.equal(rpopt.bones.detach(), popt.bones.detach()) and torch.equal(rpopt.pelvis.detach(), popt.pelvis.detach())
+    assert torch.equal(rpopt.rest_pose, popt.rest_pose)
+    assert torch.equal(rpopt_optim.state_dict()["state"][0]["exp_avg"], popt_optim.state_dict()["state"][0]["exp_avg"])
+    assert torch.equal(r["poseopt_anchors"]["bones"], ranchors["bones"])
+    # and back: the reference's modules / torch optimizers load what OUR writer produced
+    ours_path = str(tmp_path / "ours.tar")
+    for p in caster.parameters():
+        p.data.add_(0.25)
+    checkpoint.save_nerf(ours_path, 99, rk_train["ray_caster"], optimizer, popt, popt_optim, r["poseopt_anchors"])
+    ck = torch.load(ours_path, map_location="cpu", weights_only=False)
+    rcaster.load_state_dict(ck)
+    roptim.load_state_dict(ck["optimizer_state_dict"])
+    rpopt.load_state_dict(ck["poseopt_layer_state_dict"])
+    rpopt_optim.load_state_dict(ck["pose_optimizer_state_dict"])
+    for (n1, p1), (n2, p2) in zip(rcaster.named_parameters(), caster.named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2), n1
+    assert ck["global_step"] == 99

@@ -1,0 +1,212 @@
+"""GPU: the data-parallel PRODUCT path on the device (replaces nn.DataParallel, core/raycasters.py:157).
+
+Two ranks share the one GPU of the box (gloo transports the collective; RCCL refuses two ranks on one device) and each
+runs the real HIP training step -- RayParallel -> render() -> fused loss -> one-call backward accumulating into
+FusedAdam's flat bucket -> `FusedAdam.all_reduce_grads()` -> fused Adam -- on its `shard_rays` slice.  Checked against a
+single-process step on the whole batch: the averaged gradient bucket, the parameters after the step, bitwise equality of
+the two ranks, and the pose-optimiser cadence (`opt_pose_step`, trainer.py:476-478) with the pose parameters living in
+the same flat bucket.  A second test initialises RCCL itself (backend "nccl", one rank) and runs the two collectives the
+DP path uses on the real buffers.
+"""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LR = 5e-4
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _setup(mixamo, n_rays, device):
+    """caster (+ pose layer) with numpy-seeded weights, a per-ray-pose batch, one FusedAdam over one flat bucket"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_reference_args import ref_args, data_attrs
+    synth = importlib.import_module("a-nerf_amd.synth")
+    raycaster = importlib.import_module("a-nerf_amd.raycaster")
+    optim = importlib.import_module("a-nerf_amd.optim")
+    pose_opt = importlib.import_module("a-nerf_amd.pose_opt")
+    n_poses = 4
+    args = ref_args("mixamo" if mixamo else "surreal")
+    rk_train, rk_test, _, grad_vars, _, _ = raycaster.create_raycaster(args, data_attrs(n_poses), device=device)
+    caster = rk_test["ray_caster"]
+    fc = dict(framecode_ch=16, n_codes=n_poses) if mixamo else {}
+    tt = lambda P: {k: torch.tensor(v) for k, v in P.items()}
+    caster.network.load_state_dict(tt(synth.make_net_params(41, **fc)))
+    caster.network_fine.load_state_dict(tt(synth.make_net_params(42, **fc)))
+    ro, rd, kp, skts, bones, cyls, pidx = synth.scene_batch(n_rays, list(range(n_poses)), ray_seed=11, per_ray_pose=True)
+    dev = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32, device=device)
+    batch = dict(rays_o=dev(ro), rays_d=dev(rd), kp=dev(kp), skts=dev(skts), bones=dev(bones), cyls=dev(cyls),
+                 pidx=np.asarray(pidx), target=dev(np.random.default_rng(3).random((n_rays, 3))))
+    groups = [{"params": grad_vars, "lr": LR}]
+    popt = None
+    if mixamo:
+        poses = [synth.make_pose(k) for k in range(n_poses)]
+        popt = pose_opt.PoseOptLayer(np.stack([q["kp"] for q in poses]), np.stack([q["bones"] for q in poses]),
+                                     (synth.SMPL_REST_POSE * synth.SURREAL_SCALE)[None], use_rot6d=args.opt_rot6d).to(device)
+        groups.append({"params": list(popt.parameters()), "lr": args.opt_pose_lrate, "step_every": 3})   # test cadence
+    opt = optim.FusedAdam(groups, betas=(0.9, 0.999))
+    opt.attach(rk_train["ray_caster"])
+    return args, rk_train, caster, popt, opt, batch
+
+
+def _step(args, rk_train, popt, opt, batch, sl, i, reduce, weight=None):
+    """One iteration of Trainer.train_batch + Trainer.optimize (trainer.py:247-300,451-483) on rays `sl`."""
+    render_mod = importlib.import_module("a-nerf_amd.render")
+    optim = importlib.import_module("a-nerf_amd.optim")
+    b = {k: batch[k][sl] for k in ("kp", "skts", "bones", "cyls")}
+    cams = None
+    if popt is not None:
+        kp_r, bones_r, skts_r, _, _ = popt(batch["pidx"][sl])
+        b.update(kp=kp_r, skts=skts_r, bones=bones_r)
+        cams = torch.tensor(batch["pidx"][sl], device=batch["target"].device).float()
+    kw = dict(rk_train)
+    kw.update(perturb=0.0, raw_noise_std=0.0)          # deterministic per ray: shards must see what the full batch sees
+    out = render_mod.render(512, 512, 600.0, chunk=args.chunk, rays=(batch["rays_o"][sl], batch["rays_d"][sl]),
+                            kp_batch=b["kp"], skts=b["skts"], cyls=b["cyls"], bones=b["bones"], cams=cams, subject_idxs=None, **kw)
+    loss, _ = optim.fused_nerf_loss(out, batch["target"][sl], bgs=1.0, loss_fn=args.loss_fn)
+    loss.backward()
+    if reduce:
+        opt.all_reduce_grads(i=i, weight=weight)
+    due = opt._due(i)
+    seg = opt._segments()
+    scale = opt._grad_scale[0]
+    g_used = [(gi, (opt.flat_grad[seg[gi][0]:seg[gi][0] + seg[gi][1]] * opt._grad_scale[gi]).clone()) for gi in due]
+    opt.step(zero_grad=True, i=i)
+    return float(loss.detach()), dict(g_used), scale
+
+
+def _worker(rank, world, port, mixamo, n_rays, q):
+    try:
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        device = torch.device("cuda", 0)
+        sys.path.insert(0, ROOT)
+        parallel = importlib.import_module("a-nerf_amd.parallel")
+        args, rk_train, caster, popt, opt, batch = _setup(mixamo, n_rays, device)
+        rk_train["ray_caster"].train()
+        lo, hi = parallel.shard_rays(n_rays, rank, world)
+        w = parallel.shard_weight(n_rays, rank, world)
+        iters = [1, 2, 3, 4] if mixamo else [1, 2]
+        hist = []
+        for i in iters:
+            loss, g_used, scale = _step(args, rk_train, popt, opt, batch, slice(lo, hi), i, reduce=True, weight=w)
+            assert scale == 1.0 / world
+            hist.append({gi: g.cpu() for gi, g in g_used.items()})
+        flat_dp = opt.flat.detach().cpu().clone()
+        # both ranks must hold bit-identical parameters
+        other = [torch.empty_like(flat_dp) for _ in range(world)]
+        dist.all_gather(other, flat_dp)
+        same = all(torch.equal(o, flat_dp) for o in other)
+        res = {"rank": rank, "same": same}
+        if rank == 0:
+            # single-process reference: the whole batch, no collective, same cadence
+            args2, rk2, caster2, popt2, opt2, batch2 = _setup(mixamo, n_rays, device)
+            rk2["ray_caster"].train()
+            errs, perr = [], []
+            for k, i in enumerate(iters):
+                _, g_full, _ = _step(args2, rk2, popt2, opt2, batch2, slice(0, n_rays), i, reduce=False)
+                assert set(g_full) == set(hist[k]), (i, set(g_full), set(hist[k]))
+                # first use of a group's bucket: the DP-averaged gradient must equal the full-batch gradient up to summation
+                # order (group 0 at the first iteration, when both sides still hold identical parameters; the pose group at
+                # its first step, whose bucket accumulated opt_pose_step iterations)
+                for gi, g in g_full.items():
+                    if (gi == 0 and k == 0) or (gi == 1 and not any(1 in h for h in hist[:k])):
+                        g, d = g.cpu(), hist[k][gi]
+                        errs.append((i, gi, float((g - d).abs().max() / (g.abs().max() + 1e-20))))
+            flat_full = opt2.flat.detach().cpu()
+            d = (flat_dp - flat_full).abs()
+            res.update(grad_errs=errs, frac_close=float((d <= 1e-6 + 1e-6 * flat_full.abs()).float().mean()),
+                       max_diff=float(d.max()), n_groups=len(opt.param_groups),
+                       steps=list(opt._steps), steps_ref=list(opt2._steps))
+        q.put(res)
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:          # surface the failure in the parent instead of a bare exit code
+        import traceback
+        q.put({"rank": rank, "error": traceback.format_exc()})
+        raise
+
+
+@pytest.mark.parametrize("mixamo,n_rays", [(False, 256), (True, 251)])
+def test_two_ranks_on_one_gpu_equal_the_single_process_step(mixamo, n_rays):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, mixamo, n_rays, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+    for r in res:
+        assert "error" not in r, r.get("error")
+    for p in procs:
+        assert p.exitcode == 0
+    for r in res:
+        assert r["same"], "ranks diverged"
+    r0 = [r for r in res if r["rank"] == 0][0]
+    assert r0["n_groups"] == (2 if mixamo else 1)
+    assert r0["steps"] == r0["steps_ref"] == ([4, 1] if mixamo else [2])      # pose group: stepped at i = 3 only
+    assert len(r0["grad_errs"]) == (2 if mixamo else 1)
+    for i, gi, e in r0["grad_errs"]:
+        # network bucket at iteration 1: summation order only.  Pose bucket at its first step (i = 3): it accumulated three
+        # iterations during which the two runs' network parameters already differ at round-off level (see below)
+        assert e < (2e-5 if gi == 0 else 2e-3), (i, gi, e)
+    # Adam divides by |g|: elements whose gradient is at round-off level may step differently; everything else agrees
+    assert r0["frac_close"] > 0.995, r0
+    assert r0["max_diff"] <= 2.1 * LR * (4 if mixamo else 2), r0
+
+
+def _nccl_worker(port, q):
+    try:
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(0)
+        device = torch.device("cuda", 0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        sys.path.insert(0, ROOT)
+        args, rk_train, caster, popt, opt, batch = _setup(False, 64, device)
+        rk_train["ray_caster"].train()
+        _step(args, rk_train, popt, opt, batch, slice(0, 64), 1, reduce=False)
+        opt.flat_grad.normal_()
+        before = opt.flat_grad.clone()
+        dist.all_reduce(opt.flat_grad, op=dist.ReduceOp.SUM)                  # what FusedAdam.all_reduce_grads issues
+        out = torch.empty(64, 5, device=device)
+        mine = torch.randn(64, 5, device=device)
+        dist.all_gather_into_tensor(out, mine)                                # what parallel.gather_rays issues
+        torch.cuda.synchronize()
+        q.put({"ok": bool(torch.equal(opt.flat_grad, before) and torch.equal(out, mine)), "backend": dist.get_backend()})
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put({"error": traceback.format_exc()})
+        raise
+
+
+def test_rccl_world1_collectives_on_the_dp_buffers():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
+    p.start()
+    r = q.get(timeout=600)
+    p.join(timeout=120)
+    assert "error" not in r, r.get("error")
+    assert r["ok"] and r["backend"] == "nccl" and p.exitcode == 0

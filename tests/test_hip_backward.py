@@ -179,14 +179,20 @@ def test_one_call_training_step_equals_the_staged_nodes(name, n, S, Ni, precisio
     c = build(name)
     n = c["n"] if n is None else n
     res = {}
-    for route in ("one_call", "staged", "one_call_flat"):
+    for route in ("one_call", "staged", "one_call_flat", "one_call_managed"):
         caster = make_caster(c)
         caster.train()
-        caster.train_precision, caster.train_route = precision, route.replace("_flat", "")
-        if route == "one_call_flat":      # FusedAdam-managed parameters: gradients are accumulated into its flat bucket in place
+        caster.train_precision, caster.train_route = precision, route.replace("_flat", "").replace("_managed", "")
+        if route in ("one_call_flat", "one_call_managed"):
+            # FusedAdam-managed parameters.  "_flat": the optimiser is ATTACHED to the caster, so the backward adds the
+            # gradients into its flat bucket in place; "_managed": not attached, gradients arrive through autograd
+            # (AccumulateGrad adds them into the same views) -- the explicit opt-in of ADVICE r01.
             opt = importlib.import_module("a-nerf_amd.optim").FusedAdam([p for p in caster.parameters() if p.requires_grad])
             opt.materialize()
             assert float(opt.flat_grad.abs().max()) == 0.0
+            if route == "one_call_flat":
+                opt.attach(caster)
+                assert caster._anerf_grad_sink() is opt
         skts = dev(c["skts"][:n]).requires_grad_(True)
         cams = None if "cams" not in c else dev(c["cams"][:n])
         out = render_mod.render(64, 64, 75.0, chunk=4096, rays=(dev(c["rays_o"][:n]), dev(c["rays_d"][:n])), use_viewdirs=True,
@@ -201,7 +207,7 @@ def test_one_call_training_step_equals_the_staged_nodes(name, n, S, Ni, precisio
         res[route] = ({k: v.detach().clone() for k, v in out.items()}, skts.grad.clone(),
                       {f"{tag}.{k}": p.grad.clone() for tag, net in nets for k, p in net.named_parameters()})
     o2, s2, g2 = res["staged"]
-    for route in ("one_call", "one_call_flat"):
+    for route in ("one_call", "one_call_flat", "one_call_managed"):
         o1, s1, g1 = res[route]
         assert set(o1) == set(o2) and set(g1) == set(g2)
         for k in o1:
@@ -210,6 +216,55 @@ def test_one_call_training_step_equals_the_staged_nodes(name, n, S, Ni, precisio
         for k in g1:          # incl. the frame-code tables: k_code_reduce is a fixed-order reduction (no atomics)
             assert torch.equal(g1[k], g2[k]), (route, k)
         assert all(float(v.abs().max()) > 0 for k, v in g1.items())
+
+
+def test_autograd_grad_on_fused_adam_parameters_and_detach():
+    """torch.autograd.grad(loss, params) on FusedAdam-managed parameters returns the real gradients (and leaves p.grad
+    alone) unless the optimiser was explicitly attached; attach() -> in-place accumulation; detach() / dropping the
+    optimiser restores the autograd route; a replaced p.grad falls back to autograd as well."""
+    optim = importlib.import_module("a-nerf_amd.optim")
+    c = build("train_pytest")
+    n = 16
+
+    def run(caster):
+        out = render_mod.render(64, 64, 75.0, chunk=4096, rays=(dev(c["rays_o"][:n]), dev(c["rays_d"][:n])), use_viewdirs=True,
+                                ray_caster=caster, kp_batch=dev(c["kp"][:n]), skts=dev(c["skts"][:n]), cyls=dev(c["cyls"][:n]),
+                                bones=dev(c["bones"][:n]), cams=None, subject_idxs=None, N_samples=24, N_importance=8,
+                                perturb=0.0, raw_noise_std=0.0,
+                                preproc_kwargs={"density_scale": 1.0, "density_fn": torch.nn.functional.relu})
+        return (out["rgb_map"] ** 2).sum() + (out["rgb0"] ** 2).sum()
+
+    ref_caster = make_caster(c)
+    ref_caster.train()
+    ref_caster.train_route = "staged"
+    params_ref = [p for p in ref_caster.parameters() if p.requires_grad]
+    want = torch.autograd.grad(run(ref_caster), params_ref)
+    caster = make_caster(c)
+    caster.train()
+    params = [p for p in caster.parameters() if p.requires_grad]
+    opt = optim.FusedAdam(params)
+    opt.materialize()
+    got = torch.autograd.grad(run(caster), params)                       # managed, not attached
+    assert all(g is not None and torch.equal(g, w) for g, w in zip(got, want))
+    assert float(opt.flat_grad.abs().max()) == 0.0                        # p.grad untouched by autograd.grad
+    opt.attach(caster)
+    run(caster).backward()                                                # attached: lands in the bucket
+    assert all(torch.equal(p.grad, w) for p, w in zip(params, want))
+    assert opt.owns_grads(params, params[0].device)
+    opt.zero_grad()
+    params[3].grad = torch.zeros_like(params[3])                          # someone replaced a gradient tensor
+    assert not opt.owns_grads(params, params[0].device)
+    run(caster).backward()                                                # -> autograd route, values still right
+    assert all(torch.equal(p.grad, w) for p, w in zip(params, want))
+    opt.detach()
+    assert caster._anerf_grad_sink is None
+    opt.attach(caster)
+    del opt
+    import gc
+    gc.collect()
+    assert caster._anerf_grad_sink is None or caster._anerf_grad_sink() is None      # dropped optimiser: no dangling sink
+    got = torch.autograd.grad(run(caster), params)
+    assert all(torch.equal(g, w) for g, w in zip(got, want))
 
 
 @pytest.mark.parametrize("name", ["train_pytest", "mixamo_train"])

@@ -107,7 +107,7 @@ def test_eval_s32_stages(oracle, golden):
     close(ex["weights"], ref["_extras"]["weights"], atol=2e-5)
 
 
-@pytest.mark.parametrize("name", ["eval_hier", "nan_fallback", "train_pytest", "single_net"])
+@pytest.mark.parametrize("name", ["eval_hier", "eval_hier128", "nan_fallback", "train_pytest", "single_net"])
 def test_cases_vs_golden_and_oracle(oracle, golden, name):
     g = golden(name)
     c = build(name)
@@ -316,7 +316,7 @@ def test_gen_rays_and_frame_assembly(synth, golden):
     assert np.array_equal(out5[0][0], out5[0][1]) and float(np.abs(out5[0]).max()) > 0
 
 
-@pytest.mark.parametrize("name", ["eval_s32", "eval_hier", "train_pytest", "mixamo_train", "single_net"])
+@pytest.mark.parametrize("name", ["eval_s32", "eval_hier", "eval_hier128", "train_pytest", "mixamo_train", "single_net"])
 def test_bf16x3_path_meets_the_fp32_bar(oracle, golden, name):
     """bf16x3 render path (hi/lo-split bf16 MFMAs): same 1e-4 RGB bar as fp32, vs the reference golden vectors."""
     g = golden(name)

@@ -83,6 +83,15 @@ def test_eval_hier(oracle, golden):
         np.testing.assert_allclose(out[k].detach().numpy(), g[k], rtol=1e-4, atol=1e-5, err_msg=k)
 
 
+def test_eval_hier128(oracle, golden):
+    """BASELINE config 5's sample counts: 64 coarse + 128 importance samples (192-sample fine pass)."""
+    g = golden("eval_hier128")
+    out, *_ = run_case(oracle, build("eval_hier128"))
+    assert out["alpha"].shape == (96, 192) and out["alpha0"].shape == (96, 64)
+    for k in ["rgb_map", "disp_map", "acc_map", "alpha", "rgb0", "disp0", "acc0", "alpha0"]:
+        np.testing.assert_allclose(out[k].detach().numpy(), g[k], rtol=1e-4, atol=1e-5, err_msg=k)
+
+
 def test_importance_stage(oracle, golden):
     g = golden("importance")
     zs, zm, idx = oracle.importance_z(t(g["z"]), t(g["weights"]), 16)

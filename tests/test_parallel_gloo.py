@@ -59,6 +59,21 @@ def _worker(rank, world, port, q):
         P[k].grad = None
     loss_on(slice(0, n)).backward()
     err = max(float((got[k] - P[k].grad).abs().max() / (P[k].grad.abs().max() + 1e-12)) for k in names)
+    # ragged split (n = 31 -> shards of 16 and 15): weighting each rank's mean-loss gradient by shard_weight() gives the
+    # global-batch mean gradient again; the plain 1/world average does not
+    n2 = 31
+    for k in names:
+        P[k].grad = None
+    l2, h2 = parallel.shard_rays(n2, rank, world)
+    loss_on(slice(l2, h2)).backward()
+    w = parallel.shard_weight(n2, rank, world)
+    assert abs(w - (h2 - l2) * world / n2) < 1e-12
+    parallel.GradBucket([P[k] for k in names]).all_reduce_mean(weight=w)
+    got2 = {k: P[k].grad.clone() for k in names}
+    for k in names:
+        P[k].grad = None
+    loss_on(slice(0, n2)).backward()
+    err = max(err, max(float((got2[k] - P[k].grad).abs().max() / (P[k].grad.abs().max() + 1e-12)) for k in names))
     # frame assembly: every rank ends up with all rows in order
     local = torch.arange(lo, hi, dtype=torch.float32)[:, None].repeat(1, 3)
     full = parallel.gather_rays(local, n)
