@@ -41,6 +41,13 @@ def parse():
     ap.add_argument("--n-rand", type=int, default=3072, help="train workload: global rays per step")
     ap.add_argument("--torch-tail", action="store_true",
                     help="train workload: torch loss + torch.optim.Adam + copy-bucket all-reduce instead of the fused kernels")
+    ap.add_argument("--opt-pose-step", type=int, default=1,
+                    help="train_mixamo: pose parameters are stepped (and their gradients all-reduced) every k-th iteration and "
+                         "accumulate in between (trainer.py:476-478; mixamo.txt:48 uses 20).  Default 1 = every step, the more "
+                         "expensive schedule")
+    ap.add_argument("--extra", default="auto", choices=["auto", "on", "off"],
+                    help="append `extra_workloads` (5 steps each of train N_rand=3072, train 384 rays, 64+128 bf16x3 render, each "
+                         "with its own roofline) to the record; auto = only for the default invocation (render64, fp32, 1 GPU)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
                     help="exact fp32 MFMA, or hi/lo-split bf16 MFMAs (3 per product, fp32 accumulate); train workloads: "
                          "bf16x3 applies to the forward kernel only, backward + weight-gradient GEMM stay fp32")
@@ -119,8 +126,44 @@ def main():
     ops = importlib.import_module("a-nerf_amd.ops")
     pipeline = importlib.import_module("a-nerf_amd.pipeline")
     if args.workload in ("train", "train_mixamo"):
-        return bench_train(args, rank, world, device, dist, synth, mixamo=args.workload == "train_mixamo")
+        res = bench_train(args, rank, world, device, dist, synth, mixamo=args.workload == "train_mixamo")
+    else:
+        res = bench_render(args, rank, world, device, dist, synth, ops, pipeline)
+    if rank == 0:
+        want_extra = args.extra == "on" or (args.extra == "auto" and args.workload == "render64" and args.precision == "fp32")
+        if want_extra and world == 1:
+            res["extra_workloads"] = extra_workloads(args, device, synth, ops, pipeline)
+        emit(res)
+    if dist is not None:
+        dist.destroy_process_group()
 
+
+def extra_workloads(args, device, synth, ops, pipeline):
+    """BASELINE configs 3 and 5 inside the same driver-timed run: 5 steps each, same timing protocol,
+    each with its own roofline.  Compact records; the full ones come from `--workload ...`."""
+    import copy
+    out = []
+    for over in (dict(workload="train", n_rand=3072), dict(workload="train", n_rand=384),
+                 dict(workload="hier128", precision="bf16x3")):
+        a = copy.copy(args)
+        a.steps, a.warmup, a.cpu_rays, a.extra = 5, 1, 0, "off"
+        for k, v in over.items():
+            setattr(a, k, v)
+        try:
+            if a.workload == "train":
+                r = bench_train(a, 0, 1, device, None, synth, mixamo=False)
+            else:
+                r = bench_render(a, 0, 1, device, None, synth, ops, pipeline)
+            out.append({"workload": r["config"]["workload"], "value": r["value"], "unit": r["unit"], "steps": a.steps,
+                        "ms_per_step": r["ms_per_step"], "dtype": r["dtype"], "roofline": r["roofline"]})
+        except Exception as e:       # an extra must never take the headline record down with it
+            out.append({"workload": str(over), "error": f"{type(e).__name__}: {e}"})
+        torch.cuda.empty_cache()
+    return out
+
+
+def bench_render(args, rank, world, device, dist, synth, ops, pipeline):
+    backend = os.environ.get("ANERF_BENCH_BACKEND", "nccl")
     if args.workload == "render64x64":
         H = W = 64; focal = 75.0; S, Ni = 32, 0
         name = "SURREAL-shaped 64x64 frame, 32 samples/ray, forward render (BASELINE config 1)"
@@ -153,17 +196,23 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i=None):
+        # HIP events bracket the DOMINANT launch on its own stream: the only k_mlp_fwd launch (Ni = 0) or the fine pass
+        # over the S+Ni merged samples (hierarchical workloads)
         nf_raw, stats = ops.ray_bounds(rb, cyl)
         z, _ = ops.coarse_z(nf_raw, stats, rb, S)
-        if i is not None:
+        if i is not None and not Ni:
             ev[i][0].record()
         raw = ops.mlp_raw(cfg, net_c[0], net_c[1], rb, z, skt, 20.0, 20.0, cut, cut, precision=args.precision)
-        if i is not None:
+        if i is not None and not Ni:
             ev[i][1].record()
         co = ops.composite(cfg, raw, z, rb)
         if Ni:
             zs, zm, _ = ops.importance(z, co["weights"], Ni, want_idx=False)
+            if i is not None:
+                ev[i][0].record()
             raw_f = ops.mlp_raw(cfg, net_f[0], net_f[1], rb, zm, skt, 20.0, 20.0, cut, cut, precision=args.precision)
+            if i is not None:
+                ev[i][1].record()
             co = ops.composite(cfg, raw_f, zm, rb)
         if dist is not None:
             mine = torch.zeros(per, 5, device=device)
@@ -196,7 +245,7 @@ def main():
     # Side measurement (never the headline `value`): the same frame through the opt-in split-bf16 kernels, same timing
     # protocol, plus its agreement with the fp32 frame just rendered.
     alt = None
-    if args.precision == "fp32" and args.steps > 0:
+    if args.precision == "fp32" and args.steps > 0 and args.extra != "off":
         rgb_f32 = out["rgb_map"].clone()
         net_c3 = ops.pack_params(cfg, {k: dev(v) for k, v in Pc.items()}, 3)
         net_f3 = ops.pack_params(cfg, {k: dev(v) for k, v in Pf.items()}, 3) if Ni else None
@@ -220,7 +269,7 @@ def main():
         ms = dt / args.steps * 1e3
         rays_s = n_total * args.steps / dt
         # dominant kernel: k_mlp_fwd over this rank's (hi-lo)*S samples, timed with HIP events on its launch stream
-        flops_launch = F_MLP * (hi - lo) * S
+        flops_launch = F_MLP * (hi - lo) * (S + Ni)
         achieved = flops_launch / (mlp_ms * 1e-3)
         b3 = args.precision == "bf16x3"
         peak = PEAK_BF16_MFMA if b3 else PEAK_FP32_MFMA
@@ -231,26 +280,33 @@ def main():
             "data": "synthetic",
             "config": {"workload": name, "rays_per_step": n_total, "samples_per_ray": S, "n_importance": Ni,
                        "parallelism": f"ray-sharded x{world}", "weights": "numpy-seeded random init (alpha bias +1)"},
-            "roofline": {"bound": "mfma", "kernel": "k_mlp_fwd_b3<7,4,0>" if b3 else "k_mlp_fwd<7,4,0,false,false,0>",
+            "roofline": {"bound": "mfma", "kernel": ("k_mlp_fwd_b3<7,4,0>" if b3 else "k_mlp_fwd<7,4,0,false,false,0>") +
+                                                     (f" (fine pass, {S + Ni} samples/ray)" if Ni else ""),
                          "achieved": (3 if b3 else 1) * achieved / 1e12, "algorithmic": achieved / 1e12,
                          "peak": peak / 1e12, "unit": "TFLOP/s", "frac": (3 if b3 else 1) * achieved / peak,
                          "avg_launch_ms": mlp_ms, "flop_per_launch": flops_launch, "traffic": None},
         }
-        try:   # HBM bytes per launch come from a separate rocprofv3 --pmc run (committed under profiles/)
-            tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(
-                args.workload + ("_bf16x3" if b3 else ""))
-            if tr and world == 1:
-                res["roofline"]["traffic"] = tr["hbm_bytes"]
-                res["roofline"]["traffic_note"] = f"bytes/launch, FETCH_SIZE(x2)+WRITE_SIZE, {tr['source']}; algorithmic {tr['algorithmic_bytes']:.3g} B"
-        except (OSError, ValueError):
-            pass
+        attach_traffic(res, args.workload + ("_bf16x3" if b3 else ""), world)
         if alt is not None:
             res["alt_precision"] = alt
         if args.cpu_rays > 0 and world == 1:   # CPU baseline: rank 0 at N=1 only (bench contract)
             res["cpu_baseline"], res["parity"] = cpu_baseline(sc, S, Ni, Pc, Pf, out, lo, min(args.cpu_rays, hi - lo))
-        emit(res)
-    if dist is not None:
-        dist.destroy_process_group()
+        return res
+    return None
+
+
+def attach_traffic(res, key, world):
+    """roofline.traffic = HBM bytes per launch / step of the dominant kernel(s) from the rocprofv3 --pmc passes committed under
+    profiles/ (FETCH_SIZE x2 + WRITE_SIZE, separate passes, MI355X_MICROARCH.md HBM section).  profiles/pmc_traffic.json is
+    regenerated from those passes by tools/make_pmc_traffic.py and records the git SHA of the binary they ran on."""
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(key)
+    except (OSError, ValueError):
+        return
+    if tr and world == 1:
+        res["roofline"]["traffic"] = tr["hbm_bytes"]
+        res["roofline"]["traffic_note"] = (f"bytes per launch/step, FETCH_SIZE(x2)+WRITE_SIZE, {tr['source']} (build {tr.get('git_sha', '?')}); "
+                                           f"algorithmic {tr['algorithmic_bytes']:.3g} B" + ("; " + tr["note"] if tr.get("note") else ""))
 
 
 def bench_train(args, rank, world, device, dist, synth, mixamo=False):
@@ -259,8 +315,8 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
     N_rand / world rays; gradients are averaged with one RCCL all-reduce of a flat bucket per step.
     mixamo=True is BASELINE config 4 (configs/mixamo/mixamo.txt:41-55): + per-frame codes (920-wide view layer), L1
     loss, and pose refinement: skts come from the FK layer (PoseOptLayer mirror) and the hot path's dskts flow back into
-    the bone parameters, stepped by their own Adam (the reference steps them every opt_pose_step iterations; here
-    every step, which is the more expensive schedule)."""
+    the bone parameters, which live in the same flat FusedAdam bucket as the networks and are stepped every
+    --opt-pose-step iterations (default 1: every step, the more expensive schedule; mixamo.txt:48 uses 20)."""
     networks = importlib.import_module("a-nerf_amd.networks")
     raycaster = importlib.import_module("a-nerf_amd.raycaster")
     render_mod = importlib.import_module("a-nerf_amd.render")
@@ -286,8 +342,25 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
     caster.train_precision = args.precision
     params = [p for p in caster.parameters() if p.requires_grad]
     fused = not args.torch_tail
-    opt = optim.FusedAdam(params, lr=5e-4, betas=(0.9, 0.999)) if fused else torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.999))
-    bucket = None if fused else parallel.GradBucket(params)
+    popt = popt_opt = None
+    if mixamo:
+        pose_opt = importlib.import_module("a-nerf_amd.pose_opt")
+        poses = [synth.make_pose(k) for k in range(n_poses)]
+        popt = pose_opt.PoseOptLayer(np.stack([q["kp"] for q in poses]), np.stack([q["bones"] for q in poses]),
+                                     (synth.SMPL_REST_POSE * synth.SURREAL_SCALE)[None], use_rot6d=True).to(device)   # mixamo.txt:44
+    if fused:
+        # ONE flat bucket: group 0 = both networks (+ frame codes), group 1 = the pose layer's parameters, stepped every
+        # opt_pose_step iterations (accumulating in between) -- so a step's all-reduce is one collective whatever is due
+        groups = [{"params": params, "lr": 5e-4}]
+        if mixamo:
+            groups.append({"params": list(popt.parameters()), "lr": 5e-4, "step_every": args.opt_pose_step})
+        opt = optim.FusedAdam(groups, betas=(0.9, 0.999))
+        opt.attach(caster)               # opt in: the backward accumulates into the bucket in place
+    else:
+        opt = torch.optim.Adam(params, lr=5e-4, betas=(0.9, 0.999))
+        if mixamo:
+            popt_opt = torch.optim.Adam(popt.parameters(), lr=5e-4)
+    bucket = None if fused else parallel.GradBucket(params + (list(popt.parameters()) if mixamo else []))
     # per-ray replicated pose batch as the reference's collate produces it (dataset.py:813-820), 8 poses
     ro, rd, kp, skts, bones, cyls, pidx = synth.scene_batch(N_rand, list(range(n_poses)), H=512, W=512, focal=600.0, ray_seed=3,
                                                             per_ray_pose=True)
@@ -296,18 +369,15 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
     rays = (dev(ro[sl]), dev(rd[sl]))
     batch = dict(kp_batch=dev(kp[sl]), skts=dev(skts[sl]), cyls=dev(cyls[sl]), bones=dev(bones[sl]))
     target = dev(np.random.default_rng(1).random((N_rand, 3))[sl])
-    cams = popt = popt_opt = None
+    cams = None
     if mixamo:
-        pose_opt = importlib.import_module("a-nerf_amd.pose_opt")
-        poses = [synth.make_pose(k) for k in range(n_poses)]
-        popt = pose_opt.PoseOptLayer(np.stack([q["kp"] for q in poses]), np.stack([q["bones"] for q in poses]),
-                                     (synth.SMPL_REST_POSE * synth.SURREAL_SCALE)[None], use_rot6d=True).to(device)   # mixamo.txt:44
-        popt_opt = torch.optim.Adam(popt.parameters(), lr=5e-4)
         pose_idx_host = np.asarray(pidx)[sl]
         anchor6 = popt.bones.detach().clone()[torch.tensor(pose_idx_host, device=device)]     # popt_anchors (pose_opt.py:60-75)
         cams = torch.tensor(pose_idx_host, device=device).to(torch.float32)
     pk = {"density_scale": 1.0, "density_fn": torch.nn.functional.relu}
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    it = [0]                     # global iteration counter (the reference's `i`, trainer.py:451)
 
     def step(i=None):
         if i is not None:
@@ -327,20 +397,17 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
         loss.backward()
         if i is not None:
             ev[i][1].record()
+        it[0] += 1
         if fused:
-            opt.all_reduce_grads()            # one RCCL all-reduce on the flat gradient buffer; 1/world folded into Adam
-            opt.step(zero_grad=True)
-            if mixamo:
-                if dist is not None:
-                    for q in popt.parameters():
-                        dist.all_reduce(q.grad)
-                        q.grad.div_(world)
-                popt_opt.step()
-                popt_opt.zero_grad()
+            opt.all_reduce_grads(i=it[0])     # ONE RCCL all-reduce over whatever is due (networks [+ pose]); 1/world folded into Adam
+            opt.step(zero_grad=True, i=it[0])
         else:
             bucket.all_reduce_mean()
             opt.step()
             opt.zero_grad()
+            if mixamo:
+                popt_opt.step()
+                popt_opt.zero_grad()
         return loss
 
     def barrier():
@@ -388,18 +455,14 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
                             "peak": (PEAK_BF16_MFMA if b3 else PEAK_FP32_MFMA) / 1e12, "unit": "TFLOP/s",
                             "frac": (3 * achieved / PEAK_BF16_MFMA) if b3 else achieved / PEAK_FP32_MFMA,
                             "avg_launch_ms": fb_ms, "flop_per_launch": flop_step_rank, "traffic": None}}
-        try:   # HBM bytes per step from the rocprofv3 --pmc passes committed under profiles/ (fp32, N_rand 3072 only)
-            tr = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("train")
-            if tr and world == 1 and not mixamo and not b3 and N_rand == 3072:
-                res["roofline"]["traffic"] = tr["hbm_bytes"]
-                res["roofline"]["traffic_note"] = f"bytes/step, FETCH_SIZE(x2)+WRITE_SIZE of the three MFMA kernels, {tr['source']}; algorithmic {tr['algorithmic_bytes']:.3g} B"
-        except (OSError, ValueError):
-            pass
+        key = ("train_mixamo" if mixamo else "train") + ("" if N_rand == 3072 else str(N_rand)) + ("_bf16x3" if b3 else "")
+        attach_traffic(res, key, world)
+        if mixamo:
+            res["config"]["opt_pose_step"] = args.opt_pose_step
         if args.cpu_rays > 0 and world == 1 and not mixamo:
             res["cpu_baseline"] = cpu_train_baseline(synth, ro, rd, skts, cyls, S, Ni, min(args.cpu_rays, 512, N_rand))
-        emit(res)
-    if dist is not None:
-        dist.destroy_process_group()
+        return res
+    return None
 
 
 def cpu_train_baseline(synth, ro, rd, skts, cyls, S, Ni, n_cpu):

@@ -316,6 +316,45 @@ def test_gen_rays_and_frame_assembly(synth, golden):
     assert np.array_equal(out5[0][0], out5[0][1]) and float(np.abs(out5[0]).max()) > 0
 
 
+def test_render_path_chunks_smaller_than_the_frame(synth):
+    """render_path hands the frame's pose over ONCE ([1,24,4,4], stride 0); batchify_rays must not
+    slice such shared rows per chunk.  A frame rendered in chunks of 512 / 1000 rays equals the single-chunk frame bit
+    for bit, through the real RayCaster mirror (frame codes included: cams is per frame too)."""
+    render_mod = importlib.import_module("a-nerf_amd.render")
+    networks = importlib.import_module("a-nerf_amd.networks")
+    raycaster = importlib.import_module("a-nerf_amd.raycaster")
+    kw = dict(D=8, W=256, input_ch=360, input_ch_bones=72, input_ch_views=648, use_viewdirs=True, use_framecode=True,
+              framecode_ch=16, n_framecodes=4)
+    net_c, net_f = networks.NeRF(**kw), networks.NeRF(**kw)
+    net_c.load_state_dict({k: t(v) for k, v in synth.make_net_params(11, framecode_ch=16, n_codes=4).items()})
+    net_f.load_state_dict({k: t(v) for k, v in synth.make_net_params(12, framecode_ch=16, n_codes=4).items()})
+    ck = {"cutoff": True, "cutoff_dist": 0.5, "cutoff_inputs": True, "cutoff_dim": 24}
+    e_v, _ = networks.get_embedder(7, input_dims=24, cutoff_kwargs=dict(ck, dist_inputs=False))
+    e_b, _ = networks.get_embedder(0, input_dims=72, cutoff_kwargs={"cutoff": False})
+    e_d, _ = networks.get_embedder(4, input_dims=72, cutoff_kwargs=dict(ck, dist_inputs=True))
+    caster = raycaster.RayCaster(net_c, e_v, e_b, e_d, network_fine=net_f).cuda().eval()
+    sc = synth.make_scene(0, 64, 64, 75.0)
+    n = len(sc["rays_o"])
+    assert n > 1000
+    c2w = synth.default_c2w()
+    rk = {"ray_caster": caster, "N_samples": 24, "N_importance": 8, "perturb": False, "raw_noise_std": 0.0,
+          "preproc_kwargs": {"density_scale": 1.0, "density_fn": torch.nn.functional.relu}}
+    frames = {}
+    for chunk in (4096, 1000, 512):
+        for cams in (torch.tensor([2.0], device="cuda"), torch.tensor([-1.0], device="cuda")):       # a code row / the mean code
+            frames[(chunk, float(cams))] = render_mod.render_path(
+                [c2w[:3, :4]], (64, 64, 75.0), chunk, rk, kp=dev(sc["pose"]["kp"])[None], skts=dev(sc["pose"]["skts"])[None],
+                cyls=dev(sc["cyl"])[None], bones=dev(sc["pose"]["bones"])[None], cams=cams, ret_acc=True, ext_scale=0.001)
+    for cam in (2.0, -1.0):
+        ref = frames[(4096, cam)]
+        assert float(np.abs(ref[0]).max()) > 0
+        for chunk in (1000, 512):
+            got = frames[(chunk, cam)]
+            for a, b in zip(got[:3], ref[:3]):
+                assert np.array_equal(a, b), (chunk, cam)
+    assert not np.array_equal(frames[(4096, 2.0)][0], frames[(4096, -1.0)][0])
+
+
 @pytest.mark.parametrize("name", ["eval_s32", "eval_hier", "eval_hier128", "train_pytest", "mixamo_train", "single_net"])
 def test_bf16x3_path_meets_the_fp32_bar(oracle, golden, name):
     """bf16x3 render path (hi/lo-split bf16 MFMAs): same 1e-4 RGB bar as fp32, vs the reference golden vectors."""
