@@ -20,9 +20,13 @@ constexpr int LDS_BONES_OFF = LDS_AUX_OFF + LDS_AUX_BYTES;        // MAX_TILE_RA
 //     completions are not ordered the way a counted wait needs; parity tests caught it;
 //   * 4 slots + per-wave-pair stage ownership (16 glds per owner): also produced stale fragments;
 //   * 4 slots with plain vmcnt(0): correct but 6 % slower than 3 slots (same one-stage lead, worse allocation).
+// Round 2, fp32 training forward: issuing a stage's eight pieces two per k-group instead of all behind the barrier
+// (to keep the vector-memory path free for the activation stores) -- the weight stream turned out not to interfere
+// with the stores at all (ablation without weight loads: stores cost the same 0.24 ms), and hipcc either re-clusters
+// the pieces or, when they are fenced with sched_barrier masks, spills thousands of registers.
 // ------------------------------------------------------------------------------------------------
 struct Pipe3 {
-  const char* gsrc;   // per-lane source of this wave's first fragment of stage 0
+  const char* gsrc;   // wave-UNIFORM source of this wave's first fragment of stage 0 (lane l adds lane16: saddr + voffset form)
   char* smem;
   unsigned wave_dst;  // wave-uniform LDS byte offset of this wave's 8 fragments inside a stage
   unsigned lane16;    // lane * 16
@@ -31,6 +35,7 @@ struct Pipe3 {
   int slot;           // ring slot of the stage being consumed
   int stage;          // stage being consumed
   int nstages;
+  int wave;           // wave index inside the workgroup (wave-uniform)
   f32x4 pref[8];      // fragments of the next stage's first k-group, loaded before the stage barrier
 
   __device__ __forceinline__ void issue(int s, int sl) {
@@ -41,20 +46,21 @@ struct Pipe3 {
     char* l = smem + sl * STAGE_BYTES + wave_dst;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(g + i * FRAG_BYTES), (lds_ptr_t)(l + i * FRAG_BYTES), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(g + i * FRAG_BYTES + lane16), (lds_ptr_t)(l + i * FRAG_BYTES), 16, 0, 0);
   }
   __device__ __forceinline__ void set_offsets() {
     cur = lane16 + slot * STAGE_BYTES;
     nxt = lane16 + (slot == RING_SLOTS - 1 ? 0 : slot + 1) * STAGE_BYTES;
   }
   __device__ __forceinline__ void init(const float* packed, char* smem_, int wave, int lane, int nstages_) {
-    gsrc = reinterpret_cast<const char*>(packed) + wave * (8 * FRAG_BYTES) + lane * 16;
+    gsrc = reinterpret_cast<const char*>(packed) + wave * (8 * FRAG_BYTES);
     smem = smem_;
     wave_dst = wave * (8 * FRAG_BYTES);
     lane16 = lane * 16;
     slot = 0;
     stage = 0;
     nstages = nstages_;
+    this->wave = wave;
     set_offsets();
     issue(0, 0);
     if (nstages > 1) issue(1, 1);
@@ -77,7 +83,6 @@ struct Pipe3 {
     set_offsets();
   }
 };
-
 // acc[nb][r] <- bias[n(nb,r,h)] from the LDS copy of the natural-order bias vector (bias_h = vector + 4h)
 template <int NB>
 __device__ __forceinline__ void init_bias(f32x16 (&acc)[NB], const float* bias_h) {
@@ -123,8 +128,24 @@ __device__ __forceinline__ float head_dot(const f32x16* acc, const float* wrow_h
 // One k-group (8 contraction indices: 4 from each lane half) against NB 32-row feature blocks.
 // kg: k-group index relative to the segment (layer) start; first: first k-group of the layer (informational);
 // last: final k-group of the segment (segments are padded to whole stages).  All three fold at compile time.
-template <int NB>
-__device__ __forceinline__ void kgroup(Pipe3& pipe, f32x16 (&acc)[NB], int kg, bool first, bool last, float b0, float b1,
+// one float4 of a saved-activation row (ablation builds, tools/ablate.sh: NOSAVE drops the store, SAVE_NT marks it non-temporal)
+__device__ __forceinline__ void save_quad(float* dst, f32x4 q) {
+#if defined(ANERF_EXP_NOSAVE)
+  (void)dst; (void)q;
+#elif defined(ANERF_EXP_SAVE_NT)
+  __builtin_nontemporal_store(q, reinterpret_cast<f32x4*>(dst));
+#else
+  *reinterpret_cast<f32x4*>(dst) = q;
+#endif
+}
+#ifdef ANERF_EXP_SAVE_COAL   // ablation build only (wrong layout): lane-linear 1 KiB stores instead of 16 B per row
+constexpr int SAVE_QUAD_STRIDE = 256;
+#else
+constexpr int SAVE_QUAD_STRIDE = 8;
+#endif
+
+template <int NB, class PIPE>
+__device__ __forceinline__ void kgroup(PIPE& pipe, f32x16 (&acc)[NB], int kg, bool first, bool last, float b0, float b1,
                                        float b2, float b3) {
   constexpr int KPS = STAGE_FRAGS / NB;  // k-groups per stage
   const int ks = kg % KPS;
@@ -157,15 +178,31 @@ __device__ __forceinline__ void kgroup(Pipe3& pipe, f32x16 (&acc)[NB], int kg, b
   if (ks == KPS - 1 || last) pipe.end_stage();
 }
 
+
 // 32 k-groups whose B operands are the previous layer's 256 outputs, read straight from its accumulator set
 // `prev` (bias added by the accumulator init, ReLU already applied in place): no copy, no VALU in the MFMA stream.
-template <int NB, int KG0>
-__device__ __forceinline__ void hidden_part(Pipe3& pipe, f32x16 (&acc)[NB], const f32x16 (&prev)[8], bool first,
-                                            bool last) {
+// SAVE (training forward): `prev` is also written to its row of the saved-activation plane by the layer that CONSUMES
+// it, one float4 quad per k-group (quad j = the k-group's own B operands = features 8j+4h..+3 -> save_row_h + 8j).
+// A CU's vector-memory path moves ~10 B/clk (MI355X_MICROARCH.md), i.e. ~100 cycles per 1 KiB wave-store, and a wave
+// that issues into a busy path stalls -- with one wave per SIMD that is lost MFMA time.  Measured on the 3072 x 80
+// training forward (tools/microbench_train_fwd.py; no stores at all: 3.40 ms): 32 stores after the layer 3.85 ms, a
+// stage's 4 stores behind its barrier 3.95 ms, one store per k-group 3.65 ms; waiting for the stores is NOT the cost
+// (a counted vmcnt that leaves them in flight changes nothing), neither is their scatter (lane-linear 1 KiB stores: same).
+template <int NB, int KG0, bool SAVE = false, class PIPE>
+__device__ __forceinline__ void hidden_part(PIPE& pipe, f32x16 (&acc)[NB], const f32x16 (&prev)[8], bool first,
+                                            bool last, float* __restrict__ save_row_h = nullptr) {
+  constexpr int KPS = STAGE_FRAGS / NB;
 #pragma unroll
-  for (int kg = 0; kg < 32; ++kg)
+  for (int kg = 0; kg < 32; ++kg) {
+    if constexpr (SAVE) {
+      const f32x4 o = {prev[kg >> 2][4 * (kg & 3) + 0], prev[kg >> 2][4 * (kg & 3) + 1], prev[kg >> 2][4 * (kg & 3) + 2],
+                       prev[kg >> 2][4 * (kg & 3) + 3]};
+      save_quad(save_row_h + SAVE_QUAD_STRIDE * kg, o);
+      __builtin_amdgcn_sched_barrier(0);   // in front of this k-group's MFMAs (the scheduler would sink it behind them)
+    }
     kgroup<NB>(pipe, acc, KG0 + kg, first && kg == 0, last && kg == 31, prev[kg >> 2][4 * (kg & 3) + 0],
                prev[kg >> 2][4 * (kg & 3) + 1], prev[kg >> 2][4 * (kg & 3) + 2], prev[kg >> 2][4 * (kg & 3) + 3]);
+  }
 }
 
 struct MlpArgs {

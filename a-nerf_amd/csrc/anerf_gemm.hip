@@ -12,6 +12,12 @@
 // four consecutive output columns -- and it makes the inner loop 2 LDS reads + 16 MFMAs (1024 MFMA cycles) with
 // NO address arithmetic.  (The fp32 MFMA does not overlap VALU on this chip, tools/probe: every VALU instruction
 // in the loop is paid for in matrix time; the previous 64x64-per-wave version spent 2.3 VALU per MFMA.)
+// Where its time goes (round-2 ablations, tools/microbench_gemm.py at 245 760 rows, 3.6-3.8 ms): one round of 255 blocks x
+// 904 stages x 8192 MFMA cycles = 3.1 ms at 2.4 GHz (3.3 ms at the ~2.25 GHz the chip holds under this load); without
+// operand loads, barriers and column sums 3.41 ms, i.e. the loop itself is at ~97 %; tile padding (432- and 648-wide
+// operands in 128-column tiles) executes 6 % more MFMAs than the algorithmic count.  A 3-slot ring with counted
+// `s_waitcnt vmcnt(2 x tiles)` (two stage times per load instead of one) measured the same as this double buffer
+// (3.63 vs 3.60 ms): the kernel does not wait for HBM.
 // A block = 4 such waves sharing operand tiles: 2x2 (two A tiles x two B tiles: a whole 256x256 layer per block,
 // each activation row read once) or 1x4 (views layer, M = 128).  The 4-row head problems (alpha / rgb, A = draw)
 // run as "skinny" waves: 4 MFMAs per row pair against one broadcast A block.

@@ -41,7 +41,7 @@ __device__ __forceinline__ void store_act(float* __restrict__ row, const f32x16*
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       f32x4 o = {acc[nb][4 * q], acc[nb][4 * q + 1], acc[nb][4 * q + 2], acc[nb][4 * q + 3]};
-      *reinterpret_cast<f32x4*>(row + 32 * nb + 8 * q + 4 * h) = o;
+      save_quad(row + 32 * nb + 8 * q + 4 * h, o);
     }
 }
 
@@ -57,10 +57,9 @@ __device__ __forceinline__ void x_part(Pipe3& pipe, f32x16 (&acc)[8], const floa
   constexpr int NKG = 3 * (1 + 2 * LV) + 9;
   auto KG = [&](int kg, float b0, float b1, float b2, float b3) __attribute__((always_inline)) {
     if constexpr (STORE) {
-      if (xsave) {
-        f32x4 o = {b0, b1, b2, b3};
-        *reinterpret_cast<f32x4*>(xsave + 8 * kg + 4 * h) = o;
-      }
+      const f32x4 o = {b0, b1, b2, b3};
+      save_quad(xsave + 8 * kg + 4 * h, o);
+      __builtin_amdgcn_sched_barrier(0);
     }
     kgroup<8>(pipe, acc, kg, kg == 0, last && kg == NKG - 1, b0, b1, b2, b3);
   };
@@ -133,11 +132,9 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
   const long long p = (long long)blockIdx.x * TILE + wave * 32 + m;
   const bool valid = p < A.P;
   const long long pc = valid ? p : A.P - 1;
-#ifdef ANERF_EXP_NOSAVE   // ablation build only: skip every activation store of the training forward
-  const bool save = false;
-#else
-  const bool save = TRAIN && valid;
-#endif
+  // TRAIN: every lane stores its saved activations unconditionally -- tail lanes (p >= P) computed on the clamped sample
+  // pc = P - 1 and so rewrite that row with identical values -- which keeps exec-mask changes out of the MFMA stream.
+  const long long ps = pc;
 
   // ---- biases / head rows -> LDS (natural order), read back as float4 per k-group
   float* aux_l = reinterpret_cast<float*>(smem + LDS_AUX_OFF);
@@ -214,21 +211,25 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
   f32x16 accA[8], accB[8];   // ping-pong accumulator sets (pre-bias sums)
 
   // ---- layer 0: x(432) -> A
+  // TRAIN: h_l is saved by the layer that CONSUMES it (hidden_part<.., true>: one quad per k-group)
+#ifdef ANERF_EXP_SAVE_COAL   // ablation build only: wave-contiguous (lane-linear) destinations, results land in the wrong places
+  float* hsave = TRAIN ? A.save_h + ((long long)blockIdx.x * TILE + wave * 32) * 256 + lane * 4 : nullptr;
+#else
+  float* hsave = TRAIN ? A.save_h + ps * 256 + 4 * h : nullptr;      // this lane's quads in plane 0; plane l at + l * plane
+#endif
+  const long long plane = TRAIN ? A.Ppad * 256 : 0;
   init_bias<8>(accA, aux_h + AUX_B0);
-  x_part<LV, PRE, TRAIN>(pipe, accA, v, wv, rh, xrow, h, save ? A.save_x + p * DIMX : nullptr, true);
+  x_part<LV, PRE, TRAIN>(pipe, accA, v, wv, rh, xrow, h, TRAIN ? A.save_x + ps * DIMX : nullptr, true);
   relu_pass<8>(accA);
-  if (save) store_act<8>(A.save_h + p * 256, accA, h);
   // ---- layers 1..4: A -> B -> A -> B -> A
 #pragma unroll 1
   for (int L = 1; L <= 3; L += 2) {
     init_bias<8>(accB, aux_h + AUX_B0 + 256 * L);
-    hidden_part<8, 0>(pipe, accB, accA, true, true);
+    hidden_part<8, 0, TRAIN>(pipe, accB, accA, true, true, hsave + (L - 1) * plane);
     relu_pass<8>(accB);
-    if (save) store_act<8>(A.save_h + ((long long)L * A.Ppad + p) * 256, accB, h);
     init_bias<8>(accA, aux_h + AUX_B0 + 256 * (L + 1));
-    hidden_part<8, 0>(pipe, accA, accB, true, true);
+    hidden_part<8, 0, TRAIN>(pipe, accA, accB, true, true, hsave + L * plane);
     relu_pass<8>(accA);
-    if (save) store_act<8>(A.save_h + ((long long)(L + 1) * A.Ppad + p) * 256, accA, h);
   }
   // ---- layer 5: [x(432); h4(256)] -> B   (skip connection: x is re-encoded, never stored).  The asm makes v/wv
   // opaque so the compiler re-derives the sin/cos products here instead of keeping 168 of them live (spilled to
@@ -239,18 +240,15 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
   }
   init_bias<8>(accB, aux_h + AUX_B0 + 256 * 5);
   x_part<LV, PRE, false>(pipe, accB, v, wv, rh, xrow, h, nullptr, false);
-  hidden_part<8, KGX>(pipe, accB, accA, false, true);
+  hidden_part<8, KGX, TRAIN>(pipe, accB, accA, false, true, hsave + 4 * plane);
   relu_pass<8>(accB);
-  if (save) store_act<8>(A.save_h + (5 * A.Ppad + p) * 256, accB, h);
   // ---- layers 6, 7: B -> A -> B
   init_bias<8>(accA, aux_h + AUX_B0 + 256 * 6);
-  hidden_part<8, 0>(pipe, accA, accB, true, true);
+  hidden_part<8, 0, TRAIN>(pipe, accA, accB, true, true, hsave + 5 * plane);
   relu_pass<8>(accA);
-  if (save) store_act<8>(A.save_h + (6 * A.Ppad + p) * 256, accA, h);
   init_bias<8>(accB, aux_h + AUX_B0 + 256 * 7);
-  hidden_part<8, 0>(pipe, accB, accA, true, true);
+  hidden_part<8, 0, TRAIN>(pipe, accB, accA, true, true, hsave + 6 * plane);
   relu_pass<8>(accB);
-  if (save) store_act<8>(A.save_h + (7 * A.Ppad + p) * 256, accB, h);
   // ---- density head (VALU): sigma_raw = w_alpha . h7 + b_alpha
   const float sigma_raw = head_dot<8>(accB, aux_h + AUX_WA) + aux_l[AUX_BA];
   if constexpr (MODE == 1) {
@@ -259,20 +257,22 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
   }
   // ---- feature layer (no activation on its output): B -> A
   init_bias<8>(accA, aux_h + AUX_BF);
-  hidden_part<8, 0>(pipe, accA, accB, true, true);
-  if (save) store_act<8>(A.save_f + p * 256, accA, h);
+  hidden_part<8, 0, TRAIN>(pipe, accA, accB, true, true, hsave + 7 * plane);
   // ---- view layer: [feature(256); D(72*(1+2LD)); code(CODE)] -> 128 units
   f32x16 accv[4];
   constexpr int NKGU = UW / 8;
   init_bias<4>(accv, aux_h + AUX_BV);
-  hidden_part<4, 0>(pipe, accv, accA, true, false);
-  float* usave = save ? A.save_u + p * UW : nullptr;
+#ifdef ANERF_EXP_SAVE_COAL
+  hidden_part<4, 0, TRAIN>(pipe, accv, accA, true, false, TRAIN ? A.save_f + ((long long)blockIdx.x * TILE + wave * 32) * 256 + lane * 4 : nullptr);
+#else
+  hidden_part<4, 0, TRAIN>(pipe, accv, accA, true, false, TRAIN ? A.save_f + ps * 256 + 4 * h : nullptr);
+#endif
+  float* usave = TRAIN ? A.save_u + ps * UW + 4 * h : nullptr;
   auto KGV = [&](int kgu, float b0, float b1, float b2, float b3) __attribute__((always_inline)) {
     if constexpr (TRAIN) {
-      if (usave) {
-        f32x4 o = {b0, b1, b2, b3};
-        *reinterpret_cast<f32x4*>(usave + 8 * kgu + 4 * h) = o;
-      }
+      const f32x4 o = {b0, b1, b2, b3};
+      save_quad(usave + 8 * kgu, o);
+      __builtin_amdgcn_sched_barrier(0);
     }
     kgroup<4>(pipe, accv, 32 + kgu, false, kgu == NKGU - 1, b0, b1, b2, b3);
   };
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
     }
   }
   relu_pass<4>(accv);
-  if (save) store_act<4>(A.save_g + p * 128, accv, h);
+  if constexpr (TRAIN) store_act<4>(A.save_g + ps * 128, accv, h);
   // ---- rgb head (VALU)
   const float c0 = head_dot<4>(accv, aux_h + AUX_WC + 0) + aux_l[AUX_BC + 0];
   const float c1 = head_dot<4>(accv, aux_h + AUX_WC + 128) + aux_l[AUX_BC + 1];

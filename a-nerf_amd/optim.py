@@ -128,6 +128,8 @@ class FusedAdam:
         caster = getattr(caster, "module", caster)
         caster._anerf_grad_sink = weakref.ref(self)
         self._attached = weakref.ref(caster)
+        if self.params[0].is_cuda:
+            self.materialize()           # the bucket must exist before the first backward for that one to land in it
         return self
 
     def detach(self):
