@@ -67,9 +67,21 @@ int launch_code_reduce(const float* du, int uw, const float* cam, int n, int S, 
                        hipStream_t st);
 
 // ------------------------------------------------------------------------------------------------
-// weight-stream layout.  A segment = one Linear layer; its k-groups (8 input columns: 4 per lane half) are laid
-// out [kg][nb][lane][4] and padded to whole 32-fragment stages.
+// weight-stream layout (fp32 images, which = 0 / 1 / 2).  A segment = one Linear layer, padded to whole 32-fragment
+// stages; a k-group = 8 contraction indices (4 per lane half = 4 MFMA k-steps) against NB 32-row output blocks = NB
+// fragments of 64 lanes x float4, laid out QUARTER-major: fragment j = q * (NB / 4) + g of a k-group holds, for lane l,
+// the four A operands of k-step q for the output blocks nb = 4g .. 4g+3:
+//     { W[32(4g+e) + (l & 31)][col(kg, l >> 5, q)] : e = 0..3 }
+// so the registers a `ds_read_b128` fills are all consumed by ONE quarter of the k-group's MFMAs (k-step q, blocks
+// 4g..4g+3) and die together: the next k-group's fragments can be fetched a quarter at a time, three quarters (1536 MFMA
+// cycles) ahead of their use, without a second fragment buffer.  (Round 1 stored [kg][nb][lane][k-step]: a fragment's four
+// registers stayed live until the LAST quarter, every read for the next k-group had to wait for it, and the reads'
+// latency -- four lock-step waves x 8 KiB -- was exposed at each of the 420 k-groups of a tile.)
 // ------------------------------------------------------------------------------------------------
+// element offset of (block nb, lane, k-step q) inside a k-group of NB blocks
+static inline int64_t frag_pos(int NB, int nb, int lane, int q) {
+  return ((int64_t)(q * (NB / 4) + (nb >> 2)) * 64 + lane) * 4 + (nb & 3);
+}
 struct Seg {
   int tensor;  // index into AnerfNetParams.w
   int K;       // torch in_features (row length)
@@ -269,7 +281,7 @@ int anerf_build_pack_table(const AnerfConfig* cfg, int which, int32_t* table) {
             for (int t = 0; t < 4; ++t) {
               const int n = 8 * kg + 4 * (lane >> 5) + t;          // contraction index = row of W
               const int col = s.c0 + 32 * nb + (lane & 31);        // produced index   = column of W
-              table[pos + ((int64_t)(kg * 8 + nb) * 64 + lane) * 4 + t] = (s.tensor << 24) | (n * s.K + col);
+              table[pos + (int64_t)kg * 8 * FRAG_FLOATS + frag_pos(8, nb, lane, t)] = (s.tensor << 24) | (n * s.K + col);
             }
       pos += (int64_t)bseg_stages(s) * STAGE_FLOATS;
     }
@@ -311,7 +323,7 @@ int anerf_build_pack_table(const AnerfConfig* cfg, int which, int32_t* table) {
               const int n = 8 * kg + 4 * (lane >> 5) + t;
               const int cs = 256 * gi + 32 * nb + (lane & 31);     // stream column
               if (cs < (int)perm.size())
-                table[pos + ((int64_t)(kg * 8 + nb) * 64 + lane) * 4 + t] = (tensor << 24) | (n * K + colbase + perm[cs]);
+                table[pos + (int64_t)kg * 8 * FRAG_FLOATS + frag_pos(8, nb, lane, t)] = (tensor << 24) | (n * K + colbase + perm[cs]);
             }
       pos += (int64_t)(nkg * 8 / STAGE_FRAGS) * STAGE_FLOATS;
     };
@@ -329,7 +341,7 @@ int anerf_build_pack_table(const AnerfConfig* cfg, int which, int32_t* table) {
           for (int t = 0; t < 4; ++t) {
             const int n = 32 * nb + (lane & 31), h = lane >> 5;
             const int col = seg_col(cfg, s, kg, h, t);
-            table[pos + ((int64_t)(kg * s.NB + nb) * 64 + lane) * 4 + t] = (s.tensor << 24) | (n * s.K + col);
+            table[pos + (int64_t)kg * s.NB * FRAG_FLOATS + frag_pos(s.NB, nb, lane, t)] = (s.tensor << 24) | (n * s.K + col);
           }
     pos += (int64_t)seg_stages(s) * STAGE_FLOATS;
   }

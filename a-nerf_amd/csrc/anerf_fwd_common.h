@@ -25,7 +25,8 @@ constexpr int LDS_BONES_OFF = LDS_AUX_OFF + LDS_AUX_BYTES;        // MAX_TILE_RA
 // with the stores at all (ablation without weight loads: stores cost the same 0.24 ms), and hipcc either re-clusters
 // the pieces or, when they are fenced with sched_barrier masks, spills thousands of registers.
 // ------------------------------------------------------------------------------------------------
-struct Pipe3 {
+template <bool ASMDMA>
+struct Pipe3T {
   const char* gsrc;   // wave-UNIFORM source of this wave's first fragment of stage 0 (lane l adds lane16: saddr + voffset form)
   char* smem;
   unsigned wave_dst;  // wave-uniform LDS byte offset of this wave's 8 fragments inside a stage
@@ -36,7 +37,8 @@ struct Pipe3 {
   int stage;          // stage being consumed
   int nstages;
   int wave;           // wave index inside the workgroup (wave-uniform)
-  f32x4 pref[8];      // fragments of the next stage's first k-group, loaded before the stage barrier
+  f32x4 pref[8];      // split-bf16 kernels: fragments of the next stage's first k-group, loaded before the stage barrier
+  f32x4 a[8];         // fp32 kernels: the fragments of the k-group about to run (refilled a quarter at a time, see kgroup)
 
   __device__ __forceinline__ void issue(int s, int sl) {
 #ifdef ANERF_EXP_NOGLDS   // ablation build only (tools/ablate.sh): never load weights
@@ -44,9 +46,23 @@ struct Pipe3 {
 #endif
     const char* g = gsrc + (size_t)s * STAGE_BYTES;
     char* l = smem + sl * STAGE_BYTES + wave_dst;
+    if constexpr (ASMDMA) {
+      // fp32 kernels: the LDS-DMA is issued through inline asm so that hipcc does not see it.  A pending
+      // `global_load_lds` is booked by the compiler's wait-count pass as a FLAT access that may touch LDS, and while one is
+      // pending every LDS wait it emits is a full `s_waitcnt lgkmcnt(0)` -- with a DMA in flight all the time that meant
+      // every k-group drained its freshly issued fragment reads (kgroup).  Ordering against the LDS reads is the ring
+      // protocol's (vmcnt(0) + barrier, both asm with a memory clobber), exactly as before.
+      const unsigned lds0 = (unsigned)reinterpret_cast<size_t>((lds_ptr_t)l);
+      const char* gl = g + lane16;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(g + i * FRAG_BYTES + lane16), (lds_ptr_t)(l + i * FRAG_BYTES), 16, 0, 0);
+      for (int i = 0; i < 8; ++i)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                     :: "s"(lds0 + i * FRAG_BYTES), "v"(gl + i * FRAG_BYTES) : "memory", "m0");
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(g + i * FRAG_BYTES + lane16), (lds_ptr_t)(l + i * FRAG_BYTES), 16, 0, 0);
+    }
   }
   __device__ __forceinline__ void set_offsets() {
     cur = lane16 + slot * STAGE_BYTES;
@@ -71,6 +87,23 @@ struct Pipe3 {
     __syncthreads();
     if (nstages > 2) issue(2, 2);
   }
+  // fp32 kernels, once after begin(): fragments of the very first k-group
+  __device__ __forceinline__ void prime() {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = *reinterpret_cast<const f32x4*>(smem + cur + j * FRAG_BYTES);
+  }
+  // fp32 kernels: end of a stage WITHOUT draining the LDS queue.  The reads still in flight at this point are the
+  // prefetched fragments of the next k-group; they target the NEXT ring slot, not the one this barrier hands back to the
+  // weight loader, so they may cross it (the compiler tracks them and waits where their values are used).
+  __device__ __forceinline__ void end_stage_raw() {
+    // one asm block, "memory"-clobbered: neither the compiler's memory operations (the LDS-DMA issue below!) nor the
+    // asm reads may move across it, and no LDS wait is added
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // stages +1 / +2 landed for everybody; slot `slot` is free
+    if (stage + RING_SLOTS < nstages) issue(stage + RING_SLOTS, slot);
+    slot = slot == RING_SLOTS - 1 ? 0 : slot + 1;
+    ++stage;
+    set_offsets();
+  }
   // end of the stage being consumed: its slot is refilled with stage+3
   __device__ __forceinline__ void end_stage() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of stages +1 / +2 has landed
@@ -83,6 +116,9 @@ struct Pipe3 {
     set_offsets();
   }
 };
+using Pipe3 = Pipe3T<false>;    // split-bf16 kernels
+using Pipe3F = Pipe3T<true>;    // fp32 forward / backward kernels
+
 // acc[nb][r] <- bias[n(nb,r,h)] from the LDS copy of the natural-order bias vector (bias_h = vector + 4h)
 template <int NB>
 __device__ __forceinline__ void init_bias(f32x16 (&acc)[NB], const float* bias_h) {
@@ -125,59 +161,51 @@ __device__ __forceinline__ float head_dot(const f32x16* acc, const float* wrow_h
   return s + __shfl_xor(s, 32);
 }
 
-// One k-group (8 contraction indices: 4 from each lane half) against NB 32-row feature blocks.
-// kg: k-group index relative to the segment (layer) start; first: first k-group of the layer (informational);
-// last: final k-group of the segment (segments are padded to whole stages).  All three fold at compile time.
-// one float4 of a saved-activation row (ablation builds, tools/ablate.sh: NOSAVE drops the store, SAVE_NT marks it non-temporal)
+// One k-group (8 contraction indices: 4 from each lane half = 4 MFMA k-steps, "quarters") against NB 32-row feature blocks.
+// kg: k-group index relative to the segment (layer) start; last: final k-group of the segment (segments are padded to
+// whole stages).  Both fold at compile time.
+// Fragment pipeline: pipe.a[] holds this k-group's NB fragments when the call starts.  The weight image is quarter-major
+// (anerf_capi.hip): fragments q * (NB/4) .. + NB/4 - 1 carry exactly the A operands of quarter q, so they are dead as soon
+// as that quarter's MFMAs are issued and are refilled right there with the NEXT k-group's fragments of the same quarter --
+// three quarters (1536 MFMA cycles) before those are used, in the same registers.  The next k-group lies in the next ring
+// slot when this one ends a stage; that slot is complete by the ring invariant, so the reads may run ahead of the barrier.
+// (Round 1 read all NB fragments between two k-groups and paid the LDS latency of four lock-step waves x 8 KiB there,
+// ~420 times per tile.)
+template <int NB, class PIPE>
+__device__ __forceinline__ void kgroup(PIPE& pipe, f32x16 (&acc)[NB], int kg, bool first, bool last, float b0, float b1,
+                                       float b2, float b3) {
+  static_assert(NB == 8 || NB == 4, "kgroup: 8 or 4 output blocks");
+  constexpr int KPS = STAGE_FRAGS / NB;  // k-groups per stage
+  constexpr int FPQ = NB / 4;            // fragments per quarter
+  const int ks = kg % KPS;
+  const bool boundary = ks == KPS - 1 || last;
+  // the NEXT k-group's fragments: in the next ring slot when this k-group ends a stage
+  const char* nsrc = boundary ? pipe.smem + pipe.nxt : pipe.smem + pipe.cur + (ks + 1) * NB * FRAG_BYTES;
+  (void)first;
+  const float b[4] = {b0, b1, b2, b3};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+      acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(pipe.a[q * FPQ + (nb >> 2)][nb & 3], b[q], acc[nb], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < FPQ; ++g)
+      pipe.a[q * FPQ + g] = *reinterpret_cast<const f32x4*>(nsrc + (q * FPQ + g) * FRAG_BYTES);
+    // fence (only VALU / SALU may cross): left alone, the scheduler sinks these reads to just in front of their first use
+    __builtin_amdgcn_sched_barrier(0x6);
+  }
+  if (boundary) pipe.end_stage_raw();
+}
+
+// one float4 of a saved-activation row (ablation build, tools/ablate.sh: NOSAVE drops the store)
 __device__ __forceinline__ void save_quad(float* dst, f32x4 q) {
 #if defined(ANERF_EXP_NOSAVE)
   (void)dst; (void)q;
-#elif defined(ANERF_EXP_SAVE_NT)
-  __builtin_nontemporal_store(q, reinterpret_cast<f32x4*>(dst));
 #else
   *reinterpret_cast<f32x4*>(dst) = q;
 #endif
 }
-#ifdef ANERF_EXP_SAVE_COAL   // ablation build only (wrong layout): lane-linear 1 KiB stores instead of 16 B per row
-constexpr int SAVE_QUAD_STRIDE = 256;
-#else
 constexpr int SAVE_QUAD_STRIDE = 8;
-#endif
-
-template <int NB, class PIPE>
-__device__ __forceinline__ void kgroup(PIPE& pipe, f32x16 (&acc)[NB], int kg, bool first, bool last, float b0, float b1,
-                                       float b2, float b3) {
-  constexpr int KPS = STAGE_FRAGS / NB;  // k-groups per stage
-  const int ks = kg % KPS;
-  // The compiler schedules this as "NB ds_read_b128, s_waitcnt lgkmcnt(0), 4 NB MFMAs".  Hand-pipelining the reads one
-  // k-group ahead (as kstep<NB, true> does in anerf_mlp_b3.hip, where it gains 6 %) was measured here too (tools/ab_f32.sh,
-  // same box): +0.7 % on the render kernel, +1.2 % on the training step -- slower.  With 64-cycle fp32 MFMAs the read
-  // latency already hides behind the MFMAs still queued, and the second fragment buffer only adds register pressure.
-  f32x4 a[NB];
-  if (ks == 0 && kg != 0) {
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) a[nb] = pipe.pref[nb];
-  } else {
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
-      a[nb] = *reinterpret_cast<const f32x4*>(pipe.smem + pipe.cur + (ks * NB + nb) * FRAG_BYTES);
-  }
-  if (ks == KPS - 1 && !last) {
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) pipe.pref[nb] = *reinterpret_cast<const f32x4*>(pipe.smem + pipe.nxt + nb * FRAG_BYTES);
-  }
-  (void)first;
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nb].x, b0, acc[nb], 0, 0, 0);
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nb].y, b1, acc[nb], 0, 0, 0);
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nb].z, b2, acc[nb], 0, 0, 0);
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nb].w, b3, acc[nb], 0, 0, 0);
-  if (ks == KPS - 1 || last) pipe.end_stage();
-}
-
 
 // 32 k-groups whose B operands are the previous layer's 256 outputs, read straight from its accumulator set
 // `prev` (bias added by the accumulator init, ReLU already applied in place): no copy, no VALU in the MFMA stream.

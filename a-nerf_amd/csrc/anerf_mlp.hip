@@ -51,7 +51,7 @@ __device__ __forceinline__ void store_act(float* __restrict__ row, const f32x16*
 // STORE: also write the 4 operands of every k-group to xsave[8*kg + 4h .. +3] (stream column order X').
 // ------------------------------------------------------------------------------------------------
 template <int LV, bool PRE, bool STORE>
-__device__ __forceinline__ void x_part(Pipe3& pipe, f32x16 (&acc)[8], const float (&v)[12], const float (&wv)[12],
+__device__ __forceinline__ void x_part(Pipe3F& pipe, f32x16 (&acc)[8], const float (&v)[12], const float (&wv)[12],
                                        const float (&rh)[36], const float* __restrict__ xrow, int h,
                                        float* __restrict__ xsave, bool last) {
   constexpr int NKG = 3 * (1 + 2 * LV) + 9;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
 #ifdef ANERF_EXP_TILE_TIMING   // debug build only: (start, end) wall-clock stamps of every tile in A.save_h (8 B each)
   const unsigned long long tk0 = wall_clock64();
 #endif
-  Pipe3 pipe;
+  Pipe3F pipe;
   pipe.init(A.packed, smem, wave, lane, A.nstages);
 
   const long long p = (long long)blockIdx.x * TILE + wave * 32 + m;
@@ -156,6 +156,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
 #pragma unroll
     for (int a = 0; a < 36; ++a) rh[a] = 0.f;
     pipe.begin();
+    pipe.prime();
   } else {
     // ---- stage the bone matrices (rows 0..2 of each 4x4 world->bone matrix) of this tile's rays in LDS
     const long long tile_p0 = (long long)blockIdx.x * TILE;
@@ -186,6 +187,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
       x2 = fmaf(dray[2], z, rp[2]);
     }
     pipe.begin();   // barrier: aux + bones visible, weight stages 0/1 landed
+    pipe.prime();
 #pragma unroll
     for (int a = 0; a < 12; ++a) {
       const int j = 8 * (a >> 2) + 4 * h + (a & 3);
@@ -212,11 +214,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
 
   // ---- layer 0: x(432) -> A
   // TRAIN: h_l is saved by the layer that CONSUMES it (hidden_part<.., true>: one quad per k-group)
-#ifdef ANERF_EXP_SAVE_COAL   // ablation build only: wave-contiguous (lane-linear) destinations, results land in the wrong places
-  float* hsave = TRAIN ? A.save_h + ((long long)blockIdx.x * TILE + wave * 32) * 256 + lane * 4 : nullptr;
-#else
   float* hsave = TRAIN ? A.save_h + ps * 256 + 4 * h : nullptr;      // this lane's quads in plane 0; plane l at + l * plane
-#endif
   const long long plane = TRAIN ? A.Ppad * 256 : 0;
   init_bias<8>(accA, aux_h + AUX_B0);
   x_part<LV, PRE, TRAIN>(pipe, accA, v, wv, rh, xrow, h, TRAIN ? A.save_x + ps * DIMX : nullptr, true);
@@ -262,11 +260,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
   f32x16 accv[4];
   constexpr int NKGU = UW / 8;
   init_bias<4>(accv, aux_h + AUX_BV);
-#ifdef ANERF_EXP_SAVE_COAL
-  hidden_part<4, 0, TRAIN>(pipe, accv, accA, true, false, TRAIN ? A.save_f + ((long long)blockIdx.x * TILE + wave * 32) * 256 + lane * 4 : nullptr);
-#else
   hidden_part<4, 0, TRAIN>(pipe, accv, accA, true, false, TRAIN ? A.save_f + ps * 256 + 4 * h : nullptr);
-#endif
   float* usave = TRAIN ? A.save_u + ps * UW + 4 * h : nullptr;
   auto KGV = [&](int kgu, float b0, float b1, float b2, float b3) __attribute__((always_inline)) {
     if constexpr (TRAIN) {

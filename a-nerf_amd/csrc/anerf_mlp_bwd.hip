@@ -79,7 +79,7 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NB]) {
 // 512 registers (2 x 128 accumulators + 128 mask values + prefetch), spilled pointers, and the scratch reloads --
 // in-order VMEM ops behind the weight-stream loads -- made it slower (2.6 vs 2.4 ms).  The clean fix is to apply the
 // mask one block ahead of its use in the NEXT layer (32 live mask registers instead of 128); not done yet.
-__device__ __forceinline__ void bwd_layer(Pipe3& pipe, f32x16 (&out)[8], const f32x16 (&prev)[8], f32x4 (&mk)[32],
+__device__ __forceinline__ void bwd_layer(Pipe3F& pipe, f32x16 (&out)[8], const f32x16 (&prev)[8], f32x4 (&mk)[32],
                                           const float* __restrict__ mask_row_h, float* __restrict__ dz_row_h, bool valid,
                                           bool last) {
   load_mask<8>(mk, mask_row_h);
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(const BwdArgs A) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 31, h = lane >> 5;
-  Pipe3 pipe;
+  Pipe3F pipe;
   pipe.init(A.packed_t, smem, wave, lane, A.nstages);
   const long long p = (long long)blockIdx.x * TILE + wave * 32 + m;
 #ifdef ANERF_EXP_BWD_NOSTORE   // ablation build only: results are not written
@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(const BwdArgs A) {
   f32x4 mk[32];
   load_mask<4>(mk, A.save_g + pc * 128 + 4 * h);
   pipe.begin();   // barrier: aux visible, weight stages 0/1 landed
+  pipe.prime();
 
   f32x16 accA[8], accB[8];   // ping-pong: a layer's output set is the next layer's B-operand set
   f32x16 accv[4];

@@ -56,13 +56,13 @@ __device__ __forceinline__ void kgroup(Pipe& pipe, f32x16 (&acc)[NB], int kg, fl
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) a[nb] = *reinterpret_cast<const f32x4*>(pipe.smem + off + nb * FRAG_BYTES);
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nb].x, b0, acc[nb], 0, 0, 0);
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0 * (NB / 4) + (nb >> 2)][nb & 3], b0, acc[nb], 0, 0, 0);
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nb].y, b1, acc[nb], 0, 0, 0);
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1 * (NB / 4) + (nb >> 2)][nb & 3], b1, acc[nb], 0, 0, 0);
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nb].z, b2, acc[nb], 0, 0, 0);
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2 * (NB / 4) + (nb >> 2)][nb & 3], b2, acc[nb], 0, 0, 0);
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[nb].w, b3, acc[nb], 0, 0, 0);
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3 * (NB / 4) + (nb >> 2)][nb & 3], b3, acc[nb], 0, 0, 0);
 }
 
 // acc[nb][r] <- bias[n(nb,r,h)]; natural-order bias vector, float4 per (nb,q).
