@@ -20,6 +20,9 @@ constexpr int LDS_BONES_OFF = LDS_AUX_OFF + LDS_AUX_BYTES;        // MAX_TILE_RA
 //     completions are not ordered the way a counted wait needs; parity tests caught it;
 //   * 4 slots + per-wave-pair stage ownership (16 glds per owner): also produced stale fragments;
 //   * 4 slots with plain vmcnt(0): correct but 6 % slower than 3 slots (same one-stage lead, worse allocation).
+// Round 2, fp32 kernels: a 4-slot ring with ONE wait + barrier per two stages (rendezvous in front of the pair's last
+// k-group, LDS-DMA of the pair after next issued there): correct (all parity tests) but slower -- render kernel 219.5 vs
+// 216.0 ms, training forward 3.80 vs 3.63 ms (16-deep DMA bursts, 20-30 spilled VGPRs); the 3-slot pipe stays.
 // Round 2, fp32 training forward: issuing a stage's eight pieces two per k-group instead of all behind the barrier
 // (to keep the vector-memory path free for the activation stores) -- the weight stream turned out not to interfere
 // with the stores at all (ablation without weight loads: stores cost the same 0.24 ms), and hipcc either re-clusters

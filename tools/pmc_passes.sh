@@ -7,9 +7,9 @@ TAG=$1; shift; shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $ROOT/gpurun_out /tmp/prof
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d /tmp/prof/${TAG}_kt -- "$@" > /tmp/prof/${TAG}_kt.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/prof/${TAG}_kt -- "$@" > /tmp/prof/${TAG}_kt.log 2>/tmp/prof/${TAG}_kt.err
 dirs=""
-for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU" \
+for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU GRBM_GUI_ACTIVE" \
            "SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS"; do
   name=$(echo $grp | cut -d' ' -f1)
   rocprofv3 --kernel-trace --pmc $grp -d /tmp/prof/${TAG}_pmc_$name -- "$@" > /tmp/prof/${TAG}_pmc_$name.log 2>&1
