@@ -41,7 +41,7 @@ struct Pipe3T {
   int nstages;
   int wave;           // wave index inside the workgroup (wave-uniform)
   f32x4 pref[8];      // split-bf16 kernels: fragments of the next stage's first k-group, loaded before the stage barrier
-  f32x4 a[8];         // fp32 kernels: the fragments of the k-group about to run (refilled a quarter at a time, see kgroup)
+  f32x4 a[4];         // fp32 kernels: two-quarter window of weight fragments (see kgroup)
 
   __device__ __forceinline__ void issue(int s, int sl) {
 #ifdef ANERF_EXP_NOGLDS   // ablation build only (tools/ablate.sh): never load weights
@@ -93,7 +93,7 @@ struct Pipe3T {
   // fp32 kernels, once after begin(): fragments of the very first k-group
   __device__ __forceinline__ void prime() {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) a[j] = *reinterpret_cast<const f32x4*>(smem + cur + j * FRAG_BYTES);
+    for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const f32x4*>(smem + cur + j * FRAG_BYTES);   // quarters 0, 1 (NB = 8)
   }
   // fp32 kernels: end of a stage WITHOUT draining the LDS queue.  The reads still in flight at this point are the
   // prefetched fragments of the next k-group; they target the NEXT ring slot, not the one this barrier hands back to the
@@ -167,13 +167,14 @@ __device__ __forceinline__ float head_dot(const f32x16* acc, const float* wrow_h
 // One k-group (8 contraction indices: 4 from each lane half = 4 MFMA k-steps, "quarters") against NB 32-row feature blocks.
 // kg: k-group index relative to the segment (layer) start; last: final k-group of the segment (segments are padded to
 // whole stages).  Both fold at compile time.
-// Fragment pipeline: pipe.a[] holds this k-group's NB fragments when the call starts.  The weight image is quarter-major
-// (anerf_capi.hip): fragments q * (NB/4) .. + NB/4 - 1 carry exactly the A operands of quarter q, so they are dead as soon
-// as that quarter's MFMAs are issued and are refilled right there with the NEXT k-group's fragments of the same quarter --
-// three quarters (1536 MFMA cycles) before those are used, in the same registers.  The next k-group lies in the next ring
-// slot when this one ends a stage; that slot is complete by the ring invariant, so the reads may run ahead of the barrier.
-// (Round 1 read all NB fragments between two k-groups and paid the LDS latency of four lock-step waves x 8 KiB there,
-// ~420 times per tile.)
+// Fragment pipeline: the weight image is quarter-major (anerf_capi.hip): fragments q * (NB/4) .. + NB/4 - 1 of a k-group
+// carry exactly the A operands of quarter q, so they are dead as soon as that quarter's MFMAs are issued.  pipe.a[] is a
+// two-quarter window (4 fragment registers sets = 16 VGPRs): when a call starts it holds quarters 0 and 1 of this k-group;
+// after quarter q's MFMAs its slot (q & 1) is refilled with quarter q + 2 -- of this k-group (q = 0, 1) or quarters 0 / 1 of
+// the NEXT one (q = 2, 3) -- i.e. every read is issued one full quarter (512 MFMA cycles) before its data is used.  The
+// next k-group lies in the next ring slot when this one ends a stage; that slot is complete by the ring invariant, so the
+// reads may run ahead of the barrier.  (Round 1 read all NB fragments between two k-groups and paid the LDS latency of
+// four lock-step waves x 8 KiB there, ~420 times per tile; a full-k-group window (32 VGPRs) made the render kernel spill.)
 template <int NB, class PIPE>
 __device__ __forceinline__ void kgroup(PIPE& pipe, f32x16 (&acc)[NB], int kg, bool first, bool last, float b0, float b1,
                                        float b2, float b3) {
@@ -182,18 +183,19 @@ __device__ __forceinline__ void kgroup(PIPE& pipe, f32x16 (&acc)[NB], int kg, bo
   constexpr int FPQ = NB / 4;            // fragments per quarter
   const int ks = kg % KPS;
   const bool boundary = ks == KPS - 1 || last;
-  // the NEXT k-group's fragments: in the next ring slot when this k-group ends a stage
-  const char* nsrc = boundary ? pipe.smem + pipe.nxt : pipe.smem + pipe.cur + (ks + 1) * NB * FRAG_BYTES;
+  const char* csrc = pipe.smem + pipe.cur + ks * NB * FRAG_BYTES;                                   // this k-group
+  const char* nsrc = boundary ? pipe.smem + pipe.nxt : csrc + NB * FRAG_BYTES;                      // the next one
   (void)first;
   const float b[4] = {b0, b1, b2, b3};
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
+    const int sl = (q & 1) * FPQ;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
-      acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(pipe.a[q * FPQ + (nb >> 2)][nb & 3], b[q], acc[nb], 0, 0, 0);
+      acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(pipe.a[sl + (nb >> 2)][nb & 3], b[q], acc[nb], 0, 0, 0);
+    const char* src = q < 2 ? csrc + (q + 2) * FPQ * FRAG_BYTES : nsrc + (q - 2) * FPQ * FRAG_BYTES;
 #pragma unroll
-    for (int g = 0; g < FPQ; ++g)
-      pipe.a[q * FPQ + g] = *reinterpret_cast<const f32x4*>(nsrc + (q * FPQ + g) * FRAG_BYTES);
+    for (int g = 0; g < FPQ; ++g) pipe.a[sl + g] = *reinterpret_cast<const f32x4*>(src + g * FRAG_BYTES);
     // fence (only VALU / SALU may cross): left alone, the scheduler sinks these reads to just in front of their first use
     __builtin_amdgcn_sched_barrier(0x6);
   }

@@ -179,12 +179,9 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
     } else {
       const float* rp = A.rays + ray * A.ray_stride;
       const float z = A.z[pc];
-      dray[0] = rp[3];
-      dray[1] = rp[4];
-      dray[2] = rp[5];
-      x0 = fmaf(dray[0], z, rp[0]);
-      x1 = fmaf(dray[1], z, rp[1]);
-      x2 = fmaf(dray[2], z, rp[2]);
+      x0 = fmaf(rp[3], z, rp[0]);
+      x1 = fmaf(rp[4], z, rp[1]);
+      x2 = fmaf(rp[5], z, rp[2]);
     }
     pipe.begin();   // barrier: aux + bones visible, weight stages 0/1 landed
     pipe.prime();
@@ -284,7 +281,18 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
         KGV(9 * b + g, bb[0], bb[1], bb[2], bb[3]);
       }
   } else {
-    // per-ray unit direction in each owned bone frame, gated per sample by the distance gate (tau_d, cut_d)
+    // per-ray unit direction in each owned bone frame, gated per sample by the distance gate (tau_d, cut_d).  The ray
+    // direction is re-read here (12 bytes per lane, L2 hits) rather than kept in three VGPRs across the eight trunk layers,
+    // where both accumulator sets fill the AGPR file and the allocator spilled them to scratch (HBM traffic per tile).
+    if constexpr (MODE == 0) {
+      const int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      long long pe = (long long)blockIdx.x * TILE + wave * 32 + (lane_e & 31);
+      pe = pe < A.P ? pe : A.P - 1;
+      const float* rp = A.rays + (pe / A.S) * A.ray_stride;
+      dray[0] = rp[3];
+      dray[1] = rp[4];
+      dray[2] = rp[5];
+    }
     float e[36], wd[12];
 #pragma unroll
     for (int a = 0; a < 12; ++a) {
@@ -304,32 +312,44 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
     for (int g = 0; g < 9; ++g)
       KGV(g, e[4 * g] * wd[(4 * g) / 3], e[4 * g + 1] * wd[(4 * g + 1) / 3], e[4 * g + 2] * wd[(4 * g + 2) / 3],
           e[4 * g + 3] * wd[(4 * g + 3) / 3]);
-    float sbe[36], cbe[36];   // running sin/cos(2^f e): precise every 3rd band, double-angle steps in between
+    // running sin/cos(2^f e): precise every 3rd band, double-angle steps in between.  A band's values are advanced four at
+    // a time inside the k-group that consumes their sines (the cosines wait in cbe for the band's second half): only the
+    // 72 running values are live, not a second set of 72 gated operands.
+    float sbe[36], cbe[36];
 #pragma unroll
     for (int f = 0; f < LD; ++f) {
-      float se[36], ce[36];
 #pragma unroll
-      for (int i = 0; i < 36; ++i) {
-        if (f % 3 == 0) {
-          sincos_f32(e[i] * (float)(1 << f), sbe[i], cbe[i]);
-        } else {
-          const float s_old = sbe[i], c_old = cbe[i];
-          sbe[i] = 2.f * s_old * c_old;
-          cbe[i] = fmaf(-2.f * s_old, s_old, 1.f);
+      for (int g = 0; g < 9; ++g) {
+        float o[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int i = 4 * g + t;
+          if (f % 3 == 0) {
+            sincos_f32(e[i] * (float)(1 << f), sbe[i], cbe[i]);
+          } else {
+            const float s_old = sbe[i], c_old = cbe[i];
+            sbe[i] = 2.f * s_old * c_old;
+            cbe[i] = fmaf(-2.f * s_old, s_old, 1.f);
+          }
+          o[t] = sbe[i] * wd[i / 3];
         }
-        se[i] = sbe[i] * wd[i / 3];
-        ce[i] = cbe[i] * wd[i / 3];
+        KGV(9 * (1 + 2 * f) + g, o[0], o[1], o[2], o[3]);
       }
 #pragma unroll
-      for (int g = 0; g < 9; ++g) KGV(9 * (1 + 2 * f) + g, se[4 * g], se[4 * g + 1], se[4 * g + 2], se[4 * g + 3]);
-#pragma unroll
-      for (int g = 0; g < 9; ++g) KGV(9 * (2 + 2 * f) + g, ce[4 * g], ce[4 * g + 1], ce[4 * g + 2], ce[4 * g + 3]);
+      for (int g = 0; g < 9; ++g)
+        KGV(9 * (2 + 2 * f) + g, cbe[4 * g] * wd[(4 * g) / 3], cbe[4 * g + 1] * wd[(4 * g + 1) / 3],
+            cbe[4 * g + 2] * wd[(4 * g + 2) / 3], cbe[4 * g + 3] * wd[(4 * g + 3) / 3]);
     }
   }
   if constexpr (CODE > 0) {
     float fidx;
     if constexpr (PRE) fidx = xrow[DIMX + DIMD];
-    else fidx = A.cam[ray];
+    else {   // the ray index is re-derived (see the note at the final store)
+      const int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      long long pe = (long long)blockIdx.x * TILE + wave * 32 + (lane_e & 31);
+      pe = pe < A.P ? pe : A.P - 1;
+      fidx = A.cam[pe / A.S];
+    }
     int ci = (int)fidx;
     ci = ci < 0 ? 0 : (ci >= A.n_codes ? A.n_codes - 1 : ci);
     const float* crow = A.codes + (long long)ci * CODE;
@@ -345,9 +365,15 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
   const float c0 = head_dot<4>(accv, aux_h + AUX_WC + 0) + aux_l[AUX_BC + 0];
   const float c1 = head_dot<4>(accv, aux_h + AUX_WC + 128) + aux_l[AUX_BC + 1];
   const float c2 = head_dot<4>(accv, aux_h + AUX_WC + 256) + aux_l[AUX_BC + 2];
-  if (valid && h == 0) {
-    f32x4 o = {c0, c1, c2, sigma_raw};
-    *reinterpret_cast<f32x4*>(A.raw + p * 4) = o;
+  {
+    // the output position is re-derived here (mbcnt = lane id) instead of keeping `p` live through the whole kernel: that
+    // one long-lived VGPR pair was spilled to scratch, 2 KB of extra HBM traffic per tile
+    const int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const long long pe = (long long)blockIdx.x * TILE + wave * 32 + (lane_e & 31);
+    if (pe < A.P && lane_e < 32) {
+      f32x4 o = {c0, c1, c2, sigma_raw};
+      *reinterpret_cast<f32x4*>(A.raw + pe * 4) = o;
+    }
   }
 #ifdef ANERF_EXP_TILE_TIMING
   if (tid == 0 && A.save_u) {
