@@ -99,9 +99,18 @@ struct Pipe3T {
   // prefetched fragments of the next k-group; they target the NEXT ring slot, not the one this barrier hands back to the
   // weight loader, so they may cross it (the compiler tracks them and waits where their values are used).
   __device__ __forceinline__ void end_stage_raw() {
-    // one asm block, "memory"-clobbered: neither the compiler's memory operations (the LDS-DMA issue below!) nor the
-    // asm reads may move across it, and no LDS wait is added
+    stage_rendezvous();
+    stage_refill();
+  }
+  // the two halves of end_stage_raw, for callers that want to run code between them (k_mlp_bwd forms the next stage's
+  // masked operands there: whatever it loaded with ordinary global loads is complete at that point, and the compiler's
+  // counted waits for those loads must not find the freshly issued LDS-DMA pieces queued behind them)
+  __device__ __forceinline__ void stage_rendezvous() {
+    // one asm block, "memory"-clobbered: neither the compiler's memory operations (the LDS-DMA issue!) nor LDS reads may
+    // move across it, and no LDS wait is added
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // stages +1 / +2 landed for everybody; slot `slot` is free
+  }
+  __device__ __forceinline__ void stage_refill() {
     if (stage + RING_SLOTS < nstages) issue(stage + RING_SLOTS, slot);
     slot = slot == RING_SLOTS - 1 ? 0 : slot + 1;
     ++stage;
@@ -175,7 +184,9 @@ __device__ __forceinline__ float head_dot(const f32x16* acc, const float* wrow_h
 // next k-group lies in the next ring slot when this one ends a stage; that slot is complete by the ring invariant, so the
 // reads may run ahead of the barrier.  (Round 1 read all NB fragments between two k-groups and paid the LDS latency of
 // four lock-step waves x 8 KiB there, ~420 times per tile; a full-k-group window (32 VGPRs) made the render kernel spill.)
-template <int NB, class PIPE>
+// AUTO_END = false: the caller ends the stage itself (pipe.stage_rendezvous() ... pipe.stage_refill()) after the k-group
+// for which `boundary` holds.
+template <int NB, class PIPE, bool AUTO_END = true>
 __device__ __forceinline__ void kgroup(PIPE& pipe, f32x16 (&acc)[NB], int kg, bool first, bool last, float b0, float b1,
                                        float b2, float b3) {
   static_assert(NB == 8 || NB == 4, "kgroup: 8 or 4 output blocks");
@@ -199,7 +210,9 @@ __device__ __forceinline__ void kgroup(PIPE& pipe, f32x16 (&acc)[NB], int kg, bo
     // fence (only VALU / SALU may cross): left alone, the scheduler sinks these reads to just in front of their first use
     __builtin_amdgcn_sched_barrier(0x6);
   }
-  if (boundary) pipe.end_stage_raw();
+  if constexpr (AUTO_END) {
+    if (boundary) pipe.end_stage_raw();
+  }
 }
 
 // one float4 of a saved-activation row (ablation build, tools/ablate.sh: NOSAVE drops the store)

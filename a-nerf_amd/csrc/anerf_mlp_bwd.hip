@@ -68,25 +68,85 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[NB]) {
     for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
 }
 
-// One trunk layer of the backward:  out = (W^T prev) * [saved h > 0], stored as dz; `prev` stays intact (it is the
-// B operand).  The ReLU-mask row of the layer's output is fetched when the layer starts, so the 32 loads have the MFMA
-// stream of the layer to land; the dz stores are issued after the in-place mask pass and drain under the next layer's
-// first stage.  KG0 = 32 (any non-zero multiple of the k-groups per stage): the weight stream is one continuous
-// segment, so the first fragments of every layer come from the cross-barrier register prefetch.
-// Known cost: all 256 CUs run their tiles in lock step, so these layer-sized bursts (32 MB chip-wide each) outlast
-// the one stage (3.4 us) they have before the next s_waitcnt vmcnt(0): ablations say no stores -8 %, no mask loads
-// -8 %.  Slicing the traffic per stage (block j at stage j) was tried twice; both variants pushed the kernel past
-// 512 registers (2 x 128 accumulators + 128 mask values + prefetch), spilled pointers, and the scratch reloads --
-// in-order VMEM ops behind the weight-stream loads -- made it slower (2.6 vs 2.4 ms).  The clean fix is to apply the
-// mask one block ahead of its use in the NEXT layer (32 live mask registers instead of 128); not done yet.
-__device__ __forceinline__ void bwd_layer(Pipe3F& pipe, f32x16 (&out)[8], const f32x16 (&prev)[8], f32x4 (&mk)[32],
-                                          const float* __restrict__ mask_row_h, float* __restrict__ dz_row_h, bool valid,
-                                          bool last) {
-  load_mask<8>(mk, mask_row_h);
-  zero_acc<8>(out);
-  hidden_part<8, 32>(pipe, out, prev, false, last);
-  mask_pass<8>(out, mk);
-  if (valid) store_acc<8>(dz_row_h, out);
+// ------------------------------------------------------------------------------------------------
+// One layer of the backward chain:   out += W^T * m(prev),   m(prev) = prev * [saved activation of prev's layer > 0]
+// (MASK) or prev itself (the feature gradient df, which has no activation).  `prev` holds RAW sums; the ReLU mask is applied
+// where the values are consumed, stage by stage (stage s of the layer = block s of prev = 16 values per lane):
+//   * top of stage s (right behind the barrier that ends stage s-1, in front of the weight pipe's re-issue): the block's
+//     16 masked operands `bq` are formed from the accumulator block and the 4 mask quads `mk` fetched during stage s-1,
+//     and the 4 mask quads of block s+1 are requested (of block 0 of THIS layer's output during the last stage, for the
+//     next layer -- `next_mask_row_h`);
+//   * every k-group multiplies its quad of `bq` and stores it: that float4 is the k-group's row piece of dz (or df);
+// so mask loads and dz stores reach the CU's vector-memory path at most a few at a time (it takes ~100 cycles per 1 KiB
+// wave-access; round 1 issued 32-load and 32-store bursts per layer and lost 8 % of the kernel to each), 16 + 16 VGPRs
+// of mask / operand state replace the 128-register mask array, and nothing is waited for twice: the mask quads are
+// complete at the stage barrier's `vmcnt(0)`.
+// LAST: the final layer of the chain additionally collects the mask row of ITS output (h0) a block per stage into mk0.
+// ------------------------------------------------------------------------------------------------
+template <bool MASK>
+__device__ __forceinline__ void form_operands(float (&bq)[16], const f32x16& blk, const f32x4 (&mk)[4]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if constexpr (MASK) {
+      bq[4 * q + 0] = mk[q].x > 0.f ? blk[4 * q + 0] : 0.f;
+      bq[4 * q + 1] = mk[q].y > 0.f ? blk[4 * q + 1] : 0.f;
+      bq[4 * q + 2] = mk[q].z > 0.f ? blk[4 * q + 2] : 0.f;
+      bq[4 * q + 3] = mk[q].w > 0.f ? blk[4 * q + 3] : 0.f;
+    } else {
+      bq[4 * q + 0] = blk[4 * q + 0];
+      bq[4 * q + 1] = blk[4 * q + 1];
+      bq[4 * q + 2] = blk[4 * q + 2];
+      bq[4 * q + 3] = blk[4 * q + 3];
+    }
+  }
+}
+__device__ __forceinline__ void load_quads(f32x4 (&mk)[4], const float* __restrict__ row_h_blk) {
+#ifdef ANERF_EXP_BWD_NOMASK   // ablation build only: masks are not loaded (results are wrong)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) mk[q] = f32x4{1.f, 1.f, 1.f, 1.f};
+  return;
+#endif
+#pragma unroll
+  for (int q = 0; q < 4; ++q) mk[q] = *reinterpret_cast<const f32x4*>(row_h_blk + 8 * q);
+}
+
+// KG0: index of the layer's first k-group inside its weight segment (a multiple of 4).  On entry `mk` holds the mask quads
+// of prev's block 0 (MASK) and the pipe stands right behind a stage barrier with its re-issue still to do (`pending`),
+// or -- first layer of the chain -- somewhere inside a running stage (`pending` false).
+template <bool MASK, bool LAST, int KG0>
+__device__ __forceinline__ void bwd_layer(Pipe3F& pipe, f32x16 (&out)[8], const f32x16 (&prev)[8], f32x4 (&mk)[4],
+                                          const float* __restrict__ prev_mask_row_h, float* __restrict__ prev_dz_row_h,
+                                          const float* __restrict__ next_mask_row_h, f32x4 (&mk0)[32], bool& pending) {
+  float bq[16];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    form_operands<MASK>(bq, prev[s], mk);
+    if (pending) pipe.stage_refill();
+    pending = false;
+    if (s < 7) {
+      if constexpr (MASK) load_quads(mk, prev_mask_row_h + 32 * (s + 1));
+    } else if (next_mask_row_h) {
+      load_quads(mk, next_mask_row_h);
+    }
+    if constexpr (LAST) {
+      f32x4 t[4];
+      load_quads(t, next_mask_row_h + 32 * s);          // LAST: next_mask_row_h = mask row of `out` (h0), all 8 blocks
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mk0[4 * s + q] = t[q];
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int kg = 4 * s + ks;
+      const f32x4 o = {bq[4 * ks], bq[4 * ks + 1], bq[4 * ks + 2], bq[4 * ks + 3]};
+#ifndef ANERF_EXP_BWD_NOSTORE   // ablation build only: results are not written
+      *reinterpret_cast<f32x4*>(prev_dz_row_h + 8 * kg) = o;
+#endif
+      __builtin_amdgcn_sched_barrier(0);     // the store goes in front of the k-group's MFMAs
+      kgroup<8, Pipe3F, false>(pipe, out, KG0 + kg, false, false, o.x, o.y, o.z, o.w);
+    }
+    pipe.stage_rendezvous();
+    pending = true;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_mlp_bwd(const BwdArgs A) {
@@ -98,11 +158,8 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(const BwdArgs A) {
   Pipe3F pipe;
   pipe.init(A.packed_t, smem, wave, lane, A.nstages);
   const long long p = (long long)blockIdx.x * TILE + wave * 32 + m;
-#ifdef ANERF_EXP_BWD_NOSTORE   // ablation build only: results are not written
-  const bool valid = p < A.P && A.nstages < 0;   // never true at run time, opaque to the compiler
-#else
-  const bool valid = p < A.P;
-#endif
+  // every lane stores unconditionally to the clamped row pc: tail lanes (p >= P) recompute the last valid sample and rewrite
+  // its rows with identical values -- no exec-mask changes inside the MFMA stream
   const long long pc = p < A.P ? p : A.P - 1;
   // head rows (w_c, w_alpha) -> LDS copy of the aux image, read back as float4 per 8-feature group
   float* aux_l = reinterpret_cast<float*>(smem + LDS_AUX_OFF);
@@ -110,12 +167,12 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(const BwdArgs A) {
     reinterpret_cast<f32x4*>(aux_l)[i] = reinterpret_cast<const f32x4*>(A.aux)[i];
   const float* aux_h = aux_l + 4 * h;
   const f32x4 dr = *reinterpret_cast<const f32x4*>(A.draw + pc * 4);
-  f32x4 mk[32];
-  load_mask<4>(mk, A.save_g + pc * 128 + 4 * h);
+  f32x4 mk0[32];     // view-layer mask (16 quads) at the start, the h0 mask row at the end
+  load_mask<4>(mk0, A.save_g + pc * 128 + 4 * h);
   pipe.begin();   // barrier: aux visible, weight stages 0/1 landed
   pipe.prime();
 
-  f32x16 accA[8], accB[8];   // ping-pong: a layer's output set is the next layer's B-operand set
+  f32x16 accA[8], accB[8];   // ping-pong: a layer's output set (raw sums) is the next layer's operand set
   f32x16 accv[4];
   // ---- rgb head (VALU): dg = Wc^T dc ; dzv = dg * [g > 0]
 #pragma unroll
@@ -131,17 +188,15 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(const BwdArgs A) {
       accv[nb][4 * q + 2] = w0.z * dr.x + w1.z * dr.y + w2.z * dr.z;
       accv[nb][4 * q + 3] = w0.w * dr.x + w1.w * dr.y + w2.w * dr.z;
     }
-  mask_pass<4>(accv, mk);
-  if (valid) store_acc<4>(A.dzv + p * 128 + 4 * h, accv);
-  // ---- view layer, feature columns: df = Wv[:, :256]^T dzv      (16 k-groups over the 128 view units)
-  load_mask<8>(mk, A.save_h + (7 * A.Ppad + pc) * 256 + 4 * h);     // h7 mask, needed after the feature layer
+  mask_pass<4>(accv, mk0);
+  store_acc<4>(A.dzv + pc * 128 + 4 * h, accv);
+  // ---- view layer, feature columns: df = Wv[:, :256]^T dzv      (16 k-groups = 4 stages over the 128 view units)
   zero_acc<8>(accA);
 #pragma unroll
   for (int kg = 0; kg < 16; ++kg)
     kgroup<8>(pipe, accA, kg, kg == 0, false, accv[kg >> 2][4 * (kg & 3) + 0], accv[kg >> 2][4 * (kg & 3) + 1],
               accv[kg >> 2][4 * (kg & 3) + 2], accv[kg >> 2][4 * (kg & 3) + 3]);
-  if (valid) store_acc<8>(A.df + p * 256 + 4 * h, accA);
-  // ---- feature layer + density head: dh7 = Wf^T df + w_alpha * dsigma ; dz7 = dh7 * [h7 > 0]
+  // ---- feature layer + density head: dh7 = Wf^T df + w_alpha * dsigma (raw; its mask is applied by the layer below)
 #pragma unroll
   for (int nb = 0; nb < 8; ++nb)
 #pragma unroll
@@ -152,19 +207,27 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(const BwdArgs A) {
       accB[nb][4 * q + 2] = wa.z * dr.w;
       accB[nb][4 * q + 3] = wa.w * dr.w;
     }
-  hidden_part<8, 16>(pipe, accB, accA, false, false);
-  mask_pass<8>(accB, mk);
-  if (valid) store_acc<8>(A.dz + (7 * A.Ppad + p) * 256 + 4 * h, accB);
-  // ---- trunk: dz_{l-1} = (W_l^T dz_l) * [h_{l-1} > 0],  l = 7..1   (W_5: hidden columns only)
   const float* hrow = A.save_h + pc * 256 + 4 * h;
-  float* zrow = A.dz + p * 256 + 4 * h;
+  float* zrow = A.dz + pc * 256 + 4 * h;
   const long long plane = A.Ppad * 256;
+  f32x4 mk[4];
+  bool pending = false;      // the view part above ended its last stage through kgroup's own end_stage_raw
+  bwd_layer<false, false, 16>(pipe, accB, accA, mk, nullptr, A.df + pc * 256 + 4 * h, hrow + 7 * plane, mk0, pending);
+  // ---- trunk: layer L consumes dh_L (masking it with h_L and storing dz_L) and produces dh_{L-1},  L = 7..1
+  // (W_5: hidden columns only)
 #pragma unroll 1
   for (int L = 7; L >= 3; L -= 2) {
-    bwd_layer(pipe, accA, accB, mk, hrow + (L - 1) * plane, zrow + (L - 1) * plane, valid, false);
-    bwd_layer(pipe, accB, accA, mk, hrow + (L - 2) * plane, zrow + (L - 2) * plane, valid, false);
+    zero_acc<8>(accA);
+    bwd_layer<true, false, 32>(pipe, accA, accB, mk, hrow + L * plane, zrow + L * plane, hrow + (L - 1) * plane, mk0, pending);
+    zero_acc<8>(accB);
+    bwd_layer<true, false, 32>(pipe, accB, accA, mk, hrow + (L - 1) * plane, zrow + (L - 1) * plane, hrow + (L - 2) * plane, mk0,
+                               pending);
   }
-  bwd_layer(pipe, accA, accB, mk, hrow, zrow, valid, true);
+  zero_acc<8>(accA);
+  bwd_layer<true, true, 32>(pipe, accA, accB, mk, hrow + plane, zrow + plane, hrow, mk0, pending);
+  // dz0 = dh0 * [h0 > 0]: no consumer in this kernel; the mask row was collected during the last layer
+  mask_pass<8>(accA, mk0);
+  store_acc<8>(zrow, accA);
 }
 
 // ------------------------------------------------------------------------------------------------
