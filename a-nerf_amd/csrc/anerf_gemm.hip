@@ -17,7 +17,9 @@
 // operand loads, barriers and column sums 3.41 ms, i.e. the loop itself is at ~97 %; tile padding (432- and 648-wide
 // operands in 128-column tiles) executes 6 % more MFMAs than the algorithmic count.  A 3-slot ring with counted
 // `s_waitcnt vmcnt(2 x tiles)` (two stage times per load instead of one) measured the same as this double buffer
-// (3.63 vs 3.60 ms): the kernel does not wait for HBM.
+// (3.63 vs 3.60 ms): the kernel does not wait for HBM.  Issuing the LDS-DMA through inline asm (so that hipcc emits the
+// counted `lgkmcnt(2)` the two-pairs-ahead operand reads were written for, instead of `lgkmcnt(0)`) also measured the same
+// (3.87 vs 3.89 ms on one box): the loop does not wait for LDS either.
 // A block = 4 such waves sharing operand tiles: 2x2 (two A tiles x two B tiles: a whole 256x256 layer per block,
 // each activation row read once) or 1x4 (views layer, M = 128).  The 4-row head problems (alpha / rgb, A = draw)
 // run as "skinny" waves: 4 MFMAs per row pair against one broadcast A block.
