@@ -56,7 +56,8 @@ class AnerfBackwardIO(C.Structure):
                 ("packed_t_c", C.c_void_p), ("packed_t_f", C.c_void_p), ("packed_i_c", C.c_void_p), ("packed_i_f", C.c_void_p),
                 ("perm_x", C.c_void_p), ("perm_u", C.c_void_p),
                 ("grads_c", AnerfNetGrads), ("grads_f", AnerfNetGrads),
-                ("g_skts", C.c_void_p), ("g_codes_c", C.c_void_p), ("g_codes_f", C.c_void_p), ("accumulate", C.c_int32)]
+                ("g_skts", C.c_void_p), ("g_codes_c", C.c_void_p), ("g_codes_f", C.c_void_p), ("accumulate", C.c_int32),
+                ("passes", C.c_int32)]
 
 
 class AnerfTrainLayout(C.Structure):

@@ -201,10 +201,16 @@ class _RenderRaysFn(torch.autograd.Function):
         sink = meta.get("grad_sink")
         into = [p.grad for p in meta["params"]]
         direct = sink is not None and sink.owns_grads(meta["params"], dev)
+        # data-parallel overlap (opt-in on the attached optimiser): the fine network's path gradients are complete when the
+        # first half of the backward is enqueued; their all-reduce starts there and runs under the coarse pass
+        hook = None
+        if direct and hier and getattr(sink, "overlap", False):
+            fine_params = meta["params"][24:]
+            hook = lambda: sink.begin_async_all_reduce(fine_params)
         grads_c, grads_f, g_skts, g_cc, g_cf = ops.backward(
             state, dict(zip(ctx.keys, gs)), meta["packed_t_c"], meta["packed_t_f"], perm_tables(meta["kw"]["cfg"], dev, b3=b3),
             ctx.shapes[:24], ctx.shapes[24:], pi[0], pi[1], want_skts, want_cc, want_cf,
-            accumulate_into=(into[:24], into[24:]) if direct else None)
+            accumulate_into=(into[:24], into[24:]) if direct else None, after_fine=hook)
         ctx.state = None
         if direct:
             return (None, g_skts, g_cc, g_cf) + (None,) * len(ctx.shapes)

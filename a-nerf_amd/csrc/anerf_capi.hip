@@ -205,7 +205,7 @@ using namespace anerf;
 extern "C" {
 
 const char* anerf_last_error(void) { return g_err; }
-int anerf_version(void) { return 1; }
+int anerf_version(void) { return 2; }
 
 int anerf_layout(const AnerfConfig* cfg, int which, AnerfLayout* out) {
   if (!out) return set_error(ANERF_E_NULL, "out is NULL");
@@ -1032,9 +1032,13 @@ int anerf_backward(const AnerfConfig* cfg, const AnerfForwardIO* io, const Anerf
   hipStream_t st = (hipStream_t)stream;
   auto F = [&](int64_t off) { return reinterpret_cast<float*>(ws + off); };
   const int uw = u_width(cfg);
-  if (b->g_skts && hipMemsetAsync(b->g_skts, 0, (size_t)n * 24 * 16 * 4, st) != hipSuccess)
+  if (b->passes < 0 || b->passes > 3) return set_error(ANERF_E_CONFIG, "backward: passes must be 0..3");
+  const bool do_fine = hier && (b->passes == 0 || (b->passes & 1));
+  const bool do_coarse = !hier || b->passes == 0 || (b->passes & 2);
+  const bool coarse_only = hier && !do_fine;              // second half of a split backward: g_skts already holds the fine pass
+  if (b->g_skts && !coarse_only && hipMemsetAsync(b->g_skts, 0, (size_t)n * 24 * 16 * 4, st) != hipSuccess)
     return set_error(ANERF_E_LAUNCH, "backward: hipMemsetAsync");
-  bool skts_written = false;
+  bool skts_written = coarse_only;
   // one network pass: composite backward -> dz chain -> weight gradients (-> input gradients -> pose / code gradients)
   auto pass = [&](const AnerfSaved& sv, const float* raw, const float* zz, int ns, const float* noise, const float* g_rgb,
                   const float* g_acc, const float* g_disp, const float* g_alpha, const float* packed_t, const float* aux,
@@ -1072,12 +1076,13 @@ int anerf_backward(const AnerfConfig* cfg, const AnerfForwardIO* io, const Anerf
     }
     return r;
   };
-  if (hier) {   // the fine pass first, as autograd runs it
+  if (do_fine) {   // the fine pass first, as autograd runs it
     const AnerfSaved sf = saved_at(ws + t.off_f, t.sf);
     rc = pass(sf, F(t.fwd.raw_f), F(t.fwd.zm), (int)(S + Ni), io->noise_fine, b->g_rgb, b->g_acc, b->g_disp, b->g_alpha,
               b->packed_t_f, io->aux_f, b->packed_i_f, &b->grads_f, b->g_codes_f);
     if (rc) return rc;
   }
+  if (!do_coarse) return ANERF_OK;
   const AnerfSaved sc = saved_at(ws + t.off_c, t.sc);
   return pass(sc, F(t.fwd.raw), F(t.fwd.z), (int)S, io->noise, hier ? b->g_rgb0 : b->g_rgb, hier ? b->g_acc0 : b->g_acc,
               hier ? b->g_disp0 : b->g_disp, hier ? b->g_alpha0 : b->g_alpha, b->packed_t_c, io->aux_c, b->packed_i_c, &b->grads_c,

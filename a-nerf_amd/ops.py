@@ -392,11 +392,14 @@ def train_forward(cfg, net_c, net_f, rays, skts, cyls, n_samples, n_importance=0
 
 
 def backward(state, g, packed_t_c, packed_t_f, perm, shapes_c, shapes_f, packed_i_c=None, packed_i_f=None, want_skts=False,
-             want_codes_c=False, want_codes_f=False, accumulate_into=None):
+             want_codes_c=False, want_codes_f=False, accumulate_into=None, after_fine=None):
     """anerf_backward.  g: dict of gradients of the rendered maps (keys as the output dict; rgb_map and, when hierarchical,
     rgb0 are required -- missing ones are taken as zero).  shapes_*: parameter shapes in AnerfNetGrads order (w0, b0, ...).
     accumulate_into: optional (list_c, list_f) of existing gradient tensors the parameter gradients are ADDED to in place
     (then returned as they are) instead of being written to fresh tensors.
+    after_fine: optional callable; hierarchical calls are then enqueued as two halves (AnerfBackwardIO.passes = 1, then 2)
+    and `after_fine()` runs in between, when everything that produces the FINE network's parameter gradients is on the
+    stream -- the data-parallel path starts their all-reduce there, under the coarse pass.
     Returns (grads_c, grads_f, g_skts, g_codes_c, g_codes_f)."""
     cfg, io = state["cfg"], state["io"]
     n, S, Ni = io.n_rays, io.n_samples, io.n_importance
@@ -443,6 +446,10 @@ def backward(state, g, packed_t_c, packed_t_f, perm, shapes_c, shapes_f, packed_
     lib, cc = _lib.load(), cfg.c()
     want_in = int(want_skts or want_codes_c or want_codes_f)
     scratch, sbytes = _workspace(lib.anerf_backward_scratch_size, "anerf_backward_scratch_size", dev, C.byref(cc), n, S, Ni, want_in)
-    _lib.check(lib.anerf_backward(C.byref(cc), C.byref(io), C.byref(b), _p(state["ws"]), state["ws_bytes"], _p(scratch), sbytes,
-                                  _stream()), "anerf_backward")
+    for passes in ((1, 2) if (after_fine is not None and hier) else (0,)):
+        b.passes = passes
+        _lib.check(lib.anerf_backward(C.byref(cc), C.byref(io), C.byref(b), _p(state["ws"]), state["ws_bytes"], _p(scratch), sbytes,
+                                      _stream()), "anerf_backward")
+        if passes == 1:
+            after_fine()
     return grads_c, grads_f, g_skts, g_codes_c, g_codes_f

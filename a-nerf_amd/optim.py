@@ -46,6 +46,9 @@ class FusedAdam:
         self.flat = self.flat_grad = self.exp_avg = self.exp_avg_sq = None
         self.norms = None
         self._pending = None              # optimizer state loaded before the buffers exist
+        self.overlap = False              # see enable_overlap()
+        self._async = None                # (work handle, lo, hi) of an all-reduce started during the backward
+        self._side = None
         self._defaults = {"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": 0, "amsgrad": False, "step_every": 1}
         if params and isinstance(params[0], dict):
             for g in params:
@@ -180,6 +183,34 @@ class FusedAdam:
         return [gi for gi, g in enumerate(self.param_groups)
                 if (only is None or gi == only) and (i is None or g["step_every"] <= 1 or i % g["step_every"] == 0)]
 
+    # ---- overlapping the all-reduce with the backward (data parallel, opt-in) --------------------------------------
+    def enable_overlap(self, on=True):
+        """With an attached caster (attach()) and more than one rank: the all-reduce of the FINE network's gradients is
+        started in the middle of the backward -- they are complete once the fine pass is enqueued -- on a side stream,
+        and runs under the coarse pass; all_reduce_grads() then reduces the rest and joins.  Same sums as the single
+        collective (a split all-reduce adds the same numbers); needs an even ray split (no per-rank `weight`)."""
+        self.overlap = bool(on)
+        return self
+
+    def begin_async_all_reduce(self, params, group=None):
+        """Called by the caster's backward between its two halves: all-reduce (sum) the flat-bucket range that holds
+        `params` (they must be contiguous in the bucket) asynchronously.  No-op without a process group."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) <= 1 or self._async is not None:
+            return
+        fg = self.flat_grad
+        base = fg.data_ptr()
+        lo = min(p.grad.data_ptr() for p in params) - base
+        hi = max(p.grad.data_ptr() + p.grad.numel() * 4 for p in params) - base
+        if lo < 0 or hi > fg.numel() * 4 or (hi - lo) != 4 * sum(p.numel() for p in params):
+            return                                   # not one contiguous run of the bucket: leave it to the main collective
+        lo, hi = lo // 4, hi // 4
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=fg.device)
+        self._side.wait_stream(torch.cuda.current_stream(fg.device))      # everything enqueued so far = the fine pass
+        with torch.cuda.stream(self._side):
+            work = dist.all_reduce(fg[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True)
+        self._async = (work, lo, hi)
+
     def all_reduce_grads(self, group=None, i=None, weight=None):
         """Sum the gradient bucket over ranks; the 1/world scale is applied inside step().  ONE collective over the
         contiguous range of the groups due on iteration `i` (see class doc; i=None: every group).
@@ -197,8 +228,26 @@ class FusedAdam:
                 runs[-1].append(gi)
             else:
                 runs.append([gi])
-        for run in runs:
-            lo, hi = seg[run[0]][0], seg[run[-1]][0] + seg[run[-1]][1]
+        pieces = [(seg[run[0]][0], seg[run[-1]][0] + seg[run[-1]][1]) for run in runs]
+        if self._async is not None:                   # a range was already reduced under the backward: reduce around it
+            work, alo, ahi = self._async
+            self._async = None
+            if weight is not None and float(weight) != 1.0:
+                raise RuntimeError("FusedAdam: overlap needs an even ray split (the early all-reduce was not weighted)")
+            cut = []
+            for lo, hi in pieces:
+                if ahi <= lo or alo >= hi:
+                    cut.append((lo, hi))
+                else:
+                    if lo < alo:
+                        cut.append((lo, alo))
+                    if ahi < hi:
+                        cut.append((ahi, hi))
+            pieces = cut
+            work.wait()                               # the current stream now waits for the early collective
+            if self._side is not None:
+                torch.cuda.current_stream(self.flat_grad.device).wait_stream(self._side)
+        for lo, hi in pieces:
             buf = self.flat_grad[lo:hi]
             if weight is not None and float(weight) != 1.0:
                 buf.mul_(float(weight))

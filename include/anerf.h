@@ -351,6 +351,12 @@ typedef struct AnerfBackwardIO {
   AnerfNetGrads grads_c, grads_f;
   float *g_skts, *g_codes_c, *g_codes_f;
   int32_t accumulate;   /* 0: grads_c / grads_f are written; 1: added to their current contents (param.grad in place) */
+  int32_t passes;       /* ABI revision 2.  0 or 3: both network passes (fine, then coarse).  1: the fine pass only; 2: the
+                         * coarse pass only -- the two halves of one backward, enqueued as two calls so that the caller can
+                         * start reducing the fine network's gradients (complete after the first call) over RCCL while the
+                         * coarse pass runs (replaces nn.DataParallel's reduce-add, core/raycasters.py:157).  g_skts is
+                         * zero-filled by the call that runs the fine pass; a coarse-only call ADDS to it.  Ignored (both
+                         * passes = the one pass) when n_importance == 0. */
 } AnerfBackwardIO;
 int64_t anerf_train_workspace_size(const AnerfConfig* cfg, int32_t n_rays, int32_t n_samples, int32_t n_importance);
 int64_t anerf_backward_scratch_size(const AnerfConfig* cfg, int32_t n_rays, int32_t n_samples, int32_t n_importance,
