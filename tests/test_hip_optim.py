@@ -153,3 +153,74 @@ def test_training_steps_fused_tail_equals_torch_tail():
         # Adam divides by sqrt(v): the few elements whose gradient is rounding noise may move differently (bounded by the
         # 3 x lr = 1.5e-3 a weight can move at all); everything else agrees to ~1e-5
         assert np.mean(d > 3e-5) < 1e-2 and d.max() < 1.6e-3, (k, float(np.mean(d > 3e-5)), float(d.max()))
+
+
+def test_fused_adam_groups_cadence_and_checkpoint_round_trip(tmp_path):
+    """Two parameter groups in ONE flat bucket (networks + a `step_every` group, the pose-optimiser cadence of
+    trainer.py:476-478) against two torch.optim.Adam instances driven the reference's way; then the reference's checkpoint
+    layout: checkpoint.save_nerf splits the state into optimizer_state_dict / pose_optimizer_state_dict (torch format),
+    torch optimisers load them, and load_nerf restores a fresh FusedAdam to continue bit for bit."""
+    checkpoint = importlib.import_module("a-nerf_amd.checkpoint")
+    c = build("train_pytest")
+    g = torch.Generator(device="cuda").manual_seed(0)
+
+    def fresh():
+        caster = make_caster(c)
+        extra = [torch.nn.Parameter(torch.linspace(-1, 1, 37 * 3, device="cuda").reshape(37, 3).clone()),
+                 torch.nn.Parameter(torch.linspace(0, 2, 5, device="cuda").clone())]
+        return caster, [p for p in caster.parameters() if p.requires_grad], extra
+
+    caster, net_p, pose_p = fresh()
+    ref_c, ref_net, ref_pose = fresh()
+    opt = optim.FusedAdam([{"params": net_p, "lr": 5e-4}, {"params": pose_p, "lr": 2e-3, "step_every": 3}])
+    t_net, t_pose = torch.optim.Adam(ref_net, lr=5e-4), torch.optim.Adam(ref_pose, lr=2e-3)
+    opt.materialize()
+    grads = [[torch.randn(p.shape, device="cuda", generator=g) * 1e-2 for p in net_p + pose_p] for _ in range(7)]
+
+    def drive(opt_f, params_f, i):
+        for p, gr in zip(params_f, grads[i - 1]):
+            p.grad.add_(gr)
+        opt_f.step(zero_grad=True, i=i)
+
+    def drive_ref(i):
+        for p, gr in zip(ref_net + ref_pose, grads[i - 1]):
+            p.grad = gr.clone() if p.grad is None else p.grad + gr
+        t_net.step()
+        t_net.zero_grad()
+        if i % 3 == 0:                      # trainer.py:476-478
+            t_pose.step()
+            t_pose.zero_grad()
+
+    for i in range(1, 5):
+        drive(opt, net_p + pose_p, i)
+        drive_ref(i)
+    assert opt._steps == [4, 1]
+    for a, b in zip(net_p + pose_p, ref_net + ref_pose):
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=2e-6, atol=2e-7)
+    assert float(opt.flat_grad[opt._segments()[1][0]:].abs().max()) > 0          # pose bucket is accumulating (i = 4)
+    # ---- checkpoint in the reference's layout
+    path = str(tmp_path / "ck.tar")
+    checkpoint.save_nerf(path, 4, caster, opt)
+    ck = torch.load(path, map_location="cuda", weights_only=False)
+    assert len(ck["optimizer_state_dict"]["state"]) == len(net_p) and ck["optimizer_state_dict"]["param_groups"][0]["params"] == list(range(len(net_p)))
+    t2 = torch.optim.Adam(ref_net, lr=1.0)
+    t2.load_state_dict(ck["optimizer_state_dict"])                                # torch accepts it and agrees with its own state
+    for p_ref, i in zip(ref_net[:3], range(3)):
+        np.testing.assert_allclose(t2.state[p_ref]["exp_avg"].cpu().numpy(), t_net.state[p_ref]["exp_avg"].cpu().numpy(), rtol=2e-6, atol=1e-9)
+    # the pose group has no checkpoint slot without a pose layer (trainer.py:491-496); its state round-trips through group views
+    pose_sd = opt.group_optimizer(1).state_dict()
+    assert len(pose_sd["state"]) == 2 and pose_sd["param_groups"][0]["step_every"] == 3 and pose_sd["param_groups"][0]["lr"] == 2e-3
+    caster2, net2, pose2 = fresh()
+    with torch.no_grad():
+        for a, b in zip(pose2, pose_p):
+            a.copy_(b)
+    opt2 = optim.FusedAdam([{"params": net2, "lr": 5e-4}, {"params": pose2, "lr": 2e-3, "step_every": 3}])
+    r = checkpoint.load_nerf(path, caster2, opt2)
+    opt2.group_optimizer(1).load_state_dict(pose_sd)
+    assert r["global_step"] == 4 and opt2._steps == [4, 1]
+    o1, n1 = opt._segments()[1]
+    opt2.flat_grad[o1:o1 + n1].copy_(opt.flat_grad[o1:o1 + n1])                   # the half-accumulated pose gradients are trainer state
+    for i in range(5, 8):
+        drive(opt, net_p + pose_p, i)
+        drive(opt2, net2 + pose2, i)
+    assert torch.equal(opt.flat, opt2.flat) and opt._steps == opt2._steps == [7, 2]

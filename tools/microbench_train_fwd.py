@@ -23,10 +23,21 @@ raw = torch.empty(n, S, 4, device="cuda"); cut = torch.full((24,), 0.5, device="
 def go():
     _lib.check(lib.anerf_mlp_raw_train(C.byref(cc), p(packed), p(aux), p(rb), 11, p(z), p(skts), 384, None, None, 0, 20.0, 20.0, p(cut), p(cut),
                                        n, S, p(raw), C.byref(stt), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "train fwd")
+if os.environ.get("SHARED") == "1":      # one pose for every ray (stride 0) instead of per-ray replicated poses
+    skts = skts[:1].contiguous()
+STRIDE = 0 if skts.shape[0] == 1 else 384
+def go():
+    _lib.check(lib.anerf_mlp_raw_train(C.byref(cc), p(packed), p(aux), p(rb), 11, p(z), p(skts), STRIDE, None, None, 0, 20.0, 20.0, p(cut), p(cut),
+                                       n, S, p(raw), C.byref(stt), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "train fwd")
+def render():
+    _lib.check(lib.anerf_mlp_raw(C.byref(cc), p(packed), p(aux), p(rb), 11, p(z), p(skts), STRIDE, None, None, 0, 20.0, 20.0, p(cut), p(cut),
+                                 n, S, p(raw), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "render fwd")
+if os.environ.get("RENDER") == "1":
+    go = render
 go(); torch.cuda.synchronize()
 ts = []
 for _ in range(5):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(); go(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
 ms = min(ts)
-print(f"{os.path.basename(os.environ.get('ANERF_LIB', 'default')):28s} P={P} train-fwd {ms:.3f} ms  {P * 1.723648e6 / ms / 1e9:.1f} TFLOP/s  ({100 * P * 1.723648e6 / ms / 1e9 / 157.3:.1f} % of fp32 MFMA peak)")
+print(f"{os.path.basename(os.environ.get('ANERF_LIB', 'default')):28s} shared={os.environ.get('SHARED','0')} render={os.environ.get('RENDER','0')} P={P} fwd {ms:.3f} ms  {P * 1.723648e6 / ms / 1e9:.1f} TFLOP/s  ({100 * P * 1.723648e6 / ms / 1e9 / 157.3:.1f} % of fp32 MFMA peak)")
