@@ -10,10 +10,17 @@ Mirrors, with the same names and meaning where the reference has them:
 The flat gradient buffer is also the DP bucket: `all_reduce_grads()` is one RCCL all-reduce on it, the 1/world
 scale is folded into the Adam kernel.  No CPU fallback: the kernels come from libanerf_hip.so.
 """
+import os
 import weakref
 
 import torch
 import torch.distributed as dist
+
+
+def _force_collectives():
+    """ANERF_FORCE_COLLECTIVES=1: issue the collectives even in a one-rank process group (exercises the RCCL code path --
+    communicator, side stream, async handle -- on a single-GPU box; sums over one rank are the identity)."""
+    return os.environ.get("ANERF_FORCE_COLLECTIVES") == "1"
 
 from . import ops
 
@@ -195,7 +202,9 @@ class FusedAdam:
     def begin_async_all_reduce(self, params, group=None):
         """Called by the caster's backward between its two halves: all-reduce (sum) the flat-bucket range that holds
         `params` (they must be contiguous in the bucket) asynchronously.  No-op without a process group."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) <= 1 or self._async is not None:
+        if not (dist.is_available() and dist.is_initialized()) or self._async is not None:
+            return
+        if dist.get_world_size(group) <= 1 and not _force_collectives():
             return
         fg = self.flat_grad
         base = fg.data_ptr()
@@ -218,7 +227,7 @@ class FusedAdam:
         gradient is the global-batch mean gradient even when the ranks own different numbers of rays."""
         self.materialize()
         world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        if world <= 1:
+        if world <= 1 and not (_force_collectives() and dist.is_available() and dist.is_initialized()):
             return
         due = self._due(i)
         seg = self._segments()

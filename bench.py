@@ -107,6 +107,8 @@ def main():
     # ANERF_BENCH_FORCE_DIST=1: initialise the process group and run every collective even with ONE rank -- exercises the
     # RCCL code path (init with device_id, all_gather_into_tensor, all_reduce) on a single-GPU box
     if world > 1 or os.environ.get("ANERF_BENCH_FORCE_DIST") == "1":
+        if world == 1:
+            os.environ.setdefault("ANERF_FORCE_COLLECTIVES", "1")      # one rank: still run every collective of the DP path
         for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
             os.environ.setdefault(k, v)
         import torch.distributed as dist
