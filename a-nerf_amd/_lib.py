@@ -43,7 +43,8 @@ class AnerfForwardIO(C.Structure):
                 ("n_rays", C.c_int32), ("n_samples", C.c_int32), ("n_importance", C.c_int32), ("lindisp", C.c_int32),
                 ("single_net", C.c_int32), ("precision", C.c_int32),
                 ("rgb_map", C.c_void_p), ("disp_map", C.c_void_p), ("acc_map", C.c_void_p), ("alpha", C.c_void_p),
-                ("rgb0", C.c_void_p), ("disp0", C.c_void_p), ("acc0", C.c_void_p), ("alpha0", C.c_void_p)]
+                ("rgb0", C.c_void_p), ("disp0", C.c_void_p), ("acc0", C.c_void_p), ("alpha0", C.c_void_p),
+                ("pts_noise", C.c_void_p), ("pts_noise_is", C.c_void_p)]
 
 
 class AnerfNetGrads(C.Structure):

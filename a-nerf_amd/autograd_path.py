@@ -172,7 +172,7 @@ class _RenderRaysFn(torch.autograd.Function):
         out, state = ops.train_forward(
             kw["cfg"], meta["net_c"], meta["net_f"], kw["ray_batch"], skts, kw["cyls"], kw["n_samples"], kw["n_importance"],
             kw["tau_v"], kw["tau_d"], kw["cut_v"], kw["cut_d"], meta["cam"], codes_c, codes_f, kw["t_rand"], kw["u_imp"],
-            kw["noise"], kw["noise_fine"], kw["lindisp"], meta["precision"])
+            kw["noise"], kw["noise_fine"], kw["lindisp"], meta["precision"], kw.get("pts_noise"), kw.get("pts_noise_is"))
         ctx.state, ctx.meta = state, meta
         ctx.keys = _OUT_KEYS if kw["n_importance"] > 0 else _OUT_KEYS[:4]
         ctx.shapes = [tuple(p.shape) for p in params]
@@ -257,6 +257,8 @@ def render_rays_train(caster, kw):
         raise ValueError(f"train_precision must be 'fp32' or 'bf16x3', got {prec!r}")
     if not kw["single_net"] and getattr(caster, "train_route", "one_call") == "one_call":
         return _render_rays_one_node(caster, kw, prec)
+    if kw.get("pts_noise") is not None:
+        raise NotImplementedError("ray_noise_std > 0 trains through the one-call route (two-network configurations)")
     skts_c = skts.contiguous()
     with torch.no_grad():
         nf_raw, stats = ops.ray_bounds(rays, cyls)

@@ -518,4 +518,25 @@ int launch_gather_raw(const float* raw_c, const float* raw_is, const long long* 
   return check_launch("k_gather_raw");
 }
 
+// rows of 3 floats of the merged samples: out[n][k] = cat(a[n] (S rows), b[n] (Ni rows))[idx[n][k]]   (the sample offsets of
+// ray_noise_std > 0 follow their samples through the sort of the importance resampling, raycasters.py:665-709)
+__global__ void k_gather_rows3(const float* __restrict__ a, const float* __restrict__ b, const long long* __restrict__ idx, long long total,
+                               int S, int Ni, float* __restrict__ out) {
+  const long long g = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (g >= total) return;
+  const long long ray = g / (S + Ni);
+  const long long k = idx[g];
+  const float* src = k < S ? a + (ray * S + k) * 3 : b + (ray * Ni + (k - S)) * 3;
+  out[3 * g] = src[0];
+  out[3 * g + 1] = src[1];
+  out[3 * g + 2] = src[2];
+}
+
+int launch_gather_rows3(const float* a, const float* b, const long long* idx, int n, int S, int Ni, float* out, hipStream_t st) {
+  const long long total = (long long)n * (S + Ni);
+  if (total == 0) return ANERF_OK;
+  hipLaunchKernelGGL(k_gather_rows3, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, b, idx, total, S, Ni, out);
+  return check_launch("k_gather_rows3");
+}
+
 }  // namespace anerf

@@ -39,7 +39,7 @@ int mlp_raw_entry(const AnerfConfig* cfg, const float* packed, const float* aux,
                   const float* z, const float* skts, long long skt_stride, const float* cam, const float* codes,
                   int n_codes, float tau_v, float tau_d, const float* cut_v, const float* cut_d, const float* x,
                   int x_width, long long P, int N, int S, int nstages, float* raw, bool pre, const AnerfSaved* sv,
-                  hipStream_t st);
+                  hipStream_t st, const float* pnoise = nullptr);
 int mlp_bwd_entry(const float* packed_t, const float* aux, const float* draw, const AnerfSaved* sv, float* dz, float* df,
                   float* dzv, long long P, int nstages, hipStream_t st);
 int launch_gather_raw(const float* raw_c, const float* raw_is, const long long* idx, int n, int S, int Ni, float* out, hipStream_t st);
@@ -50,7 +50,7 @@ int mlp_bwd_b3_entry(const float* packed_t, const float* aux, const float* draw,
 int mlp_b3_entry(const AnerfConfig* cfg, const float* packed, const float* aux, const float* rays, int ray_stride,
                  const float* z, const float* skts, long long skt_stride, const float* cam, const float* codes, int n_codes,
                  float tau_v, float tau_d, const float* cut_v, const float* cut_d, long long P, int N, int S, int nstages,
-                 float* raw, const AnerfSaved* sv, hipStream_t st);
+                 float* raw, const AnerfSaved* sv, hipStream_t st, const float* pnoise = nullptr);
 int launch_pack_b3(const AnerfNetParams* P, const int32_t* table, long long n, void* out, hipStream_t st);
 int mlp_density_entry(const float* packed, const float* aux, const float* pts, const float* skts, float tau_v,
                       const float* cut_v, long long P, int nstages_trunk, float* sigma, hipStream_t st);
@@ -62,7 +62,9 @@ int mlp_bwd_in_entry(const float* packed_i, const float* dz, const float* dzv, f
                      long long Ppad, int nstages, int uw, hipStream_t st);
 int launch_encode_bwd(int ld, const float* dx, const float* du, int uw, const float* rays, int ray_stride, const float* z,
                       const float* skts, long long skt_stride, float tau_v, float tau_d, const float* cut_v,
-                      const float* cut_d, int n, int S, float* dY, float* dQ, float* dskts, bool accumulate, hipStream_t st);
+                      const float* cut_d, int n, int S, float* dY, float* dQ, float* dskts, bool accumulate, hipStream_t st,
+                      const float* pnoise = nullptr);
+int launch_gather_rows3(const float* a, const float* b, const long long* idx, int n, int S, int Ni, float* out, hipStream_t st);
 int launch_code_reduce(const float* du, int uw, const float* cam, int n, int S, int n_codes, float* rowsum, float* dcodes,
                        hipStream_t st);
 
@@ -809,7 +811,7 @@ int anerf_assemble_frame(const float* rgb_map, const float* acc_map, const float
 // ---- one-call forward ---------------------------------------------------------------------------------------------
 namespace {
 struct FwdWs {
-  int64_t near_far, stats, z, raw, weights, zs, zm, idx, raw_is, raw_f, weights_f, total;
+  int64_t near_far, stats, z, raw, weights, zs, zm, idx, raw_is, raw_f, weights_f, pn_f, total;
 };
 FwdWs fwd_ws(int64_t n, int64_t S, int64_t Ni) {
   auto up = [](int64_t b) { return (b + 255) / 256 * 256; };
@@ -826,6 +828,7 @@ FwdWs fwd_ws(int64_t n, int64_t S, int64_t Ni) {
   w.raw_is = o; o += up(n * Ni * 16);
   w.raw_f = o; o += up(n * (S + Ni) * 16);
   w.weights_f = o; o += up(n * (S + Ni) * 4);
+  w.pn_f = o; o += up(n * (S + Ni) * 12);      // point noise of the merged samples (ray_noise_std > 0 only)
   w.total = o;
   return w;
 }
@@ -895,8 +898,27 @@ int forward_impl(const AnerfConfig* cfg, const AnerfForwardIO* io, char* ws, con
   if (!io->rgb_map || !io->disp_map || !io->acc_map || !io->alpha) return set_error(ANERF_E_NULL, "forward: output maps");
   if (Ni > 0 && !io->single_net && (!io->packed_f || !io->aux_f)) return set_error(ANERF_E_NULL, "forward: fine network image");
   auto F = [&](int64_t off) { return reinterpret_cast<float*>(ws + off); };
+  if ((io->pts_noise != nullptr) != (Ni > 0 ? io->pts_noise_is != nullptr : io->pts_noise != nullptr))
+    return set_error(ANERF_E_NULL, "forward: pts_noise and pts_noise_is go together when n_importance > 0");
   auto mlp = [&](const float* packed, const float* aux, const float* codes, const float* zz, int ns, float* raw,
-                 const AnerfSaved* sv) {
+                 const AnerfSaved* sv, const float* pn) {
+    if (pn) {   // ray_noise_std > 0: same kernels through the internal entries, which take the point offsets
+      AnerfLayout L;
+      int r = anerf_layout(cfg, io->precision == 1 ? 3 : 0, &L);
+      if (r) return r;
+      if (!packed || !aux || !io->rays || !zz || !io->skts || !io->cutoff_v || !io->cutoff_d || !raw)
+        return set_error(ANERF_E_NULL, "forward: NULL pointer");
+      if (cfg->framecode_ch && (!io->cam_idx || !codes || io->n_codes < 1)) return set_error(ANERF_E_NULL, "forward: frame codes");
+      if (ns < MIN_SAMPLES || ns > MAX_SAMPLES) return set_error(ANERF_E_SHAPE, "forward: 8 <= samples per ray <= 512");
+      if ((io->skt_ray_stride != 0 && io->skt_ray_stride != 384) || io->ray_stride < 6) return set_error(ANERF_E_SHAPE, "forward: strides");
+      if (io->precision == 1)
+        return mlp_b3_entry(cfg, packed, aux, io->rays, io->ray_stride, zz, io->skts, io->skt_ray_stride, io->cam_idx, codes, io->n_codes,
+                            io->tau_v, io->tau_d, io->cutoff_v, io->cutoff_d, (long long)n * ns, n, ns, L.n_stages, raw, sv,
+                            (hipStream_t)stream, pn);
+      return mlp_raw_entry(cfg, packed, aux, io->rays, io->ray_stride, zz, io->skts, io->skt_ray_stride, io->cam_idx, codes, io->n_codes,
+                           io->tau_v, io->tau_d, io->cutoff_v, io->cutoff_d, nullptr, 0, (long long)n * ns, n, ns, L.n_stages, raw, false,
+                           sv, (hipStream_t)stream, pn);
+    }
     if (sv)
       return (io->precision == 1 ? anerf_mlp_raw_train_b3 : anerf_mlp_raw_train)(
           cfg, packed, aux, io->rays, io->ray_stride, zz, io->skts, io->skt_ray_stride, io->cam_idx, codes, io->n_codes,
@@ -909,7 +931,7 @@ int forward_impl(const AnerfConfig* cfg, const AnerfForwardIO* io, char* ws, con
   if (rc) return rc;
   rc = anerf_coarse_z(F(w.near_far), F(w.stats), io->rays, io->ray_stride, n, S, io->t_rand, io->lindisp, F(w.z), nullptr, stream);
   if (rc) return rc;
-  rc = mlp(io->packed_c, io->aux_c, io->codes_c, F(w.z), S, F(w.raw), sv_c);
+  rc = mlp(io->packed_c, io->aux_c, io->codes_c, F(w.z), S, F(w.raw), sv_c, io->pts_noise);
   if (rc) return rc;
   const bool hier = Ni > 0;
   float* alpha_c = hier ? io->alpha0 : io->alpha;
@@ -922,11 +944,18 @@ int forward_impl(const AnerfConfig* cfg, const AnerfForwardIO* io, char* ws, con
                         reinterpret_cast<int64_t*>(ws + w.idx), stream);
   if (rc) return rc;
   if (io->single_net) {
-    rc = mlp(io->packed_c, io->aux_c, io->codes_c, F(w.zs), Ni, F(w.raw_is), nullptr);
+    rc = mlp(io->packed_c, io->aux_c, io->codes_c, F(w.zs), Ni, F(w.raw_is), nullptr, io->pts_noise_is);
     if (rc) return rc;
     rc = launch_gather_raw(F(w.raw), F(w.raw_is), reinterpret_cast<const long long*>(ws + w.idx), n, S, Ni, F(w.raw_f), (hipStream_t)stream);
   } else {
-    rc = mlp(io->packed_f, io->aux_f, io->codes_f, F(w.zm), S + Ni, F(w.raw_f), sv_f);
+    const float* pn_f = nullptr;
+    if (io->pts_noise) {   // the merged samples keep their own offsets: gather [coarse | importance] by the sort order (raycasters.py:679-709)
+      rc = launch_gather_rows3(io->pts_noise, io->pts_noise_is, reinterpret_cast<const long long*>(ws + w.idx), n, S, Ni, F(w.pn_f),
+                               (hipStream_t)stream);
+      if (rc) return rc;
+      pn_f = F(w.pn_f);
+    }
+    rc = mlp(io->packed_f, io->aux_f, io->codes_f, F(w.zm), S + Ni, F(w.raw_f), sv_f, pn_f);
   }
   if (rc) return rc;
   return anerf_composite(cfg, F(w.raw_f), F(w.zm), io->rays, io->ray_stride, io->noise_fine, n, S + Ni, io->rgb_map, io->disp_map,
@@ -1042,7 +1071,7 @@ int anerf_backward(const AnerfConfig* cfg, const AnerfForwardIO* io, const Anerf
   // one network pass: composite backward -> dz chain -> weight gradients (-> input gradients -> pose / code gradients)
   auto pass = [&](const AnerfSaved& sv, const float* raw, const float* zz, int ns, const float* noise, const float* g_rgb,
                   const float* g_acc, const float* g_disp, const float* g_alpha, const float* packed_t, const float* aux,
-                  const float* packed_i, const AnerfNetGrads* gr, float* g_codes) {
+                  const float* packed_i, const AnerfNetGrads* gr, float* g_codes, const float* pn) {
     const int64_t P = n * ns;
     const BwdWs w = bwd_ws(cfg, P, want_in);
     auto B = [&](int64_t off) { return reinterpret_cast<float*>(sb + off); };
@@ -1066,7 +1095,7 @@ int anerf_backward(const AnerfConfig* cfg, const AnerfForwardIO* io, const Anerf
     if (r) return r;
     if (b->g_skts) {
       r = launch_encode_bwd(cfg->multires_views, B(w.dx), B(w.du), uw, io->rays, io->ray_stride, zz, io->skts, io->skt_ray_stride,
-                            io->tau_v, io->tau_d, io->cutoff_v, io->cutoff_d, (int)n, ns, B(w.dy), B(w.dq), b->g_skts, skts_written, st);
+                            io->tau_v, io->tau_d, io->cutoff_v, io->cutoff_d, (int)n, ns, B(w.dy), B(w.dq), b->g_skts, skts_written, st, pn);
       if (r) return r;
       skts_written = true;
     }
@@ -1079,14 +1108,14 @@ int anerf_backward(const AnerfConfig* cfg, const AnerfForwardIO* io, const Anerf
   if (do_fine) {   // the fine pass first, as autograd runs it
     const AnerfSaved sf = saved_at(ws + t.off_f, t.sf);
     rc = pass(sf, F(t.fwd.raw_f), F(t.fwd.zm), (int)(S + Ni), io->noise_fine, b->g_rgb, b->g_acc, b->g_disp, b->g_alpha,
-              b->packed_t_f, io->aux_f, b->packed_i_f, &b->grads_f, b->g_codes_f);
+              b->packed_t_f, io->aux_f, b->packed_i_f, &b->grads_f, b->g_codes_f, io->pts_noise ? F(t.fwd.pn_f) : nullptr);
     if (rc) return rc;
   }
   if (!do_coarse) return ANERF_OK;
   const AnerfSaved sc = saved_at(ws + t.off_c, t.sc);
   return pass(sc, F(t.fwd.raw), F(t.fwd.z), (int)S, io->noise, hier ? b->g_rgb0 : b->g_rgb, hier ? b->g_acc0 : b->g_acc,
               hier ? b->g_disp0 : b->g_disp, hier ? b->g_alpha0 : b->g_alpha, b->packed_t_c, io->aux_c, b->packed_i_c, &b->grads_c,
-              b->g_codes_c);
+              b->g_codes_c, io->pts_noise);
 }
 
 }  // extern "C"

@@ -262,6 +262,7 @@ struct MlpArgs {
   const float* cut_v;
   const float* cut_d;
   const float* x;  // PRE
+  const float* pnoise;   // [P][3] additive offset of the sample points (ray_noise_std > 0, raycasters.py:660) or nullptr
   float* raw;
   // TRAIN: saved activations, row-major planes with Ppad rows (rows >= P are never written)
   float* save_h;   // [8][Ppad][256]  h0..h7 (post-ReLU)

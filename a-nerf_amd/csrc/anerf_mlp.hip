@@ -182,6 +182,11 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
       x0 = fmaf(rp[3], z, rp[0]);
       x1 = fmaf(rp[4], z, rp[1]);
       x2 = fmaf(rp[5], z, rp[2]);
+      if (A.pnoise) {   // wave-uniform: ray_noise_std > 0, training only
+        x0 += A.pnoise[3 * pc];
+        x1 += A.pnoise[3 * pc + 1];
+        x2 += A.pnoise[3 * pc + 2];
+      }
     }
     pipe.begin();   // barrier: aux + bones visible, weight stages 0/1 landed
     pipe.prime();
@@ -416,7 +421,7 @@ int mlp_dispatch(const AnerfConfig* cfg, const MlpArgs& a, bool pre, bool train,
 int mlp_density_entry(const float* packed, const float* aux, const float* pts, const float* skts, float tau_v,
                       const float* cut_v, long long P, int nstages_trunk, float* sigma, hipStream_t st) {
   MlpArgs a;
-  memset(&a, 0, sizeof(a));
+  memset(&a, 0, sizeof(a));   // (pnoise = nullptr)
   a.packed = packed; a.aux = aux; a.z = pts; a.skts = skts; a.cut_v = cut_v; a.cut_d = cut_v; a.raw = sigma;
   a.P = P; a.Ppad = P; a.skt_stride = 0; a.S = 1; a.N = 1; a.nstages = nstages_trunk; a.tau_v = tau_v; a.tau_d = tau_v;
   const long long nblk = (P + TILE - 1) / TILE;
@@ -433,8 +438,9 @@ int mlp_raw_entry(const AnerfConfig* cfg, const float* packed, const float* aux,
                   const float* z, const float* skts, long long skt_stride, const float* cam, const float* codes,
                   int n_codes, float tau_v, float tau_d, const float* cut_v, const float* cut_d, const float* x,
                   int x_width, long long P, int N, int S, int nstages, float* raw, bool pre, const AnerfSaved* sv,
-                  hipStream_t st) {
+                  hipStream_t st, const float* pnoise) {
   MlpArgs a;
+  a.pnoise = pnoise;
   a.packed = packed; a.aux = aux; a.rays = rays; a.z = z; a.skts = skts; a.cam = cam; a.codes = codes;
   a.cut_v = cut_v; a.cut_d = cut_d; a.x = x; a.raw = raw; a.P = P; a.skt_stride = skt_stride;
   a.S = S; a.N = N; a.ray_stride = ray_stride; a.n_codes = n_codes; a.x_width = x_width; a.nstages = nstages;

@@ -261,6 +261,11 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
   dray[1] = rp[4];
   dray[2] = rp[5];
   float x0 = fmaf(dray[0], z, rp[0]), x1 = fmaf(dray[1], z, rp[1]), x2 = fmaf(dray[2], z, rp[2]);
+  if (A.pnoise) {   // wave-uniform: ray_noise_std > 0 (raycasters.py:660)
+    x0 += A.pnoise[3 * pc];
+    x1 += A.pnoise[3 * pc + 1];
+    x2 += A.pnoise[3 * pc + 2];
+  }
   pipe.begin();
   // Skeleton-relative features of the sample for the lane half's 12 joints.  Evaluated THREE times (layer 0, the skip
   // layer, the view layer's gates) from the 3 position registers + the bone matrices in LDS instead of keeping 60 values
@@ -425,8 +430,9 @@ static int launch_b3(const MlpArgs& a, hipStream_t st) {
 int mlp_b3_entry(const AnerfConfig* cfg, const float* packed, const float* aux, const float* rays, int ray_stride,
                  const float* z, const float* skts, long long skt_stride, const float* cam, const float* codes, int n_codes,
                  float tau_v, float tau_d, const float* cut_v, const float* cut_d, long long P, int N, int S, int nstages,
-                 float* raw, const AnerfSaved* sv, hipStream_t st) {
+                 float* raw, const AnerfSaved* sv, hipStream_t st, const float* pnoise) {
   MlpArgs a;
+  a.pnoise = pnoise;
   a.packed = packed; a.aux = aux; a.rays = rays; a.z = z; a.skts = skts; a.cam = cam; a.codes = codes;
   a.cut_v = cut_v; a.cut_d = cut_d; a.x = nullptr; a.raw = raw; a.P = P; a.Ppad = P; a.skt_stride = skt_stride;
   a.S = S; a.N = N; a.ray_stride = ray_stride; a.n_codes = n_codes; a.x_width = 0; a.nstages = nstages;

@@ -22,7 +22,8 @@ __global__ __launch_bounds__(256) void k_encode_bwd(const float* __restrict__ dx
                                                     const float* __restrict__ z, const float* __restrict__ skts,
                                                     long long skt_stride, float tau_v, float tau_d,
                                                     const float* __restrict__ cut_v, const float* __restrict__ cut_d,
-                                                    long long P, int S, float* __restrict__ dY, float* __restrict__ dQ) {
+                                                    long long P, int S, float* __restrict__ dY, float* __restrict__ dQ,
+                                                    const float* __restrict__ pnoise) {
   constexpr int LV = 7;
   const long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   const long long p = gid / 6;
@@ -33,7 +34,10 @@ __global__ __launch_bounds__(256) void k_encode_bwd(const float* __restrict__ dx
   const float* rp = rays + ray * ray_stride;
   const float zz = z[p];
   const float d0 = rp[3], d1 = rp[4], d2 = rp[5];
-  const float x0 = fmaf(d0, zz, rp[0]), x1 = fmaf(d1, zz, rp[1]), x2 = fmaf(d2, zz, rp[2]);
+  float x0 = fmaf(d0, zz, rp[0]), x1 = fmaf(d1, zz, rp[1]), x2 = fmaf(d2, zz, rp[2]);
+  if (pnoise) {   // ray_noise_std > 0 (raycasters.py:660): the sample points carry an additive offset
+    x0 += pnoise[3 * p]; x1 += pnoise[3 * p + 1]; x2 += pnoise[3 * p + 2];
+  }
   const float* sk = skts + ray * skt_stride;
   float v[4], wv[4], wvp[4], wd[4], wdp[4], rh[12], e[12], qn[4], dv[4], dr[12], de[12];
 #pragma unroll
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(256) void k_encode_bwd(const float* __restrict__ dx
 __global__ __launch_bounds__(128) void k_pose_reduce(const float* __restrict__ dY, const float* __restrict__ dQ,
                                                      const float* __restrict__ rays, int ray_stride,
                                                      const float* __restrict__ z, int n, int S, int accumulate,
-                                                     float* __restrict__ dskts) {
+                                                     float* __restrict__ dskts, const float* __restrict__ pnoise) {
   const int ray = blockIdx.x, l = threadIdx.x;
   if (ray >= n || l >= 72) return;
   const float* rp = rays + (long long)ray * ray_stride;
@@ -149,9 +153,13 @@ __global__ __launch_bounds__(128) void k_pose_reduce(const float* __restrict__ d
     const long long p = (long long)ray * S + s;
     const float zz = z[p];
     const float dy = dY[p * 72 + l], dq = dQ[p * 72 + l];
-    R0 = fmaf(dy, fmaf(d0, zz, o0), R0);
-    R1 = fmaf(dy, fmaf(d1, zz, o1), R1);
-    R2 = fmaf(dy, fmaf(d2, zz, o2), R2);
+    float x0 = fmaf(d0, zz, o0), x1 = fmaf(d1, zz, o1), x2 = fmaf(d2, zz, o2);
+    if (pnoise) {
+      x0 += pnoise[3 * p]; x1 += pnoise[3 * p + 1]; x2 += pnoise[3 * p + 2];
+    }
+    R0 = fmaf(dy, x0, R0);
+    R1 = fmaf(dy, x1, R1);
+    R2 = fmaf(dy, x2, R2);
     T += dy;
     Q += dq;
   }
@@ -213,19 +221,20 @@ __global__ __launch_bounds__(16 * CODE_SLOTS) void k_code_reduce(const float* __
 
 int launch_encode_bwd(int ld, const float* dx, const float* du, int uw, const float* rays, int ray_stride, const float* z,
                       const float* skts, long long skt_stride, float tau_v, float tau_d, const float* cut_v,
-                      const float* cut_d, int n, int S, float* dY, float* dQ, float* dskts, bool accumulate, hipStream_t st) {
+                      const float* cut_d, int n, int S, float* dY, float* dQ, float* dskts, bool accumulate, hipStream_t st,
+                      const float* pnoise) {
   const long long P = (long long)n * S;
   const unsigned blocks = (unsigned)((6 * P + 255) / 256);
   if (ld == 4)
     hipLaunchKernelGGL(k_encode_bwd<4>, dim3(blocks), dim3(256), 0, st, dx, du, uw, rays, ray_stride, z, skts, skt_stride,
-                       tau_v, tau_d, cut_v, cut_d, P, S, dY, dQ);
+                       tau_v, tau_d, cut_v, cut_d, P, S, dY, dQ, pnoise);
   else
     hipLaunchKernelGGL(k_encode_bwd<0>, dim3(blocks), dim3(256), 0, st, dx, du, uw, rays, ray_stride, z, skts, skt_stride,
-                       tau_v, tau_d, cut_v, cut_d, P, S, dY, dQ);
+                       tau_v, tau_d, cut_v, cut_d, P, S, dY, dQ, pnoise);
   int rc = check_launch("k_encode_bwd");
   if (rc) return rc;
   hipLaunchKernelGGL(k_pose_reduce, dim3(n), dim3(128), 0, st, (const float*)dY, (const float*)dQ, rays, ray_stride, z, n, S,
-                     accumulate ? 1 : 0, dskts);
+                     accumulate ? 1 : 0, dskts, pnoise);
   return check_launch("k_pose_reduce");
 }
 

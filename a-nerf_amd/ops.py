@@ -319,7 +319,7 @@ def fk_backward(bones, rest_pose, pelvis, g_skts=None, g_l2ws=None, g_kp=None, g
 
 
 def _forward_io(cfg, net_c, net_f, rays, skts, cyls, n_samples, n_importance, tau_v, tau_d, cut_v, cut_d, cam_idx, codes_c,
-                codes_f, t_rand, u_imp, noise, noise_fine, lindisp, single_net, precision):
+                codes_f, t_rand, u_imp, noise, noise_fine, lindisp, single_net, precision, pts_noise=None, pts_noise_is=None):
     """AnerfForwardIO of one caster call + the output dict + the tensors whose pointers it holds"""
     f = lambda t, nm: _f32c(t, nm)
     rays, skts, cyls = f(rays, "rays"), f(skts, "skts"), f(cyls, "cyls")
@@ -340,8 +340,12 @@ def _forward_io(cfg, net_c, net_f, rays, skts, cyls, n_samples, n_importance, ta
     io.skts, io.skt_ray_stride = skts.data_ptr(), 16 * cfg.n_joints if skts.shape[0] == n else 0
     io.cyls = cyls.data_ptr()
     keep = [rays, skts, cyls, cut_v, cut_d, net_c, net_f]
+    if pts_noise is not None:
+        if tuple(pts_noise.shape) != (n, S, 3) or (Ni > 0 and (pts_noise_is is None or tuple(pts_noise_is.shape) != (n, Ni, 3))):
+            raise ValueError("pts_noise must be [N,S,3] and, with importance samples, pts_noise_is [N,Ni,3]")
     for name, t in (("cam_idx", cam_idx), ("codes_c", codes_c), ("codes_f", codes_f), ("t_rand", t_rand), ("u_imp", u_imp),
-                    ("noise", noise), ("noise_fine", noise_fine)):
+                    ("noise", noise), ("noise_fine", noise_fine), ("pts_noise", pts_noise),
+                    ("pts_noise_is", pts_noise_is if Ni > 0 else None)):
         if t is not None:
             t = f(t, name)
             keep.append(t)
@@ -364,12 +368,13 @@ def _workspace(fn, name, dev, *args):
 
 def forward(cfg, net_c, net_f, rays, skts, cyls, n_samples, n_importance=0, tau_v=20.0, tau_d=20.0, cut_v=None, cut_d=None,
             cam_idx=None, codes_c=None, codes_f=None, t_rand=None, u_imp=None, noise=None, noise_fine=None, lindisp=False,
-            single_net=False, precision="fp32"):
+            single_net=False, precision="fp32", pts_noise=None, pts_noise_is=None):
     """RayCaster.render_rays for one caster call as ONE C call (anerf_forward): every intermediate lives in a single
     workspace tensor; returns the reference's output dict.  net_c / net_f: (packed, aux) from pack_params (which=0 for
-    "fp32", which=3 for "bf16x3")."""
+    "fp32", which=3 for "bf16x3").  pts_noise / pts_noise_is: sample-point offsets (ray_noise_std > 0)."""
     io, out, keep = _forward_io(cfg, net_c, net_f, rays, skts, cyls, n_samples, n_importance, tau_v, tau_d, cut_v, cut_d,
-                                cam_idx, codes_c, codes_f, t_rand, u_imp, noise, noise_fine, lindisp, single_net, precision)
+                                cam_idx, codes_c, codes_f, t_rand, u_imp, noise, noise_fine, lindisp, single_net, precision,
+                                pts_noise, pts_noise_is)
     lib, cc = _lib.load(), cfg.c()
     ws, nbytes = _workspace(lib.anerf_workspace_size, "anerf_workspace_size", rays.device, C.byref(cc), io.n_rays,
                             io.n_samples, io.n_importance)
@@ -379,11 +384,12 @@ def forward(cfg, net_c, net_f, rays, skts, cyls, n_samples, n_importance=0, tau_
 
 def train_forward(cfg, net_c, net_f, rays, skts, cyls, n_samples, n_importance=0, tau_v=20.0, tau_d=20.0, cut_v=None,
                   cut_d=None, cam_idx=None, codes_c=None, codes_f=None, t_rand=None, u_imp=None, noise=None, noise_fine=None,
-                  lindisp=False, precision="fp32"):
+                  lindisp=False, precision="fp32", pts_noise=None, pts_noise_is=None):
     """anerf_train_forward: `forward` with the training kernels.  Returns (output dict, state); `state` owns the workspace
     with the saved activations and every input the backward re-reads -- hand it to `backward` unchanged."""
     io, out, keep = _forward_io(cfg, net_c, net_f, rays, skts, cyls, n_samples, n_importance, tau_v, tau_d, cut_v, cut_d,
-                                cam_idx, codes_c, codes_f, t_rand, u_imp, noise, noise_fine, lindisp, False, precision)
+                                cam_idx, codes_c, codes_f, t_rand, u_imp, noise, noise_fine, lindisp, False, precision,
+                                pts_noise, pts_noise_is)
     lib, cc = _lib.load(), cfg.c()
     ws, nbytes = _workspace(lib.anerf_train_workspace_size, "anerf_train_workspace_size", rays.device, C.byref(cc), io.n_rays,
                             io.n_samples, io.n_importance)

@@ -18,13 +18,15 @@ from . import ops
 def render_rays_forward(cfg, net_c, net_f, ray_batch, skts, cyls, n_samples, n_importance=0,
                         tau_v=20.0, tau_d=20.0, cut_v=None, cut_d=None, cam_idx=None,
                         codes_c=None, codes_f=None, t_rand=None, u_imp=None, noise=None, noise_fine=None,
-                        lindisp=False, single_net=False, extras=False, precision="fp32"):
+                        lindisp=False, single_net=False, extras=False, precision="fp32", pts_noise=None, pts_noise_is=None):
     """net_c / net_f: (packed, aux) images from ops.pack_params (which=0 for precision "fp32", which=3 for
     "bf16x3").  Returns the reference's output dict
     (RayCaster._collect_outputs, raycasters.py:711-724); extras adds the intermediates."""
     if not extras:   # production path: one C call, one workspace (anerf_forward); bit-identical to the staged calls below
         return ops.forward(cfg, net_c, net_f, ray_batch, skts, cyls, n_samples, n_importance, tau_v, tau_d, cut_v, cut_d, cam_idx,
-                           codes_c, codes_f, t_rand, u_imp, noise, noise_fine, lindisp, single_net, precision)
+                           codes_c, codes_f, t_rand, u_imp, noise, noise_fine, lindisp, single_net, precision, pts_noise, pts_noise_is)
+    if pts_noise is not None:
+        raise NotImplementedError("sample-point offsets (ray_noise_std > 0) go through the one-call entry points only")
     dev = ray_batch.device
     if cut_v is None:
         cut_v = torch.full((cfg.n_joints,), 0.5, device=dev)

@@ -88,9 +88,9 @@ class RayCaster(nn.Module):
         if skts is None or cyls is None:
             raise ValueError("skts and cyls are required (world->bone transforms and bounding cylinders)")
         if subject_idxs is not None:
-            raise NotImplementedError("subject_idxs (multi-subject column) is not used by the shipped configs")
-        if ray_noise_std > 0.:
-            raise NotImplementedError("ray_noise_std > 0 is not used by the shipped configs")
+            # the reference's own NeRF.forward rejects the extra input column encode_inputs appends for it
+            # (torch.split sizes, nerf.py:135-137 vs raycasters.py:545-548): no network in the repository consumes it
+            raise NotImplementedError("subject_idxs: no network of the reference consumes the subject column")
         n = ray_batch.shape[0]
         dev = ray_batch.device
         net_c, net_f = self.network, self.network_fine
@@ -113,6 +113,12 @@ class RayCaster(nn.Module):
                 noise = torch.randn(n, N_samples, device=dev) * (raw_noise_std * B)
                 if N_importance > 0:
                     noise_f = torch.randn(n, N_samples + N_importance, device=dev) * (raw_noise_std * B)
+        # sample-point offsets (raycasters.py:660,674): pts + randn_like(pts) * ray_noise_std, coarse and importance samples
+        pts_noise = pts_noise_is = None
+        if ray_noise_std > 0.:
+            pts_noise = torch.randn(n, N_samples, 3, device=dev) * ray_noise_std
+            if N_importance > 0:
+                pts_noise_is = torch.randn(n, N_importance, 3, device=dev) * ray_noise_std
         tau_v, tau_d = self._taus()
         cut_v = self.embed_fn.cutoff_dist.detach()
         cut_d = self.embeddirs_fn.cutoff_dist.detach() if hasattr(self.embeddirs_fn, "cutoff_dist") else cut_v
@@ -122,7 +128,7 @@ class RayCaster(nn.Module):
         kw = dict(cfg=cfg, ray_batch=ray_batch.contiguous(), skts=skts, cyls=cyls, n_samples=N_samples,
                   n_importance=N_importance, tau_v=tau_v, tau_d=tau_d, cut_v=cut_v, cut_d=cut_d,
                   cam_idx=cam_c if cam_c is not None else cam_idx, t_rand=t_rand, u_imp=u_imp, noise=noise,
-                  noise_fine=noise_f, lindisp=lindisp, single_net=self.single_net)
+                  noise_fine=noise_f, lindisp=lindisp, single_net=self.single_net, pts_noise=pts_noise, pts_noise_is=pts_noise_is)
         needs_grad = torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or skts.requires_grad)
         if needs_grad:
             from . import autograd_path

@@ -324,6 +324,11 @@ typedef struct AnerfForwardIO {
   const float *cutoff_v, *cutoff_d; float tau_v, tau_d;
   int32_t n_rays, n_samples, n_importance, lindisp, single_net, precision;
   float *rgb_map, *disp_map, *acc_map, *alpha, *rgb0, *disp0, *acc0, *alpha0;
+  /* ABI revision 2: additive offsets of the sample points, `pts + randn_like(pts) * ray_noise_std` of
+   * RayCaster.sample_pts / sample_pts_is (core/raycasters.py:650-677).  pts_noise [N,S,3] for the coarse samples, pts_noise_is
+   * [N,Ni,3] for the importance samples (required with pts_noise when n_importance > 0); the fine pass gathers both by the
+   * sort order of the merged depths.  NULL (the default of every shipped config: ray_noise_std = 0) = no offsets. */
+  const float *pts_noise, *pts_noise_is;
 } AnerfForwardIO;
 int64_t anerf_workspace_size(const AnerfConfig* cfg, int32_t n_rays, int32_t n_samples, int32_t n_importance);
 int anerf_forward(const AnerfConfig* cfg, const AnerfForwardIO* io, void* workspace, int64_t ws_bytes, void* stream);

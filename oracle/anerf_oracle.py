@@ -252,14 +252,19 @@ def importance_z(z, weights, n_imp, u=None, single_net=False):
 def render_rays(cfg, P, P_fine, ray_batch, skts, cyls, n_samples, n_importance=0,
                 tau_v=20.0, tau_d=20.0, cut_v=None, cut_d=None, cam_idx=None,
                 t_rand=None, u_imp=None, noise=None, noise_fine=None, lindisp=False,
-                single_net=False, eval_mean_code=False, return_extras=False):
-    """ray_batch [N,>=8] = (o3,d3,near,far[,viewdirs3]); returns the reference's output dict."""
+                single_net=False, eval_mean_code=False, return_extras=False, pts_noise=None, pts_noise_is=None):
+    """ray_batch [N,>=8] = (o3,d3,near,far[,viewdirs3]); returns the reference's output dict.
+    pts_noise [N,S,3] / pts_noise_is [N,Ni,3]: `pts + randn_like(pts) * ray_noise_std` of RayCaster.sample_pts /
+    sample_pts_is (raycasters.py:650-677), the random part passed in; the merged samples of the fine pass keep their own
+    offsets (the reference merges the ENCODINGS of the two point sets by the sort order, raycasters.py:679-709)."""
     cut_v = torch.full((N_JOINTS,), 0.5) if cut_v is None else cut_v
     cut_d = torch.full((N_JOINTS,), 0.5) if cut_d is None else cut_d
     o, d = ray_batch[:, 0:3], ray_batch[:, 3:6]
     near, far = ray_bounds(o, d, cyls, ray_batch[:, 6:7], ray_batch[:, 7:8])
     z = coarse_z(near, far, n_samples, t_rand, lindisp)
     pts = o[:, None] + d[:, None] * z[..., None]
+    if pts_noise is not None:
+        pts = pts + pts_noise
     X = encode(cfg, pts, d, skts, tau_v, tau_d, cut_v, cut_d, cam_idx)
     raw = mlp(cfg, P, X, eval_mean_code)
     out = composite(cfg, raw, z, d, noise)
@@ -268,10 +273,14 @@ def render_rays(cfg, P, P_fine, ray_batch, skts, cyls, n_samples, n_importance=0
     if n_importance > 0:
         zs, zm, idx = importance_z(z, out["weights"], n_importance, u_imp, single_net)
         pts_f = o[:, None] + d[:, None] * zm[..., None]
+        pts_n = o[:, None] + d[:, None] * zs[..., None]
+        if pts_noise is not None:
+            pts_n = pts_n + pts_noise_is
+            pts_f = pts_f + torch.gather(torch.cat([pts_noise, pts_noise_is], 1), 1, idx[..., None].expand(-1, -1, 3))
         Xf = encode(cfg, pts_f, d, skts, tau_v, tau_d, cut_v, cut_d, cam_idx)
         if single_net:
             # only the new samples go through the (shared) net; raw outputs are merged (raycasters.py:462-469)
-            Xn = encode(cfg, o[:, None] + d[:, None] * zs[..., None], d, skts, tau_v, tau_d, cut_v, cut_d, cam_idx)
+            Xn = encode(cfg, pts_n, d, skts, tau_v, tau_d, cut_v, cut_d, cam_idx)
             raw_n = mlp(cfg, P_fine, Xn, eval_mean_code)
             raw_f = torch.gather(torch.cat([raw, raw_n], 1), 1, idx[..., None].expand(-1, -1, 4))
         else:

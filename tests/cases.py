@@ -25,9 +25,21 @@ CASES = {
     "train_pytest": dict(n=48, poses=[4, 5, 6], ray_seed=4, per_ray=True, S=64, Ni=16, seeds=(11, 12), cfg={}, train=True),
     "mixamo_train": dict(n=40, poses=[7, 8], ray_seed=5, per_ray=True, S=64, Ni=16, seeds=(21, 22),
                          cfg=dict(framecode_ch=16), n_codes=8, train=True, loss="L1"),
+    # ray_noise_std > 0 (raycasters.py:660,674): train mode, pytest randomness, per-ray poses, 24 + 8 samples
+    "ray_noise": dict(n=40, poses=[13, 14, 15], ray_seed=10, per_ray=True, S=24, Ni=8, seeds=(11, 12), cfg={}, train=True, ray_noise=True),
     "single_net": dict(n=32, poses=[9], ray_seed=6, per_ray=False, S=96, Ni=48, seeds=(31, 31),
                        cfg=dict(multires_views=0), single_net=True),
 }
+
+
+RAY_NOISE_STD = 0.15
+
+
+def ray_noise_arrays(n, S, Ni, std=RAY_NOISE_STD):
+    """the numpy-seeded stand-in for torch.randn_like that tests/golden/gen_golden_raynoise.py fed the reference"""
+    a = np.random.RandomState(1000 + S).randn(n, S, 3).astype(np.float32) * np.float32(std)
+    b = np.random.RandomState(1000 + Ni).randn(n, Ni, 3).astype(np.float32) * np.float32(std)
+    return a, b
 
 
 def build(name):
@@ -52,4 +64,6 @@ def build(name):
         out["noise_fine"] = pytest_rand((n, S + Ni))
     if fc:
         out["cams"] = (np.arange(c["n"]) % 8).astype(np.float32)
+    if c.get("ray_noise"):
+        out["pts_noise"], out["pts_noise_is"] = ray_noise_arrays(c["n"], c["S"], c["Ni"])
     return out

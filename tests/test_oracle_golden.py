@@ -19,7 +19,7 @@ def run_case(oracle, c, requires_grad=False, eval_mean_code=False, cams=None):
     rb = oracle.make_ray_batch(t(c["rays_o"]), t(c["rays_d"]))
     skts = t(c["skts"]).requires_grad_(requires_grad)
     kw = {}
-    for k in ["t_rand", "u_imp", "noise", "noise_fine"]:
+    for k in ["t_rand", "u_imp", "noise", "noise_fine", "pts_noise", "pts_noise_is"]:
         if k in c:
             kw[k] = t(c[k])
     cams = c.get("cams") if cams is None else cams
@@ -112,16 +112,18 @@ def test_nan_fallback(oracle, golden):
         np.testing.assert_allclose(out[k].detach().numpy(), g[k], rtol=1e-4, atol=1e-5, err_msg=k)
 
 
-@pytest.mark.parametrize("name", ["train_pytest", "mixamo_train"])
+@pytest.mark.parametrize("name", ["train_pytest", "mixamo_train", "ray_noise"])
 def test_train_mode_and_grads(oracle, golden, name):
     g = golden(name)
     c = build(name)
     out, Pc, Pf, skts = run_case(oracle, c, requires_grad=True)
     for k in ["rgb_map", "disp_map", "acc_map", "alpha", "rgb0", "disp0", "acc0", "alpha0"]:
         np.testing.assert_allclose(out[k].detach().numpy(), g[k], rtol=1e-4, atol=1e-5, err_msg=k)
-    seed = 1 if name == "train_pytest" else 2
+    seed = {"train_pytest": 1, "mixamo_train": 2, "ray_noise": 4}[name]
     target = t(np.random.default_rng(seed).random((c["n"], 3)))
     loss, _ = oracle.nerf_loss(out, target, torch.ones(c["n"], 3), loss=c.get("loss", "MSE"))
+    if name == "ray_noise":      # the vectors do pin the branch: the offsets move the image by far more than the tolerance
+        assert np.abs(g["rgb_map"] - g["rgb_map_no_noise"]).max() > 1e-3
     assert abs(float(loss.detach()) - float(g["loss"])) < 1e-6
     loss.backward()
     np.testing.assert_allclose(skts.grad.numpy(), g["dskts"], rtol=2e-3, atol=2e-8)
