@@ -8,6 +8,7 @@ namespace anerf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
@@ -71,11 +72,32 @@ __device__ __forceinline__ void sincos_f32(float x, float& s, float& c) {
   c = ((q + 1) & 2) ? -cc : cc;
 }
 
+// sin and cos for |x| <= 1 (components of a unit vector): no reduction, Taylor to x^9 / x^10 (truncation 2.5e-8 / 2e-9).
+__device__ __forceinline__ void sincos_unit_f32(float x, float& s, float& c) {
+  const float x2 = x * x;
+  float ps = fmaf(x2, 2.7557319224e-6f, -1.9841269841e-4f);
+  ps = fmaf(ps, x2, 8.3333333333e-3f);
+  ps = fmaf(ps, x2, -1.6666666667e-1f);
+  s = fmaf(ps * x2, x, x);
+  float pc = fmaf(x2, -2.7557319224e-7f, 2.4801587302e-5f);
+  pc = fmaf(pc, x2, -1.3888888889e-3f);
+  pc = fmaf(pc, x2, 4.1666666667e-2f);
+  pc = fmaf(pc, x2, -0.5f);
+  c = fmaf(pc, x2, 1.0f);
+}
+
+// 1 / x from v_rcp_f32 (1 ulp) + one Newton step: 3 VALU; the IEEE-correct `1.0f / x` hipcc emits is a 10-instruction
+// v_div_scale / v_div_fmas / v_div_fixup sequence, issued into the MFMA stream ~60 times per tile
+__device__ __forceinline__ float rcp_nr(float x) {
+  const float r = __builtin_amdgcn_rcpf(x);
+  return fmaf(fmaf(-x, r, 1.0f), r, r);
+}
+
 // cutoff gate w = 1 - sigmoid(tau * (dist - cutoff))  (core/cutoff_embedder.py:149-155), evaluated as
 // 1 / (1 + exp(a)): same value without the cancellation of "1 - sigmoid".
 __device__ __forceinline__ float cutoff_gate(float tau, float dist, float cutoff) {
-  const float a = tau * (dist - cutoff);
-  return 1.0f / (1.0f + __expf(a));
+  const float a = fminf(tau * (dist - cutoff), 80.f);   // exp stays finite (the Newton step of rcp_nr would make inf * 0)
+  return rcp_nr(1.0f + __expf(a));
 }
 #endif
 

@@ -42,6 +42,9 @@ struct Pipe3T {
   int wave;           // wave index inside the workgroup (wave-uniform)
   f32x4 pref[8];      // split-bf16 kernels: fragments of the next stage's first k-group, loaded before the stage barrier
   f32x4 a[4];         // fp32 kernels: two-quarter window of weight fragments (see kgroup)
+#ifdef ANERF_EXP_STAGE_TIMING   // debug build only (tools/exp/stage_timing.py): per-wave arrive / leave clocks of every stage barrier
+  unsigned long long* tbuf = nullptr;
+#endif
 
   __device__ __forceinline__ void issue(int s, int sl) {
 #ifdef ANERF_EXP_NOGLDS   // ablation build only (tools/ablate.sh): never load weights
@@ -108,6 +111,15 @@ struct Pipe3T {
   __device__ __forceinline__ void stage_rendezvous() {
     // one asm block, "memory"-clobbered: neither the compiler's memory operations (the LDS-DMA issue!) nor LDS reads may
     // move across it, and no LDS wait is added
+#ifdef ANERF_EXP_STAGE_TIMING
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_barrier" ::: "memory");
+    const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+    if (tbuf) { tbuf[3 * stage] = t0; tbuf[3 * stage + 1] = t1; tbuf[3 * stage + 2] = t2; }
+    return;
+#endif
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // stages +1 / +2 landed for everybody; slot `slot` is free
   }
   __device__ __forceinline__ void stage_refill() {
@@ -148,12 +160,51 @@ __device__ __forceinline__ void init_bias(f32x16 (&acc)[NB], const float* bias_h
 
 // in-place ReLU of a finished layer (one VALU pass; measured 0.7 % of a layer, vs 4.3 % when the max is
 // interleaved with the consuming MFMAs -- tools/probe/mfma_probe2.hip)
+// max(x, 0) as ONE instruction: v_max_i32 on the bit pattern (negative floats are negative integers; -0 -> +0).
+// fmaxf compiles to two -- hipcc first canonicalises the MFMA result (v_max x, x) because it cannot prove it is not a
+// signalling NaN.
+__device__ __forceinline__ float relu_i(float x) {
+  const int i = __float_as_int(x);
+  return __int_as_float(i > 0 ? i : 0);
+}
 template <int NB>
 __device__ __forceinline__ void relu_pass(f32x16 (&acc)[NB]) {
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[nb][r] = fmaxf(acc[nb][r], 0.f);
+    for (int r = 0; r < 16; ++r) acc[nb][r] = relu_i(acc[nb][r]);
+}
+// fp32 forward: a finished layer's accumulator set -> its (ReLU'd) values as 128 VGPRs = the next layer's B operands, in ONE
+// fenced VALU pass.  Measured per stage with s_memtime (tools/exp/stage_timing.py): when the compiler is left to apply the
+// ReLU where the values are consumed (it did so for every second hidden layer: v_accvgpr_read + 2 v_max per operand in
+// front of its k-group) each of those instructions costs ~14 clocks inside the MFMA stream, against 4-8 in a block.
+template <int NB, bool RELU>
+__device__ __forceinline__ void take(float (&hb)[128], const f32x16 (&acc)[NB]) {
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hb[16 * nb + r] = RELU ? relu_i(acc[nb][r]) : acc[nb][r];
+  // pin the pass here: the empty asm defines each value at this point (MachineSink would otherwise move every v_max into
+  // the stage block that consumes it -- each stage is a basic block of its own), the fence keeps the scheduler from mixing
+  // the pass with the next layer's first MFMAs
+#pragma unroll
+  for (int i = 0; i < 16 * NB; ++i) asm volatile("" : "+v"(hb[i]));
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int NB>
+__device__ __forceinline__ float head_dot_v(const float (&hb)[128], const float* wrow_h) {
+  float s = 0.f;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(wrow_h + 32 * nb + 8 * q);
+      s = fmaf(hb[16 * nb + 4 * q + 0], w.x, s);
+      s = fmaf(hb[16 * nb + 4 * q + 1], w.y, s);
+      s = fmaf(hb[16 * nb + 4 * q + 2], w.z, s);
+      s = fmaf(hb[16 * nb + 4 * q + 3], w.w, s);
+    }
+  return s + __shfl_xor(s, 32);
 }
 
 // dot of the lane's 16*NB activation values with a natural-order weight row (LDS), summed over both halves
@@ -248,6 +299,22 @@ __device__ __forceinline__ void hidden_part(PIPE& pipe, f32x16 (&acc)[NB], const
     }
     kgroup<NB>(pipe, acc, KG0 + kg, first && kg == 0, last && kg == 31, prev[kg >> 2][4 * (kg & 3) + 0],
                prev[kg >> 2][4 * (kg & 3) + 1], prev[kg >> 2][4 * (kg & 3) + 2], prev[kg >> 2][4 * (kg & 3) + 3]);
+  }
+}
+
+// the same with the previous layer's outputs held as 128 VGPRs (take<>): prev[4 kg .. 4 kg + 3] are k-group kg's operands
+template <int NB, int KG0, bool SAVE = false, class PIPE>
+__device__ __forceinline__ void hidden_part_v(PIPE& pipe, f32x16 (&acc)[NB], const float (&prev)[128], bool first,
+                                              bool last, float* __restrict__ save_row_h = nullptr) {
+#pragma unroll
+  for (int kg = 0; kg < 32; ++kg) {
+    if constexpr (SAVE) {
+      const f32x4 o = {prev[4 * kg + 0], prev[4 * kg + 1], prev[4 * kg + 2], prev[4 * kg + 3]};
+      save_quad(save_row_h + SAVE_QUAD_STRIDE * kg, o);
+      __builtin_amdgcn_sched_barrier(0);   // in front of this k-group's MFMAs (the scheduler would sink it behind them)
+    }
+    kgroup<NB>(pipe, acc, KG0 + kg, first && kg == 0, last && kg == 31, prev[4 * kg + 0], prev[4 * kg + 1],
+               prev[4 * kg + 2], prev[4 * kg + 3]);
   }
 }
 

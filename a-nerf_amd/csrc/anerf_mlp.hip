@@ -29,7 +29,7 @@
 #include "anerf_fwd_common.h"
 
 namespace anerf {
-#ifdef ANERF_EXP_TILE_TIMING
+#if defined(ANERF_EXP_TILE_TIMING) || defined(ANERF_EXP_STAGE_TIMING)
 float* g_tile_timing_buf = nullptr;   // set through anerf_debug_set_timing_buf (debug build only)
 #endif
 
@@ -84,28 +84,39 @@ __device__ __forceinline__ void x_part(Pipe3F& pipe, f32x16 (&acc)[8], const flo
     for (int g = 0; g < 3; ++g)
       KG(g, v[4 * g] * wv[4 * g], v[4 * g + 1] * wv[4 * g + 1], v[4 * g + 2] * wv[4 * g + 2],
          v[4 * g + 3] * wv[4 * g + 3]);
-    // bands f = 0..LV-1 of sin/cos(2^f v): precise evaluation every 3rd band, double-angle steps in between
-    // (sin 2x = 2 s c, cos 2x = 1 - 2 s^2): error grows <= 4x over two steps (~4e-7), 3 VALU instead of ~25.
-    float sb[12], cb[12];
+    // bands f = 0..LV-1 of the gated sin/cos(2^f v): precise evaluation every 4th band, double-angle steps in between on the
+    // pair (gs, c) = (w sin a, cos a):  w sin 2a = gs * 2c,  cos 2a = 2c * c - 1  -- the gate rides along in gs, so a step is 3
+    // operations + 1 for the gated cosine, and values are processed in pairs (v_pk_add / v_pk_mul / v_pk_fma_f32: packed fp32
+    // runs at twice the scalar VALU rate, and every VALU instruction issued into the fp32 MFMA stream is lost MFMA time).
+    // Angle error doubles per step: <= 8 x (1 ulp + 6e-8) ~ 1.3e-6 after three steps.
+    f32x2 gs[6], cc[6], w2[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) w2[i] = f32x2{wv[2 * i], wv[2 * i + 1]};
 #pragma unroll
     for (int f = 0; f < LV; ++f) {
-      float sv[12], cv[12];
+      if (f % 4 == 0) {
 #pragma unroll
-      for (int a = 0; a < 12; ++a) {
-        if (f % 3 == 0) {
-          sincos_f32(v[a] * (float)(1 << f), sb[a], cb[a]);
-        } else {
-          const float s_old = sb[a], c_old = cb[a];
-          sb[a] = 2.f * s_old * c_old;
-          cb[a] = fmaf(-2.f * s_old, s_old, 1.f);
+        for (int a = 0; a < 12; ++a) {
+          float s, c;
+          sincos_f32(v[a] * (float)(1 << f), s, c);
+          gs[a >> 1][a & 1] = s * wv[a];
+          cc[a >> 1][a & 1] = c;
         }
-        sv[a] = sb[a] * wv[a];
-        cv[a] = cb[a] * wv[a];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const f32x2 t = cc[i] + cc[i];
+          gs[i] = gs[i] * t;
+          cc[i] = t * cc[i] - 1.0f;
+        }
       }
 #pragma unroll
-      for (int g = 0; g < 3; ++g) KG(3 + 6 * f + g, sv[4 * g], sv[4 * g + 1], sv[4 * g + 2], sv[4 * g + 3]);
+      for (int g = 0; g < 3; ++g) KG(3 + 6 * f + g, gs[2 * g][0], gs[2 * g][1], gs[2 * g + 1][0], gs[2 * g + 1][1]);
+      f32x2 gc[6];
 #pragma unroll
-      for (int g = 0; g < 3; ++g) KG(6 + 6 * f + g, cv[4 * g], cv[4 * g + 1], cv[4 * g + 2], cv[4 * g + 3]);
+      for (int i = 0; i < 6; ++i) gc[i] = cc[i] * w2[i];
+#pragma unroll
+      for (int g = 0; g < 3; ++g) KG(6 + 6 * f + g, gc[2 * g][0], gc[2 * g][1], gc[2 * g + 1][0], gc[2 * g + 1][1]);
     }
 #pragma unroll
     for (int g = 0; g < 9; ++g)
@@ -128,6 +139,10 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
 #endif
   Pipe3F pipe;
   pipe.init(A.packed, smem, wave, lane, A.nstages);
+#ifdef ANERF_EXP_STAGE_TIMING   // every 997th tile: [tile][wave][stage][3] clocks in A.save_u
+  if (A.save_u && blockIdx.x % 997 == 0 && lane == 0)
+    pipe.tbuf = reinterpret_cast<unsigned long long*>(A.save_u) + ((long long)(blockIdx.x / 997) * 4 + wave) * 3 * 128;
+#endif
 
   const long long p = (long long)blockIdx.x * TILE + wave * 32 + m;
   const bool valid = p < A.P;
@@ -199,7 +214,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
       const float y1 = r1.x * x0 + r1.y * x1 + r1.z * x2 + r1.w;
       const float y2 = r2.x * x0 + r2.y * x1 + r2.z * x2 + r2.w;
       const float n = sqrtf(y0 * y0 + y1 * y1 + y2 * y2);
-      const float inv = 1.0f / fmaxf(n, 1e-12f);
+      const float inv = rcp_nr(fmaxf(n, 1e-12f));
       v[a] = n;
       rh[3 * a + 0] = y0 * inv;
       rh[3 * a + 1] = y1 * inv;
@@ -212,57 +227,59 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
   constexpr int DIMD = 72 * (1 + 2 * LD);
   constexpr int UW = DIMD + CODE;
   constexpr int KGX = DIMX / 8;
-  f32x16 accA[8], accB[8];   // ping-pong accumulator sets (pre-bias sums)
+  f32x16 accA[8], accB[8];   // ping-pong accumulator sets (AGPRs): bias + sums of the layer being computed / of the previous one
+  float hb[128];             // the previous layer's outputs, ReLU applied = this layer's B operands (VGPRs, take<>)
 
   // ---- layer 0: x(432) -> A
-  // TRAIN: h_l is saved by the layer that CONSUMES it (hidden_part<.., true>: one quad per k-group)
+  // TRAIN: h_l is saved by the layer that CONSUMES it (hidden_part_v<.., true>: one quad per k-group)
   float* hsave = TRAIN ? A.save_h + ps * 256 + 4 * h : nullptr;      // this lane's quads in plane 0; plane l at + l * plane
   const long long plane = TRAIN ? A.Ppad * 256 : 0;
   init_bias<8>(accA, aux_h + AUX_B0);
   x_part<LV, PRE, TRAIN>(pipe, accA, v, wv, rh, xrow, h, TRAIN ? A.save_x + ps * DIMX : nullptr, true);
-  relu_pass<8>(accA);
   // ---- layers 1..4: A -> B -> A -> B -> A
 #pragma unroll 1
   for (int L = 1; L <= 3; L += 2) {
+    take<8, true>(hb, accA);
     init_bias<8>(accB, aux_h + AUX_B0 + 256 * L);
-    hidden_part<8, 0, TRAIN>(pipe, accB, accA, true, true, hsave + (L - 1) * plane);
-    relu_pass<8>(accB);
+    hidden_part_v<8, 0, TRAIN>(pipe, accB, hb, true, true, hsave + (L - 1) * plane);
+    take<8, true>(hb, accB);
     init_bias<8>(accA, aux_h + AUX_B0 + 256 * (L + 1));
-    hidden_part<8, 0, TRAIN>(pipe, accA, accB, true, true, hsave + L * plane);
-    relu_pass<8>(accA);
+    hidden_part_v<8, 0, TRAIN>(pipe, accA, hb, true, true, hsave + L * plane);
   }
-  // ---- layer 5: [x(432); h4(256)] -> B   (skip connection: x is re-encoded, never stored).  The asm makes v/wv
-  // opaque so the compiler re-derives the sin/cos products here instead of keeping 168 of them live (spilled to
-  // scratch) since layer 0.
+  // ---- layer 5: [x(432); h4(256)] -> B   (skip connection: x is re-encoded, never stored; h4 waits in its accumulator
+  // set and is taken when the x part is done).  The asm makes v/wv opaque so the compiler re-derives the sin/cos products
+  // here instead of keeping 168 of them live (spilled to scratch) since layer 0.
   if constexpr (!PRE) {
 #pragma unroll
     for (int a = 0; a < 12; ++a) asm volatile("" : "+v"(v[a]), "+v"(wv[a]));
   }
   init_bias<8>(accB, aux_h + AUX_B0 + 256 * 5);
   x_part<LV, PRE, false>(pipe, accB, v, wv, rh, xrow, h, nullptr, false);
-  hidden_part<8, KGX, TRAIN>(pipe, accB, accA, false, true, hsave + 4 * plane);
-  relu_pass<8>(accB);
+  take<8, true>(hb, accA);
+  hidden_part_v<8, KGX, TRAIN>(pipe, accB, hb, false, true, hsave + 4 * plane);
   // ---- layers 6, 7: B -> A -> B
+  take<8, true>(hb, accB);
   init_bias<8>(accA, aux_h + AUX_B0 + 256 * 6);
-  hidden_part<8, 0, TRAIN>(pipe, accA, accB, true, true, hsave + 5 * plane);
-  relu_pass<8>(accA);
+  hidden_part_v<8, 0, TRAIN>(pipe, accA, hb, true, true, hsave + 5 * plane);
+  take<8, true>(hb, accA);
   init_bias<8>(accB, aux_h + AUX_B0 + 256 * 7);
-  hidden_part<8, 0, TRAIN>(pipe, accB, accA, true, true, hsave + 6 * plane);
-  relu_pass<8>(accB);
+  hidden_part_v<8, 0, TRAIN>(pipe, accB, hb, true, true, hsave + 6 * plane);
+  take<8, true>(hb, accB);
   // ---- density head (VALU): sigma_raw = w_alpha . h7 + b_alpha
-  const float sigma_raw = head_dot<8>(accB, aux_h + AUX_WA) + aux_l[AUX_BA];
+  const float sigma_raw = head_dot_v<8>(hb, aux_h + AUX_WA) + aux_l[AUX_BA];
   if constexpr (MODE == 1) {
     if (valid && h == 0) A.raw[p] = sigma_raw;
     return;
   }
   // ---- feature layer (no activation on its output): B -> A
   init_bias<8>(accA, aux_h + AUX_BF);
-  hidden_part<8, 0, TRAIN>(pipe, accA, accB, true, true, hsave + 7 * plane);
+  hidden_part_v<8, 0, TRAIN>(pipe, accA, hb, true, true, hsave + 7 * plane);
+  take<8, false>(hb, accA);
   // ---- view layer: [feature(256); D(72*(1+2LD)); code(CODE)] -> 128 units
   f32x16 accv[4];
   constexpr int NKGU = UW / 8;
   init_bias<4>(accv, aux_h + AUX_BV);
-  hidden_part<4, 0, TRAIN>(pipe, accv, accA, true, false, TRAIN ? A.save_f + ps * 256 + 4 * h : nullptr);
+  hidden_part_v<4, 0, TRAIN>(pipe, accv, hb, true, false, TRAIN ? A.save_f + ps * 256 + 4 * h : nullptr);
   float* usave = TRAIN ? A.save_u + ps * UW + 4 * h : nullptr;
   auto KGV = [&](int kgu, float b0, float b1, float b2, float b3) __attribute__((always_inline)) {
     if constexpr (TRAIN) {
@@ -307,43 +324,55 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
       const float y0 = r0.x * dray[0] + r0.y * dray[1] + r0.z * dray[2];
       const float y1 = r1.x * dray[0] + r1.y * dray[1] + r1.z * dray[2];
       const float y2 = r2.x * dray[0] + r2.y * dray[1] + r2.z * dray[2];
-      const float inv = 1.0f / fmaxf(sqrtf(y0 * y0 + y1 * y1 + y2 * y2), 1e-12f);
+      const float inv = rcp_nr(fmaxf(sqrtf(y0 * y0 + y1 * y1 + y2 * y2), 1e-12f));
       e[3 * a + 0] = y0 * inv;
       e[3 * a + 1] = y1 * inv;
       e[3 * a + 2] = y2 * inv;
       wd[a] = cutoff_gate(A.tau_d, v[a], A.cut_d[j]);
     }
+    f32x2 wd2[18];   // the gate of every direction component, in operand pairs
 #pragma unroll
-    for (int g = 0; g < 9; ++g)
-      KGV(g, e[4 * g] * wd[(4 * g) / 3], e[4 * g + 1] * wd[(4 * g + 1) / 3], e[4 * g + 2] * wd[(4 * g + 2) / 3],
-          e[4 * g + 3] * wd[(4 * g + 3) / 3]);
-    // running sin/cos(2^f e): precise every 3rd band, double-angle steps in between.  A band's values are advanced four at
-    // a time inside the k-group that consumes their sines (the cosines wait in cbe for the band's second half): only the
-    // 72 running values are live, not a second set of 72 gated operands.
-    float sbe[36], cbe[36];
+    for (int i = 0; i < 18; ++i) wd2[i] = f32x2{wd[(2 * i) / 3], wd[(2 * i + 1) / 3]};
+#pragma unroll
+    for (int g = 0; g < 9; ++g) {
+      const f32x2 o0 = f32x2{e[4 * g], e[4 * g + 1]} * wd2[2 * g], o1 = f32x2{e[4 * g + 2], e[4 * g + 3]} * wd2[2 * g + 1];
+      KGV(g, o0[0], o0[1], o1[0], o1[1]);
+    }
+    // gated sin / cos(2^f e) as in x_part: (gs, c) pairs, precise at f = 0 (|e| <= 1: no range reduction), packed
+    // double-angle steps after that.  A band's pairs are advanced inside the k-group that consumes their sines (the cosines
+    // wait in cc for the band's second half): only the running values are live.
+    f32x2 gse[18], cce[18];
 #pragma unroll
     for (int f = 0; f < LD; ++f) {
 #pragma unroll
       for (int g = 0; g < 9; ++g) {
-        float o[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int i = 4 * g + t;
-          if (f % 3 == 0) {
-            sincos_f32(e[i] * (float)(1 << f), sbe[i], cbe[i]);
+        for (int t = 0; t < 2; ++t) {
+          const int i = 2 * g + t;
+          if (f % 4 == 0) {
+            float s0, c0, s1, c1;
+            if (f == 0) {
+              sincos_unit_f32(e[2 * i], s0, c0);
+              sincos_unit_f32(e[2 * i + 1], s1, c1);
+            } else {
+              sincos_f32(e[2 * i] * (float)(1 << f), s0, c0);
+              sincos_f32(e[2 * i + 1] * (float)(1 << f), s1, c1);
+            }
+            gse[i] = f32x2{s0, s1} * wd2[i];
+            cce[i] = f32x2{c0, c1};
           } else {
-            const float s_old = sbe[i], c_old = cbe[i];
-            sbe[i] = 2.f * s_old * c_old;
-            cbe[i] = fmaf(-2.f * s_old, s_old, 1.f);
+            const f32x2 tt = cce[i] + cce[i];
+            gse[i] = gse[i] * tt;
+            cce[i] = tt * cce[i] - 1.0f;
           }
-          o[t] = sbe[i] * wd[i / 3];
         }
-        KGV(9 * (1 + 2 * f) + g, o[0], o[1], o[2], o[3]);
+        KGV(9 * (1 + 2 * f) + g, gse[2 * g][0], gse[2 * g][1], gse[2 * g + 1][0], gse[2 * g + 1][1]);
       }
 #pragma unroll
-      for (int g = 0; g < 9; ++g)
-        KGV(9 * (2 + 2 * f) + g, cbe[4 * g] * wd[(4 * g) / 3], cbe[4 * g + 1] * wd[(4 * g + 1) / 3],
-            cbe[4 * g + 2] * wd[(4 * g + 2) / 3], cbe[4 * g + 3] * wd[(4 * g + 3) / 3]);
+      for (int g = 0; g < 9; ++g) {
+        const f32x2 o0 = cce[2 * g] * wd2[2 * g], o1 = cce[2 * g + 1] * wd2[2 * g + 1];
+        KGV(9 * (2 + 2 * f) + g, o0[0], o0[1], o1[0], o1[1]);
+      }
     }
   }
   if constexpr (CODE > 0) {
@@ -446,7 +475,7 @@ int mlp_raw_entry(const AnerfConfig* cfg, const float* packed, const float* aux,
   a.S = S; a.N = N; a.ray_stride = ray_stride; a.n_codes = n_codes; a.x_width = x_width; a.nstages = nstages;
   a.tau_v = tau_v; a.tau_d = tau_d;
   a.save_h = a.save_f = a.save_g = a.save_x = a.save_u = nullptr;
-#ifdef ANERF_EXP_TILE_TIMING
+#if defined(ANERF_EXP_TILE_TIMING) || defined(ANERF_EXP_STAGE_TIMING)
   a.save_u = g_tile_timing_buf;
 #endif
   a.Ppad = P;
@@ -458,6 +487,6 @@ int mlp_raw_entry(const AnerfConfig* cfg, const float* packed, const float* aux,
 
 }  // namespace anerf
 
-#ifdef ANERF_EXP_TILE_TIMING
+#if defined(ANERF_EXP_TILE_TIMING) || defined(ANERF_EXP_STAGE_TIMING)
 extern "C" void anerf_debug_set_timing_buf(float* p) { anerf::g_tile_timing_buf = p; }
 #endif

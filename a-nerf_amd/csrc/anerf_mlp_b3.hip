@@ -168,21 +168,25 @@ __device__ __forceinline__ void x_part_b3(Pipe3& pipe, f32x16 (&acc)[8], const f
                                           const float (&rh)[36], bool last, float* __restrict__ xsave = nullptr) {
   static_assert(LV == 7, "band pairing below is written for multires = 7");
   constexpr int KS_LAST = 26;
-  float sb[12], cb[12];
+  // (gs, c) = (w sin a, cos a): precise every 4th band, double-angle steps in between -- the same arithmetic as the fp32
+  // kernel's x_part (anerf_mlp.hip), so both kernels feed identical values to the network
+  float gs[12], cb[12];
 #pragma unroll
   for (int p = 0; p < LV; ++p) {
     float val[24];
 #pragma unroll
     for (int a = 0; a < 12; ++a) {
       val[a] = (p == 0 ? v[a] : cb[a]) * wv[a];             // band 2p: raw (p = 0) or cos_{p-1}
-      if (p % 3 == 0) {
-        sincos_f32(v[a] * (float)(1 << p), sb[a], cb[a]);   // precise every third band
+      if (p % 4 == 0) {
+        float s;
+        sincos_f32(v[a] * (float)(1 << p), s, cb[a]);
+        gs[a] = s * wv[a];
       } else {
-        const float s_old = sb[a], c_old = cb[a];
-        sb[a] = 2.f * s_old * c_old;
-        cb[a] = fmaf(-2.f * s_old, s_old, 1.f);
+        const float t = cb[a] + cb[a];
+        gs[a] = gs[a] * t;
+        cb[a] = fmaf(t, cb[a], -1.0f);
       }
-      val[12 + a] = sb[a] * wv[a];                           // band 2p+1: sin_p
+      val[12 + a] = gs[a];                                   // band 2p+1: sin_p
     }
     emit<8, 24, SAVE, PIPE>(pipe, acc, 3 * p, last ? KS_LAST : -1, val, xsave);
   }
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
       const float y1 = r1.x * x0 + r1.y * x1 + r1.z * x2 + r1.w;
       const float y2 = r2.x * x0 + r2.y * x1 + r2.z * x2 + r2.w;
       const float n = sqrtf(y0 * y0 + y1 * y1 + y2 * y2);
-      const float inv = 1.0f / fmaxf(n, 1e-12f);
+      const float inv = rcp_nr(fmaxf(n, 1e-12f));
       v[a] = n;
       rh[3 * a + 0] = y0 * inv;
       rh[3 * a + 1] = y1 * inv;
@@ -361,27 +365,30 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
     const float y0 = r0.x * dray[0] + r0.y * dray[1] + r0.z * dray[2];
     const float y1 = r1.x * dray[0] + r1.y * dray[1] + r1.z * dray[2];
     const float y2 = r2.x * dray[0] + r2.y * dray[1] + r2.z * dray[2];
-    const float inv = 1.0f / fmaxf(sqrtf(y0 * y0 + y1 * y1 + y2 * y2), 1e-12f);
+    const float inv = rcp_nr(fmaxf(sqrtf(y0 * y0 + y1 * y1 + y2 * y2), 1e-12f));
     e[3 * a + 0] = y0 * inv;
     e[3 * a + 1] = y1 * inv;
     e[3 * a + 2] = y2 * inv;
     wd[a] = cutoff_gate(A.tau_d, vn, A.cut_d[j]);
   }
-  float sbe[36], cbe[36];
+  float gse[36], cbe[36];
 #pragma unroll
   for (int pq = 0; pq < LD; ++pq) {       // band pairs (2pq, 2pq+1) = (raw | cos_{pq-1}, sin_pq): 72 values = 9 k-steps
     float val[72];
 #pragma unroll
     for (int i = 0; i < 36; ++i) {
       val[i] = (pq == 0 ? e[i] : cbe[i]) * wd[i / 3];
-      if (pq % 3 == 0) {
-        sincos_f32(e[i] * (float)(1 << pq), sbe[i], cbe[i]);
+      if (pq % 4 == 0) {
+        float s;
+        if (pq == 0) sincos_unit_f32(e[i], s, cbe[i]);
+        else sincos_f32(e[i] * (float)(1 << pq), s, cbe[i]);
+        gse[i] = s * wd[i / 3];
       } else {
-        const float s_old = sbe[i], c_old = cbe[i];
-        sbe[i] = 2.f * s_old * c_old;
-        cbe[i] = fmaf(-2.f * s_old, s_old, 1.f);
+        const float t = cbe[i] + cbe[i];
+        gse[i] = gse[i] * t;
+        cbe[i] = fmaf(t, cbe[i], -1.0f);
       }
-      val[36 + i] = sbe[i] * wd[i / 3];
+      val[36 + i] = gse[i];
     }
     emit<4, 72, XS, PP>(pipe, accv, 16 + 9 * pq, KSV_LAST, val, usave, 16, NU);
   }
