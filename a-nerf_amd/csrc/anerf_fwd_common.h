@@ -342,6 +342,9 @@ struct MlpArgs {
   long long skt_stride;
   int S, N, ray_stride, n_codes, x_width, nstages;
   float tau_v, tau_d;
+#ifdef ANERF_EXP_STAGE_TIMING
+  unsigned long long* tbuf;   // debug build only: per-stage clocks (tools/exp/stage_timing.py)
+#endif
 };
 
 }  // namespace anerf

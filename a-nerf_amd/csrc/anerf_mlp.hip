@@ -139,9 +139,12 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
 #endif
   Pipe3F pipe;
   pipe.init(A.packed, smem, wave, lane, A.nstages);
+#ifdef ANERF_EXP_STAGE_TIMING
+  const unsigned long long tt0 = __builtin_amdgcn_s_memtime(), tr0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #ifdef ANERF_EXP_STAGE_TIMING   // every 997th tile: [tile][wave][stage][3] clocks in A.save_u
-  if (A.save_u && blockIdx.x % 997 == 0 && lane == 0)
-    pipe.tbuf = reinterpret_cast<unsigned long long*>(A.save_u) + ((long long)(blockIdx.x / 997) * 4 + wave) * 3 * 128;
+  if (A.tbuf && blockIdx.x % 997 == 0 && lane == 0)
+    pipe.tbuf = A.tbuf + ((long long)(blockIdx.x / 997) * 4 + wave) * 3 * 128;
 #endif
 
   const long long p = (long long)blockIdx.x * TILE + wave * 32 + m;
@@ -239,11 +242,11 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
   // ---- layers 1..4: A -> B -> A -> B -> A
 #pragma unroll 1
   for (int L = 1; L <= 3; L += 2) {
+    init_bias<8>(accB, aux_h + AUX_B0 + 256 * L);   // (LDS reads in flight under the VALU pass)
     take<8, true>(hb, accA);
-    init_bias<8>(accB, aux_h + AUX_B0 + 256 * L);
     hidden_part_v<8, 0, TRAIN>(pipe, accB, hb, true, true, hsave + (L - 1) * plane);
-    take<8, true>(hb, accB);
     init_bias<8>(accA, aux_h + AUX_B0 + 256 * (L + 1));
+    take<8, true>(hb, accB);
     hidden_part_v<8, 0, TRAIN>(pipe, accA, hb, true, true, hsave + L * plane);
   }
   // ---- layer 5: [x(432); h4(256)] -> B   (skip connection: x is re-encoded, never stored; h4 waits in its accumulator
@@ -258,11 +261,11 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
   take<8, true>(hb, accA);
   hidden_part_v<8, KGX, TRAIN>(pipe, accB, hb, false, true, hsave + 4 * plane);
   // ---- layers 6, 7: B -> A -> B
-  take<8, true>(hb, accB);
   init_bias<8>(accA, aux_h + AUX_B0 + 256 * 6);
+  take<8, true>(hb, accB);
   hidden_part_v<8, 0, TRAIN>(pipe, accA, hb, true, true, hsave + 5 * plane);
-  take<8, true>(hb, accA);
   init_bias<8>(accB, aux_h + AUX_B0 + 256 * 7);
+  take<8, true>(hb, accA);
   hidden_part_v<8, 0, TRAIN>(pipe, accB, hb, true, true, hsave + 6 * plane);
   take<8, true>(hb, accB);
   // ---- density head (VALU): sigma_raw = w_alpha . h7 + b_alpha
@@ -409,6 +412,13 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
       *reinterpret_cast<f32x4*>(A.raw + pe * 4) = o;
     }
   }
+#ifdef ANERF_EXP_STAGE_TIMING   // every tile: start / end clocks + where it ran, behind the stage records ([64][4][128][3])
+  if (tid == 0 && A.tbuf) {
+    unsigned long long* t = A.tbuf + 64 * 4 * 128 * 3 + 6 * (long long)blockIdx.x;
+    t[0] = tt0; t[1] = __builtin_amdgcn_s_memtime(); t[2] = tr0; t[3] = __builtin_amdgcn_s_memrealtime();
+    t[4] = __builtin_amdgcn_s_getreg(63492); t[5] = __builtin_amdgcn_s_getreg(63508);
+  }
+#endif
 #ifdef ANERF_EXP_TILE_TIMING
   if (tid == 0 && A.save_u) {
     unsigned long long* t = reinterpret_cast<unsigned long long*>(A.save_u) + 2 * (long long)blockIdx.x;
@@ -475,8 +485,11 @@ int mlp_raw_entry(const AnerfConfig* cfg, const float* packed, const float* aux,
   a.S = S; a.N = N; a.ray_stride = ray_stride; a.n_codes = n_codes; a.x_width = x_width; a.nstages = nstages;
   a.tau_v = tau_v; a.tau_d = tau_d;
   a.save_h = a.save_f = a.save_g = a.save_x = a.save_u = nullptr;
-#if defined(ANERF_EXP_TILE_TIMING) || defined(ANERF_EXP_STAGE_TIMING)
+#if defined(ANERF_EXP_TILE_TIMING)
   a.save_u = g_tile_timing_buf;
+#endif
+#if defined(ANERF_EXP_STAGE_TIMING)
+  a.tbuf = reinterpret_cast<unsigned long long*>(g_tile_timing_buf);
 #endif
   a.Ppad = P;
   if (sv) {

@@ -121,6 +121,11 @@ __device__ __forceinline__ void bwd_layer(Pipe3F& pipe, f32x16 (&out)[8], const 
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
     form_operands<MASK>(bq, prev[s], mk);
+    // pin the operands in front of the re-issue: their VALU is free to move, and when hipcc scheduled it behind the (hidden)
+    // LDS-DMA issue its counted vmcnt waits for the mask quads also waited for DMA pieces issued a moment before -- every
+    // second stage of the trunk took 12 500 clocks instead of 9 600 (tools/exp/stage_timing_bwd.py)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(bq[i]));
     if (pending) pipe.stage_refill();
     pending = false;
     if (s < 7) {
@@ -149,6 +154,10 @@ __device__ __forceinline__ void bwd_layer(Pipe3F& pipe, f32x16 (&out)[8], const 
   }
 }
 
+#ifdef ANERF_EXP_STAGE_TIMING   // debug build only (tools/exp/stage_timing_bwd.py)
+__device__ unsigned long long* g_bwd_tbuf = nullptr;
+#endif
+
 __global__ __launch_bounds__(256) void k_mlp_bwd(const BwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -157,6 +166,11 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(const BwdArgs A) {
   const int m = lane & 31, h = lane >> 5;
   Pipe3F pipe;
   pipe.init(A.packed_t, smem, wave, lane, A.nstages);
+#ifdef ANERF_EXP_STAGE_TIMING
+  const unsigned long long tt0 = __builtin_amdgcn_s_memtime(), tr0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long* const tb = g_bwd_tbuf;
+  if (tb && blockIdx.x % 97 == 0 && lane == 0) pipe.tbuf = tb + ((long long)(blockIdx.x / 97) * 4 + wave) * 3 * 128;
+#endif
   const long long p = (long long)blockIdx.x * TILE + wave * 32 + m;
   // every lane stores unconditionally to the clamped row pc: tail lanes (p >= P) recompute the last valid sample and rewrite
   // its rows with identical values -- no exec-mask changes inside the MFMA stream
@@ -228,6 +242,13 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(const BwdArgs A) {
   // dz0 = dh0 * [h0 > 0]: no consumer in this kernel; the mask row was collected during the last layer
   mask_pass<8>(accA, mk0);
   store_acc<8>(zrow, accA);
+#ifdef ANERF_EXP_STAGE_TIMING
+  if (tid == 0 && tb) {
+    unsigned long long* t = tb + 64 * 4 * 128 * 3 + 6 * (long long)blockIdx.x;
+    t[0] = tt0; t[1] = __builtin_amdgcn_s_memtime(); t[2] = tr0; t[3] = __builtin_amdgcn_s_memrealtime();
+    t[4] = __builtin_amdgcn_s_getreg(63492); t[5] = __builtin_amdgcn_s_getreg(63508);
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -330,3 +351,9 @@ int mlp_bwd_entry(const float* packed_t, const float* aux, const float* draw, co
 }
 
 }  // namespace anerf
+
+#ifdef ANERF_EXP_STAGE_TIMING
+extern "C" void anerf_debug_set_bwd_timing_buf(unsigned long long* p) {
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(anerf::g_bwd_tbuf), &p, sizeof(p));
+}
+#endif
