@@ -147,6 +147,10 @@ __device__ __forceinline__ void gemm_store(const GemmWave& W, float* __restrict_
   }
 }
 
+#ifdef ANERF_EXP_STAGE_TIMING   // debug build only (tools/exp/stage_timing_gemm.py)
+__device__ unsigned long long* g_gemm_tbuf = nullptr;
+#endif
+
 template <bool SKINNY>
 __device__ __forceinline__ void gemm_body(const GemmPlan& G, const GemmBlock& B, char* smem, float* __restrict__ ws,
                                           long long r0, int nst, int chunk, int wave, int lane) {
@@ -183,10 +187,23 @@ __device__ __forceinline__ void gemm_body(const GemmPlan& G, const GemmBlock& B,
   // The loop body below is straight-line code on purpose (the column sums are accumulated by every wave and only
   // stored by the ones that own a bias): any branch that touches it makes the compiler shuttle the 256 accumulators
   // between AGPRs and VGPRs at the merge points.
+#ifdef ANERF_EXP_STAGE_TIMING
+  unsigned long long* tb = g_gemm_tbuf;
+  if (tb && !SKINNY && blockIdx.x % 16 == 0 && lane == 0) tb += ((long long)(blockIdx.x / 16) * 4 + wave) * 3 * 128; else tb = nullptr;
+#endif
   for (int t = 0; t < nst; ++t) {
+#ifdef ANERF_EXP_STAGE_TIMING
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    __syncthreads();
+    const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+    if (tb && t < 128) { tb[3 * t] = t0; tb[3 * t + 1] = t1; tb[3 * t + 2] = t2; }
+#else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifndef ANERF_EXP_GEMM_NOBARRIER   // ablation build only: results are wrong
     __syncthreads();                                   // stage t landed; everyone is done with stage t-1's slot
+#endif
 #endif
     if (t + 1 < nst) issue(t + 1, (t + 1) & 1);
     const char* base = smem + (t & 1) * GSTAGE_BYTES;
@@ -232,8 +249,18 @@ __device__ __forceinline__ void gemm_body(const GemmPlan& G, const GemmBlock& B,
 #pragma unroll
           for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][a], bv[s][c], acc[a][c], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        asum += av[s];
       }
+      // column sums (bias gradients) of the stage as ONE block of packed adds behind its MFMAs: 16 v_pk_add_f32 instead of
+      // 32 v_add_f32 sprinkled between the groups (a VALU instruction inside the fp32 MFMA stream costs ~14 clocks, in a
+      // block 4-8; stage 9350 -> clocks, tools/exp/stage_timing_gemm.py)
+      f32x2 s_lo = {asum[0], asum[1]}, s_hi = {asum[2], asum[3]};
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        s_lo += f32x2{av[s][0], av[s][1]};
+        s_hi += f32x2{av[s][2], av[s][3]};
+      }
+      asum = f32x4{s_lo[0], s_lo[1], s_hi[0], s_hi[1]};
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   gemm_store<SKINNY, NA>(W, ws, chunk, acc, asum, do_bias, i, kk);
@@ -425,3 +452,9 @@ int launch_weight_grads(const GemmPlan& P, const GemmBatch& G, float* ws, bool b
 }
 
 }  // namespace anerf
+
+#ifdef ANERF_EXP_STAGE_TIMING
+extern "C" void anerf_debug_set_gemm_timing_buf(unsigned long long* p) {
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(anerf::g_gemm_tbuf), &p, sizeof(p));
+}
+#endif

@@ -128,16 +128,13 @@ __device__ __forceinline__ void bwd_layer(Pipe3F& pipe, f32x16 (&out)[8], const 
     for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(bq[i]));
     if (pending) pipe.stage_refill();
     pending = false;
+    // the next block's mask quads: one load per k-group, next to its store (all four behind the barrier piled up with the
+    // four waves' 32 LDS-DMA pieces in the CU's vector-memory queue: 10 % of the kernel, ablation in DESIGN 4.2)
+    const float* nq = nullptr;
     if (s < 7) {
-      if constexpr (MASK) load_quads(mk, prev_mask_row_h + 32 * (s + 1));
+      if constexpr (MASK) nq = prev_mask_row_h + 32 * (s + 1);
     } else if (next_mask_row_h) {
-      load_quads(mk, next_mask_row_h);
-    }
-    if constexpr (LAST) {
-      f32x4 t[4];
-      load_quads(t, next_mask_row_h + 32 * s);          // LAST: next_mask_row_h = mask row of `out` (h0), all 8 blocks
-#pragma unroll
-      for (int q = 0; q < 4; ++q) mk0[4 * s + q] = t[q];
+      nq = next_mask_row_h;
     }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -146,7 +143,14 @@ __device__ __forceinline__ void bwd_layer(Pipe3F& pipe, f32x16 (&out)[8], const 
 #ifndef ANERF_EXP_BWD_NOSTORE   // ablation build only: results are not written
       *reinterpret_cast<f32x4*>(prev_dz_row_h + 8 * kg) = o;
 #endif
-      __builtin_amdgcn_sched_barrier(0);     // the store goes in front of the k-group's MFMAs
+#ifndef ANERF_EXP_BWD_NOMASK
+      if (nq) mk[ks] = *reinterpret_cast<const f32x4*>(nq + 8 * ks);
+      if constexpr (LAST) mk0[4 * s + ks] = *reinterpret_cast<const f32x4*>(next_mask_row_h + 32 * s + 8 * ks);   // mask row of `out` (h0)
+#else
+      mk[ks] = f32x4{1.f, 1.f, 1.f, 1.f};
+      if constexpr (LAST) mk0[4 * s + ks] = f32x4{1.f, 1.f, 1.f, 1.f};
+#endif
+      __builtin_amdgcn_sched_barrier(0);     // the store / load go in front of the k-group's MFMAs
       kgroup<8, Pipe3F, false>(pipe, out, KG0 + kg, false, false, o.x, o.y, o.z, o.w);
     }
     pipe.stage_rendezvous();
