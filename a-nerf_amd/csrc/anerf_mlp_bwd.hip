@@ -128,6 +128,7 @@ __device__ __forceinline__ void bwd_layer(Pipe3F& pipe, f32x16 (&out)[8], const 
     for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(bq[i]));
     if (pending) pipe.stage_refill();
     pending = false;
+    // (spreading the weight pipe's eight re-issue pieces over k-groups 0..2 as well was slower: tile 680k -> 693k clocks)
     // the next block's mask quads: one load per k-group, next to its store (all four behind the barrier piled up with the
     // four waves' 32 LDS-DMA pieces in the CU's vector-memory queue: 10 % of the kernel, ablation in DESIGN 4.2)
     const float* nq = nullptr;
