@@ -130,9 +130,22 @@ struct Pipe3T {
   }
   // end of the stage being consumed: its slot is refilled with stage+3
   __device__ __forceinline__ void end_stage() {
+    if constexpr (ASMDMA) {   // hidden-DMA pipes never drain the LDS queue at the stage barrier (see end_stage_raw)
+      end_stage_raw();
+      return;
+    }
+#ifdef ANERF_EXP_STAGE_TIMING
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of stages +1 / +2 has landed
+#ifdef ANERF_EXP_STAGE_TIMING
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
 #ifndef ANERF_EXP_NOBARRIER   // ablation build only: results are wrong without the barrier
     __syncthreads();                                    // everybody's has; nobody reads slot `slot` any more
+#endif
+#ifdef ANERF_EXP_STAGE_TIMING
+    if (tbuf) { tbuf[3 * stage] = t0; tbuf[3 * stage + 1] = t1; tbuf[3 * stage + 2] = __builtin_amdgcn_s_memtime(); }
 #endif
     if (stage + RING_SLOTS < nstages) issue(stage + RING_SLOTS, slot);
     slot = slot == RING_SLOTS - 1 ? 0 : slot + 1;
@@ -140,7 +153,17 @@ struct Pipe3T {
     set_offsets();
   }
 };
-using Pipe3 = Pipe3T<false>;    // split-bf16 kernels
+// split-bf16 kernels: builtin LDS-DMA + __syncthreads.  Their stage barrier costs ~420 clocks of a 2 440-clock stage
+// (s_memtime profile, tools/exp/stage_timing.py B3=1) because __syncthreads drains the LDS queue; with the hidden DMA and
+// the raw barrier of the fp32 kernels (ANERF_EXP_B3_HIDDEN_DMA) that wait disappears from the barrier (park 506 -> 91
+// clocks) and reappears in front of the MFMAs: the stage stays 2 440-2 460 clocks and the render kernel spills 15-21
+// VGPRs (431 -> 419 TFLOP/s algorithmic).  The kernel is bound by its fragment reads: 4 waves x 32 KiB per stage =
+// 52 B/clk of LDS read bandwidth; only more samples per fragment read would change that.
+#ifdef ANERF_EXP_B3_HIDDEN_DMA
+using Pipe3 = Pipe3T<true>;
+#else
+using Pipe3 = Pipe3T<false>;
+#endif
 using Pipe3F = Pipe3T<true>;    // fp32 forward / backward kernels
 
 // acc[nb][r] <- bias[n(nb,r,h)] from the LDS copy of the natural-order bias vector (bias_h = vector + 4h)

@@ -17,6 +17,9 @@
 #include "anerf_split.h"
 
 namespace anerf {
+#ifdef ANERF_EXP_STAGE_TIMING
+extern float* g_tile_timing_buf;   // anerf_mlp.hip (debug build only)
+#endif
 
 // Compiler-scheduled k-step (training forward and the backward kernels: with their extra live state -- saved-row
 // stores, 128 ReLU-mask values -- the two fragment buffers of the pipelined form below cost more in spills than they gain).
@@ -222,6 +225,10 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
 
   Pipe3 pipe;
   pipe.init(A.packed, smem, wave, lane, A.nstages);
+#ifdef ANERF_EXP_STAGE_TIMING
+  if (A.tbuf && blockIdx.x % 997 == 0 && lane == 0)
+    pipe.tbuf = A.tbuf + ((long long)(blockIdx.x / 997) * 4 + wave) * 3 * 128;
+#endif
 
   const long long p = (long long)blockIdx.x * TILE + wave * 32 + m;
   const bool valid = p < A.P;
@@ -445,6 +452,9 @@ int mlp_b3_entry(const AnerfConfig* cfg, const float* packed, const float* aux, 
   a.S = S; a.N = N; a.ray_stride = ray_stride; a.n_codes = n_codes; a.x_width = 0; a.nstages = nstages;
   a.tau_v = tau_v; a.tau_d = tau_d;
   a.save_h = a.save_f = a.save_g = a.save_x = a.save_u = nullptr;
+#ifdef ANERF_EXP_STAGE_TIMING
+  a.tbuf = reinterpret_cast<unsigned long long*>(g_tile_timing_buf);
+#endif
   if (sv) {
     a.save_h = sv->h; a.save_f = sv->f; a.save_g = sv->g; a.save_x = sv->x; a.save_u = sv->u; a.Ppad = sv->p_pad;
   }
