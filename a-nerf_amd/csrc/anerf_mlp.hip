@@ -155,9 +155,23 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
   const long long ps = pc;
 
   // ---- biases / head rows -> LDS (natural order), read back as float4 per k-group
+  // (LDS-DMA, 1 KiB per wave-instruction, complete at pipe.begin()'s vmcnt(0) like the first weight stages: the former
+  // load -> ds_write loop was three dependent round trips at the head of every tile; the last 2 float4 go the old way)
   float* aux_l = reinterpret_cast<float*>(smem + LDS_AUX_OFF);
-  for (int i = tid; i < AUX_FLOATS / 4; i += 256)
-    reinterpret_cast<f32x4*>(aux_l)[i] = reinterpret_cast<const f32x4*>(A.aux)[i];
+  {
+    constexpr int NPIECE = AUX_FLOATS / 256;   // whole 1 KiB pieces (12)
+    const char* ga = reinterpret_cast<const char*>(A.aux) + lane * 16;
+#pragma unroll
+    for (int k = 0; k < (NPIECE + 3) / 4; ++k) {
+      const int piece = 4 * k + wave;
+      if (piece < NPIECE) {   // hidden from hipcc like the weight pipe's DMA (a visible one would turn every LDS wait into lgkmcnt(0))
+        const unsigned lds0 = (unsigned)reinterpret_cast<size_t>((lds_ptr_t)(smem + LDS_AUX_OFF)) + piece * 1024;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds0), "v"(ga + piece * 1024) : "memory", "m0");
+      }
+    }
+    const int i = NPIECE * 64 + tid;
+    if (i < AUX_FLOATS / 4) reinterpret_cast<f32x4*>(aux_l)[i] = reinterpret_cast<const f32x4*>(A.aux)[i];
+  }
   const float* aux_h = aux_l + 4 * h;   // this lane half's float4 inside every 8-feature group
 
   float v[12], wv[12], rh[36];
