@@ -128,7 +128,10 @@ __device__ __forceinline__ void bwd_layer(Pipe3F& pipe, f32x16 (&out)[8], const 
     for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(bq[i]));
     if (pending) pipe.stage_refill();
     pending = false;
-    // (spreading the weight pipe's eight re-issue pieces over k-groups 0..2 as well was slower: tile 680k -> 693k clocks)
+    // (spreading the weight pipe's eight re-issue pieces over k-groups 0..2 as well was slower: tile 680k -> 693k clocks;
+    // bringing the mask rows in by coalesced LDS-DMA -- 8 whole rows per instruction, XOR-swizzled chunks, 2 x 4 KiB per wave,
+    // conflict-free read-back -- instead of these 32-row gathers is correct and exactly as fast: 688k, the wait moves to the
+    // stage barrier's vmcnt(0))
     // the next block's mask quads: one load per k-group, next to its store (all four behind the barrier piled up with the
     // four waves' 32 LDS-DMA pieces in the CU's vector-memory queue: 10 % of the kernel, ablation in DESIGN 4.2)
     const float* nq = nullptr;
