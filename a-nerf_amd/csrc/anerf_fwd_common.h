@@ -42,7 +42,7 @@ struct Pipe3T {
   int wave;           // wave index inside the workgroup (wave-uniform)
   f32x4 pref[8];      // split-bf16 kernels: fragments of the next stage's first k-group, loaded before the stage barrier
   f32x4 a[4];         // fp32 kernels: two-quarter window of weight fragments (see kgroup)
-#ifdef ANERF_EXP_STAGE_TIMING   // debug build only (tools/exp/stage_timing.py): per-wave arrive / leave clocks of every stage barrier
+#ifdef ANERF_EXP_STAGE_TIMING   // debug build only (tools/stage_timing.py): per-wave arrive / leave clocks of every stage barrier
   unsigned long long* tbuf = nullptr;
 #endif
 
@@ -154,7 +154,7 @@ struct Pipe3T {
   }
 };
 // split-bf16 kernels: builtin LDS-DMA + __syncthreads.  Their stage barrier costs ~420 clocks of a 2 440-clock stage
-// (s_memtime profile, tools/exp/stage_timing.py B3=1) because __syncthreads drains the LDS queue; with the hidden DMA and
+// (s_memtime profile, tools/stage_timing.py B3=1) because __syncthreads drains the LDS queue; with the hidden DMA and
 // the raw barrier of the fp32 kernels (ANERF_EXP_B3_HIDDEN_DMA) that wait disappears from the barrier (park 506 -> 91
 // clocks) and reappears in front of the MFMAs: the stage stays 2 440-2 460 clocks and the render kernel spills 15-21
 // VGPRs (431 -> 419 TFLOP/s algorithmic).  The kernel is bound by its fragment reads: 4 waves x 32 KiB per stage =
@@ -198,7 +198,7 @@ __device__ __forceinline__ void relu_pass(f32x16 (&acc)[NB]) {
     for (int r = 0; r < 16; ++r) acc[nb][r] = relu_i(acc[nb][r]);
 }
 // fp32 forward: a finished layer's accumulator set -> its (ReLU'd) values as 128 VGPRs = the next layer's B operands, in ONE
-// fenced VALU pass.  Measured per stage with s_memtime (tools/exp/stage_timing.py): when the compiler is left to apply the
+// fenced VALU pass.  Measured per stage with s_memtime (tools/stage_timing.py): when the compiler is left to apply the
 // ReLU where the values are consumed (it did so for every second hidden layer: v_accvgpr_read + 2 v_max per operand in
 // front of its k-group) each of those instructions costs ~14 clocks inside the MFMA stream, against 4-8 in a block.
 template <int NB, bool RELU>
@@ -366,7 +366,7 @@ struct MlpArgs {
   int S, N, ray_stride, n_codes, x_width, nstages;
   float tau_v, tau_d;
 #ifdef ANERF_EXP_STAGE_TIMING
-  unsigned long long* tbuf;   // debug build only: per-stage clocks (tools/exp/stage_timing.py)
+  unsigned long long* tbuf;   // debug build only: per-stage clocks (tools/stage_timing.py)
 #endif
 };
 

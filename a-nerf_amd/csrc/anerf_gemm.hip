@@ -147,7 +147,7 @@ __device__ __forceinline__ void gemm_store(const GemmWave& W, float* __restrict_
   }
 }
 
-#ifdef ANERF_EXP_STAGE_TIMING   // debug build only (tools/exp/stage_timing_gemm.py)
+#ifdef ANERF_EXP_STAGE_TIMING   // debug build only (tools/stage_timing_gemm.py)
 __device__ unsigned long long* g_gemm_tbuf = nullptr;
 #endif
 
@@ -252,7 +252,7 @@ __device__ __forceinline__ void gemm_body(const GemmPlan& G, const GemmBlock& B,
       }
       // column sums (bias gradients) of the stage as ONE block of packed adds behind its MFMAs: 16 v_pk_add_f32 instead of
       // 32 v_add_f32 sprinkled between the groups (a VALU instruction inside the fp32 MFMA stream costs ~14 clocks, in a
-      // block 4-8; stage 9350 -> clocks, tools/exp/stage_timing_gemm.py)
+      // block 4-8; stage 9350 -> clocks, tools/stage_timing_gemm.py)
       f32x2 s_lo = {asum[0], asum[1]}, s_hi = {asum[2], asum[3]};
 #pragma unroll
       for (int s = 0; s < NS; ++s) {

@@ -123,7 +123,7 @@ __device__ __forceinline__ void bwd_layer(Pipe3F& pipe, f32x16 (&out)[8], const 
     form_operands<MASK>(bq, prev[s], mk);
     // pin the operands in front of the re-issue: their VALU is free to move, and when hipcc scheduled it behind the (hidden)
     // LDS-DMA issue its counted vmcnt waits for the mask quads also waited for DMA pieces issued a moment before -- every
-    // second stage of the trunk took 12 500 clocks instead of 9 600 (tools/exp/stage_timing_bwd.py)
+    // second stage of the trunk took 12 500 clocks instead of 9 600 (tools/stage_timing_bwd.py)
 #pragma unroll
     for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(bq[i]));
     if (pending) pipe.stage_refill();
@@ -162,7 +162,7 @@ __device__ __forceinline__ void bwd_layer(Pipe3F& pipe, f32x16 (&out)[8], const 
   }
 }
 
-#ifdef ANERF_EXP_STAGE_TIMING   // debug build only (tools/exp/stage_timing_bwd.py)
+#ifdef ANERF_EXP_STAGE_TIMING   // debug build only (tools/stage_timing_bwd.py)
 __device__ unsigned long long* g_bwd_tbuf = nullptr;
 #endif
 
