@@ -58,12 +58,18 @@ struct Pipe3T {
       // pending every LDS wait it emits is a full `s_waitcnt lgkmcnt(0)` -- with a DMA in flight all the time that meant
       // every k-group drained its freshly issued fragment reads (kgroup).  Ordering against the LDS reads is the ring
       // protocol's (vmcnt(0) + barrier, both asm with a memory clobber), exactly as before.
+      // saddr + 32-bit lane offset + immediate: the instruction offset is added to the global AND the LDS address, so four
+      // pieces share one M0 / one scalar base (8 pieces = 2 x (s_mov m0 + 4 DMA) and no VALU; the 64-bit-vaddr form needed a
+      // v_lshl_add_u64 + s_mov per piece, ~50 instructions per stage inside the MFMA stream)
       const unsigned lds0 = (unsigned)reinterpret_cast<size_t>((lds_ptr_t)l);
-      const char* gl = g + lane16;
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
-                     :: "s"(lds0 + i * FRAG_BYTES), "v"(gl + i * FRAG_BYTES) : "memory", "m0");
+      for (int half = 0; half < 2; ++half)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                     "global_load_lds_dwordx4 %1, %2 offset:3072"
+                     :: "s"(lds0 + half * 4 * FRAG_BYTES), "v"(lane16), "s"(g + half * 4 * FRAG_BYTES) : "memory", "m0");
     } else {
 #pragma unroll
       for (int i = 0; i < 8; ++i)

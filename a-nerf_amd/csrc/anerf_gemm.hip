@@ -106,8 +106,17 @@ struct GemmLoader {
       if (tile < ntiles) {
         const char* rowp = t_ptr[tile] + (long long)stage * (GEMM_ROWS * 4) * t_ld[tile];
         char* l = smem + slot * GSTAGE_BYTES + tile * GTILE_BYTES + wave * (2 * GT * 4);
+#ifdef ANERF_EXP_GEMM_BUILTIN_DMA   // round-1 form: 64-bit per-lane addresses (a v_lshl_add_u64 per piece inside the MFMA stream)
         __builtin_amdgcn_global_load_lds((glb_ptr_t)(rowp + t_lo[tile]), (lds_ptr_t)l, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((glb_ptr_t)(rowp + (long long)t_ld[tile] * 32 + t_lo[tile]), (lds_ptr_t)(l + 8 * (GT * 4)), 16, 0, 0);
+#else
+        // scalar row base + 32-bit lane offset: no VALU per piece; issued through asm as in the MLP kernels' weight pipe
+        const unsigned lds0 = (unsigned)reinterpret_cast<size_t>((lds_ptr_t)l);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     :: "s"(lds0), "v"(t_lo[tile]), "s"(rowp) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     :: "s"(lds0 + 8 * (GT * 4)), "v"(t_lo[tile]), "s"(rowp + (long long)t_ld[tile] * 32) : "memory", "m0");
+#endif
       }
   }
 };
