@@ -1,7 +1,6 @@
 // anerf_mlp_bwd.hip -- backward kernels of the fused MLP (gfx950): k_mlp_bwd (backward-data on the W^T image) and
 // k_mlp_bwd_in (input gradients for pose optimisation / frame codes).  Same register-resident transposed fp32-MFMA
 // scheme as the forward (see anerf_mlp.hip / DESIGN.md 4.2).
-#include "anerf_mlp_common.h"
 #include "anerf_fwd_common.h"
 
 namespace anerf {
@@ -276,58 +275,103 @@ struct BwdInArgs {
   int nstages, uw;
 };
 
-__device__ __forceinline__ void store_cols(float* __restrict__ row, const f32x16 (&acc)[8], int c0, int w, int h) {
+// One segment of the contraction: NKG k-groups (a multiple of 4 = whole stages) whose B operands are the float4 quads of a
+// gradient row (quad kg at src_row_h + 8 kg), into `acc`.  Same discipline as bwd_layer: the stage's four quads `cur` were
+// requested during the previous stage (complete at its barrier) and are pinned in front of the weight pipe's re-issue;
+// every k-group requests one quad of the next stage (of `next_src_row_h`, the next segment's row, at the end) and writes SPK
+// float4 of the PREVIOUS output group (`outv`, columns out_c0.. of out_row_h, width out_w) -- no load or store bursts.
+template <int NKG, int SPK>
+__device__ __forceinline__ void bwd_in_segment(Pipe3F& pipe, f32x16 (&acc)[8], f32x4 (&cur)[4], const float* __restrict__ src_row_h,
+                                               const float* __restrict__ next_src_row_h, const float (&outv)[128],
+                                               float* __restrict__ out_row_h, int out_c0, int out_w, bool& pending) {
 #pragma unroll
-  for (int nb = 0; nb < 8; ++nb)
+  for (int s = 0; s < NKG / 4; ++s) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c = c0 + 32 * nb + 8 * q + 4 * h;
-      if (c < w) {
-        f32x4 o = {acc[nb][4 * q], acc[nb][4 * q + 1], acc[nb][4 * q + 2], acc[nb][4 * q + 3]};
-        *reinterpret_cast<f32x4*>(row + c) = o;
+    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(cur[i]));
+    if (pending) pipe.stage_refill();
+    pending = false;
+    const float* nq = s < NKG / 4 - 1 ? src_row_h + 32 * (s + 1) : next_src_row_h;
+    f32x4 nxt[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int kg = 4 * s + ks;
+      if (nq) nxt[ks] = *reinterpret_cast<const f32x4*>(nq + 8 * ks);
+      else nxt[ks] = cur[ks];
+#pragma unroll
+      for (int t = 0; t < SPK; ++t) {
+        const int j = kg * SPK + t;            // quad of the previous group: block j >> 2, quad j & 3
+        if (j < 32) {
+          const int c = out_c0 + 8 * j;        // (+ 4h is in out_row_h)
+          if (c < out_w)
+            *reinterpret_cast<f32x4*>(out_row_h + c) = f32x4{outv[4 * j], outv[4 * j + 1], outv[4 * j + 2], outv[4 * j + 3]};
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      kgroup<8, Pipe3F, false>(pipe, acc, kg, false, false, cur[ks].x, cur[ks].y, cur[ks].z, cur[ks].w);
     }
+    pipe.stage_rendezvous();
+    pending = true;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cur[i] = nxt[i];
+  }
 }
 
+// Round 2: on the 3-slot hidden-DMA pipe with the two-quarter fragment window (kgroup), operands and results one float4
+// per k-group instead of 32-load / 32-store bursts per 256 columns (round 1: 2-slot pipe, bursts): 1.38 -> 1.24 ms per launch on the Mixamo step.
 __global__ __launch_bounds__(256) void k_mlp_bwd_in(const BwdInArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 31, h = lane >> 5;
-  Pipe pipe;
+  Pipe3F pipe;
   pipe.init(A.packed_i, smem, wave, lane, A.nstages);
-  pipe.issue(0);
   const long long p = (long long)blockIdx.x * TILE + wave * 32 + m;
-  const bool valid = p < A.P;
-  const long long pc = valid ? p : A.P - 1;
-  float d[128];
+  const long long pc = p < A.P ? p : A.P - 1;      // tail lanes recompute the last valid row and rewrite it with identical values
+  const float* z0 = A.dz + pc * 256 + 4 * h;
+  const float* z5 = A.dz + (5 * A.Ppad + pc) * 256 + 4 * h;
+  const float* zv = A.dzv + pc * 128 + 4 * h;
+  float* dx = A.dx + pc * 432 + 4 * h;
+  float* du = A.du + pc * A.uw + 4 * h;
+  f32x4 cur[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) cur[i] = *reinterpret_cast<const f32x4*>(z0 + 8 * i);
+  pipe.begin();
+  pipe.prime();
   f32x16 acc[8];
-#pragma unroll 1
-  for (int gi = 0; gi < 2; ++gi) {
+  float outv[128];
 #pragma unroll
-    for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-    load_row<8>(d, A.dz + pc * 256, h);                          // dz0
-    hidden_part<8, 0>(pipe, acc, d);
-    load_row<8>(d, A.dz + (5 * A.Ppad + pc) * 256, h);           // dz5
-    hidden_part<8, 0>(pipe, acc, d);
-    if (valid) store_cols(A.dx + p * 432, acc, 256 * gi, 432, h);
-  }
+  for (int i = 0; i < 128; ++i) outv[i] = 0.f;
+  bool pending = false;
+  // ---- dX' columns 0..255: W0'^T dz0 + W5x'^T dz5
+  zero_acc<8>(acc);
+  bwd_in_segment<32, 0>(pipe, acc, cur, z0, z5, outv, dx, 0, 0, pending);
+  bwd_in_segment<32, 0>(pipe, acc, cur, z5, z0, outv, dx, 0, 0, pending);
+  take<8, false>(outv, acc);
+  // ---- dX' columns 256..431 (its first 32 k-groups write group 0)
+  zero_acc<8>(acc);
+  bwd_in_segment<32, 1>(pipe, acc, cur, z0, z5, outv, dx, 0, 432, pending);
+  bwd_in_segment<32, 0>(pipe, acc, cur, z5, zv, outv, dx, 0, 0, pending);
+  take<8, false>(outv, acc);
+  // ---- dU' = Wvu'^T dzv, 256 columns at a time; group g's 16 k-groups write the group before it
   const int ngu = (A.uw + 255) / 256;
-#pragma unroll
-  for (int i = 64; i < 128; ++i) d[i] = 0.f;
-  load_row<4>(d, A.dzv + pc * 128, h);
+  zero_acc<8>(acc);
+  bwd_in_segment<16, 2>(pipe, acc, cur, zv, ngu > 1 ? zv : nullptr, outv, dx, 256, 432, pending);
+  take<8, false>(outv, acc);
 #pragma unroll 1
-  for (int gi = 0; gi < ngu; ++gi) {
+  for (int g = 1; g < ngu; ++g) {
+    zero_acc<8>(acc);
+    bwd_in_segment<16, 2>(pipe, acc, cur, zv, g + 1 < ngu ? zv : nullptr, outv, du, 256 * (g - 1), A.uw, pending);
+    take<8, false>(outv, acc);
+  }
+  // the last group's columns
+  {
+    const int c0 = 256 * (ngu - 1);
 #pragma unroll
-    for (int nb = 0; nb < 8; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[nb][r] = 0.f;
-#pragma unroll
-    for (int kg = 0; kg < 16; ++kg) kgroup<8>(pipe, acc, kg, d[4 * kg], d[4 * kg + 1], d[4 * kg + 2], d[4 * kg + 3]);
-    if (valid) store_cols(A.du + p * A.uw, acc, 256 * gi, A.uw, h);
+    for (int j = 0; j < 32; ++j) {
+      const int c = c0 + 8 * j;
+      if (c < A.uw) *reinterpret_cast<f32x4*>(du + c) = f32x4{outv[4 * j], outv[4 * j + 1], outv[4 * j + 2], outv[4 * j + 3]};
+    }
   }
 }
 
@@ -337,7 +381,7 @@ int mlp_bwd_in_entry(const float* packed_i, const float* dz, const float* dzv, f
   b.packed_i = packed_i; b.dz = dz; b.dzv = dzv; b.dx = dx; b.du = du; b.P = P; b.Ppad = Ppad; b.nstages = nstages; b.uw = uw;
   const long long nblk = (P + TILE - 1) / TILE;
   if (nblk <= 0) return ANERF_OK;
-  const size_t lds = 2 * STAGE_BYTES;
+  const size_t lds = RING_SLOTS * STAGE_BYTES;
   static unsigned long long lds_set = 0;   // per-device bits, see ensure_dynamic_lds
   ensure_dynamic_lds(reinterpret_cast<const void*>(k_mlp_bwd_in), (int)lds, &lds_set);
   hipLaunchKernelGGL(k_mlp_bwd_in, dim3((unsigned)nblk), dim3(256), lds, st, b);
