@@ -72,6 +72,10 @@ __device__ __forceinline__ void sincos_f32(float x, float& s, float& c) {
   c = ((q + 1) & 2) ? -cc : cc;
 }
 
+// sample index -> ray index.  P < 2^32 is checked by the launchers (mlp_dispatch): one 32-bit division (~25 instructions)
+// instead of the 64-bit software division (~150, three to five of them at the head of every tile).
+__device__ __forceinline__ long long div_samples(long long p, int S) { return (long long)((unsigned)p / (unsigned)S); }
+
 // sin and cos for |x| <= 1 (components of a unit vector): no reduction, Taylor to x^9 / x^10 (truncation 2.5e-8 / 2e-9).
 __device__ __forceinline__ void sincos_unit_f32(float x, float& s, float& c) {
   const float x2 = x * x;

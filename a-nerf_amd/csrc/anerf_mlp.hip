@@ -192,10 +192,10 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
   } else {
     // ---- stage the bone matrices (rows 0..2 of each 4x4 world->bone matrix) of this tile's rays in LDS
     const long long tile_p0 = (long long)blockIdx.x * TILE;
-    const long long ray0 = tile_p0 / A.S;
-    long long ray1 = (tile_p0 + TILE - 1) / A.S;
+    const long long ray0 = div_samples(tile_p0, A.S);
+    long long ray1 = div_samples(tile_p0 + TILE - 1, A.S);
     if (ray1 > A.N - 1) ray1 = A.N - 1;
-    ray = MODE == 1 ? 0 : pc / A.S;
+    ray = MODE == 1 ? 0 : div_samples(pc, A.S);
     const int n_stage_rays = (A.skt_stride == 0 || MODE == 1) ? 1 : (int)(ray1 - ray0 + 1);
     lr = (A.skt_stride == 0 || MODE == 1) ? 0 : (int)(ray - ray0);
     f32x4* bw = reinterpret_cast<f32x4*>(smem + LDS_BONES_OFF);
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
       const int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
       long long pe = (long long)blockIdx.x * TILE + wave * 32 + (lane_e & 31);
       pe = pe < A.P ? pe : A.P - 1;
-      const float* rp = A.rays + (pe / A.S) * A.ray_stride;
+      const float* rp = A.rays + div_samples(pe, A.S) * A.ray_stride;
       dray[0] = rp[3];
       dray[1] = rp[4];
       dray[2] = rp[5];
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
       const int lane_e = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
       long long pe = (long long)blockIdx.x * TILE + wave * 32 + (lane_e & 31);
       pe = pe < A.P ? pe : A.P - 1;
-      fidx = A.cam[pe / A.S];
+      fidx = A.cam[div_samples(pe, A.S)];
     }
     int ci = (int)fidx;
     ci = ci < 0 ? 0 : (ci >= A.n_codes ? A.n_codes - 1 : ci);
@@ -457,6 +457,7 @@ static int launch(const MlpArgs& a, hipStream_t st) {
 int mlp_dispatch(const AnerfConfig* cfg, const MlpArgs& a, bool pre, bool train, hipStream_t st) {
   const int lv = cfg->multires, ld = cfg->multires_views, cd = cfg->framecode_ch;
   if (lv != 7) return set_error(ANERF_E_CONFIG, "multires must be 7");
+  if (a.P > 0xFFFFFF00ll) return set_error(ANERF_E_SHAPE, "more than 2^32 - 256 samples in one call");   // div_samples is 32-bit
   if (pre && train) return set_error(ANERF_E_CONFIG, "training forward needs the fused (not pre-encoded) path");
 #define ANERF_CASE(LD_, CD_)                                               \
   if (ld == LD_ && cd == CD_) {                                            \
@@ -479,6 +480,7 @@ int mlp_density_entry(const float* packed, const float* aux, const float* pts, c
   a.P = P; a.Ppad = P; a.skt_stride = 0; a.S = 1; a.N = 1; a.nstages = nstages_trunk; a.tau_v = tau_v; a.tau_d = tau_v;
   const long long nblk = (P + TILE - 1) / TILE;
   if (nblk <= 0) return ANERF_OK;
+  if (P > 0xFFFFFF00ll) return set_error(ANERF_E_SHAPE, "more than 2^32 - 256 points in one call");
   const size_t lds = LDS_BONES_OFF + MAX_TILE_RAYS * 72 * 16;
   auto kern = k_mlp_fwd<7, 0, 0, false, false, 1>;
   static unsigned long long lds_set = 0;   // per-device bits, see ensure_dynamic_lds

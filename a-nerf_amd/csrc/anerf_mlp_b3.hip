@@ -253,10 +253,10 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
   float dray[3];
   const f32x4* bones4 = reinterpret_cast<const f32x4*>(smem + LDS_BONES_OFF);
   const long long tile_p0 = (long long)blockIdx.x * TILE;
-  const long long ray0 = tile_p0 / A.S;
-  long long ray1 = (tile_p0 + TILE - 1) / A.S;
+  const long long ray0 = div_samples(tile_p0, A.S);
+  long long ray1 = div_samples(tile_p0 + TILE - 1, A.S);
   if (ray1 > A.N - 1) ray1 = A.N - 1;
-  const long long ray = pc / A.S;
+  const long long ray = div_samples(pc, A.S);
   const int n_stage_rays = A.skt_stride == 0 ? 1 : (int)(ray1 - ray0 + 1);
   const int lr = A.skt_stride == 0 ? 0 : (int)(ray - ray0);
   {
@@ -432,6 +432,7 @@ template <int LV, int LD, int CODE, bool TRAIN>
 static int launch_b3(const MlpArgs& a, hipStream_t st) {
   const long long nblk = (a.P + TILE - 1) / TILE;
   if (nblk <= 0) return ANERF_OK;
+  if (a.P > 0xFFFFFF00ll) return set_error(ANERF_E_SHAPE, "more than 2^32 - 256 samples in one call");   // div_samples is 32-bit
   const size_t lds = LDS_BONES_OFF + MAX_TILE_RAYS * 72 * 16;
   auto kern = k_mlp_fwd_b3<LV, LD, CODE, TRAIN>;
   static unsigned long long lds_set = 0;   // per-device bits, see ensure_dynamic_lds
