@@ -14,13 +14,14 @@
 //     32 samples.  Lane l holds sample m = l&31; lanes 0-31 / 32-63 hold the two k-halves.  The accumulator layout
 //     of layer i (feature n = 32nb + (r&3) + 8(r>>2) + 4(l>>5) in register r of block nb) IS the B-operand layout
 //     of layer i+1, so activations stay in registers across all layers: no LDS round trip, no barrier for them.
-//   * two accumulator sets ping-pong between layers: a layer's accumulators start from its bias (read from an LDS
-//     copy), get ONE in-place ReLU pass when the layer is done, and are then read directly as the next layer's B
-//     operands -- no activation copy, and no VALU inside the MFMA stream of the hidden layers.
+//   * a layer's accumulators (AGPRs) start from its bias (LDS copy, read straight into the AGPRs); when the layer is done
+//     its 128 values per lane are taken into VGPRs in ONE fenced block (v_accvgpr_read + v_max_i32: the ReLU) and those
+//     VGPRs are the next layer's B operands -- no VALU inside the MFMA stream of the hidden layers (a VALU instruction
+//     there costs ~14 clocks of matrix time, in a block 4-8: fwd_common.h, take<>).
 //   * weights are pre-packed (k_pack) into a linear stream of 1 KiB MFMA fragments in consumption order and streamed
 //     L2 -> LDS with global_load_lds_dwordx4 through a 3 x 32 KiB ring, issued two stages ahead; one barrier per
-//     stage (= 8192 MFMA cycles per wave); the first fragments of the next stage are prefetched into registers
-//     BEFORE that barrier, so no LDS-read latency is exposed after it.
+//     stage (= 8192 MFMA cycles per wave); fragments are read a full quarter of a k-group ahead (two-quarter window,
+//     kgroup), across the stage barrier too, so no LDS-read latency is exposed.
 //   * the encoding is produced in registers just in time as B operands: lane half h owns joints
 //     {j : ((j>>2)&1) == h}; bone matrices of the tile's rays are staged in LDS.
 #include <hip/hip_runtime.h>
