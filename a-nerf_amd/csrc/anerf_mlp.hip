@@ -95,6 +95,7 @@ __device__ __forceinline__ void x_part(Pipe3F& pipe, f32x16 (&acc)[8], const flo
     for (int i = 0; i < 6; ++i) w2[i] = f32x2{wv[2 * i], wv[2 * i + 1]};
 #pragma unroll
     for (int f = 0; f < LV; ++f) {
+      __builtin_amdgcn_sched_barrier(0);     // a band's values as one block in front of its six k-groups (see the view layer)
       if (f % 4 == 0) {
 #pragma unroll
         for (int a = 0; a < 12; ++a) {
@@ -111,11 +112,14 @@ __device__ __forceinline__ void x_part(Pipe3F& pipe, f32x16 (&acc)[8], const flo
           cc[i] = t * cc[i] - 1.0f;
         }
       }
-#pragma unroll
-      for (int g = 0; g < 3; ++g) KG(3 + 6 * f + g, gs[2 * g][0], gs[2 * g][1], gs[2 * g + 1][0], gs[2 * g + 1][1]);
       f32x2 gc[6];
 #pragma unroll
       for (int i = 0; i < 6; ++i) gc[i] = cc[i] * w2[i];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) asm volatile("" : "+v"(gs[i]), "+v"(gc[i]));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < 3; ++g) KG(3 + 6 * f + g, gs[2 * g][0], gs[2 * g][1], gs[2 * g + 1][0], gs[2 * g + 1][1]);
 #pragma unroll
       for (int g = 0; g < 3; ++g) KG(6 + 6 * f + g, gc[2 * g][0], gc[2 * g][1], gc[2 * g + 1][0], gc[2 * g + 1][1]);
     }
@@ -357,40 +361,43 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
       KGV(g, o0[0], o0[1], o1[0], o1[1]);
     }
     // gated sin / cos(2^f e) as in x_part: (gs, c) pairs, precise at f = 0 (|e| <= 1: no range reduction), packed
-    // double-angle steps after that.  A band's pairs are advanced inside the k-group that consumes their sines (the cosines
-    // wait in cc for the band's second half): only the running values are live.
+    // double-angle steps after that.  A band's 72 values are produced in ONE fenced block in front of its 18 k-groups (the
+    // feature operands are dead by now, registers are free): sprinkled over the k-groups each of these instructions cost
+    // the matrix pipe ~14 clocks, in a block ~6.
     f32x2 gse[18], cce[18];
 #pragma unroll
     for (int f = 0; f < LD; ++f) {
+      f32x2 gce[18];
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int g = 0; g < 9; ++g) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int i = 2 * g + t;
-          if (f % 4 == 0) {
-            float s0, c0, s1, c1;
-            if (f == 0) {
-              sincos_unit_f32(e[2 * i], s0, c0);
-              sincos_unit_f32(e[2 * i + 1], s1, c1);
-            } else {
-              sincos_f32(e[2 * i] * (float)(1 << f), s0, c0);
-              sincos_f32(e[2 * i + 1] * (float)(1 << f), s1, c1);
-            }
-            gse[i] = f32x2{s0, s1} * wd2[i];
-            cce[i] = f32x2{c0, c1};
+      for (int i = 0; i < 18; ++i) {
+        if (f % 4 == 0) {
+          float s0, c0, s1, c1;
+          if (f == 0) {
+            sincos_unit_f32(e[2 * i], s0, c0);
+            sincos_unit_f32(e[2 * i + 1], s1, c1);
           } else {
-            const f32x2 tt = cce[i] + cce[i];
-            gse[i] = gse[i] * tt;
-            cce[i] = tt * cce[i] - 1.0f;
+            sincos_f32(e[2 * i] * (float)(1 << f), s0, c0);
+            sincos_f32(e[2 * i + 1] * (float)(1 << f), s1, c1);
           }
+          gse[i] = f32x2{s0, s1} * wd2[i];
+          cce[i] = f32x2{c0, c1};
+        } else {
+          const f32x2 tt = cce[i] + cce[i];
+          gse[i] = gse[i] * tt;
+          cce[i] = tt * cce[i] - 1.0f;
         }
-        KGV(9 * (1 + 2 * f) + g, gse[2 * g][0], gse[2 * g][1], gse[2 * g + 1][0], gse[2 * g + 1][1]);
+        gce[i] = cce[i] * wd2[i];
       }
 #pragma unroll
-      for (int g = 0; g < 9; ++g) {
-        const f32x2 o0 = cce[2 * g] * wd2[2 * g], o1 = cce[2 * g + 1] * wd2[2 * g + 1];
-        KGV(9 * (2 + 2 * f) + g, o0[0], o0[1], o1[0], o1[1]);
-      }
+      for (int i = 0; i < 18; ++i) asm volatile("" : "+v"(gse[i]), "+v"(gce[i]));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < 9; ++g)
+        KGV(9 * (1 + 2 * f) + g, gse[2 * g][0], gse[2 * g][1], gse[2 * g + 1][0], gse[2 * g + 1][1]);
+#pragma unroll
+      for (int g = 0; g < 9; ++g)
+        KGV(9 * (2 + 2 * f) + g, gce[2 * g][0], gce[2 * g][1], gce[2 * g + 1][0], gce[2 * g + 1][1]);
     }
   }
   if constexpr (CODE > 0) {
