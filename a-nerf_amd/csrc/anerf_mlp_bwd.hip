@@ -119,6 +119,9 @@ __device__ __forceinline__ void bwd_layer(Pipe3F& pipe, f32x16 (&out)[8], const 
   float bq[16];
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
+    // ONE block behind the stage barrier (fence in front, pins behind): hoisted piecemeal into the previous stage's k-groups --
+    // where the scheduler put them -- the ~48 instructions cost the matrix pipe ~14 clocks each instead of ~6
+    __builtin_amdgcn_sched_barrier(0);
     form_operands<MASK>(bq, prev[s], mk);
     // pin the operands in front of the re-issue: their VALU is free to move, and when hipcc scheduled it behind the (hidden)
     // LDS-DMA issue its counted vmcnt waits for the mask quads also waited for DMA pieces issued a moment before -- every
