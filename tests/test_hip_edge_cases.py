@@ -146,3 +146,25 @@ def test_chunking_invariance_and_determinism(synth):
     assert len(grads[0]) == 48
     for g0, g1 in zip(*grads):
         assert torch.equal(g0, g1)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_cutoff_gate_at_the_end_of_the_tau_schedule(oracle, precision):
+    """tau reaches 2000 at the end of training (cutoff_embedder.py:192-197): tau * (dist - cutoff) is then in the thousands,
+    exp overflows for every joint beyond its cutoff and the gate is 0 or 1 almost everywhere.  The kernels evaluate the gate as
+    rcp(1 + exp(min(a, 80))) with a Newton step: no inf * 0, finite outputs, same maps as the oracle's 1 - sigmoid."""
+    c = build("eval_hier")
+    cfg, ocfg = ops.PathConfig(), oracle.OracleConfig()
+    Pc, Pf = c["Pc"], c["Pf"]
+    which = 3 if precision == "bf16x3" else 0
+    net_c, net_f = ops.pack_params(cfg, cuda_params(Pc), which), ops.pack_params(cfg, cuda_params(Pf), which)
+    n, S, Ni = 24, 32, 16
+    ro, rd, skts, cyls = c["rays_o"][:n], c["rays_d"][:n], c["skts"][:n], c["cyls"][:n]
+    out = pipeline.render_rays_forward(cfg, net_c, net_f, pipeline.make_ray_batch(dev(ro), dev(rd)), dev(skts), dev(cyls), S, Ni,
+                                       tau_v=2000.0, tau_d=2000.0, precision=precision)
+    with torch.no_grad():
+        ref = oracle.render_rays(ocfg, oracle.params_from_numpy(Pc), oracle.params_from_numpy(Pf),
+                                 oracle.make_ray_batch(t(ro), t(rd)), t(skts), t(cyls), S, Ni, tau_v=2000.0, tau_d=2000.0)
+    for k in ("rgb_map", "acc_map", "alpha", "rgb0", "alpha0"):
+        assert torch.isfinite(out[k]).all(), k
+    assert_out(out, ref, ["rgb_map", "acc_map", "rgb0"], atol=2e-4)
