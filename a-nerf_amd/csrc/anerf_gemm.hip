@@ -97,6 +97,21 @@ struct GemmLoader {
       t_lo[tile] = (unsigned)(kk * M.ld + c) * 4u;                                      // per lane
     }
   }
+  // one tile's two pieces, predicated on `tile < ntiles` by a branch INSIDE the asm block (nothing for hipcc to restructure
+  // around the MFMA loop): for the spread issue below
+  __device__ __forceinline__ void issue_tile(int stage, int slot, int tile) const {
+#ifdef ANERF_EXP_GEMM_NOLOAD
+    (void)stage; (void)slot; (void)tile; return;
+#endif
+    const char* rowp = t_ptr[tile] + (long long)stage * (GEMM_ROWS * 4) * t_ld[tile];
+    char* l = smem + slot * GSTAGE_BYTES + tile * GTILE_BYTES + wave * (2 * GT * 4);
+    const unsigned lds0 = (unsigned)reinterpret_cast<size_t>((lds_ptr_t)l);
+    asm volatile("s_cmp_lt_i32 %5, %6\n\ts_cbranch_scc0 1f\n\t"
+                 "s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+                 "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %4\n1:"
+                 :: "s"(lds0), "s"(lds0 + 8 * (GT * 4)), "v"(t_lo[tile]), "s"(rowp), "s"(rowp + (long long)t_ld[tile] * 32),
+                    "s"(tile), "s"(ntiles) : "memory", "m0", "scc");
+  }
   __device__ __forceinline__ void issue(int stage, int slot) const {
 #ifdef ANERF_EXP_GEMM_NOLOAD   // ablation build only (tools/ablate.sh): results are wrong
     (void)stage; (void)slot; return;
@@ -214,7 +229,15 @@ __device__ __forceinline__ void gemm_body(const GemmPlan& G, const GemmBlock& B,
     __syncthreads();                                   // stage t landed; everyone is done with stage t-1's slot
 #endif
 #endif
+#ifdef ANERF_EXP_GEMM_BURST   // round-1 form: the whole next stage requested right behind the barrier
     if (t + 1 < nst) issue(t + 1, (t + 1) & 1);
+#else
+    // heavy blocks request the next stage a tile (two pieces) per MFMA group, groups 0..4: the four waves' 40 pieces no
+    // longer pile up in the CU's vector-memory queue behind the barrier (stage 9 280 -> 9 030 clocks of 8 192; the operands
+    // still arrive in time: 8 clocks of vmcnt wait per stage, tools/stage_timing_gemm.py)
+    if (SKINNY && t + 1 < nst) issue(t + 1, (t + 1) & 1);
+    const int nt_stage = t + 1 < nst ? t + 1 : t;      // (the last stage reloads itself into the idle slot: branch-free)
+#endif
     const char* base = smem + (t & 1) * GSTAGE_BYTES;
     if constexpr (SKINNY) {
       f32x4 b4 = *reinterpret_cast<const f32x4*>(base + b_off);
@@ -252,6 +275,9 @@ __device__ __forceinline__ void gemm_body(const GemmPlan& G, const GemmBlock& B,
           av[s + 2] = *reinterpret_cast<const f32x4*>(base + a_off + (s + 2) * (2 * GT * 4));
           bv[s + 2] = *reinterpret_cast<const f32x4*>(base + b_off + (s + 2) * (2 * GT * 4));
         }
+#ifndef ANERF_EXP_GEMM_BURST
+        if (s < 5) L.issue_tile(nt_stage, (t + 1) & 1, s);
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int a = 0; a < 4; ++a)
