@@ -209,6 +209,7 @@ __device__ __forceinline__ void relu_pass(f32x16 (&acc)[NB]) {
 // front of its k-group) each of those instructions costs ~14 clocks inside the MFMA stream, against 4-8 in a block.
 template <int NB, bool RELU>
 __device__ __forceinline__ void take(float (&hb)[128], const f32x16 (&acc)[NB]) {
+  __builtin_amdgcn_sched_barrier(0);   // (the first reads would otherwise be hoisted between the layer's last MFMAs)
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb)
 #pragma unroll

@@ -187,8 +187,20 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(const BwdArgs A) {
   const long long pc = p < A.P ? p : A.P - 1;
   // head rows (w_c, w_alpha) -> LDS copy of the aux image, read back as float4 per 8-feature group
   float* aux_l = reinterpret_cast<float*>(smem + LDS_AUX_OFF);
-  for (int i = tid; i < AUX_FLOATS / 4; i += 256)
-    reinterpret_cast<f32x4*>(aux_l)[i] = reinterpret_cast<const f32x4*>(A.aux)[i];
+  {   // by (hidden) LDS-DMA, as in k_mlp_fwd
+    constexpr int NPIECE = AUX_FLOATS / 256;
+    const char* ga = reinterpret_cast<const char*>(A.aux) + lane * 16;
+#pragma unroll
+    for (int k = 0; k < (NPIECE + 3) / 4; ++k) {
+      const int piece = 4 * k + wave;
+      if (piece < NPIECE) {
+        const unsigned lds0 = (unsigned)reinterpret_cast<size_t>((lds_ptr_t)(smem + LDS_AUX_OFF)) + piece * 1024;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds0), "v"(ga + piece * 1024) : "memory", "m0");
+      }
+    }
+    const int i = NPIECE * 64 + tid;
+    if (i < AUX_FLOATS / 4) reinterpret_cast<f32x4*>(aux_l)[i] = reinterpret_cast<const f32x4*>(A.aux)[i];
+  }
   const float* aux_h = aux_l + 4 * h;
   const f32x4 dr = *reinterpret_cast<const f32x4*>(A.draw + pc * 4);
   f32x4 mk0[32];     // view-layer mask (16 quads) at the start, the h0 mask row at the end
@@ -213,13 +225,18 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(const BwdArgs A) {
       accv[nb][4 * q + 3] = w0.w * dr.x + w1.w * dr.y + w2.w * dr.z;
     }
   mask_pass<4>(accv, mk0);
-  store_acc<4>(A.dzv + pc * 128 + 4 * h, accv);
-  // ---- view layer, feature columns: df = Wv[:, :256]^T dzv      (16 k-groups = 4 stages over the 128 view units)
+  // ---- view layer, feature columns: df = Wv[:, :256]^T dzv      (16 k-groups = 4 stages over the 128 view units); every
+  // k-group stores its own quad of dzv
   zero_acc<8>(accA);
+  float* dzv_row_h = A.dzv + pc * 128 + 4 * h;
 #pragma unroll
-  for (int kg = 0; kg < 16; ++kg)
-    kgroup<8>(pipe, accA, kg, kg == 0, false, accv[kg >> 2][4 * (kg & 3) + 0], accv[kg >> 2][4 * (kg & 3) + 1],
-              accv[kg >> 2][4 * (kg & 3) + 2], accv[kg >> 2][4 * (kg & 3) + 3]);
+  for (int kg = 0; kg < 16; ++kg) {
+    const f32x4 o = {accv[kg >> 2][4 * (kg & 3) + 0], accv[kg >> 2][4 * (kg & 3) + 1], accv[kg >> 2][4 * (kg & 3) + 2],
+                     accv[kg >> 2][4 * (kg & 3) + 3]};
+    *reinterpret_cast<f32x4*>(dzv_row_h + 8 * kg) = o;
+    __builtin_amdgcn_sched_barrier(0);
+    kgroup<8>(pipe, accA, kg, kg == 0, false, o.x, o.y, o.z, o.w);
+  }
   // ---- feature layer + density head: dh7 = Wf^T df + w_alpha * dsigma (raw; its mask is applied by the layer below)
 #pragma unroll
   for (int nb = 0; nb < 8; ++nb)
