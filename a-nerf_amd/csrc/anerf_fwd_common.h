@@ -163,8 +163,9 @@ struct Pipe3T {
 // (s_memtime profile, tools/stage_timing.py B3=1) because __syncthreads drains the LDS queue; with the hidden DMA and
 // the raw barrier of the fp32 kernels (ANERF_EXP_B3_HIDDEN_DMA) that wait disappears from the barrier (park 506 -> 91
 // clocks) and reappears in front of the MFMAs: the stage stays 2 440-2 460 clocks and the render kernel spills 15-21
-// VGPRs (431 -> 419 TFLOP/s algorithmic).  The kernel is bound by its fragment reads: 4 waves x 32 KiB per stage =
-// 52 B/clk of LDS read bandwidth; only more samples per fragment read would change that.
+// VGPRs (431 -> 419 TFLOP/s algorithmic).  The kernel waits for its fragment reads -- their latency under load against
+// the 256-clock look-ahead of kstep, not LDS bandwidth (the LDS unit is 22 % busy, SQ_LDS_IDX_ACTIVE) -- and has no
+// registers left for a deeper look-ahead.
 #ifdef ANERF_EXP_B3_HIDDEN_DMA
 using Pipe3 = Pipe3T<true>;
 #else
