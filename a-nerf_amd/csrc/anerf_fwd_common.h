@@ -159,17 +159,19 @@ struct Pipe3T {
     set_offsets();
   }
 };
-// split-bf16 kernels: builtin LDS-DMA + __syncthreads.  Their stage barrier costs ~420 clocks of a 2 440-clock stage
-// (s_memtime profile, tools/stage_timing.py B3=1) because __syncthreads drains the LDS queue; with the hidden DMA and
-// the raw barrier of the fp32 kernels (ANERF_EXP_B3_HIDDEN_DMA) that wait disappears from the barrier (park 506 -> 91
-// clocks) and reappears in front of the MFMAs: the stage stays 2 440-2 460 clocks and the render kernel spills 15-21
-// VGPRs (431 -> 419 TFLOP/s algorithmic).  The kernel waits for its fragment reads -- their latency under load against
-// the 256-clock look-ahead of kstep, not LDS bandwidth (the LDS unit is 22 % busy, SQ_LDS_IDX_ACTIVE) -- and has no
-// registers left for a deeper look-ahead.
-#ifdef ANERF_EXP_B3_HIDDEN_DMA
-using Pipe3 = Pipe3T<true>;
-#else
+// split-bf16 kernels.  Round 2, in three steps on the render kernel (stage = 48 MFMAs = 1 536 matrix clocks; clocks from
+// tools/stage_timing.py B3=1, throughput from tools/microbench_mlp.py --b3):
+//   builtin LDS-DMA + __syncthreads, operands split next to their MFMAs       stage 2 440   413-418 TFLOP/s algorithmic
+//   + hidden DMA / raw barrier alone: the barrier's LDS drain (420 clocks) moves in front of the MFMAs, 15-21 VGPRs spill   419
+//   + a layer's operands pre-split in one block (take_split, anerf_mlp_b3.hip), visible DMA                2 240   418-424
+//   + both                                                                                                 2 090   435-437
+// (a full k-step of fragment read-ahead on top, 16 reads at once instead of kstep's interleaved groups: 2 330, slower).
+// The other split-bf16 kernels gain 2-3 % from the hidden DMA as well (training step 9.34 -> 9.10 ms).
+// ANERF_EXP_B3_VISIBLE_DMA rebuilds the round-1 pipe.
+#ifdef ANERF_EXP_B3_VISIBLE_DMA
 using Pipe3 = Pipe3T<false>;
+#else
+using Pipe3 = Pipe3T<true>;
 #endif
 using Pipe3F = Pipe3T<true>;    // fp32 forward / backward kernels
 

@@ -13,6 +13,7 @@
 // Bias, accumulation, ReLU, heads and the encoding stay fp32.
 // Reference ops replaced: identical to anerf_mlp.hip (core/encoders.py, core/cutoff_embedder.py,
 // core/networks/nerf.py:94-148).
+#include <type_traits>
 #include "anerf_fwd_common.h"
 #include "anerf_split.h"
 
@@ -132,6 +133,42 @@ __device__ __forceinline__ void hidden_part_b3(Pipe3& pipe, f32x16 (&acc)[NB], c
     const int nbk = ks >> 1, r0 = 8 * (ks & 1);
     const BOp b = split8(prev[nbk][r0], prev[nbk][r0 + 1], prev[nbk][r0 + 2], prev[nbk][r0 + 3], prev[nbk][r0 + 4],
                          prev[nbk][r0 + 5], prev[nbk][r0 + 6], prev[nbk][r0 + 7]);
+    kstep<NB, PIPE>(pipe, acc, KS0 + ks, last && ks == 15, b);
+  }
+}
+
+// Render kernel: a finished layer's 128 values per lane as packed (hi, lo) bf16 pairs = the next layer's B operands, produced
+// in ONE fenced block (v_accvgpr_read, optional ReLU, 6 conversion instructions per pair), as take<> does for the fp32
+// kernel.  Splitting each k-step's 8 values next to its MFMAs (hidden_part_b3) puts ~36 VALU instructions into every
+// k-step; the stage clocks (tools/stage_timing.py B3=1) show hidden-layer stages of 2 440-2 500 clocks for 1 536 matrix
+// clocks with exactly that difference -- and neither the LDS wait (a full k-step of read-ahead: no change) nor the barrier
+// (raw: no change) in it.  (The training forward keeps the in-stream split: with its row stores the 128 operand registers
+// spill.)
+struct POps {
+  unsigned hi[64], lo[64];   // pair j = values 2j, 2j+1 of the layer's accumulator order (block j >> 3, registers 2(j&7), +1)
+};
+template <bool RELU>
+__device__ __forceinline__ void take_split(POps& o, const f32x16 (&acc)[8]) {
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const float a = RELU ? relu_i(acc[nb][r]) : acc[nb][r], b = RELU ? relu_i(acc[nb][r + 1]) : acc[nb][r + 1];
+      split2(a, b, o.hi[8 * nb + (r >> 1)], o.lo[8 * nb + (r >> 1)]);
+    }
+#pragma unroll
+  for (int j = 0; j < 64; ++j) asm volatile("" : "+v"(o.hi[j]), "+v"(o.lo[j]));
+  __builtin_amdgcn_sched_barrier(0);
+}
+// 16 k-steps on pre-split operands: k-step ks uses pairs 4ks .. 4ks+3
+template <int NB, int KS0, bool PIPE = false>
+__device__ __forceinline__ void hidden_part_b3p(Pipe3& pipe, f32x16 (&acc)[NB], const POps& p, bool last) {
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    BOp b;
+    b.hi = __builtin_bit_cast(bf16x8, u32x4{p.hi[4 * ks], p.hi[4 * ks + 1], p.hi[4 * ks + 2], p.hi[4 * ks + 3]});
+    b.lo = __builtin_bit_cast(bf16x8, u32x4{p.lo[4 * ks], p.lo[4 * ks + 1], p.lo[4 * ks + 2], p.lo[4 * ks + 3]});
     kstep<NB, PIPE>(pipe, acc, KS0 + ks, last && ks == 15, b);
   }
 }
@@ -312,49 +349,84 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
     encode_x(v, wv, rh);
     x_part_b3<LV, XS, PP>(pipe, accA, v, wv, rh, true, XS ? A.save_x + pc * (24 * (1 + 2 * LV) + 72) + h * (12 * (1 + 2 * LV) + 36) : nullptr);
   }
-  relu_pass<8>(accA);
-  if (save) store_rows<8>(HROW(0), accA);
-  // ---- layers 1..4
+  f32x16 accv[4];
+  float sigma_raw;
+  if constexpr (!TRAIN) {
+    // Render: a finished layer is handed over as pre-split operands in one block (take_split; the ReLU inside)
+    POps ops;
+    auto hidden = [&](auto ks0, f32x16 (&next)[8], f32x16 (&prev)[8], bool relu, const float* bias) __attribute__((always_inline)) {
+      constexpr int KS0 = decltype(ks0)::value;
+      if (bias) init_bias<8>(next, bias);       // (nullptr: already initialised -- the skip layer, whose x part came first)
+      if (relu) take_split<true>(ops, prev); else take_split<false>(ops, prev);
+      hidden_part_b3p<8, KS0, true>(pipe, next, ops, true);
+    };
+    using K0 = std::integral_constant<int, 0>;
 #pragma unroll 1
-  for (int L = 1; L <= 3; L += 2) {
-    init_bias<8>(accB, aux_h + AUX_B0 + 256 * L);
-    hidden_part_b3<8, 0, PP>(pipe, accB, accA, true);
+    for (int L = 1; L <= 3; L += 2) {
+      hidden(K0{}, accB, accA, true, aux_h + AUX_B0 + 256 * L);
+      hidden(K0{}, accA, accB, true, aux_h + AUX_B0 + 256 * (L + 1));
+    }
+    // layer 5 (skip): x re-encoded from the position; h4 waits in its accumulators until the x part is done
+    asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2));
+    init_bias<8>(accB, aux_h + AUX_B0 + 256 * 5);
+    {
+      float v[12], wv[12], rh[36];
+      encode_x(v, wv, rh);
+      x_part_b3<LV, false, PP>(pipe, accB, v, wv, rh, false);
+    }
+    hidden(std::integral_constant<int, KSX>{}, accB, accA, true, nullptr);
+    hidden(K0{}, accA, accB, true, aux_h + AUX_B0 + 256 * 6);
+    hidden(K0{}, accB, accA, true, aux_h + AUX_B0 + 256 * 7);
+    relu_pass<8>(accB);                       // h7 in place: the density head reads it
+    sigma_raw = head_dot<8>(accB, aux_h + AUX_WA) + aux_l[AUX_BA];
+    hidden(K0{}, accA, accB, false, aux_h + AUX_BF);   // feature layer (h7 is already activated)
+    init_bias<4>(accv, aux_h + AUX_BV);
+    take_split<false>(ops, accA);             // the feature: no activation
+    hidden_part_b3p<4, 0, true>(pipe, accv, ops, false);
+  } else {
+    relu_pass<8>(accA);
+    if (save) store_rows<8>(HROW(0), accA);
+    // ---- layers 1..4
+  #pragma unroll 1
+    for (int L = 1; L <= 3; L += 2) {
+      init_bias<8>(accB, aux_h + AUX_B0 + 256 * L);
+      hidden_part_b3<8, 0, PP>(pipe, accB, accA, true);
+      relu_pass<8>(accB);
+      if (save) store_rows<8>(HROW(L), accB);
+      init_bias<8>(accA, aux_h + AUX_B0 + 256 * (L + 1));
+      hidden_part_b3<8, 0, PP>(pipe, accA, accB, true);
+      relu_pass<8>(accA);
+      if (save) store_rows<8>(HROW(L + 1), accA);
+    }
+    // ---- layer 5 (skip): x re-encoded from the position (opaque so that the compiler does not keep layer 0's values alive)
+    asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2));
+    init_bias<8>(accB, aux_h + AUX_B0 + 256 * 5);
+    {
+      float v[12], wv[12], rh[36];
+      encode_x(v, wv, rh);
+      x_part_b3<LV, false, PP>(pipe, accB, v, wv, rh, false);
+    }
+    hidden_part_b3<8, KSX, PP>(pipe, accB, accA, true);
     relu_pass<8>(accB);
-    if (save) store_rows<8>(HROW(L), accB);
-    init_bias<8>(accA, aux_h + AUX_B0 + 256 * (L + 1));
+    if (save) store_rows<8>(HROW(5), accB);
+    // ---- layers 6, 7
+    init_bias<8>(accA, aux_h + AUX_B0 + 256 * 6);
     hidden_part_b3<8, 0, PP>(pipe, accA, accB, true);
     relu_pass<8>(accA);
-    if (save) store_rows<8>(HROW(L + 1), accA);
+    if (save) store_rows<8>(HROW(6), accA);
+    init_bias<8>(accB, aux_h + AUX_B0 + 256 * 7);
+    hidden_part_b3<8, 0, PP>(pipe, accB, accA, true);
+    relu_pass<8>(accB);
+    if (save) store_rows<8>(HROW(7), accB);
+    sigma_raw = head_dot<8>(accB, aux_h + AUX_WA) + aux_l[AUX_BA];
+    // ---- feature layer
+    init_bias<8>(accA, aux_h + AUX_BF);
+    hidden_part_b3<8, 0, PP>(pipe, accA, accB, true);
+    if (save) store_rows<8>(A.save_f + p * 256 + 4 * h, accA);
+    // ---- view layer: [feature (16 k-steps); D bands; code; zero padding to a multiple of 8 values per lane]
+    init_bias<4>(accv, aux_h + AUX_BV);
+    hidden_part_b3<4, 0, PP>(pipe, accv, accA, false);
   }
-  // ---- layer 5 (skip): x re-encoded from the position (opaque so that the compiler does not keep layer 0's values alive)
-  asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2));
-  init_bias<8>(accB, aux_h + AUX_B0 + 256 * 5);
-  {
-    float v[12], wv[12], rh[36];
-    encode_x(v, wv, rh);
-    x_part_b3<LV, false, PP>(pipe, accB, v, wv, rh, false);
-  }
-  hidden_part_b3<8, KSX, PP>(pipe, accB, accA, true);
-  relu_pass<8>(accB);
-  if (save) store_rows<8>(HROW(5), accB);
-  // ---- layers 6, 7
-  init_bias<8>(accA, aux_h + AUX_B0 + 256 * 6);
-  hidden_part_b3<8, 0, PP>(pipe, accA, accB, true);
-  relu_pass<8>(accA);
-  if (save) store_rows<8>(HROW(6), accA);
-  init_bias<8>(accB, aux_h + AUX_B0 + 256 * 7);
-  hidden_part_b3<8, 0, PP>(pipe, accB, accA, true);
-  relu_pass<8>(accB);
-  if (save) store_rows<8>(HROW(7), accB);
-  const float sigma_raw = head_dot<8>(accB, aux_h + AUX_WA) + aux_l[AUX_BA];
-  // ---- feature layer
-  init_bias<8>(accA, aux_h + AUX_BF);
-  hidden_part_b3<8, 0, PP>(pipe, accA, accB, true);
-  if (save) store_rows<8>(A.save_f + p * 256 + 4 * h, accA);
-  // ---- view layer: [feature (16 k-steps); D bands; code; zero padding to a multiple of 8 values per lane]
-  f32x16 accv[4];
-  init_bias<4>(accv, aux_h + AUX_BV);
-  hidden_part_b3<4, 0, PP>(pipe, accv, accA, false);
   constexpr int NU = 36 * (1 + 2 * LD) + CODE / 2;          // values per lane
   constexpr int NUP = (NU + 7) / 8 * 8;
   constexpr int KSV_LAST = 16 + NUP / 8 - 1;
