@@ -307,10 +307,10 @@ __device__ __forceinline__ void gemm_body(const GemmPlan& G, const GemmBlock& B,
 // (hi, lo) bf16x8 and issues 3 MFMAs per (a, c) block pair (48 per stage = 1536 matrix cycles).  To keep the matrix
 // pipe fed the stages are software-pipelined through a 3-slot ring: while stage s is multiplied, the raw operands of
 // stage s+1 (already landed -- same invariant as the forward kernel's pipe) are read and split, interleaved with the
-// MFMAs by sched_group_barriers (bf16 MFMAs, unlike fp32 ones, do run beside VALU) -- a request the compiler does not
-// honour today: the ISA is 16 reads, 48 MFMAs, then ~300 split VALU in a row (~5100 cycles per stage, 30 % matrix duty);
-// the 3-slot pipeline therefore only matches the plain 2-slot version.  Same accumulator layout, same epilogue, same
-// deterministic reduction.
+// MFMAs chunk by chunk (bf16 MFMAs, unlike fp32 ones, do run beside VALU; see the loop).  Same accumulator layout, same
+// epilogue, same deterministic reduction.  At ~1.4 ms per launch the kernel moves the same 5.5 GB of operand tiles as the fp32
+// one does in 3.1 ms -- 3.9 TB/s through L2 / HBM -- which is what bounds it now: writing the interleave out (below) instead
+// of requesting it changed the step time by < 1 %.
 struct SplitOps {
   BOp A[4], B[4];
 };
@@ -373,6 +373,7 @@ __device__ __forceinline__ void gemm_body_b3(const GemmPlan& G, const GemmBlock&
     gemm_read_raw(smem, a_off, b_off, ar, br);
     gemm_split(ar, br, cur, asum);
   }
+#ifdef ANERF_EXP_GEMM_B3_UNFENCED   // round-1 form: the interleave is only requested (sched_group_barrier), and not honoured
   for (int s = 0; s < nst; ++s) {
     SplitOps nxt = cur;
     f32x4 ar[8], br[8];
@@ -387,7 +388,6 @@ __device__ __forceinline__ void gemm_body_b3(const GemmPlan& G, const GemmBlock&
         acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.A[a].hi, cur.B[c].hi, acc[a][c], 0, 0, 0);
       }
     if (more) gemm_split(ar, br, nxt, asum);
-    // interleave: one MFMA, then a few of the next stage's LDS reads / split VALU
 #pragma unroll
     for (int k = 0; k < 48; ++k) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
@@ -397,6 +397,40 @@ __device__ __forceinline__ void gemm_body_b3(const GemmPlan& G, const GemmBlock&
     end_stage(s);
     cur = nxt;
   }
+#else
+  // The interleave is written out and fenced: a stage is eight chunks of 6 MFMAs (two (a, c) block pairs) + one split8 of
+  // the NEXT stage's operands (~30 VALU, which the bf16 matrix pipe runs beside), a sched_barrier(0) behind each chunk.
+  // Requested with sched_group_barriers only, the compiler emitted the 48 MFMAs first and the ~300 split instructions in a
+  // row behind them (~5 100 clocks per stage for 1 536 matrix clocks).  Branch-free: the last stage splits whatever the
+  // idle ring slot holds (never used) and its column sums are multiplied by 0.
+  for (int s = 0; s < nst; ++s) {
+    SplitOps nxt;
+    f32x4 ar[8], br[8];
+    const float mf = s + 1 < nst ? 1.f : 0.f;
+    gemm_read_raw(smem + ((s + 1) % 3) * GSTAGE_BYTES, a_off, b_off, ar, br);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int a = (2 * k + j) >> 2, c = (2 * k + j) & 3;
+        acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.A[a].lo, cur.B[c].hi, acc[a][c], 0, 0, 0);
+        acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.A[a].hi, cur.B[c].lo, acc[a][c], 0, 0, 0);
+        acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.A[a].hi, cur.B[c].hi, acc[a][c], 0, 0, 0);
+      }
+      const int q = k & 3;
+      if (k < 4) {
+        nxt.A[q] = split8(ar[0][q], ar[1][q], ar[2][q], ar[3][q], ar[4][q], ar[5][q], ar[6][q], ar[7][q]);
+        asum[q] = fmaf(mf, ((ar[0][q] + ar[1][q]) + (ar[2][q] + ar[3][q])) + ((ar[4][q] + ar[5][q]) + (ar[6][q] + ar[7][q])), asum[q]);
+      } else {
+        nxt.B[q] = split8(br[0][q], br[1][q], br[2][q], br[3][q], br[4][q], br[5][q], br[6][q], br[7][q]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    end_stage(s);
+    cur = nxt;
+  }
+#endif
   gemm_store<false, 4>(W, ws, chunk, acc, asum, do_bias, i, kh);
 }
 
