@@ -263,6 +263,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
   Pipe3 pipe;
   pipe.init(A.packed, smem, wave, lane, A.nstages);
 #ifdef ANERF_EXP_STAGE_TIMING
+  const unsigned long long tt0 = __builtin_amdgcn_s_memtime(), tr0 = __builtin_amdgcn_s_memrealtime();
   if (A.tbuf && blockIdx.x % 997 == 0 && lane == 0)
     pipe.tbuf = A.tbuf + ((long long)(blockIdx.x / 997) * 4 + wave) * 3 * 128;
 #endif
@@ -498,6 +499,13 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
     f32x4 o = {c0, c1, c2, sigma_raw};
     *reinterpret_cast<f32x4*>(A.raw + p * 4) = o;
   }
+#ifdef ANERF_EXP_STAGE_TIMING   // every tile: start / end clocks + where it ran, behind the stage records (as k_mlp_fwd)
+  if (tid == 0 && A.tbuf) {
+    unsigned long long* t = A.tbuf + 64 * 4 * 128 * 3 + 6 * (long long)blockIdx.x;
+    t[0] = tt0; t[1] = __builtin_amdgcn_s_memtime(); t[2] = tr0; t[3] = __builtin_amdgcn_s_memrealtime();
+    t[4] = __builtin_amdgcn_s_getreg(63492); t[5] = __builtin_amdgcn_s_getreg(63508);
+  }
+#endif
 }
 
 template <int LV, int LD, int CODE, bool TRAIN>

@@ -30,7 +30,7 @@ if TRAIN:
 else:
     net = ops.pack_params(cfg, {k: dev(v) for k, v in synth.make_net_params(11).items()})
     sc = synth.make_scene(0, 512, 512, 600.0)
-    n = 65536
+    n = int(os.environ.get("N_RAYS", 65536))
     rb = pipeline.make_ray_batch(dev(sc["rays_o"][:n]), dev(sc["rays_d"][:n]))
     cyl = dev(sc["cyl"])[None].expand(n, -1).contiguous(); skt = dev(sc["pose"]["skts"])[None]
     cut = torch.full((24,), 0.5, device="cuda")
@@ -86,7 +86,6 @@ print("mean stage length by stage (stage s = leave[s] - leave[s-1]):", " ".join(
 print("first stage arrive - tile start unknown; compute phase of stage 0 not shown")
 
 # ---- whole tiles: duration, and the gap between consecutive tiles on the same CU (HW_ID: cu 8..11, sh 12, se 13..15; XCC_ID)
-if os.environ.get("B3") == "1": sys.exit(0)
 dur = (tiles[:, 1] - tiles[:, 0]).astype(np.float64)
 rdur = (tiles[:, 3] - tiles[:, 2]).astype(np.float64) * 10.0     # ns (100 MHz)
 rec_tiles = np.arange(nrec) * 997
