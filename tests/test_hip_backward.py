@@ -103,7 +103,8 @@ def test_single_net_training_gradients_vs_oracle(oracle, precision):
     rnd = {"t_rand": rng.rand(n, S).astype(np.float32), "u_imp": rng.rand(n, Ni).astype(np.float32),
            "noise": rng.randn(n, S).astype(np.float32), "noise_fine": rng.randn(n, S + Ni).astype(np.float32)}
     rb = importlib.import_module("a-nerf_amd.pipeline").make_ray_batch(dev(c["rays_o"]), dev(c["rays_d"]))
-    kwargs = dict(cfg=ops.PathConfig(**c["cfg"]), ray_batch=rb, skts=dev(c["skts"]), cyls=dev(c["cyls"]), n_samples=S, n_importance=Ni,
+    skts_d = dev(c["skts"]).requires_grad_(True)      # pose gradients too: the 72-wide view input of k_mlp_bwd_in (one column group)
+    kwargs = dict(cfg=ops.PathConfig(**c["cfg"]), ray_batch=rb, skts=skts_d, cyls=dev(c["cyls"]), n_samples=S, n_importance=Ni,
                   tau_v=20.0, tau_d=20.0, cut_v=torch.full((24,), 0.5, device="cuda"), cut_d=torch.full((24,), 0.5, device="cuda"),
                   cam_idx=None, t_rand=dev(rnd["t_rand"]), u_imp=dev(rnd["u_imp"]), noise=dev(rnd["noise"]),
                   noise_fine=dev(rnd["noise_fine"]), lindisp=False, single_net=True)
@@ -113,7 +114,7 @@ def test_single_net_training_gradients_vs_oracle(oracle, precision):
     loss.backward()
     ocfg = oracle.OracleConfig(**c["cfg"])
     P = oracle.params_from_numpy(c["Pc"], True)
-    sk = t(c["skts"])
+    sk = t(c["skts"]).requires_grad_(True)
     o = oracle.render_rays(ocfg, P, P, oracle.make_ray_batch(t(c["rays_o"]), t(c["rays_d"])), sk, t(c["cyls"]), S, Ni,
                            t_rand=t(rnd["t_rand"]), u_imp=t(rnd["u_imp"]), noise=t(rnd["noise"]), noise_fine=t(rnd["noise_fine"]),
                            single_net=True)
@@ -131,6 +132,9 @@ def test_single_net_training_gradients_vs_oracle(oracle, precision):
         scale = np.abs(ref).max() + 1e-12
         np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=2e-3, atol=tol * scale, err_msg=name)
         assert abs(float(p.grad.norm()) - float(np.linalg.norm(ref))) <= 2e-3 * float(np.linalg.norm(ref)) + 1e-12, name
+    ref = sk.grad.numpy()
+    np.testing.assert_allclose(skts_d.grad.cpu().numpy(), ref, rtol=5e-3, atol=(2e-3 if precision == "fp32" else 4e-3) * np.abs(ref).max(),
+                               err_msg="dskts")
 
 
 @pytest.mark.parametrize("name", ["train_pytest", "mixamo_train"])
