@@ -33,6 +33,22 @@ class AnerfSaved(C.Structure):
                 ("p_pad", C.c_int64)]
 
 
+ABI_VERSION = 3        # revision of include/anerf.h these structures were written for (checked against anerf_version())
+PROF_SLOTS = 16
+
+
+class AnerfProfile(C.Structure):
+    _fields_ = [("ev", C.c_void_p * PROF_SLOTS)]
+
+
+class AnerfPackJob(C.Structure):
+    _fields_ = [("params", AnerfNetParams), ("table", C.c_void_p), ("n", C.c_int64), ("out", C.c_void_p), ("kind", C.c_int32)]
+
+
+class AnerfRandJob(C.Structure):
+    _fields_ = [("out", C.c_void_p), ("n", C.c_int64), ("kind", C.c_int32), ("scale", C.c_float)]
+
+
 class AnerfForwardIO(C.Structure):
     _fields_ = [("packed_c", C.c_void_p), ("aux_c", C.c_void_p), ("packed_f", C.c_void_p), ("aux_f", C.c_void_p),
                 ("rays", C.c_void_p), ("ray_stride", C.c_int32),
@@ -44,7 +60,7 @@ class AnerfForwardIO(C.Structure):
                 ("single_net", C.c_int32), ("precision", C.c_int32),
                 ("rgb_map", C.c_void_p), ("disp_map", C.c_void_p), ("acc_map", C.c_void_p), ("alpha", C.c_void_p),
                 ("rgb0", C.c_void_p), ("disp0", C.c_void_p), ("acc0", C.c_void_p), ("alpha0", C.c_void_p),
-                ("pts_noise", C.c_void_p), ("pts_noise_is", C.c_void_p)]
+                ("pts_noise", C.c_void_p), ("pts_noise_is", C.c_void_p), ("profile", C.POINTER(AnerfProfile))]
 
 
 class AnerfNetGrads(C.Structure):
@@ -58,7 +74,7 @@ class AnerfBackwardIO(C.Structure):
                 ("perm_x", C.c_void_p), ("perm_u", C.c_void_p),
                 ("grads_c", AnerfNetGrads), ("grads_f", AnerfNetGrads),
                 ("g_skts", C.c_void_p), ("g_codes_c", C.c_void_p), ("g_codes_f", C.c_void_p), ("accumulate", C.c_int32),
-                ("passes", C.c_int32)]
+                ("passes", C.c_int32), ("profile", C.POINTER(AnerfProfile))]
 
 
 class AnerfTrainLayout(C.Structure):
@@ -140,6 +156,10 @@ SIGNATURES = {
     "anerf_train_forward": (C.c_int, [C.POINTER(AnerfConfig), C.POINTER(AnerfForwardIO), C.c_void_p, C.c_int64, C.c_void_p]),
     "anerf_backward": (C.c_int, [C.POINTER(AnerfConfig), C.POINTER(AnerfForwardIO), C.POINTER(AnerfBackwardIO), C.c_void_p,
                                  C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "anerf_pack_params_multi": (C.c_int, [C.POINTER(AnerfPackJob), C.c_int32, C.c_void_p]),
+    "anerf_rand_fill": (C.c_int, [C.POINTER(AnerfRandJob), C.c_int32, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "anerf_make_ray_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
+    "anerf_cyl_bbox": (C.c_int, [C.c_void_p] * 5 + [C.c_int32, C.c_void_p, C.c_void_p]),
     "anerf_adam_blocks": (C.c_int, [C.c_int64]),
     "anerf_adam_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
                                   C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -161,6 +181,11 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    # the ctypes structures above mirror ONE revision of include/anerf.h: a library of another revision would read fields
+    # past the end of (or at other offsets in) the caller's structs -- refuse it instead of running on garbage
+    if lib.anerf_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} reports ABI revision {lib.anerf_version()}, these bindings are for revision {ABI_VERSION}: "
+                           "rebuild the library (make -C a-nerf_amd/csrc)")
     _lib = lib
     return lib
 

@@ -204,6 +204,8 @@ class _RenderRaysFn(torch.autograd.Function):
         # data-parallel overlap (opt-in on the attached optimiser): the fine network's path gradients are complete when the
         # first half of the backward is enqueued; their all-reduce starts there and runs under the coarse pass
         hook = None
+        if direct and getattr(sink, "overlap", False):
+            sink.check_one_backward()        # raises on a second backward of the same step (nothing is enqueued yet)
         if direct and hier and getattr(sink, "overlap", False):
             fine_params = meta["params"][24:]
             hook = lambda: sink.begin_async_all_reduce(fine_params)
@@ -224,9 +226,12 @@ def _render_rays_one_node(caster, kw, prec):
     hier = kw["n_importance"] > 0
     b3 = prec == "bf16x3"
     cam = kw["cam_idx"].contiguous() if net_c.use_framecode else None
-    codes_c = net_c.framecodes.codes.weight if net_c.use_framecode else None
-    codes_f = net_f.framecodes.codes.weight if (hier and net_f.use_framecode) else None
+    codes_c = _codes_with_grad(net_c)
+    codes_f = _codes_with_grad(net_f) if hier else None
     nets = [net_c] + ([net_f] if hier else [])
+    from .networks import prepack
+    want_in = kw["skts"].requires_grad or any(n.use_framecode and n.framecodes.codes.weight.requires_grad for n in nets)
+    prepack([(n, w) for n in nets for w in ((3, 4) if b3 else (0, 1)) + (((5,) if b3 else (2,)) if want_in else ())])
     meta = dict(kw=kw, precision=prec, cam=cam,
                 net_c=net_c.packed(3 if b3 else 0), net_f=net_f.packed(3 if b3 else 0) if hier else None,
                 packed_t_c=net_c.packed(4 if b3 else 1)[0], packed_t_f=net_f.packed(4 if b3 else 1)[0] if hier else None,
@@ -237,6 +242,17 @@ def _render_rays_one_node(caster, kw, prec):
     meta["grad_sink"] = sink() if sink is not None else None        # weakref to an attached FusedAdam, or nothing
     out = _RenderRaysFn.apply(meta, kw["skts"].contiguous(), codes_c, codes_f, *params)
     return dict(zip(_OUT_KEYS, out))
+
+
+def _codes_with_grad(net):
+    """The frame-code table the kernels index, as an autograd input.  Training: the embedding weight.  Eval-mode rendering with
+    gradients enabled: RayCaster.render_rays has pointed negative camera indices at row n_codes (Optcodes.table_for; the
+    reference's "mean code" rule, embedding.py:21-22), so the table gets that row here too -- built with torch ops, the gradient
+    of the mean code flows back into every code through the cat / mean."""
+    if not net.use_framecode:
+        return None
+    w = net.framecodes.codes.weight
+    return w if net.training else torch.cat([w, w.mean(0, keepdim=True)], 0)
 
 
 def _net_params(net):
@@ -265,7 +281,7 @@ def render_rays_train(caster, kw):
         z, _ = ops.coarse_z(nf_raw, stats, rays, S, kw["t_rand"], kw["lindisp"])
 
     def mlp(net, zz):
-        codes = net.framecodes.codes.weight if net.use_framecode else None
+        codes = _codes_with_grad(net)
         cam = kw["cam_idx"].contiguous() if net.use_framecode else None
         meta = dict(cfg=cfg, rays=rays, z=zz, skts=skts_c.detach(), tau_v=kw["tau_v"], tau_d=kw["tau_d"],
                     cut_v=kw["cut_v"], cut_d=kw["cut_d"], cam=cam, codes=None if codes is None else codes.detach(),

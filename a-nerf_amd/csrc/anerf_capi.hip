@@ -207,7 +207,7 @@ using namespace anerf;
 extern "C" {
 
 const char* anerf_last_error(void) { return g_err; }
-int anerf_version(void) { return 2; }
+int anerf_version(void) { return 3; }
 
 int anerf_layout(const AnerfConfig* cfg, int which, AnerfLayout* out) {
   if (!out) return set_error(ANERF_E_NULL, "out is NULL");
@@ -882,6 +882,11 @@ int zero_saved_pads(const AnerfConfig* cfg, const AnerfSaved& a, int64_t P, hipS
   return rc;
 }
 
+// ABI revision 3: optional caller-owned timing events around the MFMA kernels (AnerfProfile)
+inline void prof_rec(const AnerfProfile* p, int slot, void* stream) {
+  if (p && p->ev[slot]) (void)hipEventRecord((hipEvent_t)p->ev[slot], (hipStream_t)stream);
+}
+
 int forward_check(const AnerfConfig* cfg, const AnerfForwardIO* io, const char* who) {
   if (!config_ok(cfg)) return set_error(ANERF_E_CONFIG, "unsupported AnerfConfig");
   if (!io) return set_error(ANERF_E_NULL, "forward: io is NULL");
@@ -931,8 +936,10 @@ int forward_impl(const AnerfConfig* cfg, const AnerfForwardIO* io, char* ws, con
   if (rc) return rc;
   rc = anerf_coarse_z(F(w.near_far), F(w.stats), io->rays, io->ray_stride, n, S, io->t_rand, io->lindisp, F(w.z), nullptr, stream);
   if (rc) return rc;
+  prof_rec(io->profile, ANERF_PROF_FWD(0), stream);
   rc = mlp(io->packed_c, io->aux_c, io->codes_c, F(w.z), S, F(w.raw), sv_c, io->pts_noise);
   if (rc) return rc;
+  prof_rec(io->profile, ANERF_PROF_FWD(0) + 1, stream);
   const bool hier = Ni > 0;
   float* alpha_c = hier ? io->alpha0 : io->alpha;
   float* scratch_alpha = F(w.weights_f);            // coarse alpha lands here when the caller does not want alpha0
@@ -955,7 +962,9 @@ int forward_impl(const AnerfConfig* cfg, const AnerfForwardIO* io, char* ws, con
       if (rc) return rc;
       pn_f = F(w.pn_f);
     }
+    prof_rec(io->profile, ANERF_PROF_FWD(1), stream);
     rc = mlp(io->packed_f, io->aux_f, io->codes_f, F(w.zm), S + Ni, F(w.raw_f), sv_f, pn_f);
+    prof_rec(io->profile, ANERF_PROF_FWD(1) + 1, stream);
   }
   if (rc) return rc;
   return anerf_composite(cfg, F(w.raw_f), F(w.zm), io->rays, io->ray_stride, io->noise_fine, n, S + Ni, io->rgb_map, io->disp_map,
@@ -1069,7 +1078,7 @@ int anerf_backward(const AnerfConfig* cfg, const AnerfForwardIO* io, const Anerf
     return set_error(ANERF_E_LAUNCH, "backward: hipMemsetAsync");
   bool skts_written = coarse_only;
   // one network pass: composite backward -> dz chain -> weight gradients (-> input gradients -> pose / code gradients)
-  auto pass = [&](const AnerfSaved& sv, const float* raw, const float* zz, int ns, const float* noise, const float* g_rgb,
+  auto pass = [&](int which_pass, const AnerfSaved& sv, const float* raw, const float* zz, int ns, const float* noise, const float* g_rgb,
                   const float* g_acc, const float* g_disp, const float* g_alpha, const float* packed_t, const float* aux,
                   const float* packed_i, const AnerfNetGrads* gr, float* g_codes, const float* pn) {
     const int64_t P = n * ns;
@@ -1084,15 +1093,21 @@ int anerf_backward(const AnerfConfig* cfg, const AnerfForwardIO* io, const Anerf
     r = anerf_composite_backward(cfg, raw, zz, io->rays, io->ray_stride, noise, (int)n, ns, g_rgb, g_acc, g_disp, g_alpha, nullptr,
                                  B(w.draw), stream);
     if (r) return r;
+    prof_rec(b->profile, ANERF_PROF_BWD(which_pass), stream);
     r = (b3 ? anerf_mlp_backward_b3 : anerf_mlp_backward)(cfg, packed_t, aux, B(w.draw), &sv, B(w.dz), B(w.df), B(w.dzv), P, stream);
     if (r) return r;
+    prof_rec(b->profile, ANERF_PROF_BWD(which_pass) + 1, stream);
     AnerfTrainLayout T;
     anerf_train_layout(cfg, P, &T);
+    prof_rec(b->profile, ANERF_PROF_GEMM(which_pass), stream);
     r = weight_grads_impl(cfg, &sv, B(w.dz), B(w.df), B(w.dzv), B(w.draw), P, b->perm_x, b->perm_u, gr, B(w.gemm),
                           T.gemm_ws_floats, b3, b->accumulate != 0, stream);
+    prof_rec(b->profile, ANERF_PROF_GEMM(which_pass) + 1, stream);
     if (r || !want_in) return r;
+    prof_rec(b->profile, ANERF_PROF_BWD_IN(which_pass), stream);
     r = (b3 ? anerf_input_grads_b3 : anerf_input_grads)(cfg, packed_i, B(w.dz), B(w.dzv), pp, P, B(w.dx), B(w.du), stream);
     if (r) return r;
+    prof_rec(b->profile, ANERF_PROF_BWD_IN(which_pass) + 1, stream);
     if (b->g_skts) {
       r = launch_encode_bwd(cfg->multires_views, B(w.dx), B(w.du), uw, io->rays, io->ray_stride, zz, io->skts, io->skt_ray_stride,
                             io->tau_v, io->tau_d, io->cutoff_v, io->cutoff_d, (int)n, ns, B(w.dy), B(w.dq), b->g_skts, skts_written, st, pn);
@@ -1107,13 +1122,13 @@ int anerf_backward(const AnerfConfig* cfg, const AnerfForwardIO* io, const Anerf
   };
   if (do_fine) {   // the fine pass first, as autograd runs it
     const AnerfSaved sf = saved_at(ws + t.off_f, t.sf);
-    rc = pass(sf, F(t.fwd.raw_f), F(t.fwd.zm), (int)(S + Ni), io->noise_fine, b->g_rgb, b->g_acc, b->g_disp, b->g_alpha,
+    rc = pass(1, sf, F(t.fwd.raw_f), F(t.fwd.zm), (int)(S + Ni), io->noise_fine, b->g_rgb, b->g_acc, b->g_disp, b->g_alpha,
               b->packed_t_f, io->aux_f, b->packed_i_f, &b->grads_f, b->g_codes_f, io->pts_noise ? F(t.fwd.pn_f) : nullptr);
     if (rc) return rc;
   }
   if (!do_coarse) return ANERF_OK;
   const AnerfSaved sc = saved_at(ws + t.off_c, t.sc);
-  return pass(sc, F(t.fwd.raw), F(t.fwd.z), (int)S, io->noise, hier ? b->g_rgb0 : b->g_rgb, hier ? b->g_acc0 : b->g_acc,
+  return pass(0, sc, F(t.fwd.raw), F(t.fwd.z), (int)S, io->noise, hier ? b->g_rgb0 : b->g_rgb, hier ? b->g_acc0 : b->g_acc,
               hier ? b->g_disp0 : b->g_disp, hier ? b->g_alpha0 : b->g_alpha, b->packed_t_c, io->aux_c, b->packed_i_c, &b->grads_c,
               b->g_codes_c, io->pts_noise);
 }

@@ -82,7 +82,15 @@ class H5PoseData:
             self.bg_idxs = rd("bkgd_idxs").astype(np.int64)
         self.kp_idxs = rd("kp_idxs").astype(np.int64) if "kp_idxs" in keys else np.arange(self.n_images)
         self.cam_idxs = rd("cam_idxs").astype(np.int64) if "cam_idxs" in keys else np.arange(self.n_images)
-        self._f = f
+        # per-image pixel reads: h5py slices one row from disk per access; numpy's NpzFile is lazy per KEY, not per row -- every
+        # `f[key][idx]` would inflate the whole array again (0.2 s per row on a 39 MB `imgs`, three times per sampled image).
+        # The .npz twin's image arrays (uint8) are therefore read ONCE here and indexed in memory as the reference indexes its
+        # open h5 file (dataset.py:262-327).
+        if str(path).endswith(".npz"):
+            self._f = {k: np.asarray(f[k]) for k in ("imgs", "masks", "sampling_masks") if k in keys}
+            f.close()
+        else:
+            self._f = f
         # pre-computed pixel directions (dataset.py:147-163); the first two columns still need the division by focal
         i, j = np.meshgrid(np.arange(self.HW[1], dtype=np.float32), np.arange(self.HW[0], dtype=np.float32), indexing="xy")
         i, j = i.reshape(-1), j.reshape(-1)
@@ -112,7 +120,7 @@ class H5PoseData:
 
     def sample_pixels(self, idx, n, rng):
         """dataset.py:286-327 for patch_size 1, N_nms 0: n distinct pixels of the sampling mask, ascending"""
-        mask = np.asarray(self._f["sampling_masks"][idx]).reshape(-1)
+        mask = np.asarray(self._f["sampling_masks"][idx]).reshape(-1)      # one row (h5py: one read; .npz twin: resident array)
         valid, = np.where(mask > 0)
         return np.sort(rng.choice(valid, n, replace=False))
 

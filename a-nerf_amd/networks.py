@@ -128,6 +128,18 @@ class NeRF(nn.Module):
         flat = self._packed[which][1]
         return flat[:sf], flat[sf:]
 
+    def _stale(self, which):
+        """(version key, flat buffer to (re)fill) when image `which` is out of date, else None"""
+        P = self.named_path_params()
+        ver = tuple((p.data_ptr(), p._version) for p in P.values())
+        hit = self._packed.get(which)
+        if hit is not None and hit[0] == ver:
+            return None
+        sf, af, _, _ = ops.layout(self.path_cfg, which)
+        dev = next(iter(P.values())).device
+        flat = hit[1] if hit is not None and hit[1].device == dev else torch.empty(sf + af, dtype=torch.float32, device=dev)
+        return ver, flat, P
+
     def codes_table(self, cam_idx):
         if not self.use_framecode:
             return None, None
@@ -228,6 +240,28 @@ class CutoffEmbedder(Embedder):
         val = min(self.init_tau * rate ** (global_step / float(step * 1000)), 2000.)
         self.tau = torch.full_like(self.tau, val)
         self._tau_host = (id(self.tau), self.tau._version, float(np.float32(val)))   # what .item() of the fp32 buffer returns
+
+
+def prepack(pairs):
+    """Refresh every stale weight image among `pairs` = [(NeRF, which), ...] with ONE launch (anerf_pack_params_multi); the
+    following `net.packed(which)` calls are cache hits.  A training step needs four images (W and W^T of both networks) right
+    after each optimiser step: one launch instead of four."""
+    jobs, done, seen = [], [], set()
+    for net, which in pairs:
+        if net is None or (id(net), which) in seen:
+            continue
+        seen.add((id(net), which))
+        st = net._stale(which)
+        if st is None:
+            continue
+        ver, flat, P = st
+        jobs.append((net.path_cfg, {k: v.detach() for k, v in P.items()}, which, flat))
+        done.append((net, which, ver, flat))
+    if jobs:
+        with torch.no_grad():
+            ops.pack_params_multi(jobs)
+        for net, which, ver, flat in done:
+            net._packed[which] = (ver, flat)
 
 
 def get_embedder(multires, i=0, input_dims=3, cutoff_kwargs={"cutoff": False}, skel_type=None, kc=False):

@@ -109,6 +109,92 @@ def pack_params(cfg, params, which=0, out=None):
     return out[:sf], out[sf:]
 
 
+def pack_params_multi(jobs):
+    """Gather several weight images in ONE launch (anerf_pack_params_multi).  jobs: list of (cfg, params dict, which, out flat
+    tensor of layout(cfg, which) floats).  Replaces one k_pack / k_pack_b3 launch per image (4 per fp32 training step)."""
+    if not jobs:
+        return
+    lib = _lib.load()
+    arr, keep = [], []
+    for cfg, params, which, out in jobs:
+        dev = out.device
+        sf, af, _, _ = layout(cfg, which)
+        table = pack_table(cfg, dev, which)
+        st, k = net_params_struct(params)
+        keep += k + [table]
+        if which >= 3:     # bf16x3 image: hi/lo-split stream part (one table entry per bf16 element) + fp32 aux part
+            arr.append(_lib.AnerfPackJob(st, table.data_ptr(), 2 * sf, out.data_ptr(), 1))
+            arr.append(_lib.AnerfPackJob(st, table.data_ptr() + 4 * 2 * sf, af, out.data_ptr() + 4 * sf, 0))
+        else:
+            arr.append(_lib.AnerfPackJob(st, table.data_ptr(), sf + af, out.data_ptr(), 0))
+    for i in range(0, len(arr), 8):
+        chunk = arr[i:i + 8]
+        carr = (_lib.AnerfPackJob * len(chunk))(*chunk)
+        _lib.check(lib.anerf_pack_params_multi(carr, len(chunk), _stream()), "anerf_pack_params_multi")
+
+
+class DeviceRng:
+    """Counter-based generator behind anerf_rand_fill: (seed, offset) on the host, one launch per `fill`.  Stands where the
+    reference calls torch.rand / torch.randn on the device (ray_utils.py:171-180,240-246; nerf.py:176-182;
+    raycasters.py:660,674): same distributions, its own stream (as torch's CPU and GPU generators differ from each other)."""
+
+    def __init__(self, seed=None):
+        self.seed = int(torch.initial_seed() if seed is None else seed) & (2 ** 64 - 1)
+        self.offset = 0
+
+    def fill(self, specs, device):
+        """specs: list of (shape, kind, scale) with kind "uniform" | "normal" (None entries are skipped and returned as None).
+        Returns the tensors, all filled by ONE launch."""
+        outs, jobs = [], []
+        for sp in specs:
+            if sp is None:
+                outs.append(None)
+                continue
+            shape, kind, scale = sp
+            t = torch.empty(*shape, dtype=torch.float32, device=device)
+            outs.append(t)
+            jobs.append(_lib.AnerfRandJob(t.data_ptr(), t.numel(), 0 if kind == "uniform" else 1, float(scale)))
+        if jobs:
+            carr = (_lib.AnerfRandJob * len(jobs))(*jobs)
+            _lib.check(_lib.load().anerf_rand_fill(carr, len(jobs), self.seed, self.offset, _stream()), "anerf_rand_fill")
+            self.offset += 1
+        return outs
+
+
+def make_ray_batch(rays_o, rays_d, near=0.0, far=1.0, use_viewdirs=True):
+    """render()'s ray batch [N, 8 | 11] = (o, d, near, far [, d / |d|]) in one launch (core/trainer.py:116-135)."""
+    rays_o, rays_d = _f32c(rays_o, "rays_o"), _f32c(rays_d, "rays_d")
+    n = rays_o.shape[0]
+    stride = 11 if use_viewdirs else 8
+    out = torch.empty(n, stride, dtype=torch.float32, device=rays_o.device)
+    _lib.check(_lib.load().anerf_make_ray_batch(_p(rays_o), _p(rays_d), n, float(near), float(far), stride, _p(out), _stream()),
+               "anerf_make_ray_batch")
+    return out
+
+
+_circle_cache = {}
+
+
+def cyl_bbox(cyls, c2ws, hwf, off):
+    """Pixel boxes (x0, y0, x1, y1) int32 [F,4] of F projected bounding cylinders, one launch (anerf_cyl_bbox;
+    cylinder_to_box_2d, core/utils/skeleton_utils.py:607-690).  cyls [F,5], c2ws [F,3,4], hwf [F,4] = (H, W, fx, fy) float64
+    device tensors, off [F,2] int32 (integer principal point)."""
+    dev = cyls.device
+    if str(dev) not in _circle_cache:
+        rads = np.linspace(0.0, 2 * np.pi, 50)
+        _circle_cache[str(dev)] = torch.tensor(np.stack([np.cos(rads), np.sin(rads)], -1), dtype=torch.float64, device=dev)
+    for t, nm in ((cyls, "cyls"), (c2ws, "c2ws"), (hwf, "hwf")):
+        if t.dtype != torch.float64 or not t.is_contiguous():
+            raise TypeError(f"cyl_bbox: {nm} must be a contiguous float64 tensor")
+    if off.dtype != torch.int32 or not off.is_contiguous():
+        raise TypeError("cyl_bbox: off must be a contiguous int32 tensor")
+    F = cyls.shape[0]
+    out = torch.empty(F, 4, dtype=torch.int32, device=dev)
+    _lib.check(_lib.load().anerf_cyl_bbox(_p(cyls), _p(c2ws), _p(hwf), _p(off), _p(_circle_cache[str(dev)]), F, _p(out), _stream()),
+               "anerf_cyl_bbox")
+    return out
+
+
 def ray_bounds(rays, cyls):
     """get_near_far_in_cylinder (ray_utils.py:292): rays [N,>=8], cyls [N,5] -> (near_far [N,2] raw, stats: 32 bytes of scratch for coarse_z)."""
     rays, cyls = _f32c(rays, "rays"), _f32c(cyls, "cyls")
@@ -256,13 +342,21 @@ def loss(rgb, acc, target, rgb0=None, acc0=None, bgs=None, loss_type=0, coarse_w
         else:
             raise ValueError(f"loss: bgs must have 3 or N*3 elements, got {tuple(bgs.shape)}")
     lib = _lib.load()
-    out = torch.zeros(4, dtype=torch.float32, device=dev)
-    part = torch.empty(4 * lib.anerf_loss_blocks(n), dtype=torch.float32, device=dev)
+    nblk = lib.anerf_loss_blocks(n)
+    scratch = torch.empty(4 + 4 * nblk, dtype=torch.float32, device=dev)     # out4 (k_loss_final writes all four) + partials
+    out, part = scratch[:4], scratch[4:]
+    if n == 0:
+        out.zero_()                                   # empty batch: the library enqueues nothing
     g = None
     if want_grads:
-        g = {"rgb": torch.empty_like(rgb), "acc": torch.empty_like(acc) if bgs is not None else None,
-             "rgb0": torch.empty_like(rgb0) if rgb0 is not None else None,
-             "acc0": torch.empty_like(acc0) if (rgb0 is not None and bgs is not None) else None}
+        # the four gradient maps share ONE buffer ("flat"): the upstream gradient of the loss scales them with one launch
+        sizes = {"rgb": 3 * n, "acc": n if bgs is not None else 0, "rgb0": 3 * n if rgb0 is not None else 0,
+                 "acc0": n if (rgb0 is not None and bgs is not None) else 0}
+        flat = torch.empty(sum(sizes.values()), dtype=torch.float32, device=dev)
+        g, o = {"flat": flat}, 0
+        for k, sz in sizes.items():
+            g[k] = flat[o:o + sz].view((n, 3) if k.startswith("rgb") else (n,)) if sz else None
+            o += sz
     gp = (lambda k: _p(g[k]) if g is not None else None)
     _lib.check(lib.anerf_loss(_p(rgb), _p(acc), _p(rgb0), _p(acc0), _p(target), _p(bgs), stride, n, int(loss_type),
                               float(beta), float(coarse_weight), _p(out), gp("rgb"), gp("acc"), gp("rgb0"), gp("acc0"), _p(part), _stream()),
@@ -318,6 +412,61 @@ def fk_backward(bones, rest_pose, pelvis, g_skts=None, g_l2ws=None, g_kp=None, g
     return gb, gp
 
 
+class Profile:
+    """Caller-owned HIP timing events for AnerfProfile (ABI revision 3): created with hipEventCreate through the HIP
+    runtime already loaded in the process, recorded by the library around the MFMA kernels of the one-call training step,
+    read back here.  `with ops.profiling(prof): step()` routes the next train_forward / backward calls through it."""
+
+    SLOTS = {"fwd": 0, "bwd": 4, "gemm": 8, "bwd_in": 12}       # ANERF_PROF_* of include/anerf.h; + 2 * pass (0 coarse, 1 fine)
+
+    def __init__(self):
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+        self.hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+        self.hip.hipEventDestroy.argtypes = [C.c_void_p]
+        self.hip.hipEventSynchronize.argtypes = [C.c_void_p]
+        self.st = _lib.AnerfProfile()
+        for i in range(_lib.PROF_SLOTS):
+            ev = C.c_void_p()
+            if self.hip.hipEventCreate(C.byref(ev)) != 0:
+                raise RuntimeError("hipEventCreate failed")
+            self.st.ev[i] = ev.value
+
+    def ms(self, kind, which_pass):
+        """elapsed milliseconds of kernel `kind` ("fwd" | "bwd" | "gemm" | "bwd_in") of pass 0 (coarse) / 1 (fine), or None if
+        the pair was not recorded by the last step"""
+        a = self.SLOTS[kind] + 2 * which_pass
+        out = C.c_float()
+        if self.hip.hipEventSynchronize(self.st.ev[a + 1]) != 0:
+            return None
+        return float(out.value) if self.hip.hipEventElapsedTime(C.byref(out), self.st.ev[a], self.st.ev[a + 1]) == 0 else None
+
+    def __del__(self):
+        try:
+            for i in range(_lib.PROF_SLOTS):
+                if self.st.ev[i]:
+                    self.hip.hipEventDestroy(self.st.ev[i])
+        except Exception:
+            pass
+
+
+_active_profile = None
+
+
+class profiling:
+    def __init__(self, prof):
+        self.prof = prof
+
+    def __enter__(self):
+        global _active_profile
+        self.prev, _active_profile = _active_profile, self.prof
+        return self.prof
+
+    def __exit__(self, *a):
+        global _active_profile
+        _active_profile = self.prev
+
+
 def _forward_io(cfg, net_c, net_f, rays, skts, cyls, n_samples, n_importance, tau_v, tau_d, cut_v, cut_d, cam_idx, codes_c,
                 codes_f, t_rand, u_imp, noise, noise_fine, lindisp, single_net, precision, pts_noise=None, pts_noise_is=None):
     """AnerfForwardIO of one caster call + the output dict + the tensors whose pointers it holds"""
@@ -356,6 +505,9 @@ def _forward_io(cfg, net_c, net_f, rays, skts, cyls, n_samples, n_importance, ta
     io.lindisp, io.single_net, io.precision = int(bool(lindisp)), int(bool(single_net)), 1 if precision == "bf16x3" else 0
     for k, v in out.items():
         setattr(io, k, v.data_ptr())
+    if _active_profile is not None:
+        io.profile = C.pointer(_active_profile.st)
+        keep.append(_active_profile)
     return io, out, keep
 
 
@@ -450,6 +602,8 @@ def backward(state, g, packed_t_c, packed_t_f, perm, shapes_c, shapes_f, packed_
     g_codes_f = E((io.n_codes, 16)) if (want_codes_f and hier) else None
     b.g_skts, b.g_codes_c, b.g_codes_f = _p(g_skts), _p(g_codes_c), _p(g_codes_f)
     lib, cc = _lib.load(), cfg.c()
+    if _active_profile is not None:
+        b.profile = C.pointer(_active_profile.st)
     want_in = int(want_skts or want_codes_c or want_codes_f)
     scratch, sbytes = _workspace(lib.anerf_backward_scratch_size, "anerf_backward_scratch_size", dev, C.byref(cc), n, S, Ni, want_in)
     for passes in ((1, 2) if (after_fine is not None and hier) else (0,)):

@@ -195,9 +195,31 @@ class FusedAdam:
         """With an attached caster (attach()) and more than one rank: the all-reduce of the FINE network's gradients is
         started in the middle of the backward -- they are complete once the fine pass is enqueued -- on a side stream,
         and runs under the coarse pass; all_reduce_grads() then reduces the rest and joins.  Same sums as the single
-        collective (a split all-reduce adds the same numbers); needs an even ray split (no per-rank `weight`)."""
+        collective (a split all-reduce adds the same numbers); needs an even ray split (no per-rank `weight`).
+        Contract: exactly ONE backward per all_reduce_grads() / step().  A second backward (gradient accumulation over
+        chunks, a retained graph) would add local gradients into a range that is already reduced -- possibly while the
+        collective is still in flight -- and the ranks would diverge silently; it raises instead (`check_one_backward`).
+        Accumulate without overlap, or all-reduce between the backwards."""
         self.overlap = bool(on)
         return self
+
+    def check_one_backward(self):
+        """Called by the caster's backward BEFORE it enqueues anything: with overlap on, an early all-reduce that has not been
+        consumed by all_reduce_grads() means this is a second backward of the same step."""
+        if self.overlap and self._async is not None:
+            raise RuntimeError("FusedAdam overlap: a second backward arrived before all_reduce_grads() consumed the early "
+                               "all-reduce of the first; its gradients would be added to an already-reduced bucket range. "
+                               "Use enable_overlap(False) for gradient accumulation, or call all_reduce_grads() between backwards.")
+
+    def _drop_async(self):
+        """forget an early all-reduce nobody consumed (all_reduce_grads() was skipped after a backward): join it first so that
+        nothing is in flight on the bucket, then clear the handle -- it must not be mistaken for the next step's."""
+        if self._async is not None:
+            work, _, _ = self._async
+            self._async = None
+            work.wait()
+            if self._side is not None and self.flat_grad is not None:
+                torch.cuda.current_stream(self.flat_grad.device).wait_stream(self._side)
 
     def begin_async_all_reduce(self, params, group=None):
         """Called by the caster's backward between its two halves: all-reduce (sum) the flat-bucket range that holds
@@ -271,6 +293,7 @@ class FusedAdam:
         want_norms: returns a [2] device tensor (total_norm, avg_norm) of group 0's gradients at this step
         (`get_gradnorm(ray_caster)`, trainer.py:192-203) -- read it when convenient."""
         self.materialize()
+        self._drop_async()                # only set here if all_reduce_grads() was skipped after an overlapped backward
         seg = self._segments()
         for gi in self._due(i, only_group):
             grp = self.param_groups[gi]
@@ -293,6 +316,7 @@ class FusedAdam:
         return self.norms if want_norms else None
 
     def zero_grad(self, set_to_none=False, only_group=None):
+        self._drop_async()
         if self.flat_grad is not None:
             if only_group is None:
                 self.flat_grad.zero_()
@@ -324,8 +348,14 @@ class FusedAdam:
                 for j, (a, s) in enumerate(zip(self._views(self.exp_avg, gi), self._views(self.exp_avg_sq, gi))):
                     st[base + j] = {"step": torch.tensor(float(self._steps[gi])), "exp_avg": a.clone(), "exp_avg_sq": s.clone()}
             base += len(g["params"])
-        if self._pending is not None and group is None:      # a loaded state that has not reached the device buffers yet
-            st = self._pending["state"]
+        if self._pending is not None:      # a loaded state that has not reached the device buffers yet (model still on the host)
+            pst = {int(k): v for k, v in self._pending["state"].items()}
+            if group is None:
+                st = pst
+            else:                          # that group's slice, renumbered from 0 like a separate torch optimiser over it
+                lo = sum(len(g["params"]) for g in self.param_groups[:group])
+                n = len(self.param_groups[group]["params"])
+                st = {j - lo: v for j, v in pst.items() if lo <= j < lo + n}
         return {"state": st, "param_groups": groups}
 
     def load_state_dict(self, sd, group=None):
@@ -400,7 +430,15 @@ class _LossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, go, _):
         g = ctx.g
-        sc = lambda t: None if t is None else t * go
+        flat = g["flat"]
+        scaled = flat * go                                  # ONE launch for the four maps (they are views of one buffer)
+        base = flat.data_ptr()
+
+        def sc(t):
+            if t is None:
+                return None
+            o = (t.data_ptr() - base) // 4
+            return scaled[o:o + t.numel()].view(t.shape)
         return sc(g["rgb"]), sc(g["acc"]), sc(g["rgb0"]), sc(g["acc0"]), None, None, None, None, None
 
 

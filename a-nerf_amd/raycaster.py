@@ -99,26 +99,35 @@ class RayCaster(nn.Module):
         shift = density_shift_of(preproc_kwargs.get("density_fn", F.relu))
         cfg = ops.PathConfig(cfg.multires, cfg.multires_views, cfg.framecode_ch, density_scale=B, softplus_shift=shift)
         # randomness is generated here (device tensors) and handed to the kernels as inputs
-        t_rand = u_imp = noise = noise_f = None
-        if perturb > 0.:
-            t_rand = _rand(pytest, (n, N_samples), dev)
-            if N_importance > 0:
-                u_imp = _rand(pytest, (n, N_importance), dev)
-        if raw_noise_std > 0.:
-            if pytest:
+        t_rand = u_imp = noise = noise_f = pts_noise = pts_noise_is = None
+        hier = N_importance > 0
+        if pytest:      # the reference's numpy-seeded overrides (ray_utils.py:171-180,240-244; nerf.py:178-182)
+            if perturb > 0.:
+                t_rand = _rand(True, (n, N_samples), dev)
+                if hier:
+                    u_imp = _rand(True, (n, N_importance), dev)
+            if raw_noise_std > 0.:
                 noise = _rand(True, (n, N_samples), dev) * raw_noise_std
-                if N_importance > 0:
+                if hier:
                     noise_f = _rand(True, (n, N_samples + N_importance), dev) * raw_noise_std
-            else:
-                noise = torch.randn(n, N_samples, device=dev) * (raw_noise_std * B)
-                if N_importance > 0:
-                    noise_f = torch.randn(n, N_samples + N_importance, device=dev) * (raw_noise_std * B)
-        # sample-point offsets (raycasters.py:660,674): pts + randn_like(pts) * ray_noise_std, coarse and importance samples
-        pts_noise = pts_noise_is = None
-        if ray_noise_std > 0.:
-            pts_noise = torch.randn(n, N_samples, 3, device=dev) * ray_noise_std
-            if N_importance > 0:
-                pts_noise_is = torch.randn(n, N_importance, 3, device=dev) * ray_noise_std
+            if ray_noise_std > 0.:
+                pts_noise = torch.randn(n, N_samples, 3, device=dev) * ray_noise_std
+                if hier:
+                    pts_noise_is = torch.randn(n, N_importance, 3, device=dev) * ray_noise_std
+        elif perturb > 0. or raw_noise_std > 0. or ray_noise_std > 0.:
+            # every random input of the call in ONE launch (ops.DeviceRng / anerf_rand_fill): uniforms for the stratified
+            # jitter and the inverse-CDF draws, N(0,1) * raw_noise_std * B for the density logits (nerf.py:176-177), N(0,1) *
+            # ray_noise_std for the sample-point offsets (raycasters.py:660,674: coarse and importance samples)
+            if getattr(self, "_rng", None) is None:
+                self._rng = ops.DeviceRng()
+            sd = raw_noise_std * B
+            t_rand, u_imp, noise, noise_f, pts_noise, pts_noise_is = self._rng.fill([
+                ((n, N_samples), "uniform", 1.0) if perturb > 0. else None,
+                ((n, N_importance), "uniform", 1.0) if perturb > 0. and hier else None,
+                ((n, N_samples), "normal", sd) if raw_noise_std > 0. else None,
+                ((n, N_samples + N_importance), "normal", sd) if raw_noise_std > 0. and hier else None,
+                ((n, N_samples, 3), "normal", ray_noise_std) if ray_noise_std > 0. else None,
+                ((n, N_importance, 3), "normal", ray_noise_std) if ray_noise_std > 0. and hier else None], dev)
         tau_v, tau_d = self._taus()
         cut_v = self.embed_fn.cutoff_dist.detach()
         cut_d = self.embeddirs_fn.cutoff_dist.detach() if hasattr(self.embeddirs_fn, "cutoff_dist") else cut_v

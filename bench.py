@@ -76,8 +76,77 @@ def emit(res):
         os.write(_JSON_FD, line)
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` from a plain shell (no torchrun; replaces the reference's single-command nn.DataParallel,
+    core/raycasters.py:157): start N copies of this script, one rank per GPU, rendezvous on 127.0.0.1.  Rank 0 inherits this
+    process's stdout (the ONE JSON line), the other ranks' stdout goes to stderr.  Exit code: 0 only if every rank exits 0;
+    when a rank fails the others are stopped (by their exact PIDs) so that a dead peer cannot leave the rest hanging in a
+    collective."""
+    import socket
+    import subprocess
+    backend = os.environ.get("ANERF_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and torch.cuda.device_count() < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but this node has {torch.cuda.device_count()} GPU(s) "
+                         f"(RCCL needs one device per rank; ANERF_BENCH_BACKEND=gloo shares one GPU for a control-flow test)\n")
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.1)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                sys.stderr.write(f"bench.py: rank {procs.index(p)} exited with code {code}; stopping the other ranks\n")
+                for q in live:
+                    q.terminate()
+                t_end = time.time() + 10
+                for q in live:
+                    try:
+                        q.wait(max(0.1, t_end - time.time()))
+                    except subprocess.TimeoutExpired:
+                        q.kill()
+    return rc
+
+
+def dist_record(res, dist, device, dt_local, steps, coll_ms, backend):
+    """who ran: ranks / backend / devices as the process group saw them, every rank's own wall time, and the HIP-event time
+    of the per-step collective.  Collective on every rank (all_gather_object); returns res on rank 0."""
+    mine = {"rank": int(os.environ.get("RANK", 0)), "device": f"cuda:{device.index}", "name": torch.cuda.get_device_name(device),
+            "ms_per_step": dt_local / max(steps, 1) * 1e3, "collective_ms_per_step": coll_ms}
+    if dist is None:
+        allr, ranks, bk = [mine], 1, "none (single process)"
+    else:
+        allr = [None] * dist.get_world_size()
+        dist.all_gather_object(allr, mine)
+        ranks, bk = dist.get_world_size(), dist.get_backend() + (" (RCCL over xGMI)" if backend == "nccl" else " (control-flow test: ranks share devices)")
+    if res is not None:
+        res["ranks"] = ranks
+        res["backend"] = bk
+        res["devices"] = [f"{r['device']} {r['name']}" for r in allr]
+        res["ms_per_step_per_rank"] = [r["ms_per_step"] for r in allr]
+        res["collective_ms_per_step"] = [r["collective_ms_per_step"] for r in allr]
+    return res
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     # stdout carries exactly one line, the JSON record.  Libraries write there too -- RCCL prints a five-line version
     # banner through C stdio on communicator creation, gloo its connection notes -- and, being buffered, would land AFTER
     # the record at process exit.  So: keep the original stdout for the record only and point fd 1 at stderr for the run.
@@ -96,7 +165,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with `python bench.py --gpus {args.gpus}` (self-launching) "
+                         f"or torch.distributed.run --nproc-per-node {args.gpus}")
     # ANERF_BENCH_BACKEND=gloo: smoke-test the multi-rank control flow with all ranks on ONE GPU (RCCL refuses duplicate
     # devices); the driver's multi-GPU runs use the default, nccl (= RCCL), one rank per GPU
     backend = os.environ.get("ANERF_BENCH_BACKEND", "nccl")
@@ -123,6 +193,8 @@ def main():
             dist.all_gather_into_tensor(prime, prime[:4].clone())
         torch.cuda.synchronize()
         _flush_c_stdio()          # the communicator banner leaves the C buffers now, not at exit behind the record
+        if os.environ.get("ANERF_BENCH_FAIL_RANK") == str(rank):       # test hook: a rank dying mid-run (tests/test_step_glue.py)
+            os._exit(3)
 
     synth = importlib.import_module("a-nerf_amd.synth")
     ops = importlib.import_module("a-nerf_amd.ops")
@@ -141,22 +213,28 @@ def main():
 
 
 def extra_workloads(args, device, synth, ops, pipeline):
-    """BASELINE configs 3 and 5 inside the same driver-timed run: 5 steps each, same timing protocol,
-    each with its own roofline.  Compact records; the full ones come from `--workload ...`."""
+    """BASELINE configs 3, 4 and 5 inside the same driver-timed run: 5 steps each, same timing protocol, each with its own
+    roofline (training: executed-FLOP, per kernel).  Config 4 (Mixamo: frame codes + pose refinement) runs at the pose cadence
+    of mixamo.txt:48 (opt_pose_step = 20) and at 1 (every step: the most expensive schedule), and at its 8-GPU shard size.
+    Compact records; the full ones come from `--workload ...`."""
     import copy
     out = []
     for over in (dict(workload="train", n_rand=3072), dict(workload="train", n_rand=384),
+                 dict(workload="train_mixamo", n_rand=3072, opt_pose_step=1),
+                 dict(workload="train_mixamo", n_rand=3072, opt_pose_step=20),
+                 dict(workload="train_mixamo", n_rand=384, opt_pose_step=20),
                  dict(workload="hier128", precision="bf16x3")):
         a = copy.copy(args)
         a.steps, a.warmup, a.cpu_rays, a.extra = 5, 1, 0, "off"
         for k, v in over.items():
             setattr(a, k, v)
         try:
-            if a.workload == "train":
-                r = bench_train(a, 0, 1, device, None, synth, mixamo=False)
+            if a.workload in ("train", "train_mixamo"):
+                r = bench_train(a, 0, 1, device, None, synth, mixamo=a.workload == "train_mixamo")
             else:
                 r = bench_render(a, 0, 1, device, None, synth, ops, pipeline)
-            out.append({"workload": r["config"]["workload"], "value": r["value"], "unit": r["unit"], "steps": a.steps,
+            out.append({"workload": r["config"]["workload"] + (f", opt_pose_step={a.opt_pose_step}" if a.workload == "train_mixamo" else ""),
+                        "value": r["value"], "unit": r["unit"], "steps": a.steps,
                         "ms_per_step": r["ms_per_step"], "dtype": r["dtype"], "roofline": r["roofline"]})
         except Exception as e:       # an extra must never take the headline record down with it
             out.append({"workload": str(over), "error": f"{type(e).__name__}: {e}"})
@@ -196,6 +274,7 @@ def bench_render(args, rank, world, device, dist, synth, ops, pipeline):
     cut = torch.full((24,), 0.5, device=device)
     gather_buf = torch.empty(world * per, 5, device=device) if dist is not None else None
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev_c = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i=None):
         # HIP events bracket the DOMINANT launch on its own stream: the only k_mlp_fwd launch (Ni = 0) or the fine pass
@@ -219,10 +298,14 @@ def bench_render(args, rank, world, device, dist, synth, ops, pipeline):
         if dist is not None:
             mine = torch.zeros(per, 5, device=device)
             mine[:hi - lo, 0:3] = co["rgb_map"]; mine[:hi - lo, 3] = co["acc_map"]; mine[:hi - lo, 4] = co["disp_map"]
+            if i is not None:
+                ev_c[i][0].record()
             if backend == "nccl":
                 dist.all_gather_into_tensor(gather_buf, mine)
             else:
                 dist.all_gather(list(gather_buf.view(world, per, 5).unbind(0)), mine)
+            if i is not None:
+                ev_c[i][1].record()
         return co
 
     def barrier():
@@ -237,12 +320,13 @@ def bench_render(args, rank, world, device, dist, synth, ops, pipeline):
     for i in range(args.steps):
         out = step(i)
     barrier()
-    dt = time.perf_counter() - t0
+    dt = dt_local = time.perf_counter() - t0
     tt = torch.tensor([dt], device=device)
     if dist is not None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     mlp_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
+    coll_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_c])) if (args.steps and dist is not None) else 0.0
 
     # Side measurement (never the headline `value`): the same frame through the opt-in split-bf16 kernels, same timing
     # protocol, plus its agreement with the fp32 frame just rendered.
@@ -267,6 +351,7 @@ def bench_render(args, rank, world, device, dist, synth, ops, pipeline):
                "unit": "rays/s", "ms_per_step": float(d3.item()) / args.steps * 1e3,
                "max_abs_rgb_vs_f32": float((out3["rgb_map"] - rgb_f32).abs().max())}
 
+    res = None
     if rank == 0:
         ms = dt / args.steps * 1e3
         rays_s = n_total * args.steps / dt
@@ -293,8 +378,7 @@ def bench_render(args, rank, world, device, dist, synth, ops, pipeline):
             res["alt_precision"] = alt
         if args.cpu_rays > 0 and world == 1:   # CPU baseline: rank 0 at N=1 only (bench contract)
             res["cpu_baseline"], res["parity"] = cpu_baseline(sc, S, Ni, Pc, Pf, out, lo, min(args.cpu_rays, hi - lo))
-        return res
-    return None
+    return dist_record(res, dist, device, dt_local, args.steps, coll_ms, backend)
 
 
 def attach_traffic(res, key, world):
@@ -380,6 +464,8 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
         cams = torch.tensor(pose_idx_host, device=device).to(torch.float32)
     pk = {"density_scale": 1.0, "density_fn": torch.nn.functional.relu}
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev_c = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    backend = os.environ.get("ANERF_BENCH_BACKEND", "nccl")
 
     it = [0]                     # global iteration counter (the reference's `i`, trainer.py:451)
 
@@ -402,11 +488,17 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
         if i is not None:
             ev[i][1].record()
         it[0] += 1
+        if i is not None and dist is not None:
+            ev_c[i][0].record()
         if fused:
             opt.all_reduce_grads(i=it[0])     # ONE RCCL all-reduce over whatever is due (networks [+ pose]); 1/world folded into Adam
-            opt.step(zero_grad=True, i=it[0])
         else:
             bucket.all_reduce_mean()
+        if i is not None and dist is not None:
+            ev_c[i][1].record()
+        if fused:
+            opt.step(zero_grad=True, i=it[0])
+        else:
             opt.step()
             opt.zero_grad()
             if mixamo:
@@ -432,15 +524,63 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
     for i in range(args.steps):
         loss = step(i)
     barrier()
-    dt = time.perf_counter() - t0
+    dt = dt_local = time.perf_counter() - t0
     tt = torch.tensor([dt], device=device)
     if dist is not None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     fb_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    # HIP-event time of the gradient all-reduce as the main stream sees it (with overlap: what is left of it after the coarse
+    # half of the backward), plus the same collective on an idle GPU: the xGMI time of the 6.9 MB bucket itself
+    coll_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_c])) if (dist is not None and args.steps) else 0.0
+    coll_alone_ms = None
+    if dist is not None and fused:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        e0.record()
+        for _ in range(10):
+            dist.all_reduce(opt.flat_grad)
+        e1.record()
+        barrier()
+        coll_alone_ms = e0.elapsed_time(e1) / 10
+        opt.zero_grad()
+
+    # Per-kernel HIP-event times (AnerfProfile: events recorded by the library around each MFMA kernel of both passes) over
+    # a few extra, untimed steps -- the executed-FLOP roofline of every training kernel.  Executed FLOPs per sample: forward
+    # 2 x 861 824 MAC, backward-data 2 x 557 696 (W^T of the trunk, feature and view layers only), weight-gradient GEMM
+    # 2 x 861 824, input gradients (pose / frame-code configurations) 2 x (2 x 256 x 432 + 128 x u_width).
+    ops = importlib.import_module("a-nerf_amd.ops")
+    uw = 648 + (16 if mixamo else 0)
+    F_FWD, F_BWD, F_GEMM, F_IN = F_MLP, 2 * 557696, F_MLP, 2 * (2 * 256 * 432 + 128 * uw)
+    kernels = None
+    if args.steps > 0:
+        prof = ops.Profile()
+        acc = {}
+        n_prof = 4
+        with ops.profiling(prof):
+            for _ in range(n_prof):
+                step()
+                torch.cuda.synchronize()
+                for kind in ("fwd", "bwd", "gemm") + (("bwd_in",) if mixamo else ()):
+                    for ps in (0, 1):
+                        t = prof.ms(kind, ps)
+                        if t is not None:
+                            acc.setdefault((kind, ps), []).append(t)
+        names = {"fwd": "k_mlp_fwd<train>", "bwd": "k_mlp_bwd", "gemm": "k_gemm_tn + k_reduce_dw", "bwd_in": "k_mlp_bwd_in"}
+        flops = {"fwd": F_FWD, "bwd": F_BWD, "gemm": F_GEMM, "bwd_in": F_IN}
+        b3k = args.precision == "bf16x3"
+        kernels = []
+        for (kind, ps), ts in sorted(acc.items()):
+            ms_k = float(np.mean(ts[1:])) if len(ts) > 1 else float(ts[0])
+            fl = flops[kind] * (hi - lo) * (S + Ni if ps else S)
+            tf = fl / (ms_k * 1e-3) / 1e12
+            kernels.append({"kernel": names[kind] + ("_b3" if b3k else ""), "pass": "fine" if ps else "coarse", "ms": ms_k, "flop": fl,
+                            "tflops": tf, "frac": (3 * tf / (PEAK_BF16_MFMA / 1e12)) if b3k else tf / (PEAK_FP32_MFMA / 1e12)})
+    res = None
     if rank == 0:
-        flop_step_rank = 3 * F_MLP * (hi - lo) * (S + S + Ni)        # fwd + 2x bwd, coarse S + fine S+Ni evaluations
-        achieved = flop_step_rank / (fb_ms * 1e-3)
+        flop_step_rank = 3 * F_MLP * (hi - lo) * (S + S + Ni)        # SURVEY 8(d)'s convention: fwd + 2x bwd
+        exec_step_rank = (F_FWD + F_BWD + F_GEMM + (F_IN if mixamo else 0)) * (hi - lo) * (S + S + Ni)   # what the kernels execute
+        achieved = exec_step_rank / (fb_ms * 1e-3)
         b3 = args.precision == "bf16x3"
         res = {"metric": "rays/sec", "value": N_rand * args.steps / dt, "unit": "rays/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
@@ -453,20 +593,29 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
                           "rays_per_step": N_rand, "samples_per_ray": S, "n_importance": Ni,
                           "parallelism": f"ray-sharded x{world}, 1 all-reduce/step", "loss": float(loss.detach()),
                           "tail": "fused loss + FusedAdam (anerf_loss / anerf_adam_step)" if fused else "torch loss + torch.optim.Adam"},
-               "roofline": {"bound": "mfma", "kernel": "k_mlp_fwd<train> + k_mlp_bwd + k_gemm_tn (both nets), HIP-event time of fwd+bwd",
+               # `frac` prices the FLOPs the kernels EXECUTE (forward 1.724 + backward-data 1.115 + weight-gradient GEMM 1.724
+               # [+ input gradients] MFLOP per sample) against the HIP-event time of forward + backward; `survey_3x` keeps SURVEY
+               # 8(d)'s "training = 3 x forward" convention next to it (it over-counts the backward-data kernel)
+               "roofline": {"bound": "mfma", "kernel": "k_mlp_fwd<train> + k_mlp_bwd + k_gemm_tn" + (" + k_mlp_bwd_in" if mixamo else "") +
+                                                       " (both nets), HIP-event time of fwd+bwd",
                             # bf16x3: every algorithmic FLOP is issued as 3 bf16 MFMA FLOPs, priced against the bf16 peak
                             "achieved": (3 if b3 else 1) * achieved / 1e12, "algorithmic": achieved / 1e12,
                             "peak": (PEAK_BF16_MFMA if b3 else PEAK_FP32_MFMA) / 1e12, "unit": "TFLOP/s",
                             "frac": (3 * achieved / PEAK_BF16_MFMA) if b3 else achieved / PEAK_FP32_MFMA,
-                            "avg_launch_ms": fb_ms, "flop_per_launch": flop_step_rank, "traffic": None}}
+                            "avg_launch_ms": fb_ms, "flop_per_launch": exec_step_rank,
+                            "survey_3x": {"flop_per_step": flop_step_rank,
+                                          "frac": (3 if b3 else 1) * flop_step_rank / (fb_ms * 1e-3) / (PEAK_BF16_MFMA if b3 else PEAK_FP32_MFMA)},
+                            "kernels": kernels, "traffic": None}}
+        if coll_alone_ms is not None:
+            res["collective_alone_ms"] = coll_alone_ms
+            res["collective_bytes"] = int(opt.flat_grad.numel() * 4)
         key = ("train_mixamo" if mixamo else "train") + ("" if N_rand == 3072 else str(N_rand)) + ("_bf16x3" if b3 else "")
         attach_traffic(res, key, world)
         if mixamo:
             res["config"]["opt_pose_step"] = args.opt_pose_step
         if args.cpu_rays > 0 and world == 1 and not mixamo:
             res["cpu_baseline"] = cpu_train_baseline(synth, ro, rd, skts, cyls, S, Ni, min(args.cpu_rays, 512, N_rand))
-        return res
-    return None
+    return dist_record(res, dist, device, dt_local, args.steps, coll_ms, backend)
 
 
 def cpu_train_baseline(synth, ro, rd, skts, cyls, S, Ni, n_cpu):

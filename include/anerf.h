@@ -315,6 +315,23 @@ int anerf_weight_grads_b3(const AnerfConfig* cfg, const AnerfSaved* saved, const
  *   t_rand [N,S], u_imp [N,Ni], noise [N,S], noise_fine [N,S+Ni]: optional randomness, NULL = the deterministic variants.
  *   Outputs as RayCaster._collect_outputs (:711-724): rgb_map [N,3], disp_map/acc_map [N], alpha [N,S+Ni] of the last
  *   pass; rgb0/disp0/acc0/alpha0 of the coarse pass when n_importance > 0 (each may be NULL). */
+/* ABI revision 3: optional per-kernel timing of the one-call training step.  `ev` holds hipEvent_t handles created by the
+ * caller (hipEventCreate, timing enabled); the library only hipEventRecord()s them on `stream` around the MFMA kernels of
+ * a pass -- it never creates, waits on or reads an event.  NULL entries are skipped.  Slots (pass p = 0 coarse, 1 fine):
+ *   ANERF_PROF_FWD(p)     + {0,1}  before / after k_mlp_fwd<TRAIN>            (anerf_train_forward)
+ *   ANERF_PROF_BWD(p)     + {0,1}  before / after k_mlp_bwd                   (anerf_backward)
+ *   ANERF_PROF_GEMM(p)    + {0,1}  before / after k_gemm_tn + k_reduce_dw
+ *   ANERF_PROF_BWD_IN(p)  + {0,1}  before / after k_mlp_bwd_in (only when input gradients are requested)
+ * Used by bench.py for the executed-FLOP roofline of each training kernel; an un-profiled call passes profile = NULL. */
+#define ANERF_PROF_FWD(p) (0 + 2 * (p))
+#define ANERF_PROF_BWD(p) (4 + 2 * (p))
+#define ANERF_PROF_GEMM(p) (8 + 2 * (p))
+#define ANERF_PROF_BWD_IN(p) (12 + 2 * (p))
+#define ANERF_PROF_SLOTS 16
+typedef struct AnerfProfile {
+  void* ev[ANERF_PROF_SLOTS];
+} AnerfProfile;
+
 typedef struct AnerfForwardIO {
   const float *packed_c, *aux_c, *packed_f, *aux_f;
   const float *rays; int32_t ray_stride;
@@ -329,6 +346,7 @@ typedef struct AnerfForwardIO {
    * [N,Ni,3] for the importance samples (required with pts_noise when n_importance > 0); the fine pass gathers both by the
    * sort order of the merged depths.  NULL (the default of every shipped config: ray_noise_std = 0) = no offsets. */
   const float *pts_noise, *pts_noise_is;
+  const AnerfProfile* profile;   /* ABI revision 3 (HOST pointer, may be NULL): see AnerfProfile */
 } AnerfForwardIO;
 int64_t anerf_workspace_size(const AnerfConfig* cfg, int32_t n_rays, int32_t n_samples, int32_t n_importance);
 int anerf_forward(const AnerfConfig* cfg, const AnerfForwardIO* io, void* workspace, int64_t ws_bytes, void* stream);
@@ -362,6 +380,7 @@ typedef struct AnerfBackwardIO {
                          * coarse pass runs (replaces nn.DataParallel's reduce-add, core/raycasters.py:157).  g_skts is
                          * zero-filled by the call that runs the fine pass; a coarse-only call ADDS to it.  Ignored (both
                          * passes = the one pass) when n_importance == 0. */
+  const AnerfProfile* profile;   /* ABI revision 3 (HOST pointer, may be NULL): see AnerfProfile */
 } AnerfBackwardIO;
 int64_t anerf_train_workspace_size(const AnerfConfig* cfg, int32_t n_rays, int32_t n_samples, int32_t n_importance);
 int64_t anerf_backward_scratch_size(const AnerfConfig* cfg, int32_t n_rays, int32_t n_samples, int32_t n_importance,
@@ -369,6 +388,52 @@ int64_t anerf_backward_scratch_size(const AnerfConfig* cfg, int32_t n_rays, int3
 int anerf_train_forward(const AnerfConfig* cfg, const AnerfForwardIO* io, void* workspace, int64_t ws_bytes, void* stream);
 int anerf_backward(const AnerfConfig* cfg, const AnerfForwardIO* io, const AnerfBackwardIO* b, void* workspace,
                    int64_t ws_bytes, void* scratch, int64_t scratch_bytes, void* stream);
+
+/* ---- ABI revision 3: per-step host glue as single launches (the 384-rays-per-rank step) --------
+ * Everything a training iteration does around the caster call used to be a string of small torch launches (4 weight-image
+ * gathers, 2 x torch.rand + 2 x torch.randn + scaling, ones_like / norm / div / cat for the ray batch): ~0.3 ms of a
+ * 2.6 ms step at 384 rays per rank.  Each group is one launch here. */
+
+/* anerf_pack_params for several weight images at once (one launch, blockIdx.y = job).  kind 0: out is float[n]
+ * (fp32 images which = 0 / 1 / 2, and the aux part of a bf16x3 image); kind 1: out is uint16[n], the hi/lo-split
+ * stream part of a bf16x3 image (which = 3 / 4 / 5; table entries as in anerf_pack_params_b3).  n_jobs <= 8. */
+typedef struct AnerfPackJob {
+  AnerfNetParams params;
+  const int32_t* table;
+  int64_t n;
+  void* out;
+  int32_t kind;
+} AnerfPackJob;
+#define ANERF_MAX_PACK_JOBS 8
+int anerf_pack_params_multi(const AnerfPackJob* jobs, int32_t n_jobs, void* stream);
+
+/* The random inputs of one caster call in ONE launch: replaces torch.rand (t_rand of sample_from_lineseg,
+ * ray_utils.py:240-246; u of sample_pdf, :171-180) and torch.randn * raw_noise_std (nerf.py:176-182) /
+ * randn_like(pts) * ray_noise_std (raycasters.py:660,674).  Counter-based Philox4x32-10: element i of job j is a pure
+ * function of (seed, offset, j, i) -- reproducible, independent of the launch geometry; the caller advances `offset` by 1
+ * per call.  kind 0: uniform in [0, 1) (24 random bits, as torch.rand(float32)); kind 1: standard normal (Box-Muller) *
+ * scale.  n_jobs <= 6. */
+typedef struct AnerfRandJob {
+  float* out;
+  int64_t n;
+  int32_t kind;
+  float scale;
+} AnerfRandJob;
+#define ANERF_MAX_RAND_JOBS 6
+int anerf_rand_fill(const AnerfRandJob* jobs, int32_t n_jobs, uint64_t seed, uint64_t offset, void* stream);
+
+/* render()'s ray-batch assembly (core/trainer.py:116-135): rays_o / rays_d [N,3] -> ray_batch [N, 8 | 11] =
+ * (o, d, near, far [, d / |d|]).  out_stride 8 (no view directions) or 11. */
+int anerf_make_ray_batch(const float* rays_o, const float* rays_d, int32_t n_rays, float near, float far, int32_t out_stride,
+                         float* ray_batch, void* stream);
+
+/* 2-D pixel boxes of the projected bounding cylinders of F frames in one launch (cylinder_to_box_2d,
+ * core/utils/skeleton_utils.py:607-690 + nerf_c2w_to_extrinsic :442, as kp_to_valid_rays uses them,
+ * core/utils/ray_utils.py:83-136): per frame cyl [5], c2w [3,4] row-major (DOUBLE, as the reference computes them),
+ * hwf [4] = (H, W, fx, fy), off [2] = integer principal point; circle [50][2] = (cos, sin) of linspace(0, 2 pi, 50)
+ * computed on the host.  bbox [F,4] int32 = (x0, y0, x1, y1), clipped to the image as the reference does. */
+int anerf_cyl_bbox(const double* cyls, const double* c2ws, const double* hwf, const int32_t* off, const double* circle,
+                   int32_t n_frames, int32_t* bbox, void* stream);
 
 #ifdef __cplusplus
 }

@@ -40,6 +40,8 @@ def test_layout_round_trip_and_batch(tmp_path, oracle):
     assert raw["kp3d"].dtype == np.float32 and raw["bkgd_idxs"].dtype == np.int64 and "index" not in raw
     ds = dataset.H5PoseData(path, device="cpu")
     assert len(ds) == 3 and ds.HW == (H, W) and ds.has_bg
+    # the .npz twin's image arrays are resident (NpzFile would inflate the whole array on every per-row access)
+    assert all(isinstance(ds._f[k], np.ndarray) for k in ("imgs", "masks", "sampling_masks"))
     rng = np.random.default_rng(5)
     b = ds.sample_batch([2, 0], 40, rng=rng)
     assert set(b) == {"rays_o", "rays_d", "target_s", "kp_idx", "kp3d", "bones", "skts", "cyls", "cam_idxs", "fgs", "bgs", "rays"}

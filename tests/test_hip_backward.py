@@ -39,6 +39,17 @@ def make_caster(c):
     return raycaster.RayCaster(net_c, e_v, e_b, e_d, network_fine=net_f).cuda()
 
 
+GRAD_BAR = 5e-4        # fp32 kernels: max |got - ref| over a tensor, relative to the tensor's largest element (observed ~1e-4)
+NORM_BAR = 5e-4        # fp32 kernels: relative difference of a gradient tensor's norm
+
+
+def grad_err(got, ref):
+    """max element error of a gradient tensor relative to the tensor's largest reference element"""
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    ref = ref.detach().cpu().numpy() if torch.is_tensor(ref) else np.asarray(ref)
+    return float(np.abs(got - ref).max() / (np.abs(ref).max() + 1e-30))
+
+
 def test_train_step_gradients_vs_golden_and_oracle(oracle, golden):
     g = golden("train_pytest")
     c = build("train_pytest")
@@ -57,17 +68,22 @@ def test_train_step_gradients_vs_golden_and_oracle(oracle, golden):
     assert abs(float(loss.detach()) - float(g["loss"])) < 2e-6
     loss.backward()
     # reference golden: per-tensor norms, leading slices, a few full tensors
+    seen = {"norm": 0.0, "slice": 0.0, "full": 0.0, "oracle": 0.0}
     for tag, net in [("c", caster.network), ("f", caster.network_fine)]:
         for name, p in net.named_parameters():
             ref_n = float(g[f"gnorm_{tag}.{name}"])
             got_n = float(p.grad.norm())
-            assert abs(got_n - ref_n) <= 2e-3 * ref_n + 1e-9, (tag, name, got_n, ref_n)
-            np.testing.assert_allclose(p.grad.reshape(-1)[:64].cpu().numpy(), g[f"gslice_{tag}.{name}"], rtol=5e-3,
-                                       atol=2e-3 * ref_n / max(np.sqrt(p.numel()), 1.0) + 1e-9, err_msg=f"{tag}.{name}")
+            seen["norm"] = max(seen["norm"], abs(got_n - ref_n) / (ref_n + 1e-30))
+            assert abs(got_n - ref_n) <= NORM_BAR * ref_n + 1e-9, (tag, name, got_n, ref_n)
+            # leading 64 elements, against the tensor's RMS element (the slice may miss the tensor's large entries)
+            rms = ref_n / max(np.sqrt(p.numel()), 1.0)
+            e = float(np.abs(p.grad.reshape(-1)[:64].cpu().numpy() - g[f"gslice_{tag}.{name}"]).max() / (rms + 1e-30))
+            seen["slice"] = max(seen["slice"], e)
+            assert e <= 2e-3, (tag, name, e)
         for name in ["pts_linears.5.bias", "rgb_linear.weight", "alpha_linear.weight"]:
-            ref = g[f"gfull_{tag}.{name}"]
-            got = dict(net.named_parameters())[name].grad.cpu().numpy()
-            np.testing.assert_allclose(got, ref, rtol=5e-3, atol=1e-3 * np.abs(ref).max(), err_msg=name)
+            e = grad_err(dict(net.named_parameters())[name].grad, g[f"gfull_{tag}.{name}"])
+            seen["full"] = max(seen["full"], e)
+            assert e <= GRAD_BAR, (tag, name, e)
     # oracle autograd: every element of all 48 tensors
     ocfg = oracle.OracleConfig()
     Pc, Pf = oracle.params_from_numpy(c["Pc"], True), oracle.params_from_numpy(c["Pf"], True)
@@ -77,9 +93,11 @@ def test_train_step_gradients_vs_golden_and_oracle(oracle, golden):
     lo.backward()
     for P, net in [(Pc, caster.network), (Pf, caster.network_fine)]:
         for name, p in net.named_parameters():
-            ref = P[name].grad.numpy()
-            scale = np.abs(ref).max() + 1e-12
-            np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=2e-3, atol=2e-4 * scale, err_msg=name)
+            e = grad_err(p.grad, P[name].grad)
+            seen["oracle"] = max(seen["oracle"], e)
+            assert e <= GRAD_BAR, (name, e)
+    print("fp32 training-step gradients, observed maxima: " + ", ".join(f"{k} {v:.2e}" for k, v in seen.items()) +
+          f"  (bars: norm {NORM_BAR:g}, element / tensor max {GRAD_BAR:g})")
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
@@ -126,15 +144,18 @@ def test_single_net_training_gradients_vs_oracle(oracle, precision):
     # fp32 kernels: summation-order noise only.  bf16x3: every product carries ~2^-17 relative error (two bf16 = 16 mantissa
     # bits per operand), which the heavy cancellation inside a weight gradient (sum over thousands of samples) amplifies to
     # ~1e-3 of the tensor's largest element -- the bar the reference golden-vector tests use (2e-3) still holds.
-    tol = 2e-4 if precision == "fp32" else 4e-3
+    bar, nbar = (GRAD_BAR, NORM_BAR) if precision == "fp32" else (6e-3, 2e-3)
+    worst = wn = 0.0
     for name, p in net.named_parameters():
         ref = P[name].grad.numpy()
-        scale = np.abs(ref).max() + 1e-12
-        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=2e-3, atol=tol * scale, err_msg=name)
-        assert abs(float(p.grad.norm()) - float(np.linalg.norm(ref))) <= 2e-3 * float(np.linalg.norm(ref)) + 1e-12, name
-    ref = sk.grad.numpy()
-    np.testing.assert_allclose(skts_d.grad.cpu().numpy(), ref, rtol=5e-3, atol=(2e-3 if precision == "fp32" else 4e-3) * np.abs(ref).max(),
-                               err_msg="dskts")
+        e = grad_err(p.grad, ref)
+        en = abs(float(p.grad.norm()) - float(np.linalg.norm(ref))) / (float(np.linalg.norm(ref)) + 1e-30)
+        worst, wn = max(worst, e), max(wn, en)
+        assert e <= bar, (name, e)
+        assert en <= nbar, (name, en)
+    e_sk = grad_err(skts_d.grad, sk.grad)
+    print(f"single_net [{precision}] gradients, observed maxima: element / tensor max {worst:.2e}, norm {wn:.2e}, dskts {e_sk:.2e}")
+    assert e_sk <= (1e-3 if precision == "fp32" else 6e-3), e_sk
 
 
 @pytest.mark.parametrize("name", ["train_pytest", "mixamo_train"])
@@ -160,16 +181,45 @@ def test_pose_and_framecode_gradients(oracle, golden, name):
     ref = g["dskts"]
     got = skts.grad.cpu().numpy()
     assert np.abs(got[:, :, 3, :]).max() == 0.0
-    np.testing.assert_allclose(got, ref, rtol=5e-3, atol=2e-3 * np.abs(ref).max(), err_msg="dskts")
-    assert abs(np.linalg.norm(got) - np.linalg.norm(ref)) < 2e-3 * np.linalg.norm(ref)
+    e_sk = grad_err(got, ref)
+    assert e_sk <= 1e-3, e_sk
+    assert abs(np.linalg.norm(got) - np.linalg.norm(ref)) < NORM_BAR * np.linalg.norm(ref)
+    wn = wc = 0.0
     for tag, net in [("c", caster.network), ("f", caster.network_fine)]:
         for pname, p in net.named_parameters():
             ref_n = float(g[f"gnorm_{tag}.{pname}"])
-            assert abs(float(p.grad.norm()) - ref_n) <= 2e-3 * ref_n + 1e-9, (tag, pname)
+            wn = max(wn, abs(float(p.grad.norm()) - ref_n) / (ref_n + 1e-30))
+            assert abs(float(p.grad.norm()) - ref_n) <= NORM_BAR * ref_n + 1e-9, (tag, pname)
         if name == "mixamo_train":
-            refc = g[f"gfull_{tag}.framecodes.codes.weight"]
-            np.testing.assert_allclose(net.framecodes.codes.weight.grad.cpu().numpy(), refc, rtol=5e-3,
-                                       atol=2e-3 * np.abs(refc).max(), err_msg="framecodes")
+            e = grad_err(net.framecodes.codes.weight.grad, g[f"gfull_{tag}.framecodes.codes.weight"])
+            wc = max(wc, e)
+            assert e <= GRAD_BAR, (tag, e)
+    print(f"{name}: observed maxima dskts {e_sk:.2e} (bar 1e-3), parameter-gradient norms {wn:.2e} (bar {NORM_BAR:g}), "
+          f"frame codes {wc:.2e} (bar {GRAD_BAR:g})")
+
+
+def test_eval_mode_with_gradients_uses_the_mean_code(golden):
+    """render_rays in eval mode with autograd on and cams = -1 (the reference's "mean code" rule,
+    core/networks/embedding.py:21-22): the differentiable route must index the table that carries the mean code as its extra row
+    -- outputs equal the reference's eval golden, and the gradient reaches every code equally through the mean."""
+    g = golden("mixamo_train")
+    c = build("mixamo_train")
+    caster = make_caster(c)
+    caster.eval()
+    n = c["n"]
+    out = render_mod.render(64, 64, 75.0, chunk=4096, rays=(dev(c["rays_o"]), dev(c["rays_d"])), use_viewdirs=True,
+                            ray_caster=caster.render_rays, kp_batch=dev(c["kp"]), skts=dev(c["skts"]), cyls=dev(c["cyls"]),
+                            bones=dev(c["bones"]), cams=-torch.ones(n, device="cuda"), subject_idxs=None, N_samples=64, N_importance=16,
+                            perturb=0.0, raw_noise_std=0.0,
+                            preproc_kwargs={"density_scale": 1.0, "density_fn": torch.nn.functional.relu})
+    assert out["rgb_map"].requires_grad
+    for k in ["rgb_map", "acc_map", "rgb0"]:
+        np.testing.assert_allclose(out[k].detach().cpu().numpy(), g["eval_" + k], atol=1e-4, err_msg=k)
+    (out["rgb_map"].sum() + out["rgb0"].sum()).backward()
+    for net in (caster.network, caster.network_fine):
+        gc = net.framecodes.codes.weight.grad
+        assert gc is not None and float(gc.abs().max()) > 0
+        assert torch.allclose(gc, gc[:1].expand_as(gc), rtol=0, atol=0)       # d/d(code_i) of the mean code: the same row for all i
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])

@@ -1,4 +1,4 @@
-"""GPU: BASELINE config 3 at its REAL sizes through the C ABI (anerf_train_forward / anerf_backward).
+"""GPU: BASELINE configs 3 and 4 at their REAL sizes through the C ABI (anerf_train_forward / anerf_backward).
 
 The CPU oracle cannot run 3072 rays x 144 samples with autograd in test time, so the full-size step is pinned by
 size-independent properties (task statement, section 3):
@@ -12,6 +12,9 @@ size-independent properties (task statement, section 3):
 Sizes: N_rand = 3072 (config 3 / mixamo.txt:34) and 384 (= 3072 / 8, one rank's shard at 8 GPUs), 64 + 16 samples,
 stratified jitter + density noise on, fp32 and the split-bf16 kernels.  Small-size parity of the same entry points against
 the reference's golden gradients lives in test_hip_backward.py.
+`code = 16` is BASELINE config 4's network (configs/mixamo/mixamo.txt:41-55: per-frame codes, 920-wide view layer) with pose
+gradients: the same properties, plus the frame-code gradients [n_codes,16] of both networks (a sum over rays: the halves add
+up, bitwise repeatable -- k_code_rowsum / k_code_reduce use no atomics) and k_mlp_bwd_in at 3072 x 144 samples.
 """
 import ctypes as C
 import importlib
@@ -35,10 +38,13 @@ def dev(x):
     return torch.tensor(np.asarray(x), dtype=torch.float32, device="cuda")
 
 
+N_CODES = 8
+
+
 def _inputs(n):
     ro, rd, kp, skts, bones, cyls, pidx = synth.scene_batch(n, list(range(8)), H=512, W=512, focal=600.0, ray_seed=3, per_ray_pose=True)
     g = torch.Generator(device="cuda").manual_seed(5)
-    return dict(rb=pipeline.make_ray_batch(dev(ro), dev(rd)), skts=dev(skts), cyls=dev(cyls),
+    return dict(rb=pipeline.make_ray_batch(dev(ro), dev(rd)), skts=dev(skts), cyls=dev(cyls), cam=dev(np.asarray(pidx) % N_CODES),
                 t_rand=torch.rand(n, S, device="cuda", generator=g), u_imp=torch.rand(n, NI, device="cuda", generator=g),
                 noise=torch.randn(n, S, device="cuda", generator=g), noise_fine=torch.randn(n, S + NI, device="cuda", generator=g),
                 target=torch.rand(n, 3, device="cuda", generator=g))
@@ -46,31 +52,37 @@ def _inputs(n):
 
 def _nets(cfg, precision):
     b3 = precision == "bf16x3"
-    Pc = {k: dev(v) for k, v in synth.make_net_params(11).items()}
-    Pf = {k: dev(v) for k, v in synth.make_net_params(12).items()}
+    mk = dict(framecode_ch=cfg.framecode_ch, n_codes=N_CODES) if cfg.framecode_ch else {}
+    Pc = {k: dev(v) for k, v in synth.make_net_params(11, **mk).items()}
+    Pf = {k: dev(v) for k, v in synth.make_net_params(12, **mk).items()}
     pk = lambda P, w: ops.pack_params(cfg, P, w)
     shapes = [tuple(Pc[n + sfx].shape) for n in ops.PARAM_ORDER for sfx in (".weight", ".bias")]
     return dict(fwd_c=pk(Pc, 3 if b3 else 0), fwd_f=pk(Pf, 3 if b3 else 0), t_c=pk(Pc, 4 if b3 else 1)[0], t_f=pk(Pf, 4 if b3 else 1)[0],
-                i_c=pk(Pc, 5 if b3 else 2)[0], i_f=pk(Pf, 5 if b3 else 2)[0], shapes=shapes)
+                i_c=pk(Pc, 5 if b3 else 2)[0], i_f=pk(Pf, 5 if b3 else 2)[0], shapes=shapes,
+                codes_c=Pc.get("framecodes.codes.weight"), codes_f=Pf.get("framecodes.codes.weight"))
 
 
 def _step(cfg, nets, inp, sl, precision):
     """forward + backward of rays `sl`; loss = sum over rays of |rgb - target|^2 on both heads (+ small terms on acc / disp)"""
     f = lambda k: inp[k][sl].contiguous()
+    code = cfg.framecode_ch > 0
     out, state = ops.train_forward(cfg, nets["fwd_c"], nets["fwd_f"], f("rb"), f("skts"), f("cyls"), S, NI, t_rand=f("t_rand"),
-                                   u_imp=f("u_imp"), noise=f("noise"), noise_fine=f("noise_fine"), precision=precision)
+                                   u_imp=f("u_imp"), noise=f("noise"), noise_fine=f("noise_fine"), precision=precision,
+                                   cam_idx=f("cam") if code else None, codes_c=nets["codes_c"], codes_f=nets["codes_f"])
     tgt = f("target")
     g = {"rgb_map": 2.0 * (out["rgb_map"] - tgt), "rgb0": 2.0 * (out["rgb0"] - tgt),
          "acc_map": torch.full_like(out["acc_map"], 0.01), "disp_map": torch.full_like(out["disp_map"], 1e-3)}
-    gc, gf, g_skts, _, _ = ops.backward(state, g, nets["t_c"], nets["t_f"], ap.perm_tables(cfg, torch.device("cuda"), b3=precision == "bf16x3"),
-                                        nets["shapes"], nets["shapes"], nets["i_c"], nets["i_f"], want_skts=True)
-    return {k: v.clone() for k, v in out.items()}, [t.clone() for t in gc + gf], g_skts.clone(), state["ws_bytes"]
+    gc, gf, g_skts, gcc, gcf = ops.backward(state, g, nets["t_c"], nets["t_f"], ap.perm_tables(cfg, torch.device("cuda"), b3=precision == "bf16x3"),
+                                            nets["shapes"], nets["shapes"], nets["i_c"], nets["i_f"], want_skts=True, want_codes_c=code,
+                                            want_codes_f=code)
+    extra = [gcc.clone(), gcf.clone()] if code else []
+    return {k: v.clone() for k, v in out.items()}, [t.clone() for t in gc + gf] + extra, g_skts.clone(), state["ws_bytes"]
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
-@pytest.mark.parametrize("n", [3072, 384])
-def test_full_size_training_step_properties(n, precision):
-    cfg = ops.PathConfig()
+@pytest.mark.parametrize("n,code", [(3072, 0), (384, 0), (3072, 16), (384, 16)])
+def test_full_size_training_step_properties(n, code, precision):
+    cfg = ops.PathConfig(framecode_ch=code)
     nets = _nets(cfg, precision)
     inp = _inputs(n)
     full = _step(cfg, nets, inp, slice(0, n), precision)
@@ -107,7 +119,8 @@ def test_full_size_training_step_properties(n, precision):
     per_sample = want / (n * (2 * S + NI))
     assert 10e3 < per_sample < 40e3, per_sample       # ~14 KB saved + ~10 KB backward planes per network evaluation
     io, out2, keep = ops._forward_io(cfg, nets["fwd_c"], nets["fwd_f"], inp["rb"], inp["skts"], inp["cyls"], S, NI, 20.0, 20.0, None, None,
-                                     None, None, None, inp["t_rand"], inp["u_imp"], inp["noise"], inp["noise_fine"], False, False, precision)
+                                     inp["cam"] if code else None, nets["codes_c"], nets["codes_f"], inp["t_rand"], inp["u_imp"],
+                                     inp["noise"], inp["noise_fine"], False, False, precision)
     guard = 1 << 20
     ws = torch.empty((want + guard) // 4, dtype=torch.float32, device="cuda")
     ws.view(torch.int32)[want // 4:] = 0x7FC0DEAD

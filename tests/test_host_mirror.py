@@ -119,3 +119,45 @@ def test_fused_adam_host_contract():
         optim.FusedAdam([ps[2]])
     with pytest.raises(NotImplementedError):
         optim.fused_nerf_loss({"rgb_map": torch.zeros(1, 3), "acc_map": torch.zeros(1)}, torch.zeros(1, 3), loss_fn="BCE")
+
+
+def test_fused_adam_overlap_refuses_a_second_backward_and_pending_group_state():
+    """(a) with overlap on, an early all-reduce that all_reduce_grads() has not consumed means a second backward of
+    the same step -- refused before anything is enqueued; step() / zero_grad() join and forget a stale handle.  (b) a state
+    loaded while the model is still on the host is returned per group by state_dict(group=g) (save_nerf splits it into the
+    reference's optimizer_state_dict / pose_optimizer_state_dict)."""
+    optim = importlib.import_module("a-nerf_amd.optim")
+
+    class Work:
+        waited = 0
+
+        def wait(self):
+            Work.waited += 1
+    ps = [torch.nn.Parameter(torch.randn(4, 3)), torch.nn.Parameter(torch.randn(6))]
+    pose = [torch.nn.Parameter(torch.randn(2, 24, 6))]
+    opt = optim.FusedAdam([{"params": ps}, {"params": pose, "step_every": 20}], lr=5e-4)
+    opt.enable_overlap()
+    opt.check_one_backward()                           # nothing pending: fine
+    opt._async = (Work(), 0, 12)
+    with pytest.raises(RuntimeError, match="second backward"):
+        opt.check_one_backward()
+    opt.zero_grad()                                    # a skipped all_reduce_grads(): the stale handle is joined and dropped
+    assert opt._async is None and Work.waited == 1
+    opt.check_one_backward()
+    opt.enable_overlap(False)
+    opt._async = (Work(), 0, 12)
+    opt.check_one_backward()                           # overlap off: accumulation over several backwards is allowed
+    opt._async = None
+    # (b) torch-format state for all three parameters, loaded before the buffers exist
+    ref = torch.optim.Adam([{"params": ps}, {"params": pose}], lr=5e-4)
+    for p in ps + pose:
+        p.grad = torch.ones_like(p)
+    ref.step()
+    sd = ref.state_dict()
+    opt.load_state_dict(sd)
+    assert opt._pending is not None
+    g0, g1, allg = opt.state_dict(group=0), opt.state_dict(group=1), opt.state_dict()
+    assert sorted(g0["state"]) == [0, 1] and sorted(g1["state"]) == [0] and sorted(allg["state"]) == [0, 1, 2]
+    assert torch.equal(g1["state"][0]["exp_avg"], sd["state"][2]["exp_avg"]) and g1["param_groups"][0]["params"] == [0]
+    assert torch.equal(g0["state"][1]["exp_avg_sq"], sd["state"][1]["exp_avg_sq"])
+    torch.optim.Adam(pose, lr=1.0).load_state_dict(g1)                     # what the reference's pose optimiser would load
