@@ -160,6 +160,8 @@ SIGNATURES = {
     "anerf_rand_fill": (C.c_int, [C.POINTER(AnerfRandJob), C.c_int32, C.c_uint64, C.c_uint64, C.c_void_p]),
     "anerf_make_ray_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p]),
     "anerf_cyl_bbox": (C.c_int, [C.c_void_p] * 5 + [C.c_int32, C.c_void_p, C.c_void_p]),
+    "anerf_kp_loss": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
+                                C.c_void_p]),
     "anerf_adam_blocks": (C.c_int, [C.c_int64]),
     "anerf_adam_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
                                   C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

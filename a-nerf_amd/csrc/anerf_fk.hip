@@ -294,7 +294,58 @@ __global__ __launch_bounds__(FKT) void k_fk_bwd(const float* __restrict__ bones,
 
 using namespace anerf;
 
+// ------------------------------------------------------------------------------------------------
+// Pose regulariser (_compute_kp_loss, core/trainer.py:382-403): per joint j >= 1 of a pose, d = (anchor - value)^2 per
+// component, thresholded "d > tol ? d - tol : 0", summed over the components, averaged over rays x 23 joints, x coef.
+// The reference evaluates it on the per-ray replicated batch; with w_u = (rays of pose u) / N it is the same number over the
+// U distinct poses.  One block, thread = (pose, joint); loss and its gradient w.r.t. the values in one pass (the gradient is
+// linear in the upstream scalar, which autograd applies).  value layout: vals [U,24,stride] with the first `dim` entries of
+// the 6 (rot6d: rots[..., :3, :2] row-major = entries (r, c) at 3 r + c of a 3x3 row-major matrix) or 3 (axis-angle bones).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_kp_loss(const float* __restrict__ vals, int rot6d, const float* __restrict__ anchors,
+                                                 const float* __restrict__ w, int U, float tol, float coef,
+                                                 float* __restrict__ loss, float* __restrict__ g_vals) {
+  __shared__ float sh[4];
+  float acc = 0.f;
+  const int dim = rot6d ? 6 : 3, stride = rot6d ? 9 : 3;
+  for (int i = threadIdx.x; i < U * 24; i += blockDim.x) {
+    const int u = i / 24, j = i - 24 * u;
+    const float wu = w[u] * coef / 23.0f;
+    for (int c = 0; c < dim; ++c) {
+      const int e = rot6d ? 3 * (c >> 1) + (c & 1) : c;        // rot6d component c = (row c / 2, column c % 2)
+      float g = 0.f;
+      if (j > 0) {
+        const float d = anchors[(long long)i * dim + c] - vals[(long long)i * stride + e];
+        const float d2 = d * d;
+        if (d2 > tol) {
+          acc += wu * (d2 - tol);
+          g = -2.0f * wu * d;
+        }
+      }
+      if (g_vals) g_vals[(long long)i * stride + e] = g;
+    }
+    if (g_vals && rot6d) {
+      g_vals[(long long)i * 9 + 2] = 0.f; g_vals[(long long)i * 9 + 5] = 0.f; g_vals[(long long)i * 9 + 8] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) *loss = sh[0] + sh[1] + sh[2] + sh[3];     // fixed order: bit-reproducible
+}
+
 extern "C" {
+
+int anerf_kp_loss(const float* values, int32_t rot6d, const float* anchors, const float* pose_weights, int32_t n_poses, float tol,
+                  float coef, float* loss, float* g_values, void* stream) {
+  if (n_poses < 0) return set_error(ANERF_E_SHAPE, "kp_loss: n_poses >= 0");
+  if (!loss) return set_error(ANERF_E_NULL, "kp_loss: loss is NULL");
+  if (n_poses > 0 && (!values || !anchors || !pose_weights)) return set_error(ANERF_E_NULL, "kp_loss: NULL pointer");
+  hipLaunchKernelGGL(k_kp_loss, dim3(1), dim3(256), 0, (hipStream_t)stream, values, (int)(rot6d != 0), anchors, pose_weights,
+                     (int)n_poses, tol, coef, loss, g_values);
+  return check_launch("k_kp_loss");
+}
 
 int anerf_fk_forward(const float* bones, int32_t rot_dim, const float* pelvis, const float* rest_pose,
                      int64_t rest_pose_stride, int32_t n_poses, float* l2ws, float* skts, float* rots, float* kp,

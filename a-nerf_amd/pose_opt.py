@@ -64,6 +64,35 @@ def expand_poses(x_u, inverse_idxs):
     return x_u[torch.as_tensor(inv, device=x_u.device)]
 
 
+class _KpLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, values, anchors, weights, rot6d, tol, coef):
+        import ctypes as C
+        from . import _lib
+        values, anchors, weights = ops._f32c(values, "values"), ops._f32c(anchors, "anchors"), ops._f32c(weights, "weights")
+        u = values.shape[0]
+        loss = torch.empty(1, dtype=torch.float32, device=values.device)
+        g = torch.empty_like(values) if values.requires_grad else None
+        _lib.check(_lib.load().anerf_kp_loss(ops._p(values), int(bool(rot6d)), ops._p(anchors), ops._p(weights), u, float(tol), float(coef),
+                                             ops._p(loss), ops._p(g), ops._stream()), "anerf_kp_loss")
+        ctx.g = g
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, go):
+        return (None if ctx.g is None else ctx.g * go), None, None, None, None, None
+
+
+def kp_loss(values, anchors, pose_weights, rot6d, tol, coef):
+    """Trainer._compute_kp_loss (core/trainer.py:382-403) over the U distinct poses of a batch in one launch each way.
+    values: rots [U,24,3,3] (rot6d = True; the reference compares rots[..., :3, :2]) or axis-angle bones [U,24,3];
+    anchors [U,24,6] / [U,24,3] (popt_anchors of those poses); pose_weights [U] = rays of pose u / N."""
+    want = (24, 3, 3) if rot6d else (24, 3)
+    if tuple(values.shape[1:]) != want or tuple(anchors.shape[1:]) != ((24, 6) if rot6d else (24, 3)) or anchors.shape[0] != values.shape[0]:
+        raise ValueError(f"kp_loss: values {tuple(values.shape)} / anchors {tuple(anchors.shape)} do not match rot6d={rot6d}")
+    return _KpLossFn.apply(values, anchors, pose_weights, rot6d, tol, coef)
+
+
 def calculate_kinematic(bones, pelvis, rest_pose):
     """(kp, skts, l2ws, rots) of axis-angle `bones` [U,24,3] or rot6d `bones` [U,24,6] (+ `pelvis` [U,3]);
     differentiable w.r.t. both."""
@@ -173,9 +202,12 @@ class PoseOptLayer(nn.Module):
     def idx_to_params(self, idx):
         """pose_opt.py:318-331"""
         idx = torch.as_tensor(np.asarray(idx), device=self.pelvis.device).long().reshape(-1)
+        # index_select: its backward is one index_add_ (idx holds distinct poses on the training path); `tensor[idx]` goes
+        # through index_put_'s sort-based backward (a radix sort + two kernels per parameter and step)
+        sel = lambda t, i: torch.index_select(t, 0, i)
         if self.kp_map is None:
-            return self.pelvis[idx], self.bones[idx]
-        return self.pelvis[idx], torch.cat([self.root_bones[idx, None, :], self.bones[self.kp_map[idx]]], dim=1)
+            return sel(self.pelvis, idx), sel(self.bones, idx)
+        return sel(self.pelvis, idx), torch.cat([sel(self.root_bones, idx)[:, None, :], sel(self.bones, self.kp_map[idx])], dim=1)
 
     def get_pelvis(self, idx=None):
         return self.idx_to_params(np.arange(self.N_kps) if idx is None else idx)[0]
@@ -199,6 +231,9 @@ class PoseOptLayer(nn.Module):
         rest = self.get_rest_pose(unique_idxs, rest_pose_idxs)
         pelvis, bone = self.idx_to_params(unique_idxs)
         kp, skts, l2ws, rots = calculate_kinematic(bone.contiguous(), pelvis.contiguous(), rest)
+        # what the regulariser needs per DISTINCT pose (kp_loss): the FK outputs before the per-ray expansion
+        self.last_unique = {"idxs": unique_idxs, "counts": np.bincount(inverse_idxs, minlength=len(unique_idxs)), "rots": rots,
+                            "bones": bone}
         return tuple(expand_poses(t, inverse_idxs) for t in (kp, bone, skts, l2ws, rots))
 
     @torch.no_grad()

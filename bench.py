@@ -460,7 +460,11 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
     cams = None
     if mixamo:
         pose_idx_host = np.asarray(pidx)[sl]
-        anchor6 = popt.bones.detach().clone()[torch.tensor(pose_idx_host, device=device)]     # popt_anchors (pose_opt.py:60-75)
+        # popt_anchors (pose_opt.py:60-75) of the batch's DISTINCT poses + their share of the rays: the regulariser
+        # (_compute_kp_loss) over them equals the reference's mean over the per-ray replicated batch
+        uniq, counts = np.unique(pose_idx_host, return_counts=True)
+        anchor_u = popt.bones.detach().clone()[torch.tensor(uniq, device=device)].contiguous()
+        w_u = torch.tensor(counts / float(len(pose_idx_host)), dtype=torch.float32, device=device)
         cams = torch.tensor(pose_idx_host, device=device).to(torch.float32)
     pk = {"density_scale": 1.0, "density_fn": torch.nn.functional.relu}
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -481,9 +485,8 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
                                 preproc_kwargs=pk, **b)
         loss, _ = (optim.fused_nerf_loss if fused else render_mod.nerf_loss)(out, target, bgs=1.0,
                                                                               loss_fn="L1" if mixamo else "MSE")
-        if mixamo:   # _compute_kp_loss (trainer.py:382-401; opt_pose_tol 0.01, opt_pose_coef 2.0, mixamo.txt:45,54)
-            d2 = (anchor6 - rots_r[..., :3, :2].flatten(start_dim=-2)).pow(2.)[:, 1:]
-            loss = loss + torch.lerp(torch.zeros_like(d2), d2 - 0.01, (d2 > 0.01).float()).sum(-1).mean() * 2.0
+        if mixamo:   # _compute_kp_loss (trainer.py:382-403; opt_pose_tol 0.01, opt_pose_coef 2.0, mixamo.txt:45,54), one launch
+            loss = loss + pose_opt.kp_loss(popt.last_unique["rots"], anchor_u, w_u, True, 0.01, 2.0)
         loss.backward()
         if i is not None:
             ev[i][1].record()
@@ -544,6 +547,16 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
         barrier()
         coll_alone_ms = e0.elapsed_time(e1) / 10
         opt.zero_grad()
+
+    if os.environ.get("ANERF_BENCH_TORCH_PROFILE") == "1" and rank == 0:
+        # developer aid (tools/): which torch ops still launch small kernels in a step, with the Python lines that issue them
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+        sys.stderr.write(prof.key_averages(group_by_stack_n=8).table(sort_by="self_cuda_time_total", row_limit=60,
+                                                                      max_name_column_width=60, max_src_column_width=110) + "\n")
 
     # Per-kernel HIP-event times (AnerfProfile: events recorded by the library around each MFMA kernel of both passes) over
     # a few extra, untimed steps -- the executed-FLOP roofline of every training kernel.  Executed FLOPs per sample: forward

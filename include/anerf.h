@@ -389,6 +389,15 @@ int anerf_train_forward(const AnerfConfig* cfg, const AnerfForwardIO* io, void* 
 int anerf_backward(const AnerfConfig* cfg, const AnerfForwardIO* io, const AnerfBackwardIO* b, void* workspace,
                    int64_t ws_bytes, void* scratch, int64_t scratch_bytes, void* stream);
 
+/* Pose regulariser of the pose-refinement step (Trainer._compute_kp_loss, core/trainer.py:382-403) and its gradient in one
+ * launch:  loss = coef * sum_u w_u / 23 * sum_{j >= 1, c} max-thresholded (anchor - value)^2  ("d > tol ? d - tol : 0"),
+ * over the U DISTINCT poses of the batch with pose_weights w_u = (rays of pose u) / N -- the value the reference computes
+ * on the per-ray replicated batch.  rot6d != 0 (opt_rot6d): values = rots [U,24,3,3] (FK output, columns 0..1 are used),
+ * anchors [U,24,6]; rot6d == 0: values = anchors-shaped axis-angle bones [U,24,3].  loss [1]; g_values (same shape as values,
+ * may be NULL) = d loss / d values, every element written. */
+int anerf_kp_loss(const float* values, int32_t rot6d, const float* anchors, const float* pose_weights, int32_t n_poses, float tol,
+                  float coef, float* loss, float* g_values, void* stream);
+
 /* ---- ABI revision 3: per-step host glue as single launches (the 384-rays-per-rank step) --------
  * Everything a training iteration does around the caster call used to be a string of small torch launches (4 weight-image
  * gathers, 2 x torch.rand + 2 x torch.randn + scaling, ones_like / norm / div / cat for the ray batch): ~0.3 ms of a
@@ -429,7 +438,9 @@ int anerf_make_ray_batch(const float* rays_o, const float* rays_d, int32_t n_ray
 
 /* 2-D pixel boxes of the projected bounding cylinders of F frames in one launch (cylinder_to_box_2d,
  * core/utils/skeleton_utils.py:607-690 + nerf_c2w_to_extrinsic :442, as kp_to_valid_rays uses them,
- * core/utils/ray_utils.py:83-136): per frame cyl [5], c2w [3,4] row-major (DOUBLE, as the reference computes them),
+ * core/utils/ray_utils.py:83-136): per frame cyl [5], c2w [3,4] row-major -- DOUBLE: the reference projects the cap points in
+ * float64 (it inverts the camera matrix in the dtype it arrives in; boxes agree unless a projected extreme lies within ~1e-5
+ * px of an integer) --,
  * hwf [4] = (H, W, fx, fy), off [2] = integer principal point; circle [50][2] = (cos, sin) of linspace(0, 2 pi, 50)
  * computed on the host.  bbox [F,4] int32 = (x0, y0, x1, y1), clipped to the image as the reference does. */
 int anerf_cyl_bbox(const double* cyls, const double* c2ws, const double* hwf, const int32_t* off, const double* circle,

@@ -279,3 +279,45 @@ def test_pose_refinement_closes_the_loop_through_the_ray_march(golden):
     _, oskts, _, _ = oracle.fk_chain(ob, torch.tensor(rest))
     oskts.backward(skts_rays.grad.sum(0, keepdim=True).cpu())
     np.testing.assert_allclose(gb, ob.grad.numpy(), atol=1e-6 + 2e-4 * np.abs(ob.grad.numpy()).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rot6d", [True, False])
+def test_fused_kp_loss_equals_the_reference_expression(rot6d):
+    """anerf_kp_loss over the distinct poses (weights = share of the rays) == Trainer._compute_kp_loss on the per-ray
+    replicated batch (core/trainer.py:382-403, restated in torch), value and gradient w.r.t. the pose parameters through the
+    FK layer; pose 0's rays outnumber the others' so the weights matter."""
+    po = importlib.import_module("a-nerf_amd.pose_opt")
+    poses = [synth.make_pose(k) for k in range(5)]
+    layer = po.PoseOptLayer(np.stack([q["kp"] for q in poses]), np.stack([q["bones"] for q in poses]),
+                            (synth.SMPL_REST_POSE * synth.SURREAL_SCALE)[None], use_rot6d=rot6d).cuda()
+    kp_idx = np.array([0] * 37 + [2] * 11 + [4] * 16 + [3] * 8)
+    tol, coef = 0.01, 2.0
+    with torch.no_grad():                      # anchors = the initial poses; move the parameters away from them
+        anchors_all = layer.bones.detach().clone()
+        layer.bones.add_(torch.randn_like(layer.bones) * 0.15)
+
+    def reference():
+        kps, bones, skts, _, rots = layer(kp_idx)
+        idx = torch.tensor(kp_idx, device="cuda")
+        reg = anchors_all[idx]
+        cur = rots[..., :3, :2].flatten(start_dim=-2) if rot6d else bones
+        d = (reg - cur).pow(2.)[:, 1:]
+        m = (d > tol).float()
+        return torch.lerp(torch.zeros_like(d), d - tol, m).sum(-1).mean() * coef
+    layer.zero_grad()
+    ref = reference()
+    ref.backward()
+    g_ref = layer.bones.grad.clone()
+    layer.zero_grad()
+    layer(kp_idx)
+    lu = layer.last_unique
+    assert list(lu["idxs"]) == [0, 2, 3, 4] and list(lu["counts"]) == [37, 11, 8, 16]
+    w = torch.tensor(lu["counts"] / float(len(kp_idx)), dtype=torch.float32, device="cuda")
+    anchors_u = anchors_all[torch.tensor(lu["idxs"], device="cuda")].contiguous()
+    got = po.kp_loss(lu["rots"] if rot6d else lu["bones"], anchors_u, w, rot6d, tol, coef)
+    assert float(ref) > 0 and abs(float(got) - float(ref)) <= 2e-6 * float(ref) + 1e-9
+    (3.0 * got).backward()
+    np.testing.assert_allclose(layer.bones.grad.cpu().numpy(), 3.0 * g_ref.cpu().numpy(), rtol=2e-5,
+                               atol=2e-6 * float(g_ref.abs().max()) * 3.0)
+    assert float(layer.bones.grad[1].abs().max()) == 0.0          # pose 1 is not in the batch
