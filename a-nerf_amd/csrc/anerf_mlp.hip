@@ -129,6 +129,53 @@ __device__ __forceinline__ void x_part(Pipe3F& pipe, f32x16 (&acc)[8], const flo
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// PRE (NeRF.forward seam, pre-encoded input rows): a run of k-groups whose B operands are float4 quads of the sample's input
+// row, with the discipline of k_mlp_bwd_in (anerf_mlp_bwd.hip): the quads of a stage are requested one per k-group during the
+// stage BEFORE (each lane gathers 16 bytes of its own row: 32 rows per wave-load, ~100 cycles of the CU's vector-memory path
+// apiece, never in bursts), are complete at that stage's barrier (vmcnt(0)), and are pinned in front of the weight pipe's
+// re-issue so that the compiler's counted waits for them never find freshly issued LDS-DMA pieces queued behind them.
+// Round 2 loaded every quad as four scalar dwords right in front of its k-group (alignment unknown to hipcc) and waited there:
+// 130 TFLOP/s against 143 for the fused kernel.
+// NB output blocks -> KPS = 32 / NB k-groups per stage.  KG0: index of the run's first k-group inside its weight segment (a
+// multiple of KPS); NKG k-groups, quad of k-group i at addr(i).  ENDS: the run ends its weight segment (the last k-group
+// closes the stage); otherwise the caller continues the segment with more k-groups.  `pending`: the pipe stands behind a
+// stage barrier whose re-issue is still to do.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));    // rows are only dword-aligned when x_width is odd (frame-code column)
+template <int NB, int KG0, int NKG, bool ENDS, class ADDR>
+__device__ __forceinline__ void pre_run(Pipe3F& pipe, f32x16 (&acc)[NB], ADDR addr, bool& pending) {
+  constexpr int KPS = STAGE_FRAGS / NB;
+  static_assert(KG0 % KPS == 0, "pre_run starts on a stage boundary");
+  f32x4 cur[KPS], nxt[KPS];
+#pragma unroll
+  for (int i = 0; i < KPS; ++i) cur[i] = i < NKG ? f32x4(*reinterpret_cast<const f32x4_u*>(addr(i))) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < (NKG + KPS - 1) / KPS; ++s) {
+#pragma unroll
+    for (int i = 0; i < KPS; ++i) asm volatile("" : "+v"(cur[i]));
+    if (pending) pipe.stage_refill();
+    pending = false;
+#pragma unroll
+    for (int ks = 0; ks < KPS; ++ks) {
+      const int i = KPS * s + ks;
+      if (i < NKG) {
+        if (i + KPS < NKG) nxt[ks] = f32x4(*reinterpret_cast<const f32x4_u*>(addr(i + KPS)));
+        else nxt[ks] = cur[ks];
+        __builtin_amdgcn_sched_barrier(0);     // the request goes in front of the k-group's MFMAs
+        kgroup<NB, Pipe3F, false>(pipe, acc, KG0 + i, false, ENDS && i == NKG - 1, cur[ks].x, cur[ks].y, cur[ks].z, cur[ks].w);
+      }
+    }
+    const bool stage_done = KPS * (s + 1) <= NKG || ENDS;      // a trailing partial stage is closed only when the segment ends
+    if (stage_done) {
+      pipe.stage_rendezvous();
+      pending = true;
+    }
+#pragma unroll
+    for (int i = 0; i < KPS; ++i) cur[i] = nxt[i];
+  }
+}
+
 // MODE 0: rays + depths -> raw [P,4].   MODE 1 (density query, raycasters.py:597-648): points A.z = pts [P,3] under ONE
 // shared pose -> sigma logit [P]; only the trunk (layers 0..7 + alpha head) runs, the stream stops after layer 7.
 template <int LV, int LD, int CODE, bool PRE, bool TRAIN, int MODE = 0>
@@ -257,7 +304,20 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
   float* hsave = TRAIN ? A.save_h + ps * 256 + 4 * h : nullptr;      // this lane's quads in plane 0; plane l at + l * plane
   const long long plane = TRAIN ? A.Ppad * 256 : 0;
   init_bias<8>(accA, aux_h + AUX_B0);
-  x_part<LV, PRE, TRAIN>(pipe, accA, v, wv, rh, xrow, h, TRAIN ? A.save_x + ps * DIMX : nullptr, true);
+  bool pre_pending = false;       // PRE: the pipe stands behind a stage barrier, re-issue still to do (pre_run)
+  // PRE: k-group kg's quad of the input row.  Distance-PE channels: columns 8 kg + 4 h ..; bone directions (stream order =
+  // joint-owned 3-vectors): 12 consecutive floats per joint quad and lane half
+  auto xaddr = [&](int kg) __attribute__((always_inline)) -> const float* {
+    constexpr int NV = 3 * (1 + 2 * LV);
+    return kg < NV ? xrow + 8 * kg + 4 * h : xrow + 24 * (1 + 2 * LV) + 24 * ((kg - NV) / 3) + 12 * h + 4 * ((kg - NV) % 3);
+  };
+  if constexpr (PRE) {
+    pre_run<8, 0, KGX, true>(pipe, accA, xaddr, pre_pending);
+    if (pre_pending) pipe.stage_refill();
+    pre_pending = false;
+  } else {
+    x_part<LV, PRE, TRAIN>(pipe, accA, v, wv, rh, xrow, h, TRAIN ? A.save_x + ps * DIMX : nullptr, true);
+  }
   // ---- layers 1..4: A -> B -> A -> B -> A
 #pragma unroll 1
   for (int L = 1; L <= 3; L += 2) {
@@ -276,7 +336,13 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
     for (int a = 0; a < 12; ++a) asm volatile("" : "+v"(v[a]), "+v"(wv[a]));
   }
   init_bias<8>(accB, aux_h + AUX_B0 + 256 * 5);
-  x_part<LV, PRE, false>(pipe, accB, v, wv, rh, xrow, h, nullptr, false);
+  if constexpr (PRE) {
+    pre_run<8, 0, KGX, false>(pipe, accB, xaddr, pre_pending);      // 54 k-groups: ends mid-stage, the hidden part continues it
+    if (pre_pending) pipe.stage_refill();
+    pre_pending = false;
+  } else {
+    x_part<LV, PRE, false>(pipe, accB, v, wv, rh, xrow, h, nullptr, false);
+  }
   take<8, true>(hb, accA);
   hidden_part_v<8, KGX, TRAIN>(pipe, accB, hb, false, true, hsave + 4 * plane);
   // ---- layers 6, 7: B -> A -> B
@@ -312,18 +378,14 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
     kgroup<4>(pipe, accv, 32 + kgu, false, kgu == NKGU - 1, b0, b1, b2, b3);
   };
   if constexpr (PRE) {
-#pragma unroll
-    for (int b = 0; b < 1 + 2 * LD; ++b)
-#pragma unroll
-      for (int g = 0; g < 9; ++g) {
-        float bb[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int a = (4 * g + t) / 3, c = (4 * g + t) % 3;
-          bb[t] = xrow[DIMX + 72 * b + 3 * (8 * (a >> 2) + (a & 3)) + c + 12 * h];
-        }
-        KGV(9 * b + g, bb[0], bb[1], bb[2], bb[3]);
-      }
+    // view-direction PE: band b, joint quad g / 3: 12 consecutive floats per lane half, as for the bone directions
+    auto uaddr = [&](int kgu) __attribute__((always_inline)) -> const float* {
+      return xrow + DIMX + 72 * (kgu / 9) + 24 * ((kgu % 9) / 3) + 12 * h + 4 * ((kgu % 9) % 3);
+    };
+    constexpr int NKD = DIMD / 8;       // 81 (9 with multires_views = 0)
+    pre_run<4, 32, NKD, CODE == 0>(pipe, accv, uaddr, pre_pending);
+    if (pre_pending) pipe.stage_refill();
+    pre_pending = false;
   } else {
     // per-ray unit direction in each owned bone frame, gated per sample by the distance gate (tau_d, cut_d).  The ray
     // direction is re-read here (12 bytes per lane, L2 hits) rather than kept in three VGPRs across the eight trunk layers,

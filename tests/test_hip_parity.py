@@ -90,6 +90,28 @@ def test_mlp_forward_preencoded_vs_oracle(oracle):
     close(out, ref, atol=2e-5, msg="mlp_forward")
 
 
+@pytest.mark.parametrize("cfg_kw,n_pts", [({}, 1), ({}, 129), ({"multires_views": 0}, 300), ({"framecode_ch": 16}, 257)])
+def test_mlp_forward_seam_variants_vs_oracle(oracle, synth, cfg_kw, n_pts):
+    """NeRF.forward seam (anerf_mlp_forward, nerf.py:133-148) for every built input width -- 1080, 504 (multires_views = 0:
+    a 9-k-group view part), 1081 (frame-code column: rows only dword-aligned) -- and ragged tile counts: the operand quads of
+    the pre-encoded rows are prefetched a stage ahead (pre_run), whose first / last stages differ per width."""
+    mv, fc = cfg_kw.get("multires_views", 4), cfg_kw.get("framecode_ch", 0)
+    Pn = synth.make_net_params(41, 7, mv, fc, 8 if fc else 0)
+    cfg = ops.PathConfig(**cfg_kw)
+    g = torch.Generator().manual_seed(n_pts)
+    X = (torch.rand(n_pts, cfg.dim_x + cfg.dim_d, generator=g) * 2 - 1) * 0.7
+    codes = None
+    if fc:
+        X = torch.cat([X, torch.randint(0, 8, (n_pts, 1), generator=g).float()], -1)
+        codes = torch.tensor(Pn["framecodes.codes.weight"]).cuda()
+    ref = oracle.mlp(oracle.OracleConfig(**cfg_kw), oracle.params_from_numpy(Pn), X)
+    packed, aux = ops.pack_params(cfg, cuda_params(Pn))
+    out = ops.mlp_forward(cfg, packed, aux, X.cuda(), codes)
+    close(out, ref, atol=3e-5, msg=f"mlp_forward {cfg_kw} P={n_pts}")
+    again = ops.mlp_forward(cfg, packed, aux, X.cuda(), codes)
+    assert torch.equal(out, again)
+
+
 def test_eval_s32_stages(oracle, golden):
     g = golden("eval_s32")
     c = build("eval_s32")
