@@ -28,8 +28,21 @@ constexpr int LDS_BONES_OFF = LDS_AUX_OFF + LDS_AUX_BYTES;        // MAX_TILE_RA
 // with the stores at all (ablation without weight loads: stores cost the same 0.24 ms), and hipcc either re-clusters
 // the pieces or, when they are fenced with sched_barrier masks, spills thousands of registers.
 // ------------------------------------------------------------------------------------------------
-template <bool ASMDMA>
+// STAGGER (fp32 kernels, round 3): a stage's refill is not issued by all four waves right behind the stage barrier but by wave
+// w behind quarter w of the stage's FIRST k-group (kgroup), i.e. 512 matrix clocks apart.  The CU has ONE texture-address
+// unit: 32 wave-instructions (4 waves x 8 pieces of 1 KiB) arriving at the same moment queue up in front of it, the last wave
+// starts its MFMAs ~400 clocks late and the next barrier waits for it.  tools/probe/mfma_probe_f32.hip, the stage of these
+// kernels without any VALU work (8 192 matrix clocks): MFMA + reads 8 231, + burst behind the barrier 8 601, + staggered by wave
+// 8 375 clocks; one piece per MFMA 8 921 and 2 pieces per k-group 8 609 are worse (every vector-memory instruction between
+// two MFMAs costs far more than its issue slot), one burst of 8 per wave with nobody else at the unit is the cheapest form.
+template <bool ASMDMA, bool STAGGER = false>
 struct Pipe3T {
+  static constexpr bool kStagger = STAGGER;
+  int refill_stage = -1;   // STAGGER: stage this wave still has to request into refill_slot (-1: none)
+  int refill_slot = 0;
+  int r_sel = 7;           // STAGGER: this wave's index while a refill is pending, else 7 (matches no quarter)
+  unsigned r_lds = 0;      // ... LDS address of the MIDDLE of this wave's 8 fragments in the slot being refilled
+  const char* r_g = nullptr;   // ... global address of the middle of this wave's 8 fragments of the stage being requested
   const char* gsrc;   // wave-UNIFORM source of this wave's first fragment of stage 0 (lane l adds lane16: saddr + voffset form)
   char* smem;
   unsigned wave_dst;  // wave-uniform LDS byte offset of this wave's 8 fragments inside a stage
@@ -129,10 +142,64 @@ struct Pipe3T {
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");   // stages +1 / +2 landed for everybody; slot `slot` is free
   }
   __device__ __forceinline__ void stage_refill() {
-    if (stage + RING_SLOTS < nstages) issue(stage + RING_SLOTS, slot);
+    if constexpr (STAGGER) {
+      refill_stage = stage + RING_SLOTS < nstages ? stage + RING_SLOTS : -1;
+      refill_slot = slot;
+      // operands of the staggered request, once per stage (4 SGPRs live instead of 7 recomputed at each of the four sites: the
+      // fused kernels run out of SGPRs otherwise and spill them into VGPRs).  Addresses of the MIDDLE of the wave's 8 KiB: the
+      // instruction's signed 13-bit offset (-4096 .. +3072) reaches all eight pieces from one base, for the global and the
+      // LDS address alike.
+      r_sel = refill_stage >= 0 ? wave : 7;
+      r_g = gsrc + (size_t)(refill_stage >= 0 ? refill_stage : 0) * STAGE_BYTES + 4 * FRAG_BYTES;
+      r_lds = (unsigned)reinterpret_cast<size_t>((lds_ptr_t)(smem + slot * STAGE_BYTES + wave_dst)) + 4 * FRAG_BYTES;
+      // wave 0's turn is right here, behind the barrier, in a "memory"-clobbering statement like the burst issue it replaces:
+      // without ANY such statement at this point the fused forward kernels allocate differently and spill ~430 VGPRs (the
+      // no-weight-loads ablation build shows the same) -- hipcc's schedule of that 250 KB straight-line kernel hangs on such details
+      staggered_issue<0, true>();
+    } else {
+      if (stage + RING_SLOTS < nstages) issue(stage + RING_SLOTS, slot);
+    }
     slot = slot == RING_SLOTS - 1 ? 0 : slot + 1;
     ++stage;
     set_offsets();
+  }
+  // STAGGER: called by kgroup behind quarter q of a stage's first k-group.  The slot being refilled was consumed in the stage
+  // before (freed by its barrier); the pieces have the rest of this stage (>= 6 000 matrix clocks) to land before its vmcnt(0).
+  // The wave test is a branch INSIDE the asm block: a C++ `if` around the issue would split every k-group's straight-line
+  // block in four and cost the fused kernels 9-14 spilled VGPRs.
+  template <int Q, bool MEMCLOBBER = false>
+  __device__ __forceinline__ void staggered_issue() {
+    constexpr int q = Q;
+#ifdef ANERF_EXP_NOGLDS
+    return;
+#endif
+    // Three properties of this asm statement decide between 0 and > 1000 spilled VGPRs in the fused kernels (tested one by one,
+    // compile-only): NO "memory" clobber -- the pieces go to the slot consumed in the stage before, which nothing the compiler
+    // knows of touches until the next stage barrier, and asm volatile statements keep their order among themselves --; NO
+    // "scc" clobber (an "scc" clobber in the middle of a stage's region alone, on an asm that does nothing else, costs 700+
+    // spills); and NO "vcc" clobber (fine in the backward kernels, but the fused forward kernels keep lane masks of the
+    // encoding in VCC / SGPR pairs and run out of SGPRs).  So the wave test is a VALU compare into a scratch SGPR pair that
+    // becomes EXEC: s_cbranch_execz skips the requests, EXEC is restored behind them.
+    unsigned long long save_exec, is_mine;
+    asm volatile("s_mov_b64 %0, exec\n\t"
+                 "v_cmp_eq_u32_e64 %1, %2, %3\n\t"          // all lanes: this wave's turn?  (VALU compare into an SGPR pair: no SCC, no VCC)
+                 "s_mov_b64 exec, %1\n\t"
+                 "s_cbranch_execz 1f\n\t"
+                 "s_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %5, %6 offset:-4096\n\t"
+                 "global_load_lds_dwordx4 %5, %6 offset:-3072\n\t"
+                 "global_load_lds_dwordx4 %5, %6 offset:-2048\n\t"
+                 "global_load_lds_dwordx4 %5, %6 offset:-1024\n\t"
+                 "global_load_lds_dwordx4 %5, %6\n\t"
+                 "global_load_lds_dwordx4 %5, %6 offset:1024\n\t"
+                 "global_load_lds_dwordx4 %5, %6 offset:2048\n\t"
+                 "global_load_lds_dwordx4 %5, %6 offset:3072\n"
+                 "1:\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(save_exec), "=&s"(is_mine) : "s"(r_sel), "n"(Q), "s"(r_lds), "v"(lane16), "s"(r_g) : "m0");
+    if constexpr (MEMCLOBBER) asm volatile("" ::: "memory");
+    if (q == 3) r_sel = 7;
+    if (q == 3) refill_stage = -1;
   }
   // end of the stage being consumed: its slot is refilled with stage+3
   __device__ __forceinline__ void end_stage() {
@@ -173,7 +240,20 @@ using Pipe3 = Pipe3T<false>;
 #else
 using Pipe3 = Pipe3T<true>;
 #endif
-using Pipe3F = Pipe3T<true>;    // fp32 forward / backward kernels
+using Pipe3F = Pipe3T<true, false>;   // fp32 forward kernels: burst behind the barrier.  With the staggered refill the fused forward
+                                      // kernels (250 KB of straight-line code at exactly 256 VGPRs) spill ~430 VGPRs whatever form
+                                      // the request takes -- even with the requests compiled out, as the no-weight-loads ablation
+                                      // build does; the backward kernels take it without a spill
+// fp32 backward kernels (k_mlp_bwd, k_mlp_bwd_in): they compile with the staggered refill without a spill, but run 4 % SLOWER
+// with it (k_mlp_bwd 1.71 -> 1.79 / 2.26 -> 2.33 ms per launch of the 3072-ray step, k_mlp_bwd_in 1.05 -> 1.08): their k-groups
+// carry ordinary vector loads (mask / operand quads) whose compiler-counted `s_waitcnt vmcnt(n)` also count the hidden DMA
+// pieces issued behind them, so a staggered burst in the middle of a stage turns those waits into waits for the DMA.  The
+// probe's 2.6 % (8 601 -> 8 375 clocks per stage) stays on the table: -DANERF_EXP_STAGGER builds the variant.
+#ifdef ANERF_EXP_STAGGER
+using Pipe3B = Pipe3T<true, true>;
+#else
+using Pipe3B = Pipe3T<true, false>;
+#endif
 
 // acc[nb][r] <- bias[n(nb,r,h)] from the LDS copy of the natural-order bias vector (bias_h = vector + 4h)
 template <int NB>
@@ -281,6 +361,15 @@ __device__ __forceinline__ void kgroup(PIPE& pipe, f32x16 (&acc)[NB], int kg, bo
   const char* csrc = pipe.smem + pipe.cur + ks * NB * FRAG_BYTES;                                   // this k-group
   const char* nsrc = boundary ? pipe.smem + pipe.nxt : csrc + NB * FRAG_BYTES;                      // the next one
   (void)first;
+  // STAGGER: wave w requests the stage's refill in front of k-group w * KPS / 4 of the stage (see Pipe3T).  Between k-groups,
+  // not between the quarters of the first one: an asm statement inside a k-group's MFMA / fragment-read stream makes hipcc spill
+  // > 1000 VGPRs in the fused kernels (as the round-2 attempt to spread the pieces over the k-groups did)
+  constexpr bool STAGGER_IN_QUARTERS = false;
+  if constexpr (PIPE::kStagger) {
+    if (ks == KPS / 4) pipe.template staggered_issue<1>();
+    else if (ks == 2 * (KPS / 4)) pipe.template staggered_issue<2>();
+    else if (ks == 3 * (KPS / 4)) pipe.template staggered_issue<3>();
+  }
   const float b[4] = {b0, b1, b2, b3};
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -291,6 +380,14 @@ __device__ __forceinline__ void kgroup(PIPE& pipe, f32x16 (&acc)[NB], int kg, bo
     const char* src = q < 2 ? csrc + (q + 2) * FPQ * FRAG_BYTES : nsrc + (q - 2) * FPQ * FRAG_BYTES;
 #pragma unroll
     for (int g = 0; g < FPQ; ++g) pipe.a[sl + g] = *reinterpret_cast<const f32x4*>(src + g * FRAG_BYTES);
+    if constexpr (PIPE::kStagger) {
+      if (STAGGER_IN_QUARTERS && ks == 0) {      // this wave's turn to request the stage's refill (Pipe3T, STAGGER)?
+        if (q == 0) pipe.template staggered_issue<0>();
+        else if (q == 1) pipe.template staggered_issue<1>();
+        else if (q == 2) pipe.template staggered_issue<2>();
+        else pipe.template staggered_issue<3>();
+      }
+    }
     // fence (only VALU / SALU may cross): left alone, the scheduler sinks these reads to just in front of their first use
     __builtin_amdgcn_sched_barrier(0x6);
   }

@@ -113,7 +113,7 @@ __device__ __forceinline__ void load_quads(f32x4 (&mk)[4], const float* __restri
 // of prev's block 0 (MASK) and the pipe stands right behind a stage barrier with its re-issue still to do (`pending`),
 // or -- first layer of the chain -- somewhere inside a running stage (`pending` false).
 template <bool MASK, bool LAST, int KG0>
-__device__ __forceinline__ void bwd_layer(Pipe3F& pipe, f32x16 (&out)[8], const f32x16 (&prev)[8], f32x4 (&mk)[4],
+__device__ __forceinline__ void bwd_layer(Pipe3B& pipe, f32x16 (&out)[8], const f32x16 (&prev)[8], f32x4 (&mk)[4],
                                           const float* __restrict__ prev_mask_row_h, float* __restrict__ prev_dz_row_h,
                                           const float* __restrict__ next_mask_row_h, f32x4 (&mk0)[32], bool& pending) {
   float bq[16];
@@ -157,7 +157,7 @@ __device__ __forceinline__ void bwd_layer(Pipe3F& pipe, f32x16 (&out)[8], const 
       if constexpr (LAST) mk0[4 * s + ks] = f32x4{1.f, 1.f, 1.f, 1.f};
 #endif
       __builtin_amdgcn_sched_barrier(0);     // the store / load go in front of the k-group's MFMAs
-      kgroup<8, Pipe3F, false>(pipe, out, KG0 + kg, false, false, o.x, o.y, o.z, o.w);
+      kgroup<8, Pipe3B, false>(pipe, out, KG0 + kg, false, false, o.x, o.y, o.z, o.w);
     }
     pipe.stage_rendezvous();
     pending = true;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd(const BwdArgs A) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 31, h = lane >> 5;
-  Pipe3F pipe;
+  Pipe3B pipe;
   pipe.init(A.packed_t, smem, wave, lane, A.nstages);
 #ifdef ANERF_EXP_STAGE_TIMING
   const unsigned long long tt0 = __builtin_amdgcn_s_memtime(), tr0 = __builtin_amdgcn_s_memrealtime();
@@ -301,7 +301,7 @@ struct BwdInArgs {
 // every k-group requests one quad of the next stage (of `next_src_row_h`, the next segment's row, at the end) and writes SPK
 // float4 of the PREVIOUS output group (`outv`, columns out_c0.. of out_row_h, width out_w) -- no load or store bursts.
 template <int NKG, int SPK>
-__device__ __forceinline__ void bwd_in_segment(Pipe3F& pipe, f32x16 (&acc)[8], f32x4 (&cur)[4], const float* __restrict__ src_row_h,
+__device__ __forceinline__ void bwd_in_segment(Pipe3B& pipe, f32x16 (&acc)[8], f32x4 (&cur)[4], const float* __restrict__ src_row_h,
                                                const float* __restrict__ next_src_row_h, const float (&outv)[128],
                                                float* __restrict__ out_row_h, int out_c0, int out_w, bool& pending) {
 #pragma unroll
@@ -327,7 +327,7 @@ __device__ __forceinline__ void bwd_in_segment(Pipe3F& pipe, f32x16 (&acc)[8], f
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      kgroup<8, Pipe3F, false>(pipe, acc, kg, false, false, cur[ks].x, cur[ks].y, cur[ks].z, cur[ks].w);
+      kgroup<8, Pipe3B, false>(pipe, acc, kg, false, false, cur[ks].x, cur[ks].y, cur[ks].z, cur[ks].w);
     }
     pipe.stage_rendezvous();
     pending = true;
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_in(const BwdInArgs A) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 31, h = lane >> 5;
-  Pipe3F pipe;
+  Pipe3B pipe;
   pipe.init(A.packed_i, smem, wave, lane, A.nstages);
   const long long p = (long long)blockIdx.x * TILE + wave * 32 + m;
   const long long pc = p < A.P ? p : A.P - 1;      // tail lanes recompute the last valid row and rewrite it with identical values

@@ -199,9 +199,25 @@ class PoseOptLayer(nn.Module):
             return self.rest_pose[rest_pose_idxs]
         return self.rest_pose[self.rest_pose_idxs[kp_idxs]]
 
+    def _device_index(self, idx):
+        """pose indices as an int64 device tensor.  A host array is uploaded ONCE per distinct content and kept: the upload of
+        pageable host memory is a blocking copy queued behind everything already on the stream -- one per training step made
+        every step end in a host sync (the reference pays it too: `kp_idx.cpu().numpy()`, trainer.py:297-299)."""
+        if torch.is_tensor(idx):
+            return idx.to(self.pelvis.device).long().reshape(-1)
+        arr = np.ascontiguousarray(np.asarray(idx).reshape(-1).astype(np.int64))
+        cache = self.__dict__.setdefault("_idx_cache", {})
+        key = (arr.tobytes(), str(self.pelvis.device))
+        hit = cache.get(key)
+        if hit is None:
+            if len(cache) > 256:
+                cache.clear()
+            hit = cache[key] = torch.as_tensor(arr, device=self.pelvis.device)
+        return hit
+
     def idx_to_params(self, idx):
         """pose_opt.py:318-331"""
-        idx = torch.as_tensor(np.asarray(idx), device=self.pelvis.device).long().reshape(-1)
+        idx = self._device_index(idx)
         # index_select: its backward is one index_add_ (idx holds distinct poses on the training path); `tensor[idx]` goes
         # through index_put_'s sort-based backward (a radix sort + two kernels per parameter and step)
         sel = lambda t, i: torch.index_select(t, 0, i)
