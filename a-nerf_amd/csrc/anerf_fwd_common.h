@@ -89,6 +89,33 @@ struct Pipe3T {
         __builtin_amdgcn_global_load_lds((glb_ptr_t)(g + i * FRAG_BYTES + lane16), (lds_ptr_t)(l + i * FRAG_BYTES), 16, 0, 0);
     }
   }
+  // the burst issue's two statements (same operands, same clobbers), executed by wave 0 only: EXEC is cleared for the others
+  __device__ __forceinline__ void issue_wave0(int s, int sl) {
+#ifdef ANERF_EXP_NOGLDS
+    (void)s; (void)sl; return;
+#endif
+    const char* g = gsrc + (size_t)s * STAGE_BYTES;
+    char* l = smem + sl * STAGE_BYTES + wave_dst;
+    const unsigned lds0 = (unsigned)reinterpret_cast<size_t>((lds_ptr_t)l);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      unsigned long long save_exec, is_mine;
+      asm volatile("s_mov_b64 %0, exec\n\t"
+                   "v_cmp_eq_u32_e64 %1, %5, 0\n\t"
+                   "s_nop 3\n\t"
+                   "s_mov_b64 exec, %1\n\t"
+                   "s_cbranch_execz 1f\n\t"
+                   "s_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %3, %4\n\t"
+                   "global_load_lds_dwordx4 %3, %4 offset:1024\n\t"
+                   "global_load_lds_dwordx4 %3, %4 offset:2048\n\t"
+                   "global_load_lds_dwordx4 %3, %4 offset:3072\n"
+                   "1:\n\t"
+                   "s_mov_b64 exec, %0"
+                   : "=&s"(save_exec), "=&s"(is_mine)
+                   : "s"(lds0 + half * 4 * FRAG_BYTES), "v"(lane16), "s"(g + half * 4 * FRAG_BYTES), "s"(wave_dst) : "memory", "m0");
+    }
+  }
   __device__ __forceinline__ void set_offsets() {
     cur = lane16 + slot * STAGE_BYTES;
     nxt = lane16 + (slot == RING_SLOTS - 1 ? 0 : slot + 1) * STAGE_BYTES;
@@ -152,10 +179,11 @@ struct Pipe3T {
       r_sel = refill_stage >= 0 ? wave : 7;
       r_g = gsrc + (size_t)(refill_stage >= 0 ? refill_stage : 0) * STAGE_BYTES + 4 * FRAG_BYTES;
       r_lds = (unsigned)reinterpret_cast<size_t>((lds_ptr_t)(smem + slot * STAGE_BYTES + wave_dst)) + 4 * FRAG_BYTES;
-      // wave 0's turn is right here, behind the barrier, in a "memory"-clobbering statement like the burst issue it replaces:
-      // without ANY such statement at this point the fused forward kernels allocate differently and spill ~430 VGPRs (the
-      // no-weight-loads ablation build shows the same) -- hipcc's schedule of that 250 KB straight-line kernel hangs on such details
-      staggered_issue<0, true>();
+      // wave 0's turn is right here, behind the barrier, and in EXACTLY the statement form of the burst issue it replaces (two
+      // "memory"-clobbering statements with its operand lists, issue_wave0): with any other form at this point -- or none, as
+      // in the no-weight-loads ablation build -- the fused forward kernels allocate differently and spill ~430 VGPRs; hipcc's
+      // schedule of that 250 KB straight-line kernel hangs on such details
+      if (stage + RING_SLOTS < nstages) issue_wave0(stage + RING_SLOTS, slot);
     } else {
       if (stage + RING_SLOTS < nstages) issue(stage + RING_SLOTS, slot);
     }
@@ -163,11 +191,11 @@ struct Pipe3T {
     ++stage;
     set_offsets();
   }
-  // STAGGER: called by kgroup behind quarter q of a stage's first k-group.  The slot being refilled was consumed in the stage
-  // before (freed by its barrier); the pieces have the rest of this stage (>= 6 000 matrix clocks) to land before its vmcnt(0).
-  // The wave test is a branch INSIDE the asm block: a C++ `if` around the issue would split every k-group's straight-line
-  // block in four and cost the fused kernels 9-14 spilled VGPRs.
-  template <int Q, bool MEMCLOBBER = false>
+  // STAGGER: called by kgroup at the top of k-group Q * KPS / 4 of a stage (Q = 1..3).  The slot being refilled was consumed in the
+  // stage before (freed by its barrier); the pieces have the rest of this stage (>= 2 000 matrix clocks) to land before its
+  // vmcnt(0).  The wave test is a branch INSIDE the asm block: a C++ `if` around the issue would split the stage's straight-line
+  // block and cost the fused kernels 9-14 spilled VGPRs.
+  template <int Q>
   __device__ __forceinline__ void staggered_issue() {
     constexpr int q = Q;
 #ifdef ANERF_EXP_NOGLDS
@@ -183,6 +211,7 @@ struct Pipe3T {
     unsigned long long save_exec, is_mine;
     asm volatile("s_mov_b64 %0, exec\n\t"
                  "v_cmp_eq_u32_e64 %1, %2, %3\n\t"          // all lanes: this wave's turn?  (VALU compare into an SGPR pair: no SCC, no VCC)
+                 "s_nop 3\n\t"                              // (inline asm is invisible to the hazard recognizer: VALU-written SGPR -> SALU)
                  "s_mov_b64 exec, %1\n\t"
                  "s_cbranch_execz 1f\n\t"
                  "s_mov_b32 m0, %4\n\ts_nop 0\n\t"
@@ -197,7 +226,6 @@ struct Pipe3T {
                  "1:\n\t"
                  "s_mov_b64 exec, %0"
                  : "=&s"(save_exec), "=&s"(is_mine) : "s"(r_sel), "n"(Q), "s"(r_lds), "v"(lane16), "s"(r_g) : "m0");
-    if constexpr (MEMCLOBBER) asm volatile("" ::: "memory");
     if (q == 3) r_sel = 7;
     if (q == 3) refill_stage = -1;
   }
@@ -240,10 +268,17 @@ using Pipe3 = Pipe3T<false>;
 #else
 using Pipe3 = Pipe3T<true>;
 #endif
-using Pipe3F = Pipe3T<true, false>;   // fp32 forward kernels: burst behind the barrier.  With the staggered refill the fused forward
-                                      // kernels (250 KB of straight-line code at exactly 256 VGPRs) spill ~430 VGPRs whatever form
-                                      // the request takes -- even with the requests compiled out, as the no-weight-loads ablation
-                                      // build does; the backward kernels take it without a spill
+// fp32 forward kernels.  Round 3 built the staggered refill into them (it needs wave 0's share in the burst issue's exact statement
+// form at the barrier, issue_wave0, and the other waves' asm without "memory" / "scc" / "vcc" clobbers: any other form spills
+// hundreds of VGPRs) and measured it same-box against the burst (tools/microbench_mlp.py, 65 536 rays x 64 samples): fused 143.1-
+// 143.6 TFLOP/s with the burst, 140.7-141.3 staggered (sites at k-groups 1/2/3, 1/2/2 or 1/1/1 alike); pre-encoded 143.6 vs 139.9-
+// 141.1.  The probe's 2.6 % does not survive the real kernels: three more asm sites per stage (+10 % code in a kernel that is
+// 250 KB of straight-line code), a VALU compare + EXEC juggling at each inside the fp32 MFMA stream.  -DANERF_EXP_STAGGER rebuilds it.
+#ifdef ANERF_EXP_STAGGER
+using Pipe3F = Pipe3T<true, true>;
+#else
+using Pipe3F = Pipe3T<true, false>;
+#endif
 // fp32 backward kernels (k_mlp_bwd, k_mlp_bwd_in): they compile with the staggered refill without a spill, but run 4 % SLOWER
 // with it (k_mlp_bwd 1.71 -> 1.79 / 2.26 -> 2.33 ms per launch of the 3072-ray step, k_mlp_bwd_in 1.05 -> 1.08): their k-groups
 // carry ordinary vector loads (mask / operand quads) whose compiler-counted `s_waitcnt vmcnt(n)` also count the hidden DMA
@@ -361,14 +396,22 @@ __device__ __forceinline__ void kgroup(PIPE& pipe, f32x16 (&acc)[NB], int kg, bo
   const char* csrc = pipe.smem + pipe.cur + ks * NB * FRAG_BYTES;                                   // this k-group
   const char* nsrc = boundary ? pipe.smem + pipe.nxt : csrc + NB * FRAG_BYTES;                      // the next one
   (void)first;
-  // STAGGER: wave w requests the stage's refill in front of k-group w * KPS / 4 of the stage (see Pipe3T).  Between k-groups,
-  // not between the quarters of the first one: an asm statement inside a k-group's MFMA / fragment-read stream makes hipcc spill
-  // > 1000 VGPRs in the fused kernels (as the round-2 attempt to spread the pieces over the k-groups did)
-  constexpr bool STAGGER_IN_QUARTERS = false;
+  // STAGGER: wave w requests the stage's refill in front of k-group w * KPS / 4 of the stage (see Pipe3T): between k-groups, not
+  // between the quarters of one (the probe's other staggered form, same gain).
   if constexpr (PIPE::kStagger) {
-    if (ks == KPS / 4) pipe.template staggered_issue<1>();
-    else if (ks == 2 * (KPS / 4)) pipe.template staggered_issue<2>();
-    else if (ks == 3 * (KPS / 4)) pipe.template staggered_issue<3>();
+    // wave 0 requested its share right behind the stage barrier (stage_refill); wave Q's site is the top of k-group Q * KPS / 4.
+    // A segment's last stage may be short (layer 0 / 5: 54 / 86 k-groups of 4 per stage): its final k-group (`last`) is also the
+    // site of every wave whose own one does not exist in this stage.
+    constexpr int QK = KPS / 4;
+#ifndef ANERF_STAGGER_S1      // site (in quarters of a stage) of waves 1, 2, 3: experiment knobs
+#define ANERF_STAGGER_S1 1
+#define ANERF_STAGGER_S2 2
+#define ANERF_STAGGER_S3 3
+#endif
+    constexpr int K1 = ANERF_STAGGER_S1 * QK, K2 = ANERF_STAGGER_S2 * QK, K3 = ANERF_STAGGER_S3 * QK;
+    if (ks == K1 || (last && ks < K1)) pipe.template staggered_issue<1>();
+    if (ks == K2 || (last && ks < K2)) pipe.template staggered_issue<2>();
+    if (ks == K3 || (last && ks < K3)) pipe.template staggered_issue<3>();
   }
   const float b[4] = {b0, b1, b2, b3};
 #pragma unroll
@@ -380,14 +423,6 @@ __device__ __forceinline__ void kgroup(PIPE& pipe, f32x16 (&acc)[NB], int kg, bo
     const char* src = q < 2 ? csrc + (q + 2) * FPQ * FRAG_BYTES : nsrc + (q - 2) * FPQ * FRAG_BYTES;
 #pragma unroll
     for (int g = 0; g < FPQ; ++g) pipe.a[sl + g] = *reinterpret_cast<const f32x4*>(src + g * FRAG_BYTES);
-    if constexpr (PIPE::kStagger) {
-      if (STAGGER_IN_QUARTERS && ks == 0) {      // this wave's turn to request the stage's refill (Pipe3T, STAGGER)?
-        if (q == 0) pipe.template staggered_issue<0>();
-        else if (q == 1) pipe.template staggered_issue<1>();
-        else if (q == 2) pipe.template staggered_issue<2>();
-        else pipe.template staggered_issue<3>();
-      }
-    }
     // fence (only VALU / SALU may cross): left alone, the scheduler sinks these reads to just in front of their first use
     __builtin_amdgcn_sched_barrier(0x6);
   }
