@@ -10,5 +10,6 @@ run render64_bf16x3 --precision bf16x3 --steps 3
 run hier128_bf16x3 --workload hier128 --precision bf16x3 --steps 2
 run train3072 --workload train --steps 10
 run train384 --workload train --n-rand 384 --steps 20
+run train_mixamo384 --workload train_mixamo --n-rand 384 --opt-pose-step 20 --steps 20
 run train_mixamo --workload train_mixamo --steps 10
 ls -la gpurun_out/${TAG}_*summary.txt
