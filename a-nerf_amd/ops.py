@@ -419,8 +419,21 @@ class Profile:
 
     SLOTS = {"fwd": 0, "bwd": 4, "gemm": 8, "bwd_in": 12}       # ANERF_PROF_* of include/anerf.h; + 2 * pass (0 coarse, 1 fine)
 
+    @staticmethod
+    def _hip_runtime():
+        """the HIP runtime ALREADY mapped into this process (torch ships its own copy next to the system one: opening the bare
+        soname could map a second runtime whose events the library's stream would not know)"""
+        try:
+            for line in open("/proc/self/maps"):
+                path = line.rsplit(" ", 1)[-1].strip()
+                if "libamdhip64.so" in path and path.startswith("/"):
+                    return C.CDLL(path)
+        except OSError:
+            pass
+        return C.CDLL("libamdhip64.so")
+
     def __init__(self):
-        self.hip = C.CDLL("libamdhip64.so")
+        self.hip = self._hip_runtime()
         self.hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
         self.hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
         self.hip.hipEventDestroy.argtypes = [C.c_void_p]

@@ -72,7 +72,7 @@ class _KpLossFn(torch.autograd.Function):
         values, anchors, weights = ops._f32c(values, "values"), ops._f32c(anchors, "anchors"), ops._f32c(weights, "weights")
         u = values.shape[0]
         loss = torch.empty(1, dtype=torch.float32, device=values.device)
-        g = torch.empty_like(values) if values.requires_grad else None
+        g = torch.empty_like(values) if ctx.needs_input_grad[0] else None
         _lib.check(_lib.load().anerf_kp_loss(ops._p(values), int(bool(rot6d)), ops._p(anchors), ops._p(weights), u, float(tol), float(coef),
                                              ops._p(loss), ops._p(g), ops._stream()), "anerf_kp_loss")
         ctx.g = g
