@@ -228,6 +228,8 @@ def extra_workloads(args, device, synth, ops, pipeline):
         a.steps, a.warmup, a.cpu_rays, a.extra = 5, 1, 0, "off"
         for k, v in over.items():
             setattr(a, k, v)
+        if a.workload in ("train", "train_mixamo") and a.n_rand <= 512:
+            a.steps = 20          # 2-3 ms steps: 5 of them are a 12 ms window, one scheduler hiccup away from a wrong number
         try:
             if a.workload in ("train", "train_mixamo"):
                 r = bench_train(a, 0, 1, device, None, synth, mixamo=a.workload == "train_mixamo")
