@@ -207,6 +207,59 @@ __global__ __launch_bounds__(256) void k_probe(const char* __restrict__ wstream0
     if (threadIdx.x == 0) { clocks[2 * blockIdx.x] = t1 - t0; clocks[2 * blockIdx.x + 1] = r1 - r0; }
     return;
   }
+  if (DMA == 8) {
+    // weights through REGISTERS instead of LDS-DMA: global_load_dwordx4 into 8 staging registers during stage s, ds_write_b128
+    // into the freed slot at the top of stage s + 1 (LDS writes at the full 128 B/clk instead of the DMA's ~57)
+    f32x4 stg[8];
+    long long go = 3LL * STAGE_BYTES;
+    int sl = 0;
+    const char* gw = wstream + wave * 8 * FRAG + lane16;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) stg[i] = *reinterpret_cast<const f32x4*>(gw + go + i * FRAG);
+    if (READS == 3) rd(fa, smem + lane16, 0, 0, 4);
+    for (int st = 0; st < stages; ++st) {
+      const char* cur = smem + sl * STAGE_BYTES + lane16;
+      const int nsl = sl == 2 ? 0 : sl + 1, fill = sl == 0 ? 2 : sl - 1;
+      const char* nxt = smem + nsl * STAGE_BYTES + lane16;
+      // top of the stage: last stage's staged registers -> the slot freed by the barrier; request the next stage's
+      char* dstl = smem + fill * STAGE_BYTES + wave * 8 * FRAG + lane16;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(dstl + i * FRAG) = stg[i];
+      go += STAGE_BYTES;
+      if (go + STAGE_BYTES > stream_bytes) go = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) stg[i] = *reinterpret_cast<const f32x4*>(gw + go + i * FRAG);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int b0 = (gq & 1) * 4;
+        if (gq < 2) mm(fa, b0); else mm(fb, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (READS == 3) {
+          if (gq == 0) rd(fa, cur, 0, 4, 4);
+          else if (gq == 1) rd(fb, cur, 1, 0, 4);
+          else if (gq == 2) rd(fb, cur, 1, 4, 4);
+          else rd(fa, nxt, 0, 0, 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (gq < 2) { mm(fa, b0 + 1); mm(fa, b0 + 2); mm(fa, b0 + 3); }
+        else { mm(fb, b0 + 1); mm(fb, b0 + 2); mm(fb, b0 + 3); }
+      }
+      __syncthreads();
+      sl = nsl;
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[b][r];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += stg[i][0];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0) { clocks[2 * blockIdx.x] = t1 - t0; clocks[2 * blockIdx.x + 1] = r1 - r0; }
+    return;
+  }
   if (READS == 2) rd(fa, smem + lane16, 0, 0, 8);
   if (READS == 3) rd(fa, smem + lane16, 0, 0, 4);
   for (int st = 0; st < stages; ++st) {
@@ -335,6 +388,8 @@ int main() {
   run<6, 0, 1>("NO MFMA: LDS-DMA only, spread, 4-slot (32 KiB / stage and CU)", w, stream_bytes, out, clocks, blocks, stages);
   run<6, 3, 1>("NO MFMA: fragment reads + LDS-DMA", w, stream_bytes, out, clocks, blocks, stages);
   run<2, 0, 1>("NO MFMA: LDS-DMA only, burst + vmcnt(0) + barrier, 3-slot", w, stream_bytes, out, clocks, blocks, stages);
+  run<8, 0>("weights through registers (global_load + ds_write), no reads", w, stream_bytes, out, clocks, blocks, stages);
+  run<8, 3>("weights through registers (global_load + ds_write), reads one group ahead", w, stream_bytes, out, clocks, blocks, stages);
   run<3, 0>("hidden DMA HALF volume (16 KiB / stage) + raw barrier, no reads", w, stream_bytes, out, clocks, blocks, stages);
   run<4, 0>("hidden DMA, vmcnt(0) but NO barrier, no reads", w, stream_bytes, out, clocks, blocks, stages);
   run<5, 0>("barrier only (no DMA), no reads", w, stream_bytes, out, clocks, blocks, stages);
