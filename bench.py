@@ -6,12 +6,17 @@ forward-only render (ray bounds -> z -> fused encode+MLP -> composite), fp32.  O
 With --gpus N the frame's rays are split into N contiguous slices (strong scaling: total work fixed), one
 process per GPU, and the per-ray outputs are all-gathered over RCCL at the end of every step.
 
-  python bench.py [--gpus N --steps K --warmup W] [--workload render64|hier|render64x64]
+  python bench.py [--gpus N --steps K --warmup W] [--workload render64|hier|hier128|render64x64|train|train_mixamo]
+
+--gpus N > 1 from a plain shell starts N ranks of this script (one per GPU, RCCL, rendezvous on 127.0.0.1); under
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it joins the ranks it is given.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel
 (k_mlp_fwd, MFMA-bound: algorithmic FLOPs / HIP-event time on the launch stream vs the 157.3 TFLOP/s fp32
-matrix peak) and `cpu_baseline` (the torch-CPU oracle = port of the reference path, timed on this host's
-cores over a bounded ray sample of the same frame).
+matrix peak; training workloads: the FLOPs the kernels execute, with a per-kernel list), `cpu_baseline` (the torch-CPU
+oracle = port of the reference path, timed on this host's cores over a bounded ray sample of the same frame), who ran
+(`ranks`, `backend`, `devices`, per-rank and collective times) and, for the default invocation, `extra_workloads`
+(BASELINE configs 3, 4 and 5 under the same clock).
 """
 import argparse
 import importlib
