@@ -239,3 +239,51 @@ def test_bench_launches_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--workload", "render64x64",
                         "--cpu-rays", "0"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode != 0 and r.stdout.strip() == ""
+
+
+@pytest.mark.gpu
+def test_caster_draws_its_randomness_from_the_device_rng():
+    """The non-pytest training call (perturb, raw_noise_std, ray_noise_std all on): every random input comes from ONE
+    anerf_rand_fill launch of the caster's DeviceRng -- same seed and offset => bit-identical outputs and gradients, the next call
+    differs, and the draws do what the reference's do (jittered depths differ from the deterministic ones)."""
+    networks = importlib.import_module("a-nerf_amd.networks")
+    raycaster = importlib.import_module("a-nerf_amd.raycaster")
+    render_mod = importlib.import_module("a-nerf_amd.render")
+    d = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32, device="cuda")
+    kw = dict(D=8, W=256, input_ch=360, input_ch_bones=72, input_ch_views=648, use_viewdirs=True)
+    net_c, net_f = networks.NeRF(**kw), networks.NeRF(**kw)
+    net_c.load_state_dict({k: torch.tensor(v) for k, v in synth.make_net_params(11).items()})
+    net_f.load_state_dict({k: torch.tensor(v) for k, v in synth.make_net_params(12).items()})
+    ck = {"cutoff": True, "cutoff_dist": 0.5, "cutoff_inputs": True, "cutoff_dim": 24}
+    e_v, _ = networks.get_embedder(7, input_dims=24, cutoff_kwargs=dict(ck, dist_inputs=False))
+    e_b, _ = networks.get_embedder(0, input_dims=72, cutoff_kwargs={"cutoff": False})
+    e_d, _ = networks.get_embedder(4, input_dims=72, cutoff_kwargs=dict(ck, dist_inputs=True))
+    caster = raycaster.RayCaster(net_c, e_v, e_b, e_d, network_fine=net_f).cuda()
+    caster.train()
+    ro, rd, kp, skts, bones, cyls, _ = synth.scene_batch(96, [0, 1], ray_seed=7, per_ray_pose=True)
+
+    def run(seed, ray_noise=0.05, perturb=1.0, raw_noise=1.0):
+        if seed is not None:
+            caster._rng = ops.DeviceRng(seed)
+        for p in caster.parameters():
+            p.grad = None
+        out = render_mod.render(64, 64, 75.0, chunk=4096, rays=(d(ro), d(rd)), use_viewdirs=True, ray_caster=caster, kp_batch=d(kp),
+                                skts=d(skts), cyls=d(cyls), bones=d(bones), cams=None, subject_idxs=None, N_samples=24, N_importance=8,
+                                perturb=perturb, raw_noise_std=raw_noise, ray_noise_std=ray_noise,
+                                preproc_kwargs={"density_scale": 1.0, "density_fn": torch.nn.functional.relu})
+        (out["rgb_map"].sum() + out["rgb0"].sum()).backward()
+        g = torch.cat([p.grad.reshape(-1) for p in caster.parameters() if p.grad is not None])
+        return {k: v.detach().clone() for k, v in out.items()}, g.clone()
+    a, ga = run(123)
+    off = caster._rng.offset
+    assert off == 1                                   # one launch for the whole call
+    b, gb = run(None)                                 # next call of the same generator: other draws
+    c, gc = run(123)                                  # re-seeded: the first call again, bit for bit
+    for k in a:
+        assert torch.isfinite(a[k]).all(), k
+        assert torch.equal(a[k], c[k]), k
+    assert torch.equal(ga, gc)
+    assert not torch.equal(a["rgb_map"], b["rgb_map"]) and not torch.equal(a["alpha"], b["alpha"])
+    det, _ = run(123, ray_noise=0.0, perturb=0.0, raw_noise=0.0)
+    assert caster._rng.offset == 0                    # nothing random asked for: no launch, no draw consumed
+    assert float((det["rgb_map"] - a["rgb_map"]).abs().max()) > 1e-4

@@ -67,9 +67,9 @@ __global__ __launch_bounds__(256) void k_probe(float* out, int kgroups, unsigned
 //   ISSUE 3  staggered over k-groups: wave w behind k-group w's first quarter (2 048 clocks apart)
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr int STAGE_BYTES = 32768, FRAG = 1024;
-template <int ISSUE, int READS>
+template <int ISSUE, int READS, int STORE = 0>
 __global__ __launch_bounds__(256) void k_stage(const char* __restrict__ wstream, long long stream_bytes, int stages, float* out,
-                                               unsigned long long* clocks) {
+                                               unsigned long long* clocks, float* sink) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (int i = threadIdx.x; i < 3 * STAGE_BYTES / 4; i += 256) ((float*)smem)[i] = 1e-3f * (i & 31);
@@ -95,6 +95,18 @@ __global__ __launch_bounds__(256) void k_stage(const char* __restrict__ wstream,
                    "global_load_lds_dwordx4 %1, %2 offset:3072"
                    :: "s"(lds0 + half * 4 * FRAG), "v"(lane16), "s"(g + half * 4 * FRAG) : "memory", "m0");
   };
+  // STORE: the training forward's saved-activation stores -- one float4 per lane and k-group into a row-major [sample][256] plane
+  // (lane (m, h): row m, 16 bytes at column 8 kg + 4 h): 1 all four waves in front of the k-group (today), 2 wave w behind quarter
+  // w of the k-group (EXEC masks prepared once per wave: no compare, no branch at the sites), 3 like 2 but only two sites
+  // (waves 0, 1 behind quarter 0, waves 2, 3 behind quarter 2)
+  float* srow = sink + ((long long)blockIdx.x * 128 + wave * 32 + (lane & 31)) * 256 + 4 * (lane >> 5);
+  unsigned mq[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const unsigned m = __builtin_amdgcn_readfirstlane((STORE == 3 ? (wave >> 1) == (q >> 1) && (q & 1) == 0 : wave == q) ? ~0u : 0u);
+    mq[q] = m;
+  }
+  const f32x4 sv = {1.f * lane, 2.f, 3.f, 4.f};
   const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   int slot = 0;
   long long goff = 0;
@@ -118,6 +130,10 @@ __global__ __launch_bounds__(256) void k_stage(const char* __restrict__ wstream,
     for (int ks = 0; ks < 4; ++ks) {
       const char* csrc = cur + ks * 8 * FRAG;
       const char* nsrc = ks == 3 ? nxt : csrc + 8 * FRAG;
+      if (STORE == 1) {
+        *reinterpret_cast<f32x4*>(srow + 8 * ((st * 4 + ks) & 31)) = sv;
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int sl = (q & 1) * 2;
@@ -162,6 +178,12 @@ __global__ __launch_bounds__(256) void k_stage(const char* __restrict__ wstream,
                          "global_load_lds_dwordx4 %1, %2 offset:2048\n\tglobal_load_lds_dwordx4 %1, %2 offset:3072"
                          :: "s"(lds0), "v"(lane16), "s"(g) : "memory", "m0");
         }
+        if (STORE == 2 || (STORE == 3 && (q & 1) == 0)) {
+          float* pp = srow + 8 * ((st * 4 + ks) & 31);
+          unsigned tmp;
+          asm volatile("v_readfirstlane_b32 %0, %1\n\ts_nop 3\n\ts_mov_b32 exec_lo, %0\n\ts_mov_b32 exec_hi, %0\n\tglobal_store_dwordx4 %2, %3, off\n\ts_mov_b64 exec, -1"
+                       : "=&s"(tmp) : "v"(mq[q]), "v"(pp), "v"(sv) : "memory");
+        }
         if (ISSUE == 2 && st > 0 && ks == 0 && wave == q) issue(goff, fill);
         if (ISSUE == 3 && st > 0 && q == 0 && wave == ks) issue(goff, fill);
         __builtin_amdgcn_sched_barrier(0x6);
@@ -184,16 +206,16 @@ __global__ __launch_bounds__(256) void k_stage(const char* __restrict__ wstream,
   if (threadIdx.x == 0) { clocks[2 * blockIdx.x] = t1 - t0; clocks[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
-template <int ISSUE, int READS>
-void run_stage(const char* name, const char* w, long long stream_bytes, float* out, unsigned long long* clocks, int blocks, int stages) {
-  hipFuncSetAttribute((const void*)k_stage<ISSUE, READS>, hipFuncAttributeMaxDynamicSharedMemorySize, 131584);
+template <int ISSUE, int READS, int STORE = 0>
+void run_stage(const char* name, const char* w, long long stream_bytes, float* out, unsigned long long* clocks, int blocks, int stages, float* sink = nullptr) {
+  hipFuncSetAttribute((const void*)k_stage<ISSUE, READS, STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, 131584);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL((k_stage<ISSUE, READS>), dim3(blocks), dim3(256), 131584, 0, w, stream_bytes, 16, out, clocks);
+  hipLaunchKernelGGL((k_stage<ISSUE, READS, STORE>), dim3(blocks), dim3(256), 131584, 0, w, stream_bytes, 16, out, clocks, sink);
   hipDeviceSynchronize();
   float best = 1e30f; double ghz = 0, cps = 0;
   for (int rep = 0; rep < 3; ++rep) {
     hipEventRecord(e0);
-    hipLaunchKernelGGL((k_stage<ISSUE, READS>), dim3(blocks), dim3(256), 131584, 0, w, stream_bytes, stages, out, clocks);
+    hipLaunchKernelGGL((k_stage<ISSUE, READS, STORE>), dim3(blocks), dim3(256), 131584, 0, w, stream_bytes, stages, out, clocks, sink);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     unsigned long long h[2 * 1024];
@@ -251,6 +273,11 @@ int main() {
   run_stage<4, 1>("stage: + DMA, wave w in quarter w of k-group 0, one piece per MFMA", w, stream_bytes, out, clocks, blocks, stages);
   run_stage<5, 1>("stage: + DMA, 2 pieces behind quarter w of every k-group", w, stream_bytes, out, clocks, blocks, stages);
   run_stage<6, 1>("stage: + DMA, 4 pieces behind quarter w of k-groups 0 and 1", w, stream_bytes, out, clocks, blocks, stages);
+  float* sink; hipMalloc(&sink, (size_t)blocks * 128 * 256 * 4);
+  run_stage<1, 1, 0>("stage: burst DMA + reads, no stores (reference)", w, stream_bytes, out, clocks, blocks, stages, sink);
+  run_stage<1, 1, 1>("stage: + one float4 store per k-group, all waves at once", w, stream_bytes, out, clocks, blocks, stages, sink);
+  run_stage<1, 1, 2>("stage: + stores staggered: wave w behind quarter w (EXEC masks)", w, stream_bytes, out, clocks, blocks, stages, sink);
+  run_stage<1, 1, 3>("stage: + stores at two sites (waves 0,1 / waves 2,3)", w, stream_bytes, out, clocks, blocks, stages, sink);
   run_stage<1, 0>("stage: DMA behind the barrier, no reads", w, stream_bytes, out, clocks, blocks, stages);
   run_stage<2, 0>("stage: DMA staggered by quarter, no reads", w, stream_bytes, out, clocks, blocks, stages);
   return 0;
