@@ -478,13 +478,12 @@ int anerf_importance(const float* z_vals, const float* weights, int32_t n_rays, 
 // ---------------------------------------------------------------------------------------------------------------
 // training path
 // ---------------------------------------------------------------------------------------------------------------
-// Number of heavy (4 x 128x128 wave tiles) and skinny (alpha / rgb heads) blocks of the weight-gradient GEMM.
-static void gemm_block_counts(const AnerfConfig* cfg, int* nheavy, int* nskinny) {
+// Number of blocks (4 x 128x128 wave tiles each) of the weight-gradient GEMM; the alpha / rgb head problems ride in two of them.
+static void gemm_block_counts(const AnerfConfig* cfg, int* nheavy) {
   const int tx = (dim_x(cfg) + 127) / 128;                       // column tiles of X'
   const int tv = 2 + (u_width(cfg) + 127) / 128;                 // views layer: feature (2 tiles) + U' tiles, M = 128
   // M = 256 problems pair their column tiles 2 x 2:  L0 (X'), L1-4, L5 (X' and h4), L6, L7, feature
   *nheavy = (tx + 1) / 2 + 4 + (tx + 1) / 2 + 1 + 2 + 1 + (tv + 3) / 4;
-  *nskinny = 1;
 }
 
 int anerf_train_layout(const AnerfConfig* cfg, int64_t n_points, AnerfTrainLayout* out) {
@@ -495,15 +494,15 @@ int anerf_train_layout(const AnerfConfig* cfg, int64_t n_points, AnerfTrainLayou
   if (out->p_pad == 0) out->p_pad = 128;
   out->x_width = dim_x(cfg);
   out->u_width = u_width(cfg);
-  int nh, ns, rh, ch, rs, cs;
-  gemm_block_counts(cfg, &nh, &ns);
-  gemm_plan_rows(out->p_pad, nh, ns, &rh, &ch, &rs, &cs);
+  int nh, rh, ch;
+  gemm_block_counts(cfg, &nh);
+  gemm_plan_rows(out->p_pad, nh, &rh, &ch);
   out->gemm_chunks = ch;
-  // partials: heavy problems (M*N + bias M) x chunks_h, head problems x chunks_s
+  // partials: heavy problems (M*N + bias M) x chunks; head problems (alpha 1 x 256 in 2 row slots, rgb 3 x 128 in 4) likewise
   const int64_t heavy = 256LL * dim_x(cfg) + 256 + 6 * (256LL * 256 + 256) + 256LL * dim_x(cfg) + 256 + 256LL * 256 +
                         (256LL * 256 + 256) + (128LL * 256 + 128) + 128LL * u_width(cfg);
-  const int64_t heads = (4LL * 128 + 4) + (4LL * 256 + 4);
-  out->gemm_ws_floats = heavy * ch + heads * cs;
+  const int64_t heads = 4 * (3LL * 128 + 3) + 2 * (1LL * 256 + 1);
+  out->gemm_ws_floats = (heavy + heads) * ch;
   return ANERF_OK;
 }
 
@@ -621,8 +620,8 @@ static int weight_grads_impl(const AnerfConfig* cfg, const AnerfSaved* sv, const
   memset(&G, 0, sizeof(G));
   memset(&P, 0, sizeof(P));
   P.p_pad = pp;
-  gemm_block_counts(cfg, &P.nheavy, &P.nskinny);
-  gemm_plan_rows(pp, P.nheavy, P.nskinny, &P.rows_h, &P.chunks_h, &P.rows_s, &P.chunks_s);
+  gemm_block_counts(cfg, &P.nheavy);
+  gemm_plan_rows(pp, P.nheavy, &P.rows_h, &P.chunks_h);
   long long ws_pos = 0, out_pos = 0;
   int np = 0, nmat = 0;
   auto mat = [&](const float* ptr, int ld) {
@@ -632,10 +631,11 @@ static int weight_grads_impl(const AnerfConfig* cfg, const AnerfSaved* sv, const
     return nmat++;
   };
   struct WT { int prob, a_mat, b_mat, m0, n0; };                 // one wave tile
-  std::vector<WT> sq, wide, skinny;                              // M = 256 (2 x 2 blocks), M = 128 (1 x 4), M = 4
+  std::vector<WT> sq, wide;                                      // M = 256 (2 x 2 blocks), M = 128 (1 x 4)
+  // `slots` > 0: a head problem (no wave tiles; hosted, see GemmHead) whose partials come in chunks x slots pieces
   auto add = [&](const float* A, int lda, int M, const float* B, int ldb, int N, float* dst, int dst_ld, int col0,
-                 const int* cmap, int m_first, int m_count, float* bias, int bm_first, int bm_count) {
-    const int chunks = M == 4 ? P.chunks_s : P.chunks_h;
+                 const int* cmap, int m_first, int m_count, float* bias, int bm_first, int bm_count, int slots = 0) {
+    const int chunks = P.chunks_h * (slots ? slots : 1);
     GemmProb& p = G.p[np];
     p.dst = dst; p.bias_dst = bias; p.colmap = cmap; p.M = M; p.N = N; p.chunks = chunks;
     p.dst_ld = dst_ld; p.dst_col0 = col0; p.m_first = m_first; p.m_count = m_count;
@@ -645,10 +645,12 @@ static int weight_grads_impl(const AnerfConfig* cfg, const AnerfSaved* sv, const
     if (bias) { p.bias_off = ws_pos; ws_pos += (long long)chunks * M; }
     p.out_base = out_pos; out_pos += (long long)M * N + (bias ? M : 0);
     const int am = mat(A, lda), bm = mat(B, ldb);
-    std::vector<WT>& list = M == 256 ? sq : (M == 128 ? wide : skinny);
-    for (int n0 = 0; n0 < N; n0 += 128)
-      for (int m0 = 0; m0 < M; m0 += 128) list.push_back({np, am, bm, m0, n0});
-    ++np;
+    if (!slots) {
+      std::vector<WT>& list = M == 256 ? sq : wide;
+      for (int n0 = 0; n0 < N; n0 += 128)
+        for (int m0 = 0; m0 < M; m0 += 128) list.push_back({np, am, bm, m0, n0});
+    }
+    return np++;
   };
   auto DZ = [&](int l) { return dz + (long long)l * pp * 256; };
   auto H = [&](int l) { return sv->h + (long long)l * pp * 256; };
@@ -657,12 +659,14 @@ static int weight_grads_impl(const AnerfConfig* cfg, const AnerfSaved* sv, const
   add(DZ(5), 256, 256, sv->x, DX, DX, gr->w[5], DX + 256, 0, perm_x, 0, 256, gr->b[5], 0, 256);
   add(DZ(5), 256, 256, H(4), 256, 256, gr->w[5], DX + 256, DX, nullptr, 0, 256, nullptr, 0, 0);
   add(DZ(6), 256, 256, H(5), 256, 256, gr->w[6], 256, 0, nullptr, 0, 256, gr->b[6], 0, 256);
-  add(DZ(7), 256, 256, H(6), 256, 256, gr->w[7], 256, 0, nullptr, 0, 256, gr->b[7], 0, 256);
-  add(df, 256, 256, H(7), 256, 256, gr->w[9], 256, 0, nullptr, 0, 256, gr->b[9], 0, 256);
+  const int p_rgb_host = add(DZ(7), 256, 256, H(6), 256, 256, gr->w[7], 256, 0, nullptr, 0, 256, gr->b[7], 0, 256);
+  const int p_alpha_host = add(df, 256, 256, H(7), 256, 256, gr->w[9], 256, 0, nullptr, 0, 256, gr->b[9], 0, 256);
   add(dzv, 128, 128, sv->f, 256, 256, gr->w[10], KV, 0, nullptr, 0, 128, gr->b[10], 0, 128);
   add(dzv, 128, 128, sv->u, UW, UW, gr->w[10], KV, 256, perm_u, 0, 128, nullptr, 0, 0);
-  add(draw, 4, 4, sv->g, 128, 128, gr->w[11], 128, 0, nullptr, 0, 3, gr->b[11], 0, 3);
-  add(draw, 4, 4, H(7), 256, 256, gr->w[8], 256, 0, nullptr, 3, 1, gr->b[8], 3, 1);
+  // heads: rgb_linear <- draw[:, 0:3]^T g (4 row slots), alpha_linear <- draw[:, 3]^T h7 (2 row slots)
+  const int p_rgb = add(draw, 4, 3, sv->g, 128, 128, gr->w[11], 128, 0, nullptr, 0, 3, gr->b[11], 0, 3, 4);
+  const int p_alpha = add(draw, 4, 1, H(7), 256, 256, gr->w[8], 256, 0, nullptr, 0, 1, gr->b[8], 0, 1, 2);
+  P.draw_mat = mat(draw, 4);
   G.nprob = np;
   G.accumulate = accumulate ? 1 : 0;
   G.total_out = out_pos;
@@ -675,10 +679,13 @@ static int weight_grads_impl(const AnerfConfig* cfg, const AnerfSaved* sv, const
     B.t[B.ntiles].mat = m; B.t[B.ntiles].col0 = col0;
     return B.ntiles++;
   };
-  auto emit = [&](const std::vector<WT>& list, size_t per_block, int skinny_flag) {
+  P.head[0].blk = P.head[1].blk = -1;
+  auto emit = [&](const std::vector<WT>& list, size_t per_block) {
     for (size_t i0 = 0; i0 < list.size(); i0 += per_block) {
+      if (!list.empty() && list[i0].prob == p_alpha_host) P.head[0].blk = nb;
+      if (!list.empty() && list[i0].prob == p_rgb_host) P.head[1].blk = nb;
       GemmBlock& B = P.blk[nb++];
-      B.ntiles = 0; B.skinny = skinny_flag;
+      B.ntiles = 0; B.pad_ = 0;
       for (int w = 0; w < 4; ++w) B.w[w].a_tile = -1;
       for (size_t k = 0; k < per_block && i0 + k < list.size(); ++k) {
         const WT& t = list[i0 + k];
@@ -698,16 +705,21 @@ static int weight_grads_impl(const AnerfConfig* cfg, const AnerfSaved* sv, const
     std::vector<WT> run;
     for (size_t i = 0; i <= sq.size(); ++i) {
       if (i == sq.size() || (!run.empty() && sq[i].prob != run.back().prob)) {
-        emit(run, 4, 0);
+        emit(run, 4);
         run.clear();
       }
       if (i < sq.size()) run.push_back(sq[i]);
     }
   }
-  emit(wide, 4, 0);       // views layer: one A tile (dzv) x up to 4 column tiles of f / U'
-  if (nb != P.nheavy) return set_error(ANERF_E_CONFIG, "weight_grads: block plan mismatch");
-  emit(skinny, 4, 1);
-  if (nb != P.nheavy + P.nskinny || nb > 16 || nmat > 24) return set_error(ANERF_E_CONFIG, "weight_grads: block plan mismatch");
+  emit(wide, 4);          // views layer: one A tile (dzv) x up to 4 column tiles of f / U'
+  if (nb != P.nheavy || nb > 16 || nmat > 24) return set_error(ANERF_E_CONFIG, "weight_grads: block plan mismatch");
+  // head hosts: the feature layer's block (its two B tiles ARE the h7 rows) and layer 7's block + the g rows as a fifth tile
+  if (P.head[0].blk < 0 || P.head[1].blk < 0 || P.blk[P.head[0].blk].ntiles != 4 || P.blk[P.head[1].blk].ntiles != 4)
+    return set_error(ANERF_E_CONFIG, "weight_grads: head host blocks");
+  P.head[0].tile = -1;    // (each wave's own b_tile)
+  P.head[0].part_off = (int)G.p[p_alpha].part_off; P.head[0].bias_off = (int)G.p[p_alpha].bias_off;
+  P.head[1].tile = tile_of(P.blk[P.head[1].blk], mat(sv->g, 128), 0);
+  P.head[1].part_off = (int)G.p[p_rgb].part_off; P.head[1].bias_off = (int)G.p[p_rgb].bias_off;
   return launch_weight_grads(P, G, workspace, b3, (hipStream_t)stream);
 }
 

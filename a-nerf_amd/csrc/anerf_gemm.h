@@ -24,8 +24,9 @@ struct GemmBatch {
   long long total_out;
 };
 
-// ---- compute side: a block = 4 waves, each owning one 128x128 (or, "skinny", 4x128) output tile of some problem,
-// sharing up to 5 LDS operand tiles (16 sample rows x 128 columns each) per stage.
+// ---- compute side: a block = 4 waves, each owning one 128x128 output tile of some problem, sharing up to 5 LDS operand
+// tiles (16 sample rows x 128 columns each) per stage.  The two head problems (alpha: 1 x 256, rgb: 3 x 128; A = the
+// [p][4] head-gradient rows) have no block of their own: they ride as VALU FMAs in two of the heavy blocks (GemmHead).
 struct GemmMat {         // a row-major [p_pad][ld] operand matrix
   const float* ptr;
   int ld, ncols;
@@ -40,23 +41,32 @@ struct GemmWave {
   int M, N, m0, n0;      // problem dims (partial row stride N) and this tile's origin
 };
 struct GemmBlock {
-  int ntiles, skinny;
+  int ntiles, pad_;
   GemmTile t[5];
   GemmWave w[4];
 };
+// A head problem dW[m][n] = sum_p draw[p][comp0 + m] * Hm[p][n] hosted by block `blk`: every stage the block also stages the
+// 16 draw rows (256 B behind the five operand tiles) and its four waves share the 16 rows -- alpha: wave (r, c) of the
+// feature layer's 2 x 2 block takes the rows of row pairs s = r (mod 2) against ITS OWN B tile (h7 columns 128c..), i.e. 2
+// row slots; rgb: wave k takes s = k (mod 4) against LDS tile `tile` (the g rows, loaded as the block's fifth tile), 4 row
+// slots.  Partials: [chunk * slots + slot][M][N] at part_off, column sums of draw [chunk * slots + slot][M] at bias_off.
+struct GemmHead {
+  int blk, tile, part_off, bias_off;
+};
 struct GemmPlan {
   GemmMat mat[24];
-  GemmBlock blk[16];     // heavy blocks first, then the skinny ones
-  int nheavy, nskinny;
-  int rows_h, chunks_h;  // sample rows per heavy block (multiple of 16) and number of row chunks
-  int rows_s, chunks_s;  // same for skinny blocks (currently identical to the heavy chunking)
+  GemmBlock blk[16];
+  GemmHead head[2];      // [0] alpha (M = 1, N = 256, draw column 3), [1] rgb (M = 3, N = 128, draw columns 0..2)
+  int draw_mat;          // index of the [p_pad][4] head-gradient matrix
+  int nheavy;
+  int rows_h, chunks_h;  // sample rows per block (multiple of 16) and number of row chunks
   long long p_pad;
 };
 
 constexpr int GEMM_ROWS = 16;   // sample rows per LDS stage
 
 // rows-per-block search shared by anerf_train_layout (workspace size) and anerf_weight_grads
-void gemm_plan_rows(long long p_pad, int nheavy, int nskinny, int* rows_h, int* chunks_h, int* rows_s, int* chunks_s);
+void gemm_plan_rows(long long p_pad, int nheavy, int* rows_h, int* chunks_h);
 
 int launch_weight_grads(const GemmPlan& P, const GemmBatch& G, float* ws, bool b3, hipStream_t st);
 

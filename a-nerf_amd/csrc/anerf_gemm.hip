@@ -21,8 +21,11 @@
 // counted `lgkmcnt(2)` the two-pairs-ahead operand reads were written for, instead of `lgkmcnt(0)`) also measured the same
 // (3.87 vs 3.89 ms on one box): the loop does not wait for LDS either.
 // A block = 4 such waves sharing operand tiles: 2x2 (two A tiles x two B tiles: a whole 256x256 layer per block,
-// each activation row read once) or 1x4 (views layer, M = 128).  The 4-row head problems (alpha / rgb, A = draw)
-// run as "skinny" waves: 4 MFMAs per row pair against one broadcast A block.
+// each activation row read once) or 1x4 (views layer, M = 128).  The two head problems (alpha 1 x 256, rgb 3 x 128; A = the
+// [p][4] rows of draw) have no block of their own (rounds 1-2: a "skinny" block of 4-MFMA waves that held a CU per row chunk
+// -- 17 of 256 -- for a load-bound trickle): the feature layer's block already stages the h7 rows, so its waves add
+// draw[p][3] * h7[p][:] with 16 v_fma per stage, and one more 2x2 block stages the g rows as its fifth tile for the rgb rows
+// (24 v_fma per wave and stage); 14 jobs x 18 row chunks = 252 CUs instead of 15 x 17 (head_stage / GemmHead).
 // Blocks write partial tiles; k_reduce_dw sums the row chunks in a fixed order (deterministic) and scatters into
 // the torch-layout gradient tensors (undoing the stream column order of X'/U').  Bias gradients = column sums of
 // A, accumulated by the waves that own a problem's first column tile.
@@ -37,13 +40,14 @@ namespace anerf {
 
 constexpr int GT = 128;                         // tile edge (columns of an operand tile, rows/cols of an output tile)
 constexpr int GTILE_BYTES = GEMM_ROWS * GT * 4; // 8 KiB
-constexpr int GSTAGE_BYTES = 5 * GTILE_BYTES;   // 40 KiB
+constexpr int GMINI_OFF = 5 * GTILE_BYTES;      // the stage's 16 draw rows ([16][4] floats) behind the five operand tiles
+constexpr int GSTAGE_BYTES = GMINI_OFF + 256;   // 40 KiB + 256 B
 constexpr int GLDS_BYTES = 2 * GSTAGE_BYTES;    // double buffer (fp32 kernel)
 constexpr int GLDS3_BYTES = 3 * GSTAGE_BYTES;   // 3-slot ring (split-bf16 kernel)
 
-// Chunking: every block (heavy or skinny) covers the same rows_h sample rows; one block per CU at a time (256 AGPRs).
+// Chunking: every block covers the same rows_h sample rows; one block per CU at a time (256 AGPRs).
 // Pick rows_h (multiple of 16) minimising  rounds(blocks over 256 CUs) x (rows + epilogue).
-void gemm_plan_rows(long long p_pad, int nheavy, int nskinny, int* rows_h, int* chunks_h, int* rows_s, int* chunks_s) {
+void gemm_plan_rows(long long p_pad, int nheavy, int* rows_h, int* chunks_h) {
   const int NCU = 256;
   long long best_cost = -1;
   int best_r = 0;
@@ -52,7 +56,7 @@ void gemm_plan_rows(long long p_pad, int nheavy, int nskinny, int* rows_h, int* 
     if (r <= 0) continue;
     const long long ch = (p_pad + r - 1) / r;
     if (ch > 96) continue;
-    const long long blocks = (nheavy + nskinny) * ch;                // a skinny block is shorter but holds a CU too
+    const long long blocks = nheavy * ch;
     const long long rounds = (blocks + NCU - 1) / NCU;
     const long long cost = rounds * (r + 96);
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_r = (int)r; }
@@ -63,8 +67,6 @@ void gemm_plan_rows(long long p_pad, int nheavy, int nskinny, int* rows_h, int* 
 #endif
   *rows_h = best_r;
   *chunks_h = (int)((p_pad + best_r - 1) / best_r);
-  *rows_s = *rows_h;
-  *chunks_s = *chunks_h;
 }
 
 // ---- loader: every operand tile of a stage is 8 two-row wave-instructions; wave w issues rows {2w, 2w+1} and
@@ -79,12 +81,19 @@ struct GemmLoader {
   unsigned t_lo[5];
   int ntiles, wave;
   char* smem;
+  const char* d_ptr;     // the block's draw rows (head hosts); requested by wave 0 only
+  unsigned d_lo;
+  int d_on;
 
-  __device__ __forceinline__ void init(const GemmPlan& G, const GemmBlock& B, char* smem_, long long r0, int wave_, int lane) {
+  __device__ __forceinline__ void init(const GemmPlan& G, const GemmBlock& B, char* smem_, long long r0, int wave_, int lane,
+                                       bool head) {
     const int i = lane & 31, kk = lane >> 5;
     smem = smem_;
     wave = wave_;
     ntiles = B.ntiles;
+    d_ptr = reinterpret_cast<const char*>(G.mat[G.draw_mat].ptr + r0 * 4);
+    d_lo = (unsigned)lane * 4u;
+    d_on = __builtin_amdgcn_readfirstlane((head && wave_ == 0) ? 1 : 0);
 #pragma unroll
     for (int tile = 0; tile < 5; ++tile) {
       const int tt = tile < B.ntiles ? tile : 0;
@@ -112,10 +121,22 @@ struct GemmLoader {
                  :: "s"(lds0), "s"(lds0 + 8 * (GT * 4)), "v"(t_lo[tile]), "s"(rowp), "s"(rowp + (long long)t_ld[tile] * 32),
                     "s"(tile), "s"(ntiles) : "memory", "m0", "scc");
   }
+  // the stage's 16 draw rows = 256 contiguous bytes = one dword per lane of ONE wave-instruction (predicated like issue_tile)
+  __device__ __forceinline__ void issue_mini(int stage, int slot) const {
+#ifdef ANERF_EXP_GEMM_NOLOAD
+    (void)stage; (void)slot; return;
+#endif
+    const char* rowp = d_ptr + (long long)stage * (GEMM_ROWS * 16);
+    const unsigned lds0 = (unsigned)reinterpret_cast<size_t>((lds_ptr_t)(smem + slot * GSTAGE_BYTES + GMINI_OFF));
+    asm volatile("s_cmp_lg_i32 %3, 0\n\ts_cbranch_scc0 1f\n\t"
+                 "s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n1:"
+                 :: "s"(lds0), "v"(d_lo), "s"(rowp), "s"(d_on) : "memory", "m0", "scc");
+  }
   __device__ __forceinline__ void issue(int stage, int slot) const {
 #ifdef ANERF_EXP_GEMM_NOLOAD   // ablation build only (tools/ablate.sh): results are wrong
     (void)stage; (void)slot; return;
 #endif
+    issue_mini(stage, slot);
 #pragma unroll
     for (int tile = 0; tile < 5; ++tile)
       if (tile < ntiles) {
@@ -137,20 +158,19 @@ struct GemmLoader {
 };
 
 // partial tile -> workspace [chunk][M][N]: accumulator block (a, c), register r, lane (i, kk) holds output row
-// 4*((r&3) + 8*(r>>2) + 4*kk) + a, column 4*i + c   (skinny: row (r&3), rows >= 4 are copies); then the bias partials
-template <bool SKINNY, int NA>
-__device__ __forceinline__ void gemm_store(const GemmWave& W, float* __restrict__ ws, int chunk, const f32x16 (&acc)[NA][4],
+// 4*((r&3) + 8*(r>>2) + 4*kk) + a, column 4*i + c; then the bias partials
+__device__ __forceinline__ void gemm_store(const GemmWave& W, float* __restrict__ ws, int chunk, const f32x16 (&acc)[4][4],
                                            f32x4 asum, bool do_bias, int i, int kk) {
   float* part = ws + W.part_off + (long long)chunk * W.M * W.N;
   const int n = W.n0 + 4 * i;
   if (n < W.N) {
 #pragma unroll
-    for (int a = 0; a < NA; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rowi = (r & 3) + 8 * (r >> 2) + 4 * kk;
-        const int m = SKINNY ? rowi : W.m0 + 4 * rowi + a;
-        if (SKINNY ? (rowi < 4 && m < W.M) : (m < W.M)) {
+        const int m = W.m0 + 4 * rowi + a;
+        if (m < W.M) {
           const f32x4 o = {acc[a][0][r], acc[a][1][r], acc[a][2][r], acc[a][3][r]};
           *reinterpret_cast<f32x4*>(part + (long long)m * W.N + n) = o;
         }
@@ -161,21 +181,84 @@ __device__ __forceinline__ void gemm_store(const GemmWave& W, float* __restrict_
 #pragma unroll
     for (int a = 0; a < 4; ++a) asum[a] += __shfl_xor(asum[a], 32);
     if (kk == 0) {
-      if constexpr (SKINNY) {
-        if (i < 4 && i < W.M) bp[i] = asum[0];
-      } else {
-        const int m = W.m0 + 4 * i;
-        if (m < W.M) *reinterpret_cast<f32x4*>(bp + m) = asum;   // M is a multiple of 4 for every heavy problem
-      }
+      const int m = W.m0 + 4 * i;
+      if (m < W.M) *reinterpret_cast<f32x4*>(bp + m) = asum;   // M is a multiple of 4 for every heavy problem
     }
   }
 }
+
+// ---- the head problems, hosted by two heavy blocks (GemmHead).  HEAD = 1 (alpha): wave (r, c) = (wave & 1, wave >> 1) of the
+// feature layer's block multiplies draw[p][3] into the h7 columns of its own B tile for the row pairs s = r, r+2, r+4, r+6;
+// HEAD = 2 (rgb): wave k multiplies draw[p][0..2] into the g tile's columns for s = k, k+4.  Lane (i, kk) owns row 2s+kk,
+// columns 4i..4i+3, like the MFMA operands; the values come from LDS again (re-using the B operands' registers would need a
+// per-wave select on every value).  Plain fp32 FMAs in sample order; the two (four) waves' sums and the chunks are added in
+// fixed order by k_reduce_dw: deterministic like everything else here.
+template <int HEAD>
+struct HeadWork {
+  static constexpr int NM = HEAD == 2 ? 3 : 1;       // output rows
+  static constexpr int NQ = HEAD == 2 ? 2 : 4;       // row pairs of a stage this wave takes
+  f32x4 acc[NM];
+  float sum[NM];
+  f32x4 hv[NQ];
+  f32x4 dv[NQ];
+  unsigned h_off, d_off;
+
+  __device__ __forceinline__ void init(const GemmPlan& G, const GemmWave& W, int wave, int i, int kk) {
+#pragma unroll
+    for (int m = 0; m < NM; ++m) { acc[m] = f32x4{0.f, 0.f, 0.f, 0.f}; sum[m] = 0.f; }
+    const int s0 = HEAD == 2 ? wave : (wave & 1);
+    const int tile = HEAD == 2 ? G.head[1].tile : W.b_tile;
+    h_off = tile * GTILE_BYTES + (2 * s0 + kk) * (GT * 4) + i * 16;
+    d_off = GMINI_OFF + (2 * s0 + kk) * 16;
+  }
+  __device__ __forceinline__ void read(const char* base) {
+    constexpr int STEP = HEAD == 2 ? 8 : 4;          // rows between two of the wave's row pairs
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      hv[q] = *reinterpret_cast<const f32x4*>(base + h_off + q * STEP * (GT * 4));
+      if constexpr (HEAD == 2) dv[q] = *reinterpret_cast<const f32x4*>(base + d_off + q * STEP * 16);
+      else dv[q][0] = *reinterpret_cast<const float*>(base + d_off + 12 + q * STEP * 16);
+    }
+  }
+  __device__ __forceinline__ void fma() {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        const float d = dv[q][m];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[m][c] = fmaf(d, hv[q][c], acc[m][c]);
+        sum[m] += d;
+      }
+  }
+  __device__ __forceinline__ void store(const GemmPlan& G, float* __restrict__ ws, int chunk, int wave, int i, int kk) {
+    constexpr int SLOTS = HEAD == 2 ? 4 : 2, N = HEAD == 2 ? 128 : 256;
+    const GemmHead& Hd = G.head[HEAD - 1];
+    const int slot = chunk * SLOTS + (HEAD == 2 ? wave : (wave & 1));
+    const int n0 = HEAD == 2 ? 0 : 128 * (wave >> 1);
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[m][c] += __shfl_xor(acc[m][c], 32);
+      sum[m] += __shfl_xor(sum[m], 32);
+      if (kk == 0) *reinterpret_cast<f32x4*>(ws + Hd.part_off + ((long long)slot * NM + m) * N + n0 + 4 * i) = acc[m];
+      if (kk == 0 && i == 0 && n0 == 0) ws[Hd.bias_off + (long long)slot * NM + m] = sum[m];
+    }
+  }
+};
+template <>
+struct HeadWork<0> {
+  __device__ __forceinline__ void init(const GemmPlan&, const GemmWave&, int, int, int) {}
+  __device__ __forceinline__ void read(const char*) {}
+  __device__ __forceinline__ void fma() {}
+  __device__ __forceinline__ void store(const GemmPlan&, float*, int, int, int, int) {}
+};
 
 #ifdef ANERF_EXP_STAGE_TIMING   // debug build only (tools/stage_timing_gemm.py)
 __device__ unsigned long long* g_gemm_tbuf = nullptr;
 #endif
 
-template <bool SKINNY>
+template <int HEAD>
 __device__ __forceinline__ void gemm_body(const GemmPlan& G, const GemmBlock& B, char* smem, float* __restrict__ ws,
                                           long long r0, int nst, int chunk, int wave, int lane) {
   const int i = lane & 31, kk = lane >> 5;
@@ -183,20 +266,21 @@ __device__ __forceinline__ void gemm_body(const GemmPlan& G, const GemmBlock& B,
   const bool active = W.a_tile >= 0;
   const bool do_bias = active && W.bias_off >= 0;
   GemmLoader L;
-  L.init(G, B, smem, r0, wave, lane);
+  L.init(G, B, smem, r0, wave, lane, HEAD != 0);
   auto issue = [&](int stage, int slot) { L.issue(stage, slot); };
 
-  constexpr int NA = SKINNY ? 1 : 4;
-  f32x16 acc[NA][4];
+  f32x16 acc[4][4];
 #pragma unroll
-  for (int a = 0; a < NA; ++a)
+  for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   f32x4 asum = {0.f, 0.f, 0.f, 0.f};
+  HeadWork<HEAD> hw;
+  hw.init(G, W, wave, i, kk);
 
-  const unsigned a_off = W.a_tile * GTILE_BYTES + kk * (GT * 4) + (SKINNY ? (i & 3) * 4 : i * 16);
+  const unsigned a_off = W.a_tile * GTILE_BYTES + kk * (GT * 4) + i * 16;
   const unsigned b_off = W.b_tile * GTILE_BYTES + kk * (GT * 4) + i * 16;
 
   if (nst > 0) issue(0, 0);
@@ -213,7 +297,7 @@ __device__ __forceinline__ void gemm_body(const GemmPlan& G, const GemmBlock& B,
   // between AGPRs and VGPRs at the merge points.
 #ifdef ANERF_EXP_STAGE_TIMING
   unsigned long long* tb = g_gemm_tbuf;
-  if (tb && !SKINNY && blockIdx.x % 16 == 0 && lane == 0) tb += ((long long)(blockIdx.x / 16) * 4 + wave) * 3 * 128; else tb = nullptr;
+  if (tb && blockIdx.x % 16 == 0 && lane == 0) tb += ((long long)(blockIdx.x / 16) * 4 + wave) * 3 * 128; else tb = nullptr;
 #endif
   for (int t = 0; t < nst; ++t) {
 #ifdef ANERF_EXP_STAGE_TIMING
@@ -232,73 +316,55 @@ __device__ __forceinline__ void gemm_body(const GemmPlan& G, const GemmBlock& B,
 #ifdef ANERF_EXP_GEMM_BURST   // round-1 form: the whole next stage requested right behind the barrier
     if (t + 1 < nst) issue(t + 1, (t + 1) & 1);
 #else
-    // heavy blocks request the next stage a tile (two pieces) per MFMA group, groups 0..4: the four waves' 40 pieces no
-    // longer pile up in the CU's vector-memory queue behind the barrier (stage 9 280 -> 9 030 clocks of 8 192; the operands
-    // still arrive in time: 8 clocks of vmcnt wait per stage, tools/stage_timing_gemm.py)
-    if (SKINNY && t + 1 < nst) issue(t + 1, (t + 1) & 1);
+    // the next stage is requested a tile (two pieces) per MFMA group, groups 0..4 (+ the draw rows with group 5): the four
+    // waves' 40 pieces no longer pile up in the CU's vector-memory queue behind the barrier (stage 9 280 -> 9 030 clocks of
+    // 8 192; the operands still arrive in time: 8 clocks of vmcnt wait per stage, tools/stage_timing_gemm.py)
     const int nt_stage = t + 1 < nst ? t + 1 : t;      // (the last stage reloads itself into the idle slot: branch-free)
 #endif
     const char* base = smem + (t & 1) * GSTAGE_BYTES;
-    if constexpr (SKINNY) {
-      f32x4 b4 = *reinterpret_cast<const f32x4*>(base + b_off);
-      float a1 = *reinterpret_cast<const float*>(base + a_off);
+    // Operands are read TWO row pairs ahead: the s_waitcnt in front of a group's MFMAs then only has to cover reads
+    // issued a full group (1024 MFMA cycles) earlier and may leave the newest pair in flight (lgkmcnt(2)).  The
+    // sched_barriers pin that order: left alone, the scheduler hoists the column-sum adds of later pairs above the
+    // MFMAs and drags a wait for the freshly issued reads in front of them.
+    constexpr int NS = GEMM_ROWS / 2;
+    f32x4 av[NS], bv[NS];
+    av[0] = *reinterpret_cast<const f32x4*>(base + a_off);
+    bv[0] = *reinterpret_cast<const f32x4*>(base + b_off);
+    av[1] = *reinterpret_cast<const f32x4*>(base + a_off + 2 * GT * 4);
+    bv[1] = *reinterpret_cast<const f32x4*>(base + b_off + 2 * GT * 4);
 #pragma unroll
-      for (int s = 0; s < GEMM_ROWS / 2; ++s) {
-        f32x4 bn = b4;
-        float an = a1;
-        if (s + 1 < GEMM_ROWS / 2) {
-          bn = *reinterpret_cast<const f32x4*>(base + b_off + (s + 1) * (2 * GT * 4));
-          an = *reinterpret_cast<const float*>(base + a_off + (s + 1) * (2 * GT * 4));
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b4[c], acc[0][c], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        asum[0] += a1;
-        a1 = an;
-        b4 = bn;
+    for (int s = 0; s < NS; ++s) {
+      if (s + 2 < NS) {
+        av[s + 2] = *reinterpret_cast<const f32x4*>(base + a_off + (s + 2) * (2 * GT * 4));
+        bv[s + 2] = *reinterpret_cast<const f32x4*>(base + b_off + (s + 2) * (2 * GT * 4));
       }
-    } else {
-      // Operands are read TWO row pairs ahead: the s_waitcnt in front of a group's MFMAs then only has to cover reads
-      // issued a full group (1024 MFMA cycles) earlier and may leave the newest pair in flight (lgkmcnt(2)).  The
-      // sched_barriers pin that order: left alone, the scheduler hoists the column-sum adds of later pairs above the
-      // MFMAs and drags a wait for the freshly issued reads in front of them.
-      constexpr int NS = GEMM_ROWS / 2;
-      f32x4 av[NS], bv[NS];
-      av[0] = *reinterpret_cast<const f32x4*>(base + a_off);
-      bv[0] = *reinterpret_cast<const f32x4*>(base + b_off);
-      av[1] = *reinterpret_cast<const f32x4*>(base + a_off + 2 * GT * 4);
-      bv[1] = *reinterpret_cast<const f32x4*>(base + b_off + 2 * GT * 4);
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        if (s + 2 < NS) {
-          av[s + 2] = *reinterpret_cast<const f32x4*>(base + a_off + (s + 2) * (2 * GT * 4));
-          bv[s + 2] = *reinterpret_cast<const f32x4*>(base + b_off + (s + 2) * (2 * GT * 4));
-        }
+      if (s == NS - 2) hw.read(base);                  // behind the last operand reads: consumed after the stage's MFMAs
 #ifndef ANERF_EXP_GEMM_BURST
-        if (s < 5) L.issue_tile(nt_stage, (t + 1) & 1, s);
+      if (s < 5) L.issue_tile(nt_stage, (t + 1) & 1, s);
+      if (HEAD != 0 && s == 5) L.issue_mini(nt_stage, (t + 1) & 1);
 #endif
-        __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < 4; ++a)
 #pragma unroll
-          for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][a], bv[s][c], acc[a][c], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // column sums (bias gradients) of the stage as ONE block of packed adds behind its MFMAs: 16 v_pk_add_f32 instead of
-      // 32 v_add_f32 sprinkled between the groups (a VALU instruction inside the fp32 MFMA stream costs ~14 clocks, in a
-      // block 4-8; stage 9350 -> clocks, tools/stage_timing_gemm.py)
-      f32x2 s_lo = {asum[0], asum[1]}, s_hi = {asum[2], asum[3]};
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        s_lo += f32x2{av[s][0], av[s][1]};
-        s_hi += f32x2{av[s][2], av[s][3]};
-      }
-      asum = f32x4{s_lo[0], s_lo[1], s_hi[0], s_hi[1]};
+        for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s][a], bv[s][c], acc[a][c], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    // column sums (bias gradients) of the stage as ONE block of packed adds behind its MFMAs: 16 v_pk_add_f32 instead of
+    // 32 v_add_f32 sprinkled between the groups (a VALU instruction inside the fp32 MFMA stream costs ~14 clocks, in a
+    // block 4-8; stage 9350 -> clocks, tools/stage_timing_gemm.py); the head hosts' FMAs go in the same block
+    f32x2 s_lo = {asum[0], asum[1]}, s_hi = {asum[2], asum[3]};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      s_lo += f32x2{av[s][0], av[s][1]};
+      s_hi += f32x2{av[s][2], av[s][3]};
+    }
+    asum = f32x4{s_lo[0], s_lo[1], s_hi[0], s_hi[1]};
+    hw.fma();
+    __builtin_amdgcn_sched_barrier(0);
   }
-  gemm_store<SKINNY, NA>(W, ws, chunk, acc, asum, do_bias, i, kk);
+  gemm_store(W, ws, chunk, acc, asum, do_bias, i, kk);
+  hw.store(G, ws, chunk, wave, i, kk);
 }
 
 // ---- split-bf16 variant of the heavy body (anerf_weight_grads_b3): the products run on v_mfma_f32_32x32x16_bf16 with
@@ -333,6 +399,7 @@ __device__ __forceinline__ void gemm_split(const f32x4 (&ar)[8], const f32x4 (&b
   }
 }
 
+template <int HEAD>
 __device__ __forceinline__ void gemm_body_b3(const GemmPlan& G, const GemmBlock& B, char* smem, float* __restrict__ ws,
                                              long long r0, int nst, int chunk, int wave, int lane) {
   const int i = lane & 31, kh = lane >> 5;
@@ -340,7 +407,9 @@ __device__ __forceinline__ void gemm_body_b3(const GemmPlan& G, const GemmBlock&
   const bool active = W.a_tile >= 0;
   const bool do_bias = active && W.bias_off >= 0;
   GemmLoader L;
-  L.init(G, B, smem, r0, wave, lane);
+  L.init(G, B, smem, r0, wave, lane, HEAD != 0);
+  HeadWork<HEAD> hw;                                   // the hosted head rows stay fp32 FMAs (as they were fp32 MFMAs before)
+  hw.init(G, W, wave, i, kh);
   // ring protocol: while stage s is consumed, stages s and s+1 have landed and s+2 is in flight
   if (nst > 0) L.issue(0, 0);
   if (nst > 1) L.issue(1, 1);
@@ -379,6 +448,8 @@ __device__ __forceinline__ void gemm_body_b3(const GemmPlan& G, const GemmBlock&
     f32x4 ar[8], br[8];
     const bool more = s + 1 < nst;
     if (more) gemm_read_raw(smem + ((s + 1) % 3) * GSTAGE_BYTES, a_off, b_off, ar, br);
+    hw.read(smem + (s % 3) * GSTAGE_BYTES);
+    hw.fma();
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -408,6 +479,7 @@ __device__ __forceinline__ void gemm_body_b3(const GemmPlan& G, const GemmBlock&
     f32x4 ar[8], br[8];
     const float mf = s + 1 < nst ? 1.f : 0.f;
     gemm_read_raw(smem + ((s + 1) % 3) * GSTAGE_BYTES, a_off, b_off, ar, br);
+    hw.read(smem + (s % 3) * GSTAGE_BYTES);            // stage s's own slot: valid until end_stage(s)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -425,13 +497,15 @@ __device__ __forceinline__ void gemm_body_b3(const GemmPlan& G, const GemmBlock&
       } else {
         nxt.B[q] = split8(br[0][q], br[1][q], br[2][q], br[3][q], br[4][q], br[5][q], br[6][q], br[7][q]);
       }
+      if (k == 7) hw.fma();
       __builtin_amdgcn_sched_barrier(0);
     }
     end_stage(s);
     cur = nxt;
   }
 #endif
-  gemm_store<false, 4>(W, ws, chunk, acc, asum, do_bias, i, kh);
+  gemm_store(W, ws, chunk, acc, asum, do_bias, i, kh);
+  hw.store(G, ws, chunk, wave, i, kh);
 }
 
 template <bool B3>
@@ -443,35 +517,38 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const GemmPlan G, float* __rest
   // L2): within a full group of 8 chunks, chunk c of every job gets id = 8 * job + c % 8, so the jobs that share
   // activation rows share one L2.  No padding ids: every XCD gets the same number of blocks (an earlier version
   // padded the chunk count to a multiple of 8 with empty blocks -- XCD 0 then ran 3 chunks while the others ran 2,
-  // and the kernel took two rounds instead of one).  Skinny blocks come last.
+  // and the kernel took two rounds instead of one).
   const int bid = blockIdx.x;
-  const int heavy_grid = G.chunks_h * G.nheavy;
   const int full = (G.chunks_h / 8) * 8 * G.nheavy;          // ids covered by full groups of 8 chunks
-  int job, chunk, rows;
+  int job, chunk;
   if (bid < full) {
     const int grp = bid / (8 * G.nheavy), rem = bid - grp * (8 * G.nheavy);
     job = rem >> 3;
     chunk = grp * 8 + (rem & 7);
-    rows = G.rows_h;
-  } else if (bid < heavy_grid) {
+  } else {
     const int m = G.chunks_h & 7, k = bid - full;
     job = k / m;
     chunk = (G.chunks_h / 8) * 8 + k % m;
-    rows = G.rows_h;
-  } else {
-    const int s = bid - heavy_grid;
-    job = G.nheavy + s % G.nskinny;
-    chunk = s / G.nskinny;
-    rows = G.rows_s;
   }
-  const long long r0 = (long long)chunk * rows;
-  long long r1 = r0 + rows;
+  const long long r0 = (long long)chunk * G.rows_h;
+  long long r1 = r0 + G.rows_h;
   if (r1 > G.p_pad) r1 = G.p_pad;
   const int nst = (int)((r1 - r0) / GEMM_ROWS);
   const GemmBlock& B = G.blk[job];
-  if (B.skinny) gemm_body<true>(G, B, smem, ws, r0, nst, chunk, wave, lane);
-  else if constexpr (B3) gemm_body_b3(G, B, smem, ws, r0, nst, chunk, wave, lane);
-  else gemm_body<false>(G, B, smem, ws, r0, nst, chunk, wave, lane);
+#ifdef ANERF_EXP_GEMM_NOHEAD   // ablation build only (tools/ablate.sh): head gradients are not computed
+  const int head = 0;
+#else
+  const int head = job == G.head[0].blk ? 1 : (job == G.head[1].blk ? 2 : 0);      // block-uniform
+#endif
+  if constexpr (B3) {
+    if (head == 1) gemm_body_b3<1>(G, B, smem, ws, r0, nst, chunk, wave, lane);
+    else if (head == 2) gemm_body_b3<2>(G, B, smem, ws, r0, nst, chunk, wave, lane);
+    else gemm_body_b3<0>(G, B, smem, ws, r0, nst, chunk, wave, lane);
+  } else {
+    if (head == 1) gemm_body<1>(G, B, smem, ws, r0, nst, chunk, wave, lane);
+    else if (head == 2) gemm_body<2>(G, B, smem, ws, r0, nst, chunk, wave, lane);
+    else gemm_body<0>(G, B, smem, ws, r0, nst, chunk, wave, lane);
+  }
 }
 
 // Sum the chunk partials in index order and scatter into the gradient tensors.
@@ -511,7 +588,7 @@ int launch_weight_grads(const GemmPlan& P, const GemmBatch& G, float* ws, bool b
   static unsigned long long lds_set[2] = {};   // per-device bits, see ensure_dynamic_lds
   ensure_dynamic_lds(reinterpret_cast<const void*>(k_gemm_tn<false>), GLDS_BYTES, &lds_set[0]);
   ensure_dynamic_lds(reinterpret_cast<const void*>(k_gemm_tn<true>), GLDS3_BYTES, &lds_set[1]);
-  const int grid = P.chunks_h * P.nheavy + P.chunks_s * P.nskinny;
+  const int grid = P.chunks_h * P.nheavy;
   if (b3) hipLaunchKernelGGL(k_gemm_tn<true>, dim3((unsigned)grid), dim3(256), GLDS3_BYTES, st, P, ws);
   else hipLaunchKernelGGL(k_gemm_tn<false>, dim3((unsigned)grid), dim3(256), GLDS_BYTES, st, P, ws);
   int rc = check_launch("k_gemm_tn");

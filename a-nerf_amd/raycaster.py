@@ -70,7 +70,9 @@ class RayCaster(nn.Module):
         if fwd_type == "mesh":
             return self.render_mesh_density(*args, **kwargs)
         if fwd_type == "density_color":
-            raise NotImplementedError("fwd_type='density_color' needs texture layers no shipped config has")
+            # raycasters.py:352-353, 623-624: `color=True` asserts the network has `texture_linears`; no network class of the
+            # reference has them (nerf.py), so the reference's own call ends in this AssertionError, message and all
+            raise AssertionError("need to have texture layer!")
         if not self.training:
             return self.forward_eval(*args, **kwargs)
         return self.render_rays(*args, **kwargs)

@@ -104,11 +104,12 @@ def _worker(rank, world, port, mixamo, n_rays, q):
         lo, hi = parallel.shard_rays(n_rays, rank, world)
         w = parallel.shard_weight(n_rays, rank, world)
         iters = [1, 2, 3, 4] if mixamo else [1, 2]
-        hist = []
+        hist, flat_hist = [], []
         for i in iters:
             loss, g_used, scale = _step(args, rk_train, popt, opt, batch, slice(lo, hi), i, reduce=True, weight=w)
             assert scale == 1.0 / world
             hist.append({gi: g.cpu() for gi, g in g_used.items()})
+            flat_hist.append(opt.flat.detach().cpu().clone())
         flat_dp = opt.flat.detach().cpu().clone()
         # the same steps with the fine network's all-reduce overlapped with the coarse half of the backward
         # (FusedAdam.enable_overlap: AnerfBackwardIO.passes = 1 / 2, early collective on a side stream): same sums
@@ -132,9 +133,11 @@ def _worker(rank, world, port, mixamo, n_rays, q):
             # single-process reference: the whole batch, no collective, same cadence
             args2, rk2, caster2, popt2, opt2, batch2 = _setup(mixamo, n_rays, device)
             rk2["ray_caster"].train()
-            errs, perr = [], []
+            errs, perr, frac_iter = [], [], []
             for k, i in enumerate(iters):
                 _, g_full, _ = _step(args2, rk2, popt2, opt2, batch2, slice(0, n_rays), i, reduce=False)
+                ff = opt2.flat.detach().cpu()
+                frac_iter.append(float(((flat_hist[k] - ff).abs() <= 1e-6 + 1e-6 * ff.abs()).float().mean()))
                 assert set(g_full) == set(hist[k]), (i, set(g_full), set(hist[k]))
                 # first use of a group's bucket: the DP-averaged gradient must equal the full-batch gradient up to summation
                 # order (group 0 at the first iteration, when both sides still hold identical parameters; the pose group at
@@ -145,6 +148,15 @@ def _worker(rank, world, port, mixamo, n_rays, q):
                         errs.append((i, gi, float((g - d).abs().max() / (g.abs().max() + 1e-20))))
             flat_full = opt2.flat.detach().cpu()
             d = (flat_dp - flat_full).abs()
+            far = d > 1e-6 + 1e-6 * flat_full.abs()
+            where, o = [], 0                                   # which tensors hold the elements that stepped differently
+            for gi_, grp in enumerate(opt.param_groups):
+                for k_, prm in enumerate(grp["params"]):
+                    c = int(far[o:o + prm.numel()].sum())
+                    if c:
+                        where.append((c, gi_, k_, tuple(prm.shape)))
+                    o += prm.numel()
+            res.update(where=sorted(where, reverse=True)[:8], frac_iter=frac_iter)
             res.update(grad_errs=errs, frac_close=float((d <= 1e-6 + 1e-6 * flat_full.abs()).float().mean()),
                        max_diff=float(d.max()), n_groups=len(opt.param_groups),
                        steps=list(opt._steps), steps_ref=list(opt2._steps))
@@ -180,11 +192,22 @@ def test_two_ranks_on_one_gpu_equal_the_single_process_step(mixamo, n_rays):
     assert r0["steps"] == r0["steps_ref"] == ([4, 1] if mixamo else [2])      # pose group: stepped at i = 3 only
     assert len(r0["grad_errs"]) == (2 if mixamo else 1)
     for i, gi, e in r0["grad_errs"]:
-        # network bucket at iteration 1: summation order only.  Pose bucket at its first step (i = 3): it accumulated three
-        # iterations during which the two runs' network parameters already differ at round-off level (see below)
-        assert e < (2e-5 if gi == 0 else 2e-3), (i, gi, e)
-    # Adam divides by |g|: elements whose gradient is at round-off level may step differently; everything else agrees
-    assert r0["frac_close"] > 0.995, r0
+        # THE accuracy gate.  Network bucket at iteration 1 (both sides still hold identical parameters): the averaged shard
+        # gradients equal the full-batch gradient up to summation order -- 1.3e-7 .. 3.5e-7 of the largest element measured, gate
+        # 2e-6.  Pose bucket at its first step (i = 3): it accumulated three iterations during which the two runs' network
+        # parameters already differ at round-off level (below)
+        assert e < (2e-6 if gi == 0 else 2e-3), (i, gi, e)
+    # Parameters: the first Adam step is +-lr whatever the gradient's magnitude, so after iteration 1 every element agrees.
+    # From then on an element whose gradient sits at round-off level may step the other way (2 lr apart), the forward then
+    # differs by more than round-off, and the two trajectories separate at the rate Adam amplifies it -- a property of the
+    # optimiser, not of the kernels (which gradient order the kernels sum in moves the count several-fold: 0.9991 with 17 row
+    # chunks in the weight-gradient GEMM, 0.9909 with 18, same first-iteration agreement).  So: exact agreement after the first
+    # step, >= 0.999 after the second, most elements after the last, and nothing further apart than lr-sized steps allow.
+    print("frac_close", r0["frac_close"], "max_diff", r0["max_diff"], "per iteration", r0["frac_iter"], "grad_errs", r0["grad_errs"],
+          "where", r0["where"][:3])
+    assert r0["frac_iter"][0] == 1.0, r0
+    assert r0["frac_iter"][1] > 0.999, r0
+    assert r0["frac_close"] > 0.98, r0
     assert r0["max_diff"] <= 2.1 * LR * (4 if mixamo else 2), r0
 
 

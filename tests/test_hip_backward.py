@@ -461,6 +461,23 @@ def test_backward_kernels_are_bitwise_repeatable_and_precisions_agree():
         for a, b in zip(runs[0], runs[2]):
             assert torch.equal(a, b)
         outs[tag] = runs[0]
+        # the two head problems ride as fp32 FMAs inside two of the GEMM's blocks (GemmHead, anerf_gemm.hip): rows of `draw`
+        # against h7 / g, summed in sample order per wave, then over the waves' row slots and the row chunks -- against float64
+        dz, df, dzv = runs[0][0], runs[0][1], runs[0][2]
+        grads = runs[0][5:]
+        d64 = draw[:P].double()
+        ix = {n_: 2 * i for i, n_ in enumerate(ops.PARAM_ORDER)}
+        checks = [("alpha_linear", d64[:, 3:4].T @ sv["h"][7][:P].double(), d64[:, 3:4].sum(0)),
+                  ("rgb_linear", d64[:, :3].T @ sv["g"][:P].double(), d64[:, :3].sum(0)),
+                  ("pts_linears.1", dz[1][:P].double().T @ sv["h"][0][:P].double(), dz[1][:P].double().sum(0)),
+                  ("feature_linear", df[:P].double().T @ sv["h"][7][:P].double(), df[:P].double().sum(0)),
+                  ("pts_linears.7", dz[7][:P].double().T @ sv["h"][6][:P].double(), dz[7][:P].double().sum(0))]
+        for name, w64, b64 in checks:
+            gw, gb = grads[ix[name]].double(), grads[ix[name] + 1].double()
+            assert gw.shape == w64.shape and gb.shape == b64.shape, name
+            tol = 2e-6 if tag == "fp32" else 3e-5
+            assert float((gw - w64).abs().max()) <= tol * float(w64.abs().max()), (tag, name, float((gw - w64).abs().max()))
+            assert float((gb - b64).abs().max()) <= tol * float(b64.abs().max()) + 1e-9, (tag, name)
     for k, (a, b) in enumerate(zip(outs["fp32"], outs["b3"])):
         scale = float(a.abs().max())
         assert float((a - b).abs().max()) <= 3e-5 * scale + 1e-12, (k, float((a - b).abs().max()), scale)
