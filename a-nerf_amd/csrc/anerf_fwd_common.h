@@ -385,10 +385,13 @@ __device__ __forceinline__ float head_dot(const f32x16* acc, const float* wrow_h
 // four lock-step waves x 8 KiB there, ~420 times per tile; a full-k-group window (32 VGPRs) made the render kernel spill.)
 // AUTO_END = false: the caller ends the stage itself (pipe.stage_rendezvous() ... pipe.stage_refill()) after the k-group
 // for which `boundary` holds.
-template <int NB, class PIPE, bool AUTO_END = true>
+// NBU <= NB: only the first NBU output blocks are multiplied (a narrow last column group of k_mlp_bwd_in: the stage keeps its
+// NB-block layout and fragment reads, the MFMAs of the blocks past the edge are simply not issued).
+template <int NB, class PIPE, bool AUTO_END = true, int NBU = NB>
 __device__ __forceinline__ void kgroup(PIPE& pipe, f32x16 (&acc)[NB], int kg, bool first, bool last, float b0, float b1,
                                        float b2, float b3) {
   static_assert(NB == 8 || NB == 4, "kgroup: 8 or 4 output blocks");
+  static_assert(NBU >= 1 && NBU <= NB, "kgroup: used blocks");
   constexpr int KPS = STAGE_FRAGS / NB;  // k-groups per stage
   constexpr int FPQ = NB / 4;            // fragments per quarter
   const int ks = kg % KPS;
@@ -418,7 +421,7 @@ __device__ __forceinline__ void kgroup(PIPE& pipe, f32x16 (&acc)[NB], int kg, bo
   for (int q = 0; q < 4; ++q) {
     const int sl = (q & 1) * FPQ;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+    for (int nb = 0; nb < NBU; ++nb)
       acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(pipe.a[sl + (nb >> 2)][nb & 3], b[q], acc[nb], 0, 0, 0);
     const char* src = q < 2 ? csrc + (q + 2) * FPQ * FRAG_BYTES : nsrc + (q - 2) * FPQ * FRAG_BYTES;
 #pragma unroll

@@ -24,14 +24,16 @@ extern float* g_tile_timing_buf;   // anerf_mlp.hip (debug build only)
 
 // Compiler-scheduled k-step (training forward and the backward kernels: with their extra live state -- saved-row
 // stores, 128 ReLU-mask values -- the two fragment buffers of the pipelined form below cost more in spills than they gain).
-template <int NB>
+// NBU <= NB: only the first NBU blocks are read and multiplied (narrow last column group of k_mlp_bwd_in_b3; the stage keeps its
+// NB-block layout).
+template <int NB, int NBU = NB>
 __device__ __forceinline__ void kstep_plain(Pipe3& pipe, f32x16 (&acc)[NB], int ks, bool last, const BOp& b) {
   constexpr int KPS = STAGE_FRAGS / (2 * NB);   // k-steps per 32-fragment stage
   constexpr int NPF = NB < 4 ? NB : 4;          // blocks whose fragments are prefetched across the stage barrier
   const int kk = ks % KPS;
   bf16x8 ah[NB], al[NB];
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
+  for (int nb = 0; nb < NBU; ++nb) {
     if (kk == 0 && ks != 0 && nb < NPF) {
       ah[nb] = __builtin_bit_cast(bf16x8, pipe.pref[2 * nb]);
       al[nb] = __builtin_bit_cast(bf16x8, pipe.pref[2 * nb + 1]);
@@ -45,7 +47,7 @@ __device__ __forceinline__ void kstep_plain(Pipe3& pipe, f32x16 (&acc)[NB], int 
     for (int i = 0; i < 2 * NPF; ++i) pipe.pref[i] = *reinterpret_cast<const f32x4*>(pipe.smem + pipe.nxt + i * FRAG_BYTES);
   }
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
+  for (int nb = 0; nb < NBU; ++nb) {
     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[nb], b.hi, acc[nb], 0, 0, 0);
     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[nb], b.lo, acc[nb], 0, 0, 0);
     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[nb], b.hi, acc[nb], 0, 0, 0);
@@ -64,12 +66,13 @@ __device__ __forceinline__ void kstep_plain(Pipe3& pipe, f32x16 (&acc)[NB], int 
 // "2 reads, s_waitcnt lgkmcnt(0), 3 MFMAs" per block through one 8-register buffer (the kernel is at the register
 // limit), which exposes the LDS latency behind every block.  The sched_barrier fences pin the order of MFMA and DS
 // instructions only (mask 0x6: VALU / SALU -- the next operand split, the encoding -- may move across them).
-template <int NB, bool PIPE = false>
+template <int NB, bool PIPE = false, int NBU = NB>
 __device__ __forceinline__ void kstep(Pipe3& pipe, f32x16 (&acc)[NB], int ks, bool last, const BOp& b) {
   if constexpr (!PIPE) {
-    kstep_plain<NB>(pipe, acc, ks, last, b);
+    kstep_plain<NB, NBU>(pipe, acc, ks, last, b);
     return;
   }
+  static_assert(NBU == NB || !PIPE, "the hand-pipelined form multiplies every block");
   static_assert(NB == 8 || NB == 4, "groups of 4 feature blocks");
   constexpr int KPS = STAGE_FRAGS / (2 * NB);   // k-steps per 32-fragment stage
   const int kk = ks % KPS;
@@ -724,13 +727,13 @@ __device__ __forceinline__ void load_dz_row(f32x4 (&d)[32], const float* __restr
   }
 }
 
-template <int NKS>
+template <int NKS, int NBU = 8>
 __device__ __forceinline__ void contract_row(Pipe3& pipe, f32x16 (&acc)[8], const f32x4 (&d)[32], int ks0, bool last) {
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) {
     const BOp b = split8(d[2 * ks].x, d[2 * ks].y, d[2 * ks].z, d[2 * ks].w, d[2 * ks + 1].x, d[2 * ks + 1].y,
                          d[2 * ks + 1].z, d[2 * ks + 1].w);
-    kstep<8>(pipe, acc, ks0 + ks, last && ks == NKS - 1, b);
+    kstep<8, false, NBU>(pipe, acc, ks0 + ks, last && ks == NKS - 1, b);
   }
 }
 
@@ -769,15 +772,19 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_in_b3(const BwdInArgs3 A) {
   contract_row<16>(pipe, acc, d0, 0, false);
   contract_row<16>(pipe, acc, d5, 16, false);
   if (valid) store_cols3(A.dx + p * 432, acc, 0, 432, h);
-  zero_acc3<8>(acc);
-  contract_row<16>(pipe, acc, d0, 16, false);
-  contract_row<16>(pipe, acc, d5, 16, false);
+  zero_acc3<8>(acc);                                         // columns 256..431 = 5.5 blocks: 6 of the 8 are multiplied
+  contract_row<16, 6>(pipe, acc, d0, 16, false);
+  contract_row<16, 6>(pipe, acc, d5, 16, false);
   if (valid) store_cols3(A.dx + p * 432, acc, 256, 432, h);
   load_dz_row<8>(d0, A.dzv + pc * 128 + 4 * h);
+  const int nbl = (A.uw - 256 * (ngu - 1) + 31) / 32;         // blocks of the (narrow) last group: 5 (648 / 664) or 3 (72)
 #pragma unroll 1
   for (int gi = 0; gi < ngu; ++gi) {
     zero_acc3<8>(acc);
-    contract_row<8>(pipe, acc, d0, 16, gi == ngu - 1);
+    const bool lastg = gi == ngu - 1;
+    if (!lastg || nbl > 5) contract_row<8>(pipe, acc, d0, 16, lastg);
+    else if (nbl > 3) contract_row<8, 5>(pipe, acc, d0, 16, true);
+    else contract_row<8, 3>(pipe, acc, d0, 16, true);
     if (valid) store_cols3(A.du + p * A.uw, acc, 256 * gi, A.uw, h);
   }
 }

@@ -300,7 +300,8 @@ struct BwdInArgs {
 // requested during the previous stage (complete at its barrier) and are pinned in front of the weight pipe's re-issue;
 // every k-group requests one quad of the next stage (of `next_src_row_h`, the next segment's row, at the end) and writes SPK
 // float4 of the PREVIOUS output group (`outv`, columns out_c0.. of out_row_h, width out_w) -- no load or store bursts.
-template <int NKG, int SPK>
+// NBU: 32-column blocks of the output group that exist (a narrow last group skips the MFMAs of the others).
+template <int NKG, int SPK, int NBU = 8>
 __device__ __forceinline__ void bwd_in_segment(Pipe3B& pipe, f32x16 (&acc)[8], f32x4 (&cur)[4], const float* __restrict__ src_row_h,
                                                const float* __restrict__ next_src_row_h, const float (&outv)[128],
                                                float* __restrict__ out_row_h, int out_c0, int out_w, bool& pending) {
@@ -327,7 +328,7 @@ __device__ __forceinline__ void bwd_in_segment(Pipe3B& pipe, f32x16 (&acc)[8], f
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      kgroup<8, Pipe3B, false>(pipe, acc, kg, false, false, cur[ks].x, cur[ks].y, cur[ks].z, cur[ks].w);
+      kgroup<8, Pipe3B, false, NBU>(pipe, acc, kg, false, false, cur[ks].x, cur[ks].y, cur[ks].z, cur[ks].w);
     }
     pipe.stage_rendezvous();
     pending = true;
@@ -368,22 +369,25 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_in(const BwdInArgs A) {
   bwd_in_segment<32, 0>(pipe, acc, cur, z0, z5, outv, dx, 0, 0, pending);
   bwd_in_segment<32, 0>(pipe, acc, cur, z5, z0, outv, dx, 0, 0, pending);
   take<8, false>(outv, acc);
-  // ---- dX' columns 256..431 (its first 32 k-groups write group 0)
+  // ---- dX' columns 256..431 = 5.5 blocks: 6 of the group's 8 are multiplied (its first 32 k-groups write group 0)
   zero_acc<8>(acc);
-  bwd_in_segment<32, 1>(pipe, acc, cur, z0, z5, outv, dx, 0, 432, pending);
-  bwd_in_segment<32, 0>(pipe, acc, cur, z5, zv, outv, dx, 0, 0, pending);
+  bwd_in_segment<32, 1, 6>(pipe, acc, cur, z0, z5, outv, dx, 0, 432, pending);
+  bwd_in_segment<32, 0, 6>(pipe, acc, cur, z5, zv, outv, dx, 0, 0, pending);
   take<8, false>(outv, acc);
-  // ---- dU' = Wvu'^T dzv, 256 columns at a time; group g's 16 k-groups write the group before it
+  // ---- dU' = Wvu'^T dzv, 256 columns at a time; group g's 16 k-groups write the group before it.  The last group is narrow in
+  // every configuration (648 / 664 = 2 x 256 + 136 / 152: 5 blocks; 72: 3 blocks)
   const int ngu = (A.uw + 255) / 256;
-  zero_acc<8>(acc);
-  bwd_in_segment<16, 2>(pipe, acc, cur, zv, ngu > 1 ? zv : nullptr, outv, dx, 256, 432, pending);
-  take<8, false>(outv, acc);
-#pragma unroll 1
-  for (int g = 1; g < ngu; ++g) {
+  const int nbl = (A.uw - 256 * (ngu - 1) + 31) / 32;        // blocks of the last group
+  auto u_group = [&](int g, const float* next_row, float* out_row, int out_c0, int out_w) {
     zero_acc<8>(acc);
-    bwd_in_segment<16, 2>(pipe, acc, cur, zv, g + 1 < ngu ? zv : nullptr, outv, du, 256 * (g - 1), A.uw, pending);
+    if (g + 1 < ngu || nbl > 5) bwd_in_segment<16, 2, 8>(pipe, acc, cur, zv, next_row, outv, out_row, out_c0, out_w, pending);
+    else if (nbl > 3) bwd_in_segment<16, 2, 5>(pipe, acc, cur, zv, next_row, outv, out_row, out_c0, out_w, pending);
+    else bwd_in_segment<16, 2, 3>(pipe, acc, cur, zv, next_row, outv, out_row, out_c0, out_w, pending);
     take<8, false>(outv, acc);
-  }
+  };
+  u_group(0, ngu > 1 ? zv : nullptr, dx, 256, 432);
+#pragma unroll 1
+  for (int g = 1; g < ngu; ++g) u_group(g, g + 1 < ngu ? zv : nullptr, du, 256 * (g - 1), A.uw);
   // the last group's columns
   {
     const int c0 = 256 * (ngu - 1);
