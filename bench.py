@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="render64", choices=["render64", "hier", "hier128", "render64x64", "train", "train_mixamo"])
-    ap.add_argument("--cpu-rays", type=int, default=8192, help="ray sample for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-rays", type=int, default=16384, help="ray sample for the CPU baseline (0 = skip); 16384 rays = ~10 s of host work")
     ap.add_argument("--n-rand", type=int, default=3072, help="train workload: global rays per step")
     ap.add_argument("--torch-tail", action="store_true",
                     help="train workload: torch loss + torch.optim.Adam + copy-bucket all-reduce instead of the fused kernels")
