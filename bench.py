@@ -107,8 +107,21 @@ def self_launch(args):
                                       stdout=None if r == 0 else sys.stderr))
     rc = 0
     live = list(procs)
+    # watchdog: a rank stuck in a rendezvous or a collective must not hold the caller for ever (ANERF_BENCH_TIMEOUT seconds)
+    deadline = time.time() + float(os.environ.get("ANERF_BENCH_TIMEOUT", "1800"))
     while live:
         time.sleep(0.1)
+        if time.time() > deadline:
+            sys.stderr.write(f"bench.py: ranks {[procs.index(p) for p in live]} still running at the ANERF_BENCH_TIMEOUT deadline; stopping them\n")
+            for q in live:
+                q.terminate()
+            t_end = time.time() + 10
+            for q in live:
+                try:
+                    q.wait(max(0.1, t_end - time.time()))
+                except subprocess.TimeoutExpired:
+                    q.kill()
+            return 124
         for p in list(live):
             code = p.poll()
             if code is None:
@@ -152,6 +165,8 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+    if os.environ.get("RANK", "") in os.environ.get("ANERF_BENCH_HANG_RANK", "-").split(","):   # test hook: a rank that never
+        time.sleep(3600)                                                                         # reaches the rendezvous
     # stdout carries exactly one line, the JSON record.  Libraries write there too -- RCCL prints a five-line version
     # banner through C stdio on communicator creation, gloo its connection notes -- and, being buffered, would land AFTER
     # the record at process exit.  So: keep the original stdout for the record only and point fd 1 at stderr for the run.
@@ -187,10 +202,12 @@ def main():
         for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
             os.environ.setdefault(k, v)
         import torch.distributed as dist
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=float(os.environ.get("ANERF_BENCH_PG_TIMEOUT", "600")))   # a dead peer: error, not a hang
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, timeout=pg_timeout)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=pg_timeout)
         # prime the communicator (RCCL builds its rings on the first collective) outside any timed region, whatever --warmup is
         prime = torch.zeros(4 * world, device=device)
         dist.all_reduce(prime)

@@ -9,6 +9,7 @@ import importlib
 import json
 import os
 import subprocess
+import time
 import sys
 
 import numpy as np
@@ -216,6 +217,18 @@ def test_profile_events_bracket_the_training_kernels():
     out2, state2 = ops.train_forward(cfg, ops.pack_params(cfg, Pc), ops.pack_params(cfg, Pf), rb, d(skts), d(cyls), S, Ni)
     assert not state2["io"].profile
     assert torch.equal(out2["rgb_map"], out["rgb_map"])
+
+
+def test_bench_self_launch_watchdog_stops_hung_ranks():
+    """Ranks that never reach the rendezvous (test hook) must not hold `python bench.py --gpus N` for ever: at the
+    ANERF_BENCH_TIMEOUT deadline the launcher stops its children by PID, prints no record and exits 124."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(ANERF_BENCH_BACKEND="gloo", ANERF_BENCH_HANG_RANK="0,1", ANERF_BENCH_TIMEOUT="4")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--cpu-rays", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 124 and r.stdout.strip() == "" and "ANERF_BENCH_TIMEOUT" in r.stderr, (r.returncode, r.stderr[-500:])
+    assert time.time() - t0 < 120
 
 
 @pytest.mark.gpu
