@@ -12,7 +12,8 @@ size-independent properties (task statement, section 3):
 Sizes: N_rand = 3072 (config 3 / mixamo.txt:34) and 384 (= 3072 / 8, one rank's shard at 8 GPUs), 64 + 16 samples,
 stratified jitter + density noise on, fp32 and the split-bf16 kernels.  Small-size parity of the same entry points against
 the reference's golden gradients lives in test_hip_backward.py.
-`code = 16` is BASELINE config 4's network (configs/mixamo/mixamo.txt:41-55: per-frame codes, 920-wide view layer) with pose
+`code = -1` is the `multires_views = 0` view encoding (72-wide view input: 13 blocks x 19 row chunks in the weight-gradient GEMM,
+3 of 8 column blocks in the narrow group of k_mlp_bwd_in).  `code = 16` is BASELINE config 4's network (configs/mixamo/mixamo.txt:41-55: per-frame codes, 920-wide view layer) with pose
 gradients: the same properties, plus the frame-code gradients [n_codes,16] of both networks (a sum over rays: the halves add
 up, bitwise repeatable -- k_code_rowsum / k_code_reduce use no atomics) and k_mlp_bwd_in at 3072 x 144 samples.
 """
@@ -53,6 +54,7 @@ def _inputs(n):
 def _nets(cfg, precision):
     b3 = precision == "bf16x3"
     mk = dict(framecode_ch=cfg.framecode_ch, n_codes=N_CODES) if cfg.framecode_ch else {}
+    mk["multires_views"] = cfg.multires_views
     Pc = {k: dev(v) for k, v in synth.make_net_params(11, **mk).items()}
     Pf = {k: dev(v) for k, v in synth.make_net_params(12, **mk).items()}
     pk = lambda P, w: ops.pack_params(cfg, P, w)
@@ -80,9 +82,11 @@ def _step(cfg, nets, inp, sl, precision):
 
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
-@pytest.mark.parametrize("n,code", [(3072, 0), (384, 0), (3072, 16), (384, 16)])
+@pytest.mark.parametrize("n,code", [(3072, 0), (384, 0), (3072, 16), (384, 16), (384, -1)])
 def test_full_size_training_step_properties(n, code, precision):
-    cfg = ops.PathConfig(framecode_ch=code)
+    # code = -1: the multires_views = 0 configuration (surreal_single.txt's view encoding: a 72-wide view input, 13 GEMM jobs)
+    cfg = ops.PathConfig(multires_views=0) if code < 0 else ops.PathConfig(framecode_ch=code)
+    code = max(code, 0)
     nets = _nets(cfg, precision)
     inp = _inputs(n)
     full = _step(cfg, nets, inp, slice(0, n), precision)
