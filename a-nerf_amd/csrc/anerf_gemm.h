@@ -63,6 +63,8 @@ struct GemmPlan {
   long long p_pad;
 };
 
+static_assert(sizeof(GemmPlan) + 8 <= 4096 && sizeof(GemmBatch) + 8 <= 4096, "passed by value: HIP kernel arguments are limited to 4 KiB");
+
 constexpr int GEMM_ROWS = 16;   // sample rows per LDS stage
 
 // rows-per-block search shared by anerf_train_layout (workspace size) and anerf_weight_grads
