@@ -442,6 +442,9 @@ class _LossFn(torch.autograd.Function):
         return sc(g["rgb"]), sc(g["acc"]), sc(g["rgb0"]), sc(g["acc0"]), None, None, None, None, None
 
 
+_BG_CACHE = {}
+
+
 def fused_nerf_loss(preds, target, bgs=1.0, loss_fn="MSE", coarse_weight=1.0, use_background=True, beta=0.1):
     """render.nerf_loss (= _compute_nerf_loss, trainer.py:353-380) as one kernel.
     Returns (loss, stats) with stats = [total, fine, coarse, fine_mse] on the device (PSNR = mse2psnr(stats[3]))."""
@@ -456,7 +459,10 @@ def fused_nerf_loss(preds, target, bgs=1.0, loss_fn="MSE", coarse_weight=1.0, us
         if bg.numel() == 1:
             bg = bg.reshape(1).expand(3).contiguous()
     else:
-        bg = torch.full((3,), float(bgs), dtype=torch.float32, device=rgb.device)
+        key = (rgb.device, float(bgs))               # a constant background colour: one fill per (device, value), not one per step
+        bg = _BG_CACHE.get(key)
+        if bg is None:
+            bg = _BG_CACHE[key] = torch.full((3,), float(bgs), dtype=torch.float32, device=rgb.device)
     loss, stats = _LossFn.apply(rgb, preds["acc_map"], preds.get("rgb0"), preds.get("acc0"), target, bg,
                                 kinds[loss_fn], coarse_weight, beta)
     return loss, stats

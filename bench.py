@@ -581,6 +581,14 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
             torch.cuda.synchronize()
         sys.stderr.write(prof.key_averages(group_by_stack_n=8).table(sort_by="self_cuda_time_total", row_limit=60,
                                                                       max_name_column_width=60, max_src_column_width=110) + "\n")
+        seen = set()
+        for e in prof.events():          # who issues the small fills / copies: first Python frames of each distinct call site
+            if e.name in ("aten::zeros", "aten::full", "aten::ones_like", "aten::mul", "aten::add", "aten::copy_", "aten::clone",
+                          "aten::contiguous", "aten::index_select", "aten::index_add_", "aten::zeros_like", "aten::fill_"):
+                st = tuple(f for f in (e.stack or []) if ".py" in f)[:4]
+                if (e.name, st) not in seen:
+                    seen.add((e.name, st))
+                    sys.stderr.write(f"{e.name}: " + " <- ".join(st) + "\n")
 
     # Per-kernel HIP-event times (AnerfProfile: events recorded by the library around each MFMA kernel of both passes) over
     # a few extra, untimed steps -- the executed-FLOP roofline of every training kernel.  Executed FLOPs per sample: forward
