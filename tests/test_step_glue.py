@@ -255,6 +255,29 @@ def test_bench_launches_its_own_ranks():
 
 
 @pytest.mark.gpu
+def test_bench_under_torch_distributed_run():
+    """The driver's N > 1 command line, verbatim: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr
+    127.0.0.1 --master-port P bench.py --gpus 2 --steps K --warmup W` (gloo here: both ranks share the one GPU of the box).
+    Exactly one JSON line on the launcher's stdout, from rank 0, with both ranks in it."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["ANERF_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+                        "--warmup", "1", "--cpu-rays", "0"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1
+    assert rec["metric"] == "rays/sec" and rec["scaling"] == "strong" and rec["value"] > 0
+    assert len(rec["ms_per_step_per_rank"]) == 2 and rec["config"]["rays_per_step"] == 261121
+
+
+@pytest.mark.gpu
 def test_caster_draws_its_randomness_from_the_device_rng():
     """The non-pytest training call (perturb, raw_noise_std, ray_noise_std all on): every random input comes from ONE
     anerf_rand_fill launch of the caster's DeviceRng -- same seed and offset => bit-identical outputs and gradients, the next call
