@@ -25,6 +25,10 @@ import os
 import sys
 import time
 
+# dmabuf IPC: RCCL's intra-node transport needs it on this driver (already exported on the GPU boxes; set before the HIP runtime
+# starts so that a rank launched by torch.distributed.run from a bare environment has it too)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 
