@@ -265,16 +265,17 @@ def test_bench_under_torch_distributed_run():
         port = sk.getsockname()[1]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
     env["ANERF_BENCH_BACKEND"] = "gloo"
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-                        "--warmup", "1", "--cpu-rays", "0"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["ranks"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1
-    assert rec["metric"] == "rays/sec" and rec["scaling"] == "strong" and rec["value"] > 0
-    assert len(rec["ms_per_step_per_rank"]) == 2 and rec["config"]["rays_per_step"] == 261121
+    for extra, rays in ([], 261121), (["--workload", "train", "--n-rand", "256"], 256):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+                            "--warmup", "1", "--cpu-rays", "0"] + extra, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        rec = json.loads(lines[0])
+        assert rec["n_gpus"] == 2 and rec["ranks"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1
+        assert rec["metric"] == "rays/sec" and rec["scaling"] == "strong" and rec["value"] > 0
+        assert len(rec["ms_per_step_per_rank"]) == 2 and rec["config"]["rays_per_step"] == rays
 
 
 @pytest.mark.gpu
