@@ -11,8 +11,10 @@ def wrap(mod, name):
         counts[(name, " <- ".join(st[-3:]))] += 1
         return orig(*a, **k)
     setattr(mod, name, f)
-for n in ("zeros", "full", "ones_like", "zeros_like", "cat", "stack", "tensor", "as_tensor"):
+for n in ("zeros", "full", "ones_like", "zeros_like", "cat", "stack", "tensor", "as_tensor", "clone", "empty_like"):
     wrap(torch, n)
+for n in ("copy_", "clone", "contiguous", "to", "float", "detach", "index_select", "mul", "__mul__", "__getitem__"):
+    wrap(torch.Tensor, n)
 sys.argv = [os.path.join(ROOT, "bench.py")] + sys.argv[1:]
 try:
     runpy.run_path(sys.argv[0], run_name="__main__")
