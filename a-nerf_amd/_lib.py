@@ -33,7 +33,7 @@ class AnerfSaved(C.Structure):
                 ("p_pad", C.c_int64)]
 
 
-ABI_VERSION = 3        # revision of include/anerf.h these structures were written for (checked against anerf_version())
+ABI_VERSION = 4        # revision of include/anerf.h these structures were written for (checked against anerf_version())
 PROF_SLOTS = 16
 
 
@@ -60,7 +60,7 @@ class AnerfForwardIO(C.Structure):
                 ("single_net", C.c_int32), ("precision", C.c_int32),
                 ("rgb_map", C.c_void_p), ("disp_map", C.c_void_p), ("acc_map", C.c_void_p), ("alpha", C.c_void_p),
                 ("rgb0", C.c_void_p), ("disp0", C.c_void_p), ("acc0", C.c_void_p), ("alpha0", C.c_void_p),
-                ("pts_noise", C.c_void_p), ("pts_noise_is", C.c_void_p), ("profile", C.POINTER(AnerfProfile))]
+                ("pts_noise", C.c_void_p), ("pts_noise_is", C.c_void_p), ("profile", C.POINTER(AnerfProfile)), ("cyl_shared", C.c_int32)]
 
 
 class AnerfNetGrads(C.Structure):

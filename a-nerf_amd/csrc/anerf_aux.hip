@@ -39,7 +39,7 @@ __global__ void k_pack(AnerfNetParams P, const int32_t* __restrict__ table, long
 // 64-bit integers: the sums in 2^-32 fixed point, so that the cross-wave accumulation (integer atomics) is exact and
 // order-independent -- the fallback value, and with it every z of a missed ray, is bit-reproducible.
 constexpr double STATS_FIX = 4294967296.0;   // 2^32
-__global__ void k_ray_bounds(const float* __restrict__ rays, int ray_stride, const float* __restrict__ cyls, int n,
+__global__ void k_ray_bounds(const float* __restrict__ rays, int ray_stride, const float* __restrict__ cyls, int cyl_stride, int n,
                              float* __restrict__ near_far, unsigned long long* __restrict__ stats) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   float sn = 0.f, sf = 0.f, cn = 0.f, cf = 0.f;
@@ -48,7 +48,7 @@ __global__ void k_ray_bounds(const float* __restrict__ rays, int ray_stride, con
     const float ox = r[0], oz = r[2], dx = r[3], dz = r[5], near = r[6], far = r[7];
     const float pnx = fmaf(dx, near, ox), pnz = fmaf(dz, near, oz);
     const float pfx = fmaf(dx, far, ox), pfz = fmaf(dz, far, oz);
-    const float* c = cyls + (long long)i * 5;
+    const float* c = cyls + (long long)i * cyl_stride;   // 5, or 0: one cylinder shared by every ray of the call
     const float ncx = c[0] - pnx, ncz = c[1] - pnz;
     const float nfx = pfx - pnx, nfz = pfz - pnz;
     const float nf_len = sqrtf(nfx * nfx + nfz * nfz);
@@ -443,10 +443,10 @@ int launch_pack(const AnerfNetParams* P, const int32_t* table, long long n, floa
   return check_launch("k_pack");
 }
 
-int launch_ray_bounds(const float* rays, int ray_stride, const float* cyls, int n, float* near_far, float* stats,
+int launch_ray_bounds(const float* rays, int ray_stride, const float* cyls, int cyl_stride, int n, float* near_far, float* stats,
                       hipStream_t st) {
   if (hipMemsetAsync(stats, 0, 4 * sizeof(unsigned long long), st) != hipSuccess) return set_error(ANERF_E_LAUNCH, "memset stats");
-  hipLaunchKernelGGL(k_ray_bounds, dim3((n + 255) / 256), dim3(256), 0, st, rays, ray_stride, cyls, n, near_far,
+  hipLaunchKernelGGL(k_ray_bounds, dim3((n + 255) / 256), dim3(256), 0, st, rays, ray_stride, cyls, cyl_stride, n, near_far,
                      reinterpret_cast<unsigned long long*>(stats));
   return check_launch("k_ray_bounds");
 }

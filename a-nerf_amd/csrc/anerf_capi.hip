@@ -26,7 +26,7 @@ int check_launch(const char* what) {
 // launchers defined in the kernel translation units
 struct MlpArgs;
 int launch_pack(const AnerfNetParams*, const int32_t*, long long, float*, hipStream_t);
-int launch_ray_bounds(const float*, int, const float*, int, float*, float*, hipStream_t);
+int launch_ray_bounds(const float*, int, const float*, int, int, float*, float*, hipStream_t);
 int launch_coarse_z(const float*, const float*, const float*, int, int, int, const float*, int, float*, float*,
                     hipStream_t);
 int launch_composite(const AnerfConfig*, const float*, const float*, const float*, int, const float*, int, int, float*,
@@ -207,7 +207,7 @@ using namespace anerf;
 extern "C" {
 
 const char* anerf_last_error(void) { return g_err; }
-int anerf_version(void) { return 3; }
+int anerf_version(void) { return 4; }
 
 int anerf_layout(const AnerfConfig* cfg, int which, AnerfLayout* out) {
   if (!out) return set_error(ANERF_E_NULL, "out is NULL");
@@ -395,14 +395,18 @@ int anerf_mlp_raw_b3(const AnerfConfig* cfg, const float* packed, const float* a
                       (hipStream_t)stream);
 }
 
-int anerf_ray_bounds(const float* rays, int32_t ray_stride, const float* cyls, int32_t n_rays, float* near_far,
-                     float* stats_ws, void* stream) {
+static int ray_bounds_checked(const float* rays, int32_t ray_stride, const float* cyls, int cyl_stride, int32_t n_rays, float* near_far,
+                              float* stats_ws, void* stream) {
   if (n_rays == 0) return ANERF_OK;   /* empty batch: nothing to enqueue, pointers may be NULL */
   if (!rays || !cyls || !near_far || !stats_ws) return set_error(ANERF_E_NULL, "ray_bounds: NULL pointer");
   if ((uintptr_t)stats_ws & 7) return set_error(ANERF_E_WORKSPACE, "ray_bounds: stats_ws must be 8-byte aligned");
   if (ray_stride < 8 || n_rays < 0) return set_error(ANERF_E_SHAPE, "ray_bounds: ray_stride >= 8 required");
-  if (n_rays == 0) return ANERF_OK;
-  return launch_ray_bounds(rays, ray_stride, cyls, n_rays, near_far, stats_ws, (hipStream_t)stream);
+  return launch_ray_bounds(rays, ray_stride, cyls, cyl_stride, n_rays, near_far, stats_ws, (hipStream_t)stream);
+}
+
+int anerf_ray_bounds(const float* rays, int32_t ray_stride, const float* cyls, int32_t n_rays, float* near_far,
+                     float* stats_ws, void* stream) {
+  return ray_bounds_checked(rays, ray_stride, cyls, 5, n_rays, near_far, stats_ws, stream);
 }
 
 int anerf_coarse_z(const float* near_far, const float* stats_ws, const float* rays, int32_t ray_stride,
@@ -944,7 +948,8 @@ int forward_impl(const AnerfConfig* cfg, const AnerfForwardIO* io, char* ws, con
         cfg, packed, aux, io->rays, io->ray_stride, zz, io->skts, io->skt_ray_stride, io->cam_idx, codes, io->n_codes,
         io->tau_v, io->tau_d, io->cutoff_v, io->cutoff_d, n, ns, raw, stream);
   };
-  int rc = anerf_ray_bounds(io->rays, io->ray_stride, io->cyls, n, F(w.near_far), F(w.stats), stream);
+  // ABI revision 4: io->cyl_shared = one cylinder [5] for every ray of the call (a frame's rays under render_path)
+  int rc = ray_bounds_checked(io->rays, io->ray_stride, io->cyls, io->cyl_shared ? 0 : 5, n, F(w.near_far), F(w.stats), stream);
   if (rc) return rc;
   rc = anerf_coarse_z(F(w.near_far), F(w.stats), io->rays, io->ray_stride, n, S, io->t_rand, io->lindisp, F(w.z), nullptr, stream);
   if (rc) return rc;

@@ -50,6 +50,20 @@ def _f32c(t, name):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def row_shared(t):
+    """True for a tensor whose rows are ONE row seen N times: a stride-0 expand along dim 0 -- what run_nerf.render_path's
+    `reuse_input(x, expand)` hands the caster for the frame's pose / cylinder / camera index (run_nerf.py:62-72,84-88:
+    `y.expand(expand, *x.shape[1:])`).  Such an input is passed to the kernels as its single row with a zero ray stride;
+    `.contiguous()` would write N copies of it (6.3 MB of bone matrices per 4096-ray chunk) and select the per-ray-pose
+    prologue of the MLP kernel."""
+    return t is not None and t.dim() >= 1 and t.shape[0] > 1 and t.stride(0) == 0
+
+
+def first_row(t):
+    """the one row of a row_shared tensor, [1, ...] (no copy when the row itself is contiguous)"""
+    return t[:1] if row_shared(t) else t
+
+
 _layout_cache = {}
 _table_cache = {}
 
@@ -439,7 +453,18 @@ class Profile:
         self.hip.hipEventDestroy.argtypes = [C.c_void_p]
         self.hip.hipEventSynchronize.argtypes = [C.c_void_p]
         self.st = _lib.AnerfProfile()
+        self.reset()
+
+    def reset(self):
+        """Replace every event by a fresh, never-recorded one.  Call before each profiled step: hipEventSynchronize succeeds on
+        a stale event and hipEventElapsedTime then returns the PREVIOUS step's value, so a pair the coming step does not record
+        (a skipped pass, no input gradients) could not be told from a recorded one; on a never-recorded event
+        hipEventElapsedTime fails and ms() returns None.  The caller synchronises before resetting (the library may still
+        hold the old handles in a call it has enqueued -- events are recorded at enqueue time, so after the call returned
+        they are no longer referenced)."""
         for i in range(_lib.PROF_SLOTS):
+            if self.st.ev[i]:
+                self.hip.hipEventDestroy(self.st.ev[i])
             ev = C.c_void_p()
             if self.hip.hipEventCreate(C.byref(ev)) != 0:
                 raise RuntimeError("hipEventCreate failed")
@@ -447,7 +472,7 @@ class Profile:
 
     def ms(self, kind, which_pass):
         """elapsed milliseconds of kernel `kind` ("fwd" | "bwd" | "gemm" | "bwd_in") of pass 0 (coarse) / 1 (fine), or None if
-        the pair was not recorded by the last step"""
+        the pair was not recorded since the last reset()"""
         a = self.SLOTS[kind] + 2 * which_pass
         out = C.c_float()
         if self.hip.hipEventSynchronize(self.st.ev[a + 1]) != 0:
@@ -484,7 +509,8 @@ def _forward_io(cfg, net_c, net_f, rays, skts, cyls, n_samples, n_importance, ta
                 codes_f, t_rand, u_imp, noise, noise_fine, lindisp, single_net, precision, pts_noise=None, pts_noise_is=None):
     """AnerfForwardIO of one caster call + the output dict + the tensors whose pointers it holds"""
     f = lambda t, nm: _f32c(t, nm)
-    rays, skts, cyls = f(rays, "rays"), f(skts, "skts"), f(cyls, "cyls")
+    # stride-0 expanded per-frame inputs (the reference's render_path) travel as their single row
+    rays, skts, cyls = f(rays, "rays"), f(first_row(skts), "skts"), f(first_row(cyls), "cyls")
     n, dev, S, Ni = rays.shape[0], rays.device, int(n_samples), int(n_importance)
     cut_v = torch.full((cfg.n_joints,), 0.5, device=dev) if cut_v is None else f(cut_v, "cut_v")
     cut_d = torch.full((cfg.n_joints,), 0.5, device=dev) if cut_d is None else f(cut_d, "cut_d")
@@ -500,7 +526,9 @@ def _forward_io(cfg, net_c, net_f, rays, skts, cyls, n_samples, n_importance, ta
     if skts.shape[0] not in (1, n):
         raise ValueError(f"skts must hold one pose or one per ray, got {tuple(skts.shape)} for {n} rays")
     io.skts, io.skt_ray_stride = skts.data_ptr(), 16 * cfg.n_joints if skts.shape[0] == n else 0
-    io.cyls = cyls.data_ptr()
+    if cyls.shape[0] not in (1, n):
+        raise ValueError(f"cyls must hold one cylinder or one per ray, got {tuple(cyls.shape)} for {n} rays")
+    io.cyls, io.cyl_shared = cyls.data_ptr(), int(cyls.shape[0] == 1 and n > 1)
     keep = [rays, skts, cyls, cut_v, cut_d, net_c, net_f]
     if pts_noise is not None:
         if tuple(pts_noise.shape) != (n, S, 3) or (Ni > 0 and (pts_noise_is is None or tuple(pts_noise_is.shape) != (n, Ni, 3))):

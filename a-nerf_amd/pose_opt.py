@@ -249,7 +249,7 @@ class PoseOptLayer(nn.Module):
         kp, skts, l2ws, rots = calculate_kinematic(bone.contiguous(), pelvis.contiguous(), rest)
         # what the regulariser needs per DISTINCT pose (kp_loss): the FK outputs before the per-ray expansion
         self.last_unique = {"idxs": unique_idxs, "counts": np.bincount(inverse_idxs, minlength=len(unique_idxs)), "rots": rots,
-                            "bones": bone}
+                            "bones": bone, "kp": kp}
         return tuple(expand_poses(t, inverse_idxs) for t in (kp, bone, skts, l2ws, rots))
 
     @torch.no_grad()

@@ -1,0 +1,214 @@
+"""Host-side mirror of the reference's training iteration, `Trainer.train_batch` (core/trainer.py:205-277): the caller of the
+hot path on the training side.  Same constructor, same `train_batch(batch, i, global_step)` ->
+`(loss_dict, stats)`, same order of work per iteration:
+
+    pose data (batch, or the PoseOptLayer)  ->  render()  ->  loss (+ pose regulariser)  ->  backward  ->  optimiser step(s)
+    ->  decay_optimizer_lrate  ->  RayCaster.update_embed_fns
+
+Every numeric step is a kernel of libanerf_hip.so (RayCaster, optim.fused_nerf_loss, pose_opt.kp_loss, FusedAdam); this file
+is sequencing only.  Two optimiser forms are accepted, as the reference's trainer gets them from run_nerf.py:518-535:
+  * torch optimisers (`optimizer`, `pose_optimizer`): stepped as the reference steps them;
+  * a `FusedAdam` whose group 0 holds the networks and whose group 1 (with `step_every = opt_pose_step`) holds the pose
+    layer: pass `optimizer = fused.group_optimizer(0)`, `pose_optimizer = fused.group_optimizer(1)` (or the FusedAdam itself as
+    `optimizer` and None); one `step(zero_grad=True, i=i)` then does both on the reference's cadence, and with
+    `torch.distributed` initialised the gradient bucket is all-reduced first (one collective over whatever is due).
+
+Differences from the reference, all in what is REPORTED, none in what is computed:
+  * `stats` values are 0-dim device tensors (the reference calls `.item()` on each: eight host syncs per iteration);
+    `float(v)` them when logging;
+  * `total_norm` / `avg_norm` are the gradient norms of the step in both branches; the reference's pose branch calls
+    get_gradnorm after `zero_grad()` (trainer.py:466-472), i.e. reports zeros under torch 1.x and divides by zero under
+    torch >= 2.0.
+"""
+import numpy as np
+import torch
+
+from . import optim, pose_opt
+from .render import img2mse, mse2psnr, nerf_loss, render
+
+
+def decay_optimizer_lrate(lrate, lrate_decay, decay_rate, optimizer, global_step=None, decay_unit=1000):
+    """core/trainer.py:173-183: lr = lrate * decay_rate ^ ((Adam step count // decay_unit) / lrate_decay), written to every
+    param group of `optimizer` (a torch optimiser, a FusedAdam, or one group of a FusedAdam).  The count is the optimiser's
+    own, not `global_step`, exactly as in the reference."""
+    groups = optimizer.param_groups
+    st = optimizer.state
+    first = groups[0]["params"][0]
+    step = st[first]["step"] if first in st else 0
+    step = float(step.item()) if torch.is_tensor(step) else float(step)
+    new_lrate = lrate * (decay_rate ** ((step // decay_unit) / lrate_decay))
+    for g in groups:
+        g["lr"] = new_lrate
+    return new_lrate, None
+
+
+@torch.no_grad()
+def get_gradnorm(module):
+    """core/trainer.py:192-203 without its per-tensor `.item()`: (total_norm, avg_norm) as device scalars"""
+    sq = [p.grad.detach().float().pow(2).sum() for p in module.parameters() if p.grad is not None]
+    if not sq:
+        z = torch.zeros(())
+        return z, z
+    tot = torch.stack(sq).sum()
+    return tot.sqrt(), (tot / len(sq)).sqrt()
+
+
+class Trainer:
+    def __init__(self, args, data_attrs, optimizer, pose_optimizer, render_kwargs_train, render_kwargs_test, popt_kwargs=None,
+                 device=None):
+        self.args, self.optimizer, self.pose_optimizer = args, optimizer, pose_optimizer
+        self.render_kwargs_train, self.render_kwargs_test = render_kwargs_train, render_kwargs_test
+        self.popt_kwargs, self.device = popt_kwargs, device
+        self.hwf, self.data_attrs = data_attrs["hwf"], data_attrs
+        self._fused = self._fused_of(optimizer)
+        self._anchor_cache = {}
+
+    @staticmethod
+    def _fused_of(optimizer):
+        if isinstance(optimizer, optim.FusedAdam):
+            return optimizer
+        if isinstance(optimizer, optim._GroupView):
+            return optimizer.opt
+        return None
+
+    # ---- step 1: pose data of the batch (trainer.py:290-317) ---------------------------------------------------------
+    def get_kp_args(self, batch, detach=False):
+        layer = None if self.popt_kwargs is None else self.popt_kwargs.get("popt_layer")
+        if layer is None:
+            return dict(kp_batch=batch["kp3d"], skts=batch["skts"], bones=batch["bones"], cyls=batch["cyls"]), {}
+        kp_idx = batch["kp_idx"]
+        if torch.is_tensor(kp_idx):
+            # the layer groups rays by pose on the host (np.unique): a host copy of the index, cached by content inside the
+            # layer, so a repeated batch layout costs no transfer
+            kp_idx = self._host_index(kp_idx)
+        kps, bones, skts, _, rots = layer(kp_idx)
+        kp_args, extras = dict(kp_batch=kps, skts=skts, bones=bones, cyls=batch["cyls"]), {"rots": rots}
+        if detach:
+            kp_args = {k: (v.detach() if v is not None else None) for k, v in kp_args.items()}
+            extras = {k: v.detach() for k, v in extras.items()}
+        return kp_args, extras
+
+    def _host_index(self, idx):
+        key = (idx.data_ptr(), idx._version, tuple(idx.shape))
+        hit = self.__dict__.get("_idx_host")
+        if hit is None or hit[0] != key:
+            hit = self._idx_host = (key, idx.detach().cpu().numpy())
+        return hit[1]
+
+    def get_fwd_args(self, batch):
+        return {"rays": batch["rays"], "cams": batch["cam_idxs"] if self.args.opt_framecode else None,
+                "subject_idxs": batch.get("subject_idxs")}
+
+    # ---- step 3: losses (trainer.py:325-403) -------------------------------------------------------------------------
+    def compute_loss(self, batch, preds, kp_opts=None, popt_detach=False):
+        args = self.args
+        if getattr(args, "reg_fn", None) is not None:
+            raise NotImplementedError("reg_fn (acc_map regulariser) is used by no shipped config")
+        bgs = batch["bgs"] if "bgs" in batch else 1.0
+        kw = dict(bgs=bgs, loss_fn=args.loss_fn, coarse_weight=args.coarse_weight, use_background=args.use_background,
+                  beta=args.loss_beta)
+        loss_dict, stats = {}, {}
+        if preds["rgb_map"].is_cuda:
+            total, st = optim.fused_nerf_loss(preds, batch["target_s"], **kw)
+            loss_dict["rgb_loss"] = st[1]
+            stats["psnr"] = mse2psnr(st[3])
+            if "rgb0" in preds:
+                loss_dict["rgb_loss0"] = st[2]
+        else:
+            total, _ = nerf_loss(preds, batch["target_s"], **kw)
+        if "rgb0" in preds:
+            with torch.no_grad():        # PSNR of the coarse head: a statistic only (trainer.py:370)
+                comp = preds["rgb0"] + ((1. - preds["acc0"])[..., None] * bgs if args.use_background else 0.)
+                stats["psnr0"] = mse2psnr(img2mse(comp, batch["target_s"]))
+        if not popt_detach:
+            kp_l, kp_stats = self._compute_kp_loss(batch, kp_opts)
+            loss_dict.update(kp_l)
+            stats.update(kp_stats)
+            total = total + kp_l["kp_loss"]
+        loss_dict["total_loss"] = total
+        return loss_dict, stats
+
+    def _compute_kp_loss(self, batch, kp_opts):
+        """trainer.py:382-403 over the batch's DISTINCT poses (pose_opt.kp_loss: one launch each way); equals the reference's
+        mean over the per-ray replicated batch.  `use_temp_loss` is used by no shipped config."""
+        args = self.args
+        if getattr(args, "use_temp_loss", False):
+            raise NotImplementedError("use_temp_loss is used by no shipped config")
+        layer, anchors = self.popt_kwargs["popt_layer"], self.popt_kwargs["popt_anchors"]
+        lu = layer.last_unique
+        dev = lu["rots"].device
+        key = (lu["idxs"].tobytes(), lu["counts"].tobytes(), bool(args.opt_rot6d))
+        hit = self._anchor_cache.get(key)
+        if hit is None:
+            if len(self._anchor_cache) > 64:
+                self._anchor_cache.clear()
+            sel = torch.as_tensor(lu["idxs"], device=dev)
+            if args.opt_rot6d:
+                anc = anchors["rots"].to(dev)[sel][..., :3, :2].flatten(start_dim=-2).contiguous()
+            else:
+                anc = anchors["bones"].to(dev)[sel].contiguous()
+            w = torch.tensor(lu["counts"] / float(lu["counts"].sum()), dtype=torch.float32, device=dev)
+            hit = self._anchor_cache[key] = (anc, w, anchors["kps"].to(dev)[sel].contiguous())
+        anc, w, anc_kps = hit
+        values = lu["rots"] if args.opt_rot6d else lu["bones"]
+        loss = pose_opt.kp_loss(values, anc, w, bool(args.opt_rot6d), args.opt_pose_tol, args.opt_pose_coef)
+        with torch.no_grad():            # mean per-joint position change, in mm (trainer.py:400-401)
+            pj = (anc_kps - lu["kp"].detach()).pow(2.).sum(-1).pow(0.5)
+            mpjpc = (pj.mean(-1) * w).sum() / args.ext_scale
+        return {"kp_loss": loss}, {"MPJPC": mpjpc}
+
+    # ---- step 3b: backward + optimiser steps (trainer.py:441-483) ------------------------------------------------------
+    def optimize(self, loss, i, popt_detach=False):
+        args = self.args
+        caster = self.render_kwargs_train["ray_caster"]
+        loss.backward()
+        if self._fused is not None:
+            f = self._fused
+            f.all_reduce_grads(i=i)                       # no-op in a single process; ONE collective over what is due otherwise
+            norms = f.step(zero_grad=True, want_norms=True, i=i)
+            return {"total_norm": norms[0], "avg_norm": norms[1]}
+        total_norm, avg_norm = get_gradnorm(caster)
+        self.optimizer.step()
+        self.optimizer.zero_grad()
+        if not popt_detach and self.pose_optimizer is not None and i % args.opt_pose_step == 0:
+            self.pose_optimizer.step()
+            self.pose_optimizer.zero_grad()
+            if getattr(args, "opt_pose_cache", False):
+                self.popt_kwargs["popt_layer"].update_cache()
+        return {"total_norm": total_norm, "avg_norm": avg_norm}
+
+    # ---- one iteration (trainer.py:228-277) --------------------------------------------------------------------------
+    def train_batch(self, batch, i=0, global_step=0):
+        args = self.args
+        H, W, focal = self.hwf
+        batch = {k: (v.to(self.device) if torch.is_tensor(v) and self.device is not None else v) for k, v in batch.items()}
+        popt_detach = not (args.opt_pose_stop is None or i < args.opt_pose_stop)
+        kp_args, extra_args = self.get_kp_args(batch, detach=popt_detach)
+        preds = render(H, W, focal, chunk=args.chunk, verbose=i < 10, retraw=False, **kp_args, **self.get_fwd_args(batch),
+                       **self.render_kwargs_train)
+        no_pose = popt_detach or not args.opt_pose
+        loss_dict, stats = self.compute_loss(batch, preds, kp_opts={**kp_args, **extra_args}, popt_detach=no_pose)
+        optim_stats = self.optimize(loss_dict["total_loss"], i, no_pose)
+        net_opt = self._fused.group_optimizer(0) if self._fused is not None else self.optimizer
+        new_lrate, _ = decay_optimizer_lrate(args.lrate, args.lrate_decay, decay_rate=args.lrate_decay_rate, optimizer=net_opt,
+                                             global_step=global_step, decay_unit=args.decay_unit)
+        caster = self.render_kwargs_train["ray_caster"]
+        caster = getattr(caster, "module", caster)
+        if not args.finetune:
+            caster.update_embed_fns(global_step, args)
+        stats = {"lrate": new_lrate, "alpha": preds["acc_map"].detach().mean(), "cutoff": caster.embed_fn.get_tau(), **stats,
+                 **optim_stats}
+        return loss_dict, stats
+
+    # ---- checkpoints (trainer.py:485-517) ------------------------------------------------------------------------------
+    def save_nerf(self, path, global_step):
+        from . import checkpoint
+        caster = self.render_kwargs_train["ray_caster"]
+        layer = None if self.popt_kwargs is None else self.popt_kwargs["popt_layer"]
+        checkpoint.save_nerf(path, global_step, getattr(caster, "module", caster), self.optimizer, popt_layer=layer,
+                             pose_optimizer=self.pose_optimizer,
+                             popt_anchors=None if self.popt_kwargs is None else self.popt_kwargs["popt_anchors"])
+
+    def save_popt(self, path, global_step):
+        from . import checkpoint
+        checkpoint.save_popt(path, global_step, self.popt_kwargs["popt_layer"], self.popt_kwargs["popt_anchors"])

@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="render64", choices=["render64", "hier", "hier128", "render64x64", "train", "train_mixamo"])
+    ap.add_argument("--workload", default="render64", choices=["render64", "hier", "hier128", "render64x64", "api_render64", "train", "train_mixamo"])
     ap.add_argument("--cpu-rays", type=int, default=16384, help="ray sample for the CPU baseline (0 = skip); 16384 rays = ~10 s of host work")
     ap.add_argument("--n-rand", type=int, default=3072, help="train workload: global rays per step")
     ap.add_argument("--torch-tail", action="store_true",
@@ -64,6 +64,36 @@ def parse():
 
 
 _JSON_FD = None
+
+
+def step_stats(ms):
+    """per-step HIP-event times of the timed steps: a mean alone cannot tell a hiccup from a regression"""
+    a = np.asarray(ms, dtype=np.float64)
+    if a.size == 0:
+        return None
+    med = float(np.median(a))
+    return {"n": int(a.size), "mean": float(a.mean()), "median": med, "p95": float(np.percentile(a, 95)), "min": float(a.min()),
+            "max": float(a.max()), "over_1p5x_median": int((a > 1.5 * med).sum())}
+
+
+def outliers(gpu_ms, host_ms=None):
+    """steps that took more than 1.5 x the median on the GPU timeline, with the host's enqueue time of the same step (a
+    host-side stall -- allocator growth, a collector pass, a blocking copy -- shows as host_ms ~ gpu_ms; a slow kernel does not)"""
+    a = np.asarray(gpu_ms, dtype=np.float64)
+    if a.size == 0:
+        return []
+    med = float(np.median(a))
+    return [{"step": int(i), "gpu_ms": float(a[i])} | ({"host_ms": float(host_ms[i])} if host_ms is not None else {})
+            for i in np.nonzero(a > 1.5 * med)[0]]
+
+
+_ALLOC_KEYS = ("num_device_alloc", "num_device_free", "num_alloc_retries", "num_sync_all_streams")
+
+
+def alloc_counters(device):
+    """the caching allocator's hipMalloc / hipFree / retry counters: a timed region that grows the pool pays milliseconds per call"""
+    st = torch.cuda.memory_stats(device)
+    return {k: int(st.get(k, 0)) for k in _ALLOC_KEYS}
 
 
 def _flush_c_stdio():
@@ -227,46 +257,117 @@ def main():
     pipeline = importlib.import_module("a-nerf_amd.pipeline")
     if args.workload in ("train", "train_mixamo"):
         res = bench_train(args, rank, world, device, dist, synth, mixamo=args.workload == "train_mixamo")
+    elif args.workload == "api_render64":
+        if world != 1:
+            raise SystemExit("api_render64 is the single-process drop-in route (render() -> batchify_rays -> RayCaster); use render64 with --gpus N")
+        res = bench_api_render(args, device, synth)
     else:
         res = bench_render(args, rank, world, device, dist, synth, ops, pipeline)
     if rank == 0:
         want_extra = args.extra == "on" or (args.extra == "auto" and args.workload == "render64" and args.precision == "fp32")
         if want_extra and world == 1:
-            res["extra_workloads"] = extra_workloads(args, device, synth, ops, pipeline)
+            ex = extra_workloads(args, device, synth, ops, pipeline)
+            if dist is None:
+                res["scaling_model_8gpu"] = scaling_model(ex, device)
+            for e in ex:
+                e.pop("_key", None)
+                if e.get("workload", "").startswith("reference-shaped") and "value" in e:
+                    e["vs_headline_kernel_bench"] = e["value"] / res["value"]
+            res["extra_workloads"] = ex
         emit(res)
     if dist is not None:
         dist.destroy_process_group()
 
 
 def extra_workloads(args, device, synth, ops, pipeline):
-    """BASELINE configs 3, 4 and 5 inside the same driver-timed run: 5 steps each, same timing protocol, each with its own
-    roofline (training: executed-FLOP, per kernel).  Config 4 (Mixamo: frame codes + pose refinement) runs at the pose cadence
-    of mixamo.txt:48 (opt_pose_step = 20) and at 1 (every step: the most expensive schedule), and at its 8-GPU shard size.
+    """BASELINE configs 3, 4 and 5 and the drop-in route inside the same driver-timed run: >= 20 timed steps each, same timing
+    protocol, each with its own roofline (training: executed-FLOP, per kernel, priced at the MEDIAN step) and per-step
+    statistics (median / p95 / max, slow steps listed).  Config 4 (Mixamo: frame codes + pose refinement) runs at the pose
+    cadence of mixamo.txt:48 (opt_pose_step = 20) and at 1 (every step: the most expensive schedule), and at its 8-GPU shard
+    size.  `api_render64` is config 2 through the reference-shaped API with the reference's own stride-0 expanded inputs.
     Compact records; the full ones come from `--workload ...`."""
     import copy
     out = []
-    for over in (dict(workload="train", n_rand=3072), dict(workload="train", n_rand=384),
+    for over in (dict(workload="api_render64"),
+                 dict(workload="train", n_rand=3072), dict(workload="train", n_rand=384),
                  dict(workload="train_mixamo", n_rand=3072, opt_pose_step=1),
                  dict(workload="train_mixamo", n_rand=3072, opt_pose_step=20),
                  dict(workload="train_mixamo", n_rand=384, opt_pose_step=20),
                  dict(workload="hier128", precision="bf16x3")):
         a = copy.copy(args)
-        a.steps, a.warmup, a.cpu_rays, a.extra = 5, 1, 0, "off"
+        a.steps, a.warmup, a.cpu_rays, a.extra = max(20, args.steps), max(1, min(args.warmup, 3)), 0, "off"
         for k, v in over.items():
             setattr(a, k, v)
-        if a.workload in ("train", "train_mixamo") and a.n_rand <= 512:
-            a.steps = 20          # 2-3 ms steps: 5 of them are a 12 ms window, one scheduler hiccup away from a wrong number
         try:
             if a.workload in ("train", "train_mixamo"):
                 r = bench_train(a, 0, 1, device, None, synth, mixamo=a.workload == "train_mixamo")
+            elif a.workload == "api_render64":
+                r = bench_api_render(a, device, synth)
             else:
                 r = bench_render(a, 0, 1, device, None, synth, ops, pipeline)
-            out.append({"workload": r["config"]["workload"] + (f", opt_pose_step={a.opt_pose_step}" if a.workload == "train_mixamo" else ""),
-                        "value": r["value"], "unit": r["unit"], "steps": a.steps,
-                        "ms_per_step": r["ms_per_step"], "dtype": r["dtype"], "roofline": r["roofline"]})
+            rec = {"workload": r["config"]["workload"] + (f", opt_pose_step={a.opt_pose_step}" if a.workload == "train_mixamo" else ""),
+                   "value": r["value"], "unit": r["unit"], "steps": a.steps,
+                   "ms_per_step": r["ms_per_step"], "dtype": r["dtype"], "roofline": r["roofline"]}
+            for k in ("step_ms", "period_ms", "host_enqueue_ms", "slow_steps", "allocator_in_timed_region",
+                      "gc_collections_in_timed_region", "vs_headline_kernel_bench"):
+                if k in r:
+                    rec[k] = r[k]
+            rec["_key"] = (a.workload, getattr(a, "n_rand", None), getattr(a, "opt_pose_step", None))
+            out.append(rec)
         except Exception as e:       # an extra must never take the headline record down with it
             out.append({"workload": str(over), "error": f"{type(e).__name__}: {e}"})
         torch.cuda.empty_cache()
+    return out
+
+
+def scaling_model(extras, device):
+    """What the N = 1 run can say about the 8-GPU strong-scaling target before a SCALE run exists: the 384-ray shard step
+    measured here (= each rank's compute at N = 8), the gradient bucket's all-reduce on a ONE-rank RCCL communicator (the fixed
+    launch + kernel cost of the collective; no xGMI traffic) and a ring model for the wire time (2 (G-1)/G x bytes over one
+    xGMI link at ~153 GB/s -- RCCL's rings over the 7-link mesh can only be faster), with the fine network's half of it hidden
+    under the coarse backward (FusedAdam.enable_overlap).  A model on file, not a measurement."""
+    by = {tuple(e["_key"]): e for e in extras if "_key" in e}
+    out = {"note": "prediction from single-GPU measurements + a ring model; the measured curve is the driver's SCALE_rNN.json"}
+    bucket_bytes = 2 * 864260 * 4
+    coll1 = None
+    try:
+        import torch.distributed as dist
+        created = False
+        if not dist.is_initialized():
+            import socket
+            with socket.socket() as sck:
+                sck.bind(("127.0.0.1", 0))
+                port = sck.getsockname()[1]
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=device)
+            created = True
+        buf = torch.zeros(bucket_bytes // 4, device=device)
+        for _ in range(3):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            dist.all_reduce(buf)
+        e1.record()
+        torch.cuda.synchronize()
+        coll1 = e0.elapsed_time(e1) / 20
+        if created:
+            dist.destroy_process_group()
+        _flush_c_stdio()
+    except Exception as e:
+        out["collective_world1_error"] = f"{type(e).__name__}: {e}"
+    G, link = 8, 153e9
+    wire_ms = 2 * (G - 1) / G * bucket_bytes / link * 1e3
+    out.update({"collective_bytes": bucket_bytes, "collective_world1_ms": coll1, "ring_wire_ms_8gpu": wire_ms,
+                "xgmi_link_GBps_assumed": link / 1e9})
+    exposed = (coll1 or 0.0) + 0.5 * wire_ms          # the fine network's half runs under the coarse backward
+    for name, full, shard, n in (("config3", ("train", 3072, 1), ("train", 384, 1), 3072),
+                                 ("config4_opt_pose_step20", ("train_mixamo", 3072, 20), ("train_mixamo", 384, 20), 3072)):
+        if full in by and shard in by:
+            t1, t8 = by[full]["step_ms"]["median"], by[shard]["step_ms"]["median"]
+            out[name] = {"step_ms_1gpu": t1, "shard_step_ms": t8, "speedup_before_allreduce": t1 / t8,
+                         "predicted_step_ms_8gpu": t8 + exposed, "predicted_speedup_8gpu": t1 / (t8 + exposed),
+                         "predicted_rays_per_s_8gpu": n / ((t8 + exposed) * 1e-3)}
     return out
 
 
@@ -303,10 +404,13 @@ def bench_render(args, rank, world, device, dist, synth, ops, pipeline):
     gather_buf = torch.empty(world * per, 5, device=device) if dist is not None else None
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     ev_c = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev_s = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i=None):
         # HIP events bracket the DOMINANT launch on its own stream: the only k_mlp_fwd launch (Ni = 0) or the fine pass
-        # over the S+Ni merged samples (hierarchical workloads)
+        # over the S+Ni merged samples (hierarchical workloads); ev_s brackets the whole step
+        if i is not None:
+            ev_s[i][0].record()
         nf_raw, stats = ops.ray_bounds(rb, cyl)
         z, _ = ops.coarse_z(nf_raw, stats, rb, S)
         if i is not None and not Ni:
@@ -334,6 +438,8 @@ def bench_render(args, rank, world, device, dist, synth, ops, pipeline):
                 dist.all_gather(list(gather_buf.view(world, per, 5).unbind(0)), mine)
             if i is not None:
                 ev_c[i][1].record()
+        if i is not None:
+            ev_s[i][1].record()
         return co
 
     def barrier():
@@ -344,16 +450,22 @@ def bench_render(args, rank, world, device, dist, synth, ops, pipeline):
     for _ in range(args.warmup):
         out = step()
     barrier()
+    alloc0 = alloc_counters(device)
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(i)
     barrier()
     dt = dt_local = time.perf_counter() - t0
+    alloc1 = alloc_counters(device)
     tt = torch.tensor([dt], device=device)
     if dist is not None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
-    mlp_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
+    mlp_all = [a.elapsed_time(b) for a, b in ev]
+    step_all = [a.elapsed_time(b) for a, b in ev_s]
+    # the roofline prices the MEDIAN launch (a mean over a handful of launches cannot tell a hiccup from a regression); the mean,
+    # p95 and max are in `launch_ms`
+    mlp_ms = float(np.median(mlp_all)) if args.steps else float("nan")
     coll_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_c])) if (args.steps and dist is not None) else 0.0
 
     # Side measurement (never the headline `value`): the same frame through the opt-in split-bf16 kernels, same timing
@@ -399,7 +511,9 @@ def bench_render(args, rank, world, device, dist, synth, ops, pipeline):
                                                      (f" (fine pass, {S + Ni} samples/ray)" if Ni else ""),
                          "achieved": (3 if b3 else 1) * achieved / 1e12, "algorithmic": achieved / 1e12,
                          "peak": peak / 1e12, "unit": "TFLOP/s", "frac": (3 if b3 else 1) * achieved / peak,
-                         "avg_launch_ms": mlp_ms, "flop_per_launch": flops_launch, "traffic": None},
+                         "avg_launch_ms": mlp_ms, "launch_ms": step_stats(mlp_all), "flop_per_launch": flops_launch, "traffic": None},
+            "step_ms": step_stats(step_all), "slow_steps": outliers(step_all),
+            "allocator_in_timed_region": {k: alloc1[k] - alloc0[k] for k in alloc0},
         }
         attach_traffic(res, args.workload + ("_bf16x3" if b3 else ""), world)
         if alt is not None:
@@ -407,6 +521,90 @@ def bench_render(args, rank, world, device, dist, synth, ops, pipeline):
         if args.cpu_rays > 0 and world == 1:   # CPU baseline: rank 0 at N=1 only (bench contract)
             res["cpu_baseline"], res["parity"] = cpu_baseline(sc, S, Ni, Pc, Pf, out, lo, min(args.cpu_rays, hi - lo))
     return dist_record(res, dist, device, dt_local, args.steps, coll_ms, backend)
+
+
+def bench_api_render(args, device, synth):
+    """BASELINE config 2 through the drop-in route, with the inputs the reference's own render_path builds (run_nerf.py:62-88):
+    `render(h, w, focal, rays=(rays_o, rays_d), chunk=4096, kp_batch / skts / cyls / bones = x.clone().expand(n_rays, ...)`
+    (stride-0 views of the frame's pose), **render_kwargs_test)` -> batchify_rays -> RayCaster.forward per 4096-ray chunk ->
+    torch.cat of the chunks' dicts.  What a maintainer who applies INTEGRATION.md's two-line patch gets per frame."""
+    networks = importlib.import_module("a-nerf_amd.networks")
+    raycaster = importlib.import_module("a-nerf_amd.raycaster")
+    render_mod = importlib.import_module("a-nerf_amd.render")
+    ops = importlib.import_module("a-nerf_amd.ops")
+    H = W = 512; focal = 600.0; S, Ni, chunk = 64, 0, 4096
+    dev = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32, device=device)
+    kw = dict(D=8, W=256, input_ch=360, input_ch_bones=72, input_ch_views=648, use_viewdirs=True)
+    net_c = networks.NeRF(**kw)
+    net_c.load_state_dict({k: torch.tensor(v) for k, v in synth.make_net_params(11).items()})
+    ck = {"cutoff": True, "cutoff_dist": 0.5, "cutoff_inputs": True, "cutoff_dim": 24}
+    e_v, _ = networks.get_embedder(7, input_dims=24, cutoff_kwargs=dict(ck, dist_inputs=False))
+    e_b, _ = networks.get_embedder(0, input_dims=72, cutoff_kwargs={"cutoff": False})
+    e_d, _ = networks.get_embedder(4, input_dims=72, cutoff_kwargs=dict(ck, dist_inputs=True))
+    caster = raycaster.RayCaster(net_c, e_v, e_b, e_d, network_fine=None).to(device).eval()
+    caster.render_precision = args.precision
+    sc = synth.make_scene(0, H, W, focal)
+    n = len(sc["rays_o"])
+    rays = (dev(sc["rays_o"]), dev(sc["rays_d"]))
+    reuse = lambda x, *sh: dev(x)[None].clone().expand(n, *sh)          # run_nerf.py:62-72 reuse_input(x, expand)
+    batch = dict(kp_batch=reuse(sc["pose"]["kp"], 24, 3), skts=reuse(sc["pose"]["skts"], 24, 4, 4), cyls=reuse(sc["cyl"], 5),
+                 bones=reuse(sc["pose"]["bones"], 24, 3))
+    rk = dict(ray_caster=caster, perturb=False, N_importance=Ni, N_samples=S, use_viewdirs=True, raw_noise_std=0., ray_noise_std=0.,
+              ext_scale=0.001, preproc_kwargs={"density_scale": 1.0, "density_fn": torch.nn.functional.relu}, lindisp=False,
+              nerf_type="nerf")
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def frame(i=None):
+        if i is not None:
+            ev[i][0].record()
+        with torch.no_grad():
+            ret = render_mod.render(H, W, focal, rays=rays, chunk=chunk, c2w=None, cams=None, subject_idxs=None, **batch, **rk)
+        if i is not None:
+            ev[i][1].record()
+        return ret
+
+    for _ in range(max(1, args.warmup)):
+        out = frame()
+    torch.cuda.synchronize()
+    alloc0 = alloc_counters(device)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = frame(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    alloc1 = alloc_counters(device)
+    frame_all = [a.elapsed_time(b) for a, b in ev]
+    med = float(np.median(frame_all))
+    # agreement with ONE launch over the whole frame under the shared pose (the kernel-level bench's form): same kernels on the
+    # same values -- identical unless a chunk-local NaN fallback (ray_utils.py:327-339) triggers, which this frame has none of
+    rb = ops.make_ray_batch(*rays)
+    which = 3 if args.precision == "bf16x3" else 0
+    one = ops.forward(net_c.path_cfg, net_c.packed(which), None, rb, dev(sc["pose"]["skts"])[None], dev(sc["cyl"])[None], S, 0,
+                      tau_v=e_v.get_tau(), tau_d=e_d.get_tau(), cut_v=e_v.cutoff_dist.detach(), cut_d=e_d.cutoff_dist.detach(),
+                      precision=args.precision)
+    max_diff = float((one["rgb_map"] - out["rgb_map"]).abs().max())
+    b3 = args.precision == "bf16x3"
+    peak = PEAK_BF16_MFMA if b3 else PEAK_FP32_MFMA
+    flops = F_MLP * n * S
+    achieved = flops / (med * 1e-3)
+    n_chunks = (n + chunk - 1) // chunk
+    return {"metric": "rays/sec", "value": n * args.steps / dt, "unit": "rays/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "bf16x3 (hi/lo-split bf16 MFMA operands, f32 accumulate)" if b3 else "f32", "data": "synthetic",
+            "config": {"workload": "reference-shaped API route: render() -> batchify_rays(chunk 4096) -> RayCaster.forward with run_nerf.render_path's "
+                                   "stride-0 expanded pose inputs, SURREAL-shaped 512x512 frame, 64 samples/ray (BASELINE config 2)",
+                       "rays_per_step": n, "samples_per_ray": S, "n_importance": Ni, "chunk": chunk, "caster_calls_per_frame": n_chunks,
+                       "parallelism": "single process"},
+            # the WHOLE frame's HIP-event time (all chunks' k_mlp_fwd launches, the small kernels, the gaps and the final cat)
+            # against the frame's algorithmic FLOPs: a lower bound of the kernel's own fraction
+            "roofline": {"bound": "mfma", "kernel": f"{n_chunks} launches of " + ("k_mlp_fwd_b3<7,4,0>" if b3 else "k_mlp_fwd<7,4,0,false,false,0>") +
+                                                    " per frame; priced on the whole frame's HIP-event time (median)",
+                         "achieved": (3 if b3 else 1) * achieved / 1e12, "algorithmic": achieved / 1e12, "peak": peak / 1e12,
+                         "unit": "TFLOP/s", "frac": (3 if b3 else 1) * achieved / peak, "avg_launch_ms": med,
+                         "launch_ms": step_stats(frame_all), "flop_per_launch": flops, "traffic": None},
+            "step_ms": step_stats(frame_all), "slow_steps": outliers(frame_all),
+            "allocator_in_timed_region": {k: alloc1[k] - alloc0[k] for k in alloc0},
+            "max_abs_rgb_vs_single_launch": max_diff}
 
 
 def attach_traffic(res, key, world):
@@ -497,12 +695,15 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
     pk = {"density_scale": 1.0, "density_fn": torch.nn.functional.relu}
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     ev_c = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev_e = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]        # end of the step (after the optimiser kernel)
+    host_t = np.zeros(args.steps + 1)                                               # host clock at the start of each timed step
     backend = os.environ.get("ANERF_BENCH_BACKEND", "nccl")
 
     it = [0]                     # global iteration counter (the reference's `i`, trainer.py:451)
 
     def step(i=None):
         if i is not None:
+            host_t[i] = time.perf_counter()
             ev[i][0].record()
         b = batch
         if mixamo:   # per-ray pose indices, as the reference calls its layer (kp_idx of the batch): FK once per distinct pose
@@ -535,6 +736,8 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
             if mixamo:
                 popt_opt.step()
                 popt_opt.zero_grad()
+        if i is not None:
+            ev_e[i].record()
         return loss
 
     def barrier():
@@ -551,16 +754,28 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
     gc.collect()
     gc.freeze()
     barrier()
+    alloc0 = alloc_counters(device)
+    gc0 = [g["collections"] for g in gc.get_stats()]
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(i)
+    host_t[args.steps] = time.perf_counter()
     barrier()
     dt = dt_local = time.perf_counter() - t0
+    alloc1 = alloc_counters(device)
+    gc1 = [g["collections"] for g in gc.get_stats()]
     tt = torch.tensor([dt], device=device)
     if dist is not None:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
-    fb_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    fb_all = [a.elapsed_time(b) for a, b in ev]
+    # a step on the GPU timeline: from its first launch to the end of its optimiser kernel; its period (start to next start)
+    # also holds whatever idle time the host left in front of the next step
+    step_all = [ev[i][0].elapsed_time(ev_e[i]) for i in range(args.steps)]
+    period_all = [ev[i][0].elapsed_time(ev[i + 1][0]) for i in range(args.steps - 1)]
+    host_all = list(np.diff(host_t) * 1e3)
+    # the roofline prices the MEDIAN step (mean / p95 / max next to it): 5-step means once hid a one-off stall in config 4
+    fb_ms = float(np.median(fb_all))
     # HIP-event time of the gradient all-reduce as the main stream sees it (with overlap: what is left of it after the coarse
     # half of the backward), plus the same collective on an idle GPU: the xGMI time of the 6.9 MB bucket itself
     coll_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_c])) if (dist is not None and args.steps) else 0.0
@@ -605,9 +820,10 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
     if args.steps > 0:
         prof = ops.Profile()
         acc = {}
-        n_prof = 4
+        n_prof = 8
         with ops.profiling(prof):
             for _ in range(n_prof):
+                prof.reset()             # fresh events: a pair this step does not record reads as None, not as last step's value
                 step()
                 torch.cuda.synchronize()
                 for kind in ("fwd", "bwd", "gemm") + (("bwd_in",) if mixamo else ()):
@@ -620,7 +836,7 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
         b3k = args.precision == "bf16x3"
         kernels = []
         for (kind, ps), ts in sorted(acc.items()):
-            ms_k = float(np.mean(ts[1:])) if len(ts) > 1 else float(ts[0])
+            ms_k = float(np.median(ts[1:])) if len(ts) > 1 else float(ts[0])
             fl = flops[kind] * (hi - lo) * (S + Ni if ps else S)
             tf = fl / (ms_k * 1e-3) / 1e12
             kernels.append({"kernel": names[kind] + ("_b3" if b3k else ""), "pass": "fine" if ps else "coarse", "ms": ms_k, "flop": fl,
@@ -651,10 +867,17 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
                             "achieved": (3 if b3 else 1) * achieved / 1e12, "algorithmic": achieved / 1e12,
                             "peak": (PEAK_BF16_MFMA if b3 else PEAK_FP32_MFMA) / 1e12, "unit": "TFLOP/s",
                             "frac": (3 * achieved / PEAK_BF16_MFMA) if b3 else achieved / PEAK_FP32_MFMA,
-                            "avg_launch_ms": fb_ms, "flop_per_launch": exec_step_rank,
+                            "avg_launch_ms": fb_ms, "launch_ms": step_stats(fb_all), "flop_per_launch": exec_step_rank,
                             "survey_3x": {"flop_per_step": flop_step_rank,
                                           "frac": (3 if b3 else 1) * flop_step_rank / (fb_ms * 1e-3) / (PEAK_BF16_MFMA if b3 else PEAK_FP32_MFMA)},
-                            "kernels": kernels, "traffic": None}}
+                            "kernels": kernels, "traffic": None},
+               # per-step HIP-event statistics of the timed steps: the step itself (first launch .. optimiser kernel), the period
+               # between step starts (adds host-side gaps), the host's enqueue time per step; steps slower than 1.5 x the median
+               # are listed with both clocks
+               "step_ms": step_stats(step_all), "period_ms": step_stats(period_all), "host_enqueue_ms": step_stats(host_all),
+               "slow_steps": outliers(step_all, host_all),
+               "allocator_in_timed_region": {k: alloc1[k] - alloc0[k] for k in alloc0},
+               "gc_collections_in_timed_region": [b - a for a, b in zip(gc0, gc1)]}
         if coll_alone_ms is not None:
             res["collective_alone_ms"] = coll_alone_ms
             res["collective_bytes"] = int(opt.flat_grad.numel() * 4)

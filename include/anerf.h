@@ -347,6 +347,9 @@ typedef struct AnerfForwardIO {
    * sort order of the merged depths.  NULL (the default of every shipped config: ray_noise_std = 0) = no offsets. */
   const float *pts_noise, *pts_noise_is;
   const AnerfProfile* profile;   /* ABI revision 3 (HOST pointer, may be NULL): see AnerfProfile */
+  /* ABI revision 4: != 0 = `cyls` holds ONE cylinder [5] shared by every ray of the call -- what run_nerf.render_path's
+   * `reuse_input(cyls, expand)` (run_nerf.py:62-72: a stride-0 expand of the frame's cylinder) means; 0 = per-ray [N,5]. */
+  int32_t cyl_shared;
 } AnerfForwardIO;
 int64_t anerf_workspace_size(const AnerfConfig* cfg, int32_t n_rays, int32_t n_samples, int32_t n_importance);
 int anerf_forward(const AnerfConfig* cfg, const AnerfForwardIO* io, void* workspace, int64_t ws_bytes, void* stream);

@@ -1,0 +1,159 @@
+"""The whole training iteration against the REFERENCE's own: tests/golden/trajectory_{surreal,mixamo}.npz hold five iterations
+of `core.trainer.Trainer.train_batch` (render -> losses -> backward -> Adam [+ pose optimiser on its cadence] ->
+decay_optimizer_lrate -> update_embed_fns; pytest=True randomness) run by tests/golden/gen_golden_trajectory.py in the build
+container.  Here the mirror `anerf_amd.trainer.Trainer` drives the HIP path (RayCaster, fused loss, FusedAdam, PoseOptLayer,
+pose regulariser) through the same five iterations from the same seeded inputs.
+
+Bars: loss within 5e-6 and every watched parameter within 2 x lr of the reference at every iteration
+(Adam moves a parameter by ~lr per step whatever the gradient's size, so a gradient that differs in the last bits around
+zero may flip one update's sign: 2 x lr is one such flip; the observed fraction of elements beyond lr / 100 is printed).
+CPU part: the schedule mirrors (learning-rate decay, tau) against the same file.
+"""
+import argparse
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+raycaster = importlib.import_module("a-nerf_amd.raycaster")
+trainer_mod = importlib.import_module("a-nerf_amd.trainer")
+optim = importlib.import_module("a-nerf_amd.optim")
+pose_opt = importlib.import_module("a-nerf_amd.pose_opt")
+networks = importlib.import_module("a-nerf_amd.networks")
+synth = importlib.import_module("a-nerf_amd.synth")
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+N_POSES = 8
+WATCH = ["pts_linears.0.weight", "pts_linears.5.bias", "alpha_linear.weight", "views_linears.0.bias", "rgb_linear.weight"]
+# the generator's cases (tests/golden/gen_golden_trajectory.py CASES / EXTRA), restated
+CASES = {
+    "surreal": dict(args="surreal", seeds=(11, 12), n=64, poses=[0, 1, 2, 3], ray_seed=21, target_seed=5, mixamo=False),
+    "mixamo": dict(args="mixamo", seeds=(21, 22), n=64, poses=list(range(8)), ray_seed=22, target_seed=6, mixamo=True),
+}
+
+
+def ref_args(name, **over):
+    d = json.load(open(os.path.join(GOLDEN, f"args_{name}.json")))
+    d.pop("_config_file")
+    d.update(basedir="/nonexistent", decay_unit=1, lrate_decay=5, **over)
+    return argparse.Namespace(**d)
+
+
+class Skel:
+    joint_names = ["j%d" % i for i in range(24)]
+    joint_trees = np.asarray(synth.SMPL_PARENTS)
+
+
+def test_schedule_mirrors_reproduce_the_reference_sequences():
+    """decay_optimizer_lrate (trainer.py:173-183) on a torch Adam and CutoffEmbedder.update_tau (cutoff_embedder.py:181-183)
+    against the lr / tau the reference's trainer reported after each of its five iterations"""
+    g = dict(np.load(os.path.join(GOLDEN, "trajectory_surreal.npz")))
+    p = torch.nn.Parameter(torch.zeros(3))
+    opt = torch.optim.Adam([p], lr=float(g["lrate0"]))
+    e_v, _ = networks.get_embedder(7, input_dims=24, cutoff_kwargs={"cutoff": True, "cutoff_dist": 0.5, "cutoff_inputs": True,
+                                                                     "cutoff_dim": 24, "dist_inputs": False})
+    args = ref_args("surreal")
+    for i in range(1, int(g["n_iters"]) + 1):
+        p.grad = torch.ones(3)
+        opt.step()
+        lr, _ = trainer_mod.decay_optimizer_lrate(args.lrate, args.lrate_decay, args.lrate_decay_rate, opt, decay_unit=args.decay_unit)
+        assert lr == pytest.approx(float(g[f"it{i}.lrate"]), rel=1e-6)
+        assert opt.param_groups[0]["lr"] == lr
+        e_v.update_threshold(int(g["global_step_per_iter"]) * i, args.cutoff_step, args.cutoff_rate, args.freq_schedule_step, args.multires - 1)
+        assert e_v.get_tau() == pytest.approx(float(g[f"it{i}.tau"]), rel=1e-6)
+
+
+def _batch(case, dev):
+    ro, rd, kp, skts, bones, cyls, which = synth.scene_batch(case["n"], case["poses"], ray_seed=case["ray_seed"], per_ray_pose=True)
+    n = case["n"]
+    t = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32, device=dev)
+    return dict(rays=t(np.stack([ro, rd])), target_s=t(np.random.default_rng(case["target_seed"]).random((n, 3))),
+                kp_idx=torch.tensor(np.asarray(which), dtype=torch.int64, device=dev), kp3d=t(kp), bones=t(bones), skts=t(skts),
+                cyls=t(cyls), cam_idxs=t(np.asarray(which, dtype=np.float32)), fgs=torch.ones(n, 1, device=dev),
+                bgs=torch.ones(n, 3, device=dev))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["surreal", "mixamo"])
+@pytest.mark.parametrize("tail", ["fused", "torch"])
+def test_five_training_iterations_follow_the_reference_trajectory(name, tail):
+    case = CASES[name]
+    g = dict(np.load(os.path.join(GOLDEN, f"trajectory_{name}.npz")))
+    dev = torch.device("cuda")
+    args = ref_args(case["args"], **({"opt_pose_step": 2} if case["mixamo"] else {}))
+    assert int(g["opt_pose_step"]) == args.opt_pose_step and int(g["N_samples"]) == args.N_samples
+    data_attrs = {"skel_type": Skel, "near": 0.0, "far": 1.0, "n_views": N_POSES, "hwf": (512, 512, 600.0),
+                  "joint_coords": np.tile(np.eye(3, dtype=np.float32), (24, 1, 1))}
+    rk_train, rk_test, _, grad_vars, torch_opt, _ = raycaster.create_raycaster(args, data_attrs, device=dev)
+    caster = rk_test["ray_caster"]
+    fc = 16 if args.opt_framecode else 0
+    for net, seed in ((caster.network, case["seeds"][0]), (caster.network_fine, case["seeds"][1])):
+        net.load_state_dict({k: torch.tensor(v) for k, v in synth.make_net_params(seed, args.multires, args.multires_views, fc, N_POSES).items()})
+    rk_train["pytest"] = True
+    popt_kwargs = pose_torch_opt = layer = None
+    if case["mixamo"]:
+        poses = [synth.make_pose(k) for k in range(N_POSES)]
+        kps, bones = np.stack([q["kp"] for q in poses]), np.stack([q["bones"] for q in poses])
+        layer = pose_opt.PoseOptLayer(kps, bones, (synth.SMPL_REST_POSE * synth.SURREAL_SCALE)[None], use_rot6d=args.opt_rot6d).to(dev)
+        anchors = {"kps": torch.tensor(kps), "bones": torch.tensor(bones),
+                   "rots": pose_opt.axisang_to_rot(torch.tensor(bones).reshape(-1, 3)).reshape(N_POSES, 24, 3, 3), "beta": None}
+        with torch.no_grad():     # the generator's seeded perturbation of the pose parameters (regulariser active)
+            layer.bones.add_(torch.tensor((np.random.RandomState(77).randn(*layer.bones.shape) * 0.12).astype(np.float32), device=dev))
+        popt_kwargs = {"popt_layer": layer, "popt_anchors": anchors, "skel_type": Skel}
+        pose_torch_opt = torch.optim.Adam(layer.parameters(), lr=args.opt_pose_lrate, betas=(0.9, 0.999))
+    if tail == "fused":
+        groups = [{"params": grad_vars, "lr": args.lrate}]
+        if case["mixamo"]:
+            groups.append({"params": list(layer.parameters()), "lr": args.opt_pose_lrate, "step_every": args.opt_pose_step})
+        fused = optim.FusedAdam(groups, betas=(0.9, 0.999)).attach(caster)
+        opt, popt = fused.group_optimizer(0), (fused.group_optimizer(1) if case["mixamo"] else None)
+    else:
+        opt, popt = torch_opt, pose_torch_opt
+    tr = trainer_mod.Trainer(args, data_attrs, opt, popt, rk_train, rk_test, popt_kwargs=popt_kwargs, device=dev)
+    caster.train()
+    batch = _batch(case, dev)
+    worst = {"loss": 0.0, "param": 0.0, "beyond": 0.0}
+    for i in range(1, int(g["n_iters"]) + 1):
+        lr_used = float(g["lrate0"]) if i == 1 else float(g[f"it{i - 1}.lrate"])
+        loss_dict, stats = tr.train_batch(batch, i=i, global_step=int(g["global_step_per_iter"]) * i)
+        G = lambda k: float(g[f"it{i}.{k}"])
+        d_loss = abs(float(loss_dict["total_loss"]) - G("loss"))
+        worst["loss"] = max(worst["loss"], d_loss)
+        assert d_loss <= 5e-6, (i, float(loss_dict["total_loss"]), G("loss"))
+        assert abs(float(loss_dict["rgb_loss"]) - G("rgb_loss")) <= 5e-6 and abs(float(loss_dict["rgb_loss0"]) - G("rgb_loss0")) <= 5e-6
+        assert abs(float(stats["psnr"]) - G("psnr")) <= 1e-3 and abs(float(stats["psnr0"]) - G("psnr0")) <= 1e-3      # dB (north_star)
+        assert float(stats["lrate"]) == pytest.approx(G("lrate"), rel=1e-6)
+        assert float(stats["cutoff"]) == pytest.approx(G("tau"), rel=1e-6)
+        assert caster.embeddirs_fn.get_tau() == pytest.approx(G("tau_d"), rel=1e-6)
+        assert float(stats["alpha"]) == pytest.approx(G("alpha_mean"), abs=1e-5)
+        if not case["mixamo"]:     # get_gradnorm before the step (the reference's pose branch reports it after zero_grad: zeros)
+            assert float(stats["total_norm"]) == pytest.approx(G("total_norm"), rel=2e-3)
+            assert float(stats["avg_norm"]) == pytest.approx(G("avg_norm"), rel=2e-3)
+        else:
+            assert abs(float(loss_dict["kp_loss"]) - G("kp_loss")) <= 5e-6
+            assert float(stats["MPJPC"]) == pytest.approx(G("mpjpc"), rel=1e-4)
+        watched = []
+        for tag, net in (("c", caster.network), ("f", caster.network_fine)):
+            sd = dict(net.named_parameters())
+            watched += [(f"{tag}.{w}", sd[w]) for w in WATCH]
+            if case["mixamo"]:
+                watched.append((f"{tag}.framecodes.codes.weight", sd["framecodes.codes.weight"]))
+        if case["mixamo"]:
+            watched += [("popt.bones", layer.bones), ("popt.pelvis", layer.pelvis)]
+        for key, p in watched:
+            ref = g[f"it{i}.{key}"]
+            got = p.detach().cpu().numpy()
+            got = got if got.size <= 4096 or key.startswith("popt") or "framecodes" in key else got.reshape(-1)[:4096]
+            d = np.abs(got.reshape(ref.shape) - ref)
+            lr_p = args.opt_pose_lrate if key.startswith("popt") else lr_used
+            worst["param"] = max(worst["param"], float(d.max() / lr_p))
+            worst["beyond"] = max(worst["beyond"], float((d > 0.01 * lr_p).mean()))
+            assert d.max() <= 2.0 * lr_p * 1.001, (i, key, float(d.max()), lr_p)
+    print(f"{name}/{tail}: max |dloss| {worst['loss']:.2e}, max parameter distance {worst['param']:.3f} x lr, "
+          f"largest fraction of a tensor's elements beyond lr/100: {worst['beyond']:.2e}")
+    if case["mixamo"]:      # the pose cadence: stepped at i = 2 and 4 only -> Adam step count 2
+        steps = (fused._steps[1] if tail == "fused" else int(pose_torch_opt.state[layer.bones]["step"]))
+        assert steps == 2
