@@ -73,6 +73,7 @@ def test_a_chunk_call_allocates_its_outputs_and_workspace_only():
     rays, batch = frame_inputs(n, True)
     rb = ops.make_ray_batch(*rays)
     rk = dict(RK, N_importance=0, N_samples=S)
+    rk.pop("use_viewdirs")                          # consumed by render(); the caster call itself does not take it
     with torch.no_grad():
         caster(rb, **batch, **rk)                   # warm: weight image packed, tables cached
         torch.cuda.synchronize()
