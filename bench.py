@@ -57,6 +57,10 @@ def parse():
     ap.add_argument("--extra", default="auto", choices=["auto", "on", "off"],
                     help="append `extra_workloads` (5 steps each of train N_rand=3072, train 384 rays, 64+128 bf16x3 render, each "
                          "with its own roofline) to the record; auto = only for the default invocation (render64, fp32, 1 GPU)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="multi-rank plumbing without a GPU: rendezvous (gloo), the real shard arithmetic of the workload, the "
+                         "collectives with their real shapes (frame all-gather / gradient-bucket all-reduce), record assembly and "
+                         "the watchdog; the kernels are replaced by rank-tagged fills.  The record carries dry_run = true and no value")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
                     help="exact fp32 MFMA, or hi/lo-split bf16 MFMAs (3 per product, fp32 accumulate); train workloads: "
                          "bf16x3 applies to the forward kernel only, backward + weight-gradient GEMM stay fp32")
@@ -123,7 +127,7 @@ def self_launch(args):
     collective."""
     import socket
     import subprocess
-    backend = os.environ.get("ANERF_BENCH_BACKEND", "nccl")
+    backend = "gloo" if args.dry_run else os.environ.get("ANERF_BENCH_BACKEND", "nccl")
     if backend == "nccl" and torch.cuda.device_count() < args.gpus:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but this node has {torch.cuda.device_count()} GPU(s) "
                          f"(RCCL needs one device per rank; ANERF_BENCH_BACKEND=gloo shares one GPU for a control-flow test)\n")
@@ -221,6 +225,8 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with `python bench.py --gpus {args.gpus}` (self-launching) "
                          f"or torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.dry_run:
+        return dry_run(args, rank, world)
     # ANERF_BENCH_BACKEND=gloo: smoke-test the multi-rank control flow with all ranks on ONE GPU (RCCL refuses duplicate
     # devices); the driver's multi-GPU runs use the default, nccl (= RCCL), one rank per GPU
     backend = os.environ.get("ANERF_BENCH_BACKEND", "nccl")
@@ -277,6 +283,103 @@ def main():
         emit(res)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def dry_run(args, rank, world):
+    """`--dry-run`: everything of a multi-rank run except the kernels, on the CPU over gloo -- what can be exercised of the N > 1
+    path where no second GPU exists.  Same rendezvous (env RANK / WORLD_SIZE / MASTER_*), the workload's REAL shard arithmetic
+    (render: the 261 121-ray frame in ceil-sized contiguous slices, ragged last shard; training: parallel.shard_rays /
+    shard_weight of N_rand), the step's collective with its real shape and dtype (all-gather of the padded [per, 5] per-ray
+    outputs / ONE all-reduce of the flat gradient bucket of both networks [+ frame codes + pose parameters], laid out by the
+    same segment rule as FusedAdam), the barrier + max-over-ranks timing protocol and the record assembly.  Each rank's
+    "kernel" is a fill with rank-tagged values, so the collectives' results are checked exactly on every rank."""
+    import datetime
+    import torch.distributed as dist
+    for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+        os.environ.setdefault(k, v)
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=float(os.environ.get("ANERF_BENCH_PG_TIMEOUT", "600"))))
+    if os.environ.get("ANERF_BENCH_FAIL_RANK") == str(rank):
+        os._exit(3)
+    synth = importlib.import_module("a-nerf_amd.synth")
+    parallel = importlib.import_module("a-nerf_amd.parallel")
+    train = args.workload in ("train", "train_mixamo")
+    checks = {}
+    if train:
+        N, mixamo = args.n_rand, args.workload == "train_mixamo"
+        lo, hi = parallel.shard_rays(N, rank, world)
+        w = parallel.shard_weight(N, rank, world)
+        n_net = 864260 + (8 * 16 if mixamo else 0) + (128 * 16 if mixamo else 0)     # + frame codes [8,16] + 16 view-layer columns
+        seg = [2 * n_net] + ([8 * 3 + 8 * 24 * 6] if mixamo else [])                 # group 1: pelvis [8,3] + rot6d bones [8,24,6]
+        offs, o = [], 0
+        for n in seg:                                                                # FusedAdam._segments: 16-byte padded groups
+            offs.append((o, (n + 3) // 4 * 4))
+            o += (n + 3) // 4 * 4
+        bucket = torch.zeros(o)
+        units, name = N, f"training step plumbing, N_rand={N}" + (" (config 4 bucket: + frame codes + pose group)" if mixamo else " (config 3 bucket)")
+
+        def step(i):
+            bucket.fill_(float(rank + 1) * (hi - lo) / max(N, 1))                    # this rank's mean-loss gradient x its ray share
+            due = [0] + ([1] if mixamo and (i + 1) % args.opt_pose_step == 0 else [])
+            lo_e, hi_e = offs[due[0]][0], offs[due[-1]][0] + offs[due[-1]][1]
+            dist.all_reduce(bucket[lo_e:hi_e])                                       # ONE collective over what is due
+            return lo_e, hi_e
+        expect = sum(float(r + 1) * (min(N, (r + 1) * ((N + world - 1) // world)) - min(N, r * ((N + world - 1) // world))) / max(N, 1)
+                     for r in range(world))
+    else:
+        H, W, focal = (64, 64, 75.0) if args.workload == "render64x64" else (512, 512, 600.0)
+        sc = synth.make_scene(0, H, W, focal)
+        N = len(sc["rays_o"])
+        per = (N + world - 1) // world
+        lo, hi = parallel.shard_rays(N, rank, world)                                 # as bench_render
+        w = 1.0
+        gather_buf = torch.empty(world * per, 5)
+        units, name = N, f"render plumbing, {H}x{W} frame, {N} bbox rays"
+
+        def step(i):
+            mine = torch.zeros(per, 5)
+            mine[:hi - lo] = float(rank + 1)
+            dist.all_gather(list(gather_buf.view(world, per, 5).unbind(0)), mine)
+            return 0, world * per
+    for _ in range(args.warmup):
+        step(0)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        span = step(i)
+    dist.barrier()
+    dt_local = time.perf_counter() - t0
+    tt = torch.tensor([dt_local])
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    # exact checks of the last step's collective on EVERY rank
+    if train:
+        # (a ring all-reduce sums each chunk in its own rank order: elements may differ in the last bit for ragged shares)
+        ok = float((bucket[span[0]:span[1]] - expect).abs().max()) < 1e-5 * max(1.0, expect)
+        checks = {"all_reduce_sum_ok": ok, "expected": expect, "got": float(bucket[span[0]]), "bucket_floats": int(bucket.numel()),
+                  "reduced_floats_last_step": int(span[1] - span[0])}
+    else:
+        frame = gather_buf[:N]                       # the assembled frame: row r belongs to rank r // per
+        owner = torch.arange(N) // per
+        ok = bool(torch.all(frame[:, 0] == (owner + 1).float()).item())
+        pad_ok = bool(torch.all(gather_buf.view(world, per, 5)[-1, (N - (world - 1) * per):] == 0).item()) if world * per > N else True
+        checks = {"all_gather_frame_ok": ok and pad_ok, "gathered_rows": int(world * per), "frame_rows": int(N)}
+    mine = {"rank": rank, "shard": [int(lo), int(hi)], "rays": int(hi - lo), "weight": float(w), "ms_per_step": dt_local / max(args.steps, 1) * 1e3,
+            "checks": checks}
+    allr = [None] * world
+    dist.all_gather_object(allr, mine)
+    if rank == 0:
+        assert [r["rank"] for r in allr] == list(range(world))
+        assert sum(r["rays"] for r in allr) == units and all(a["shard"][1] == b["shard"][0] for a, b in zip(allr, allr[1:]))
+        res = {"metric": "rays/sec", "value": None, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": float(tt.item()) / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic", "dry_run": True,
+               "config": {"workload": "DRY RUN (no kernels, CPU, gloo): " + name, "rays_per_step": units,
+                          "parallelism": f"ray-sharded x{world}" + (", 1 all-reduce/step" if train else ", 1 all-gather/step")},
+               "ranks": dist.get_world_size(), "backend": dist.get_backend() + " (dry run: rendezvous, sharding, collectives, record; no kernels)",
+               "shards": [r["shard"] for r in allr], "shard_weights": [r["weight"] for r in allr],
+               "ms_per_step_per_rank": [r["ms_per_step"] for r in allr], "checks_per_rank": [r["checks"] for r in allr],
+               "all_checks_ok": all(all(v for k, v in r["checks"].items() if k.endswith("_ok")) for r in allr)}
+        emit(res)
+    dist.destroy_process_group()
 
 
 def extra_workloads(args, device, synth, ops, pipeline):
@@ -396,7 +499,7 @@ def bench_render(args, rank, world, device, dist, synth, ops, pipeline):
 
     # this rank's contiguous slice of the frame's rays (inputs resident in HBM before timing starts)
     per = (n_total + world - 1) // world
-    lo, hi = rank * per, min(n_total, (rank + 1) * per)
+    lo, hi = importlib.import_module("a-nerf_amd.parallel").shard_rays(n_total, rank, world)     # contiguous ceil-sized slices
     rb = pipeline.make_ray_batch(dev(sc["rays_o"][lo:hi]), dev(sc["rays_d"][lo:hi]))
     cyl = dev(sc["cyl"])[None].expand(hi - lo, -1).contiguous()
     skt = dev(sc["pose"]["skts"])[None]          # one pose per frame: shared (stride-0) bone matrices
