@@ -859,9 +859,13 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
     barrier()
     alloc0 = alloc_counters(device)
     gc0 = [g["collections"] for g in gc.get_stats()]
+    trace = [] if os.environ.get("ANERF_BENCH_ALLOC_TRACE") == "1" else None     # diagnostic: pool growth per step (costs host time)
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(i)
+        if trace is not None:
+            st = torch.cuda.memory_stats(device)
+            trace.append((st["num_device_alloc"], st["reserved_bytes.all.current"], st["allocated_bytes.all.peak"]))
     host_t[args.steps] = time.perf_counter()
     barrier()
     dt = dt_local = time.perf_counter() - t0
@@ -981,6 +985,10 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
                "slow_steps": outliers(step_all, host_all),
                "allocator_in_timed_region": {k: alloc1[k] - alloc0[k] for k in alloc0},
                "gc_collections_in_timed_region": [b - a for a, b in zip(gc0, gc1)]}
+        if trace is not None:
+            res["alloc_trace"] = [{"step": i, "new_segments": trace[i][0] - (trace[i - 1][0] if i else alloc0["num_device_alloc"]),
+                                   "reserved_MB": trace[i][1] / 2 ** 20, "grew_MB": (trace[i][1] - trace[i - 1][1]) / 2 ** 20 if i else None,
+                                   "step_ms": step_all[i], "host_ms": host_all[i]} for i in range(len(trace))]
         if coll_alone_ms is not None:
             res["collective_alone_ms"] = coll_alone_ms
             res["collective_bytes"] = int(opt.flat_grad.numel() * 4)
