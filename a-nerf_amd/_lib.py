@@ -151,6 +151,11 @@ SIGNATURES = {
     "anerf_loss": (C.c_int, [C.c_void_p] * 6 + [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float] + [C.c_void_p] * 7),
     "anerf_fk_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 5),
     "anerf_fk_backward": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32] + [C.c_void_p] * 7),
+    "anerf_pose_batch_forward": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32] +
+                                 [C.c_void_p] * 9),
+    "anerf_pose_batch_backward": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32] +
+                                  [C.c_void_p] * 10 + [C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "anerf_pose_batch_scratch_size": (C.c_int64, [C.c_int32, C.c_int32]),
     "anerf_train_workspace_size": (C.c_int64, [C.POINTER(AnerfConfig), C.c_int32, C.c_int32, C.c_int32]),
     "anerf_backward_scratch_size": (C.c_int64, [C.POINTER(AnerfConfig), C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "anerf_train_forward": (C.c_int, [C.POINTER(AnerfConfig), C.POINTER(AnerfForwardIO), C.c_void_p, C.c_int64, C.c_void_p]),

@@ -209,12 +209,23 @@ class _RenderRaysFn(torch.autograd.Function):
         if direct and hier and getattr(sink, "overlap", False):
             fine_params = meta["params"][24:]
             hook = lambda: sink.begin_async_all_reduce(fine_params)
+        # frame codes ride along: when the tables handed to the kernels ARE the embedding weights (training mode) and their .grad
+        # lives in the same bucket, the code gradients are added in place as well (no zero fill, no AccumulateGrad add)
+        codes_into = None
+        if direct and (want_cc or want_cf):
+            cp = meta.get("code_params", (None, None))
+            ok = all(p is None or (p.grad is not None and sink.owns_grads([p], dev)) for p in cp) and \
+                (not want_cc or cp[0] is not None) and (not want_cf or cp[1] is not None)
+            if ok:
+                codes_into = (cp[0].grad if cp[0] is not None else None, cp[1].grad if cp[1] is not None else None)
         grads_c, grads_f, g_skts, g_cc, g_cf = ops.backward(
             state, dict(zip(ctx.keys, gs)), meta["packed_t_c"], meta["packed_t_f"], perm_tables(meta["kw"]["cfg"], dev, b3=b3),
             ctx.shapes[:24], ctx.shapes[24:], pi[0], pi[1], want_skts, want_cc, want_cf,
-            accumulate_into=(into[:24], into[24:]) if direct else None, after_fine=hook)
+            accumulate_into=(into[:24], into[24:]) if direct else None, after_fine=hook, codes_into=codes_into)
         ctx.state = None
         if direct:
+            if codes_into is not None:
+                g_cc = g_cf = None
             return (None, g_skts, g_cc, g_cf) + (None,) * len(ctx.shapes)
         if not hier:
             grads_f = [None] * (len(ctx.shapes) - 24)
@@ -238,6 +249,9 @@ def _render_rays_one_node(caster, kw, prec):
                 packed_i=lambda: tuple(n.packed(5 if b3 else 2)[0] for n in nets) + ((None,) if not hier else ()))
     params = [p for n in nets for p in _net_params(n)]
     meta["params"] = params
+    # the embedding weights behind codes_c / codes_f when the kernels index them directly (training mode), else None
+    code_w = lambda n: n.framecodes.codes.weight if (n is not None and n.use_framecode and n.training) else None
+    meta["code_params"] = (code_w(net_c), code_w(net_f) if hier else None)
     sink = getattr(caster, "_anerf_grad_sink", None)
     meta["grad_sink"] = sink() if sink is not None else None        # weakref to an attached FusedAdam, or nothing
     out = _RenderRaysFn.apply(meta, kw["skts"].contiguous(), codes_c, codes_f, *params)

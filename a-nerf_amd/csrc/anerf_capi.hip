@@ -1132,7 +1132,8 @@ int anerf_backward(const AnerfConfig* cfg, const AnerfForwardIO* io, const Anerf
       skts_written = true;
     }
     if (g_codes) {
-      if (hipMemsetAsync(g_codes, 0, (size_t)io->n_codes * 16 * 4, st) != hipSuccess) return set_error(ANERF_E_LAUNCH, "backward: hipMemsetAsync");
+      // accumulate = 1: the frame-code gradients are ADDED to the caller's tensor too (k_code_reduce adds; no zero fill)
+      if (!b->accumulate && hipMemsetAsync(g_codes, 0, (size_t)io->n_codes * 16 * 4, st) != hipSuccess) return set_error(ANERF_E_LAUNCH, "backward: hipMemsetAsync");
       r = anerf_code_grads(cfg, B(w.du), io->cam_idx, (int)n, ns, g_codes, io->n_codes, B(w.rowsum), stream);
     }
     return r;

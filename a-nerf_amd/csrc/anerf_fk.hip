@@ -290,6 +290,259 @@ __global__ __launch_bounds__(FKT) void k_fk_bwd(const float* __restrict__ bones,
   for (int e = 0; e < rd; ++e) g_bones[((long long)u * NJ + j) * rd + e] = da[e];
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The pose layer's per-iteration work in three launches (round 4; the 384-rays-per-rank Mixamo step spent ~25 small torch
+// launches here: index_select x 2, five per-ray expansions, their reshaped sums, two index_add_, zero fills, gradient
+// accumulation adds -- PoseOptLayer.forward of core/pose_opt.py:318-331,372-445 and its autograd):
+//   k_pose_batch_fwd   block (c, u) = ray chunk c (64 rays) x distinct pose u: if the chunk holds rays of pose u -- one ballot --
+//                      the parameters are gathered through pose_idx[u], the chain is evaluated and the PER-RAY rows the
+//                      reference's layer returns (kp / bones / skts / l2ws / rots [N, ...]) are written for those rays, a wave
+//                      per ray, coalesced; chunk 0's blocks also write the unique-level outputs the regulariser reads.
+//   k_pose_partial     block (c, u): the chunk's rays of pose u compacted in ray order (ballot prefix), their per-ray gradients
+//                      summed in that order -> partial[u][c][1200] (+ the count, so that empty chunks are skipped later);
+//   k_pose_batch_bwd   block u: partials summed in chunk order (fixed order: bit-reproducible), the unique-level gradients
+//                      added, the reverse chain, and the result written or ADDED to rows pose_idx[u] of the full-size parameter
+//                      gradients (distinct poses: no two blocks touch a row).
+// (A first version with one block per pose for everything was SLOWER than the launches it replaced: 8 blocks writing 15 MB of
+// rows and summing 384 rays each serially cost 0.75 ms at 3072 rays.)
+// ------------------------------------------------------------------------------------------------
+constexpr int PBT = 256;
+constexpr int RPB = 64;           // rays per chunk = one ballot
+constexpr int PW = NJ * 16 + NJ * 16 + NJ * 9 + NJ * 3 + NJ * 6;     // 1200: [skts | l2ws | rots | kp | bones(6)] of one pose
+struct PoseRows {     // one pose's outputs (or summed output gradients) staged in LDS
+  float skts[NJ * 16], l2ws[NJ * 16], rots[NJ * 9], kp[NJ * 3], bones[NJ * 6];
+};
+static_assert(sizeof(PoseRows) == PW * 4, "PoseRows is the 1200-float row");
+
+__global__ __launch_bounds__(PBT) void k_pose_batch_fwd(const float* __restrict__ bones_all, int rd, const float* __restrict__ pelvis_all,
+                                                        const float* __restrict__ rest, const long long* __restrict__ pose_idx,
+                                                        const int* __restrict__ inverse, int n_rays,
+                                                        float* __restrict__ u_kp, float* __restrict__ u_bones, float* __restrict__ u_rots,
+                                                        float* __restrict__ r_kp, float* __restrict__ r_bones, float* __restrict__ r_skts,
+                                                        float* __restrict__ r_l2ws, float* __restrict__ r_rots) {
+  __shared__ FkShared S;
+  __shared__ PoseRows R;
+  __shared__ unsigned long long hits;
+  const int c = blockIdx.x, u = blockIdx.y, t = threadIdx.x;
+  const int n0 = c * RPB;
+  if (t < 64) {
+    const int n = n0 + t;
+    const unsigned long long b = __ballot(n < n_rays && inverse[n] == u);
+    if (t == 0) hits = b;
+  }
+  __syncthreads();
+  const unsigned long long mine = hits;
+  if (mine == 0ull && c != 0) return;          // no ray of this pose in the chunk (chunk 0 still owes the unique outputs)
+  const long long pi = pose_idx[u];
+  __shared__ float rest_s[NJ * 3], bones_s[NJ * 6];      // the chain reads these level by level: one global round trip, not nine
+  if (t < NJ * 3) rest_s[t] = rest[t];
+  for (int e = t; e < NJ * rd; e += PBT) bones_s[e] = bones_all[pi * NJ * rd + e];
+  __syncthreads();
+  const float* bones_u = bones_s;
+  fk_chain(S, bones_u, rd, rest_s, t);
+  if (t < NJ) {
+    const int j = t;
+    float pv[3] = {0.f, 0.f, 0.f};
+    if (pelvis_all) { pv[0] = pelvis_all[3 * pi]; pv[1] = pelvis_all[3 * pi + 1]; pv[2] = pelvis_all[3 * pi + 2]; }
+    const float* Rg = S.Rg[j];
+    const float cc[3] = {S.tg[j][0] + pv[0], S.tg[j][1] + pv[1], S.tg[j][2] + pv[2]};
+    for (int e = 0; e < 9; ++e) R.rots[9 * j + e] = S.Rl[j][e];
+    for (int r = 0; r < 3; ++r) {
+      R.l2ws[16 * j + 4 * r] = Rg[3 * r]; R.l2ws[16 * j + 4 * r + 1] = Rg[3 * r + 1]; R.l2ws[16 * j + 4 * r + 2] = Rg[3 * r + 2];
+      R.l2ws[16 * j + 4 * r + 3] = cc[r];
+      R.skts[16 * j + 4 * r] = Rg[r]; R.skts[16 * j + 4 * r + 1] = Rg[3 + r]; R.skts[16 * j + 4 * r + 2] = Rg[6 + r];
+      R.skts[16 * j + 4 * r + 3] = -(Rg[r] * cc[0] + Rg[3 + r] * cc[1] + Rg[6 + r] * cc[2]);
+      R.kp[3 * j + r] = cc[r];
+    }
+    for (int e = 0; e < 3; ++e) { R.l2ws[16 * j + 12 + e] = 0.f; R.skts[16 * j + 12 + e] = 0.f; }
+    R.l2ws[16 * j + 15] = 1.f; R.skts[16 * j + 15] = 1.f;
+    for (int e = 0; e < rd; ++e) R.bones[rd * j + e] = bones_u[rd * j + e];
+  }
+  __syncthreads();
+  if (c == 0) {     // unique-level outputs
+    for (int e = t; e < NJ * 3; e += PBT) if (u_kp) u_kp[(long long)u * NJ * 3 + e] = R.kp[e];
+    for (int e = t; e < NJ * rd; e += PBT) if (u_bones) u_bones[(long long)u * NJ * rd + e] = R.bones[e];
+    for (int e = t; e < NJ * 9; e += PBT) if (u_rots) u_rots[(long long)u * NJ * 9 + e] = R.rots[e];
+  }
+  // per-ray rows: a wave per ray of this pose in the chunk
+  const int lane = t & 63, wave = t >> 6;
+  for (int k = wave; k < RPB; k += PBT / 64) {
+    if (!((mine >> k) & 1ull)) continue;       // wave-uniform
+    const long long n = n0 + k;
+    if (r_skts) for (int e = lane; e < NJ * 16; e += 64) r_skts[n * NJ * 16 + e] = R.skts[e];
+    if (r_l2ws) for (int e = lane; e < NJ * 16; e += 64) r_l2ws[n * NJ * 16 + e] = R.l2ws[e];
+    if (r_rots) for (int e = lane; e < NJ * 9; e += 64) r_rots[n * NJ * 9 + e] = R.rots[e];
+    if (r_kp) for (int e = lane; e < NJ * 3; e += 64) r_kp[n * NJ * 3 + e] = R.kp[e];
+    if (r_bones) for (int e = lane; e < NJ * rd; e += 64) r_bones[n * NJ * rd + e] = R.bones[e];
+  }
+}
+
+// per-ray gradient sums of one (chunk, pose): partial [U][C][PW], count [U][C]
+__global__ __launch_bounds__(PBT) void k_pose_partial(const int* __restrict__ inverse, int n_rays, int rd, const float* __restrict__ gr_kp,
+                                                      const float* __restrict__ gr_bones, const float* __restrict__ gr_skts,
+                                                      const float* __restrict__ gr_l2ws, const float* __restrict__ gr_rots,
+                                                      float* __restrict__ partial, int* __restrict__ count) {
+  __shared__ int list[RPB];
+  __shared__ int n_list;
+  const int c = blockIdx.x, u = blockIdx.y, C = gridDim.x, t = threadIdx.x;
+  const int n0 = c * RPB;
+  if (t < 64) {
+    const int n = n0 + t;
+    const bool hit = n < n_rays && inverse[n] == u;
+    const unsigned long long b = __ballot(hit);
+    if (hit) list[__popcll(b & ((1ull << t) - 1ull))] = n;
+    if (t == 0) { n_list = __popcll(b); count[u * C + c] = __popcll(b); }
+  }
+  __syncthreads();
+  const int nl = n_list;
+  if (nl == 0) return;
+  float* out = partial + ((long long)u * C + c) * PW;
+  // thread = element of the 1200-float row, loop = the chunk's rays of this pose in ray order (independent loads: unrolled)
+  for (int e = t; e < PW; e += PBT) {
+    const float* src; int w, o;
+    if (e < NJ * 16) { src = gr_skts; w = NJ * 16; o = e; }
+    else if (e < 2 * NJ * 16) { src = gr_l2ws; w = NJ * 16; o = e - NJ * 16; }
+    else if (e < 2 * NJ * 16 + NJ * 9) { src = gr_rots; w = NJ * 9; o = e - 2 * NJ * 16; }
+    else if (e < 2 * NJ * 16 + NJ * 12) { src = gr_kp; w = NJ * 3; o = e - 2 * NJ * 16 - NJ * 9; }
+    else { src = gr_bones; w = NJ * rd; o = e - 2 * NJ * 16 - NJ * 12; if (o >= w) src = nullptr; }
+    float a = 0.f;
+    if (src) {
+#pragma unroll 8
+      for (int k = 0; k < nl; ++k) a += src[(long long)list[k] * w + o];
+    }
+    out[e] = a;
+  }
+}
+
+__global__ __launch_bounds__(PBT) void k_pose_batch_bwd(const float* __restrict__ bones_all, int rd, const float* __restrict__ pelvis_all,
+                                                        const float* __restrict__ rest_g, const long long* __restrict__ pose_idx, int C,
+                                                        const float* __restrict__ partial, const int* __restrict__ count,
+                                                        const float* __restrict__ gu_kp, const float* __restrict__ gu_bones,
+                                                        const float* __restrict__ gu_rots, float* __restrict__ g_bones_all,
+                                                        float* __restrict__ g_pelvis_all, int accumulate) {
+  __shared__ FkShared S;
+  __shared__ PoseRows G;           // summed gradients w.r.t. this pose's outputs
+  __shared__ float dpel[NJ][3];
+  const int u = blockIdx.x, t = threadIdx.x;
+  const long long pi = pose_idx[u];
+  __shared__ float rest_s[NJ * 3], bones_s[NJ * 6];      // read level by level by the chains below: staged once
+  if (t < NJ * 3) rest_s[t] = rest_g[t];
+  for (int e = t; e < NJ * rd; e += PBT) bones_s[e] = bones_all[pi * NJ * rd + e];
+  const float* rest = rest_s;
+  const float* bones_u = bones_s;
+  float* Gf = reinterpret_cast<float*>(&G);
+  // the non-empty chunks of this pose, in chunk order (wave 0: ballot + prefix count), then thread = element, loop = those chunks:
+  // independent loads (a loop over ALL chunks with a branch on the count was 48 serial round trips per element: 0.17 ms)
+  constexpr int CL = 2048, EPT = (PW + PBT - 1) / PBT;
+  __shared__ int clist[CL];
+  __shared__ int n_clist;
+  float a[EPT];
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) a[i] = 0.f;
+  for (int cb = 0; partial && cb < C; cb += CL) {
+    if (t < 64) {
+      int cnt = 0;
+      for (int c0 = cb; c0 < C && c0 < cb + CL; c0 += 64) {
+        const int c = c0 + t;
+        const bool hit = c < C && c < cb + CL && count[u * C + c] > 0;
+        const unsigned long long b = __ballot(hit);
+        if (hit) clist[cnt + __popcll(b & ((1ull << t) - 1ull))] = c;
+        cnt += __popcll(b);
+      }
+      if (t == 0) n_clist = cnt;
+    }
+    __syncthreads();
+    const int nc = n_clist;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int e = t + i * PBT;
+      if (e < PW) {
+        float acc = a[i];
+#pragma unroll 8
+        for (int k = 0; k < nc; ++k) acc += partial[((long long)u * C + clist[k]) * PW + e];
+        a[i] = acc;
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < EPT; ++i) if (t + i * PBT < PW) Gf[t + i * PBT] = a[i];
+  __syncthreads();
+  for (int e = t; e < NJ * 9; e += PBT) if (gu_rots) G.rots[e] += gu_rots[(long long)u * NJ * 9 + e];
+  for (int e = t; e < NJ * 3; e += PBT) if (gu_kp) G.kp[e] += gu_kp[(long long)u * NJ * 3 + e];
+  for (int e = t; e < NJ * rd; e += PBT) if (gu_bones) G.bones[e] += gu_bones[(long long)u * NJ * rd + e];
+  // ---- reverse chain on the summed gradients (k_fk_bwd's arithmetic)
+  fk_chain(S, bones_u, rd, rest, t);
+  float pv[3] = {0.f, 0.f, 0.f};
+  if (pelvis_all) { pv[0] = pelvis_all[3 * pi]; pv[1] = pelvis_all[3 * pi + 1]; pv[2] = pelvis_all[3 * pi + 2]; }
+  const int j = t;
+  if (j < NJ) {
+    float dRg[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dc[3] = {0.f, 0.f, 0.f};
+    const float* Rg = S.Rg[j];
+    const float c[3] = {S.tg[j][0] + pv[0], S.tg[j][1] + pv[1], S.tg[j][2] + pv[2]};
+    const float* gl = G.l2ws + 16 * j;
+    const float* gs = G.skts + 16 * j;
+    for (int r = 0; r < 3; ++r) {
+      dRg[3 * r] += gl[4 * r]; dRg[3 * r + 1] += gl[4 * r + 1]; dRg[3 * r + 2] += gl[4 * r + 2];
+      dc[r] += gl[4 * r + 3];
+    }
+    float ds[3];
+    for (int r = 0; r < 3; ++r) {
+      ds[r] = gs[4 * r + 3];
+      for (int k = 0; k < 3; ++k) dRg[3 * k + r] += gs[4 * r + k];
+    }
+    for (int k = 0; k < 3; ++k) {
+      dc[k] -= Rg[3 * k] * ds[0] + Rg[3 * k + 1] * ds[1] + Rg[3 * k + 2] * ds[2];
+      for (int r = 0; r < 3; ++r) dRg[3 * k + r] -= c[k] * ds[r];
+    }
+    for (int r = 0; r < 3; ++r) dc[r] += G.kp[3 * j + r];
+    for (int e = 0; e < 9; ++e) S.dRg[j][e] = dRg[e];
+    for (int r = 0; r < 3; ++r) { S.dc[j][r] = dc[r]; dpel[j][r] = dc[r]; }
+  }
+  __syncthreads();
+  if (g_pelvis_all && j < 3) {
+    float s = 0.f;
+    for (int q = 0; q < NJ; ++q) s += dpel[q][j];
+    float* o = g_pelvis_all + 3 * pi + j;
+    *o = accumulate ? *o + s : s;
+  }
+  for (int lvl = NLEVEL - 2; lvl >= 0; --lvl) {
+    if (j < NJ && kDepth[j] == lvl) {
+      for (int ch = j + 1; ch < NJ; ++ch) {
+        if (kParent[ch] != j) continue;
+        const float o[3] = {rest[3 * ch] - rest[3 * j], rest[3 * ch + 1] - rest[3 * j + 1], rest[3 * ch + 2] - rest[3 * j + 2]};
+        for (int r = 0; r < 3; ++r) {
+          for (int c = 0; c < 3; ++c)
+            S.dRg[j][3 * r + c] += S.dRg[ch][3 * r] * S.Rl[ch][3 * c] + S.dRg[ch][3 * r + 1] * S.Rl[ch][3 * c + 1] +
+                                   S.dRg[ch][3 * r + 2] * S.Rl[ch][3 * c + 2] + S.dc[ch][r] * o[c];
+          S.dc[j][r] += S.dc[ch][r];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (j >= NJ) return;
+  float dRl[9];
+  if (j == 0) {
+    for (int e = 0; e < 9; ++e) dRl[e] = S.dRg[0][e];
+  } else {
+    const int p = kParent[j];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c)
+        dRl[3 * r + c] = S.Rg[p][r] * S.dRg[j][c] + S.Rg[p][3 + r] * S.dRg[j][3 + c] + S.Rg[p][6 + r] * S.dRg[j][6 + c];
+  }
+  for (int e = 0; e < 9; ++e) dRl[e] += G.rots[9 * j + e];
+  float da[6];
+  if (rd == 6) rot6d_backward(bones_u + 6 * j, dRl, da);
+  else aa_backward(bones_u + 3 * j, dRl, da);
+  for (int e = 0; e < rd; ++e) {
+    float* o = g_bones_all + (pi * NJ + j) * rd + e;
+    const float v = da[e] + G.bones[rd * j + e];
+    *o = accumulate ? *o + v : v;
+  }
+}
+
 }  // namespace anerf
 
 using namespace anerf;
@@ -369,6 +622,56 @@ int anerf_fk_backward(const float* bones, int32_t rot_dim, const float* pelvis, 
   hipLaunchKernelGGL(k_fk_bwd, dim3(n_poses), dim3(FKT), 0, (hipStream_t)stream, bones, (int)rot_dim, pelvis,
                      rest_pose, (long long)rest_pose_stride, (int)n_poses, g_skts, g_l2ws, g_kp, g_rots, g_bones, g_pelvis);
   return check_launch("k_fk_bwd");
+}
+
+
+int anerf_pose_batch_forward(const float* bones, int32_t rot_dim, const float* pelvis, const float* rest_pose, const int64_t* pose_idx,
+                             int32_t n_unique, const int32_t* inverse, int32_t n_rays, float* u_kp, float* u_bones, float* u_rots,
+                             float* r_kp, float* r_bones, float* r_skts, float* r_l2ws, float* r_rots, void* stream) {
+  if (rot_dim != 3 && rot_dim != 6) return set_error(ANERF_E_CONFIG, "pose_batch_forward: rot_dim must be 3 (axis-angle) or 6 (rot6d)");
+  if (n_unique < 0 || n_rays < 0 || n_unique > 65535) return set_error(ANERF_E_SHAPE, "pose_batch_forward: 0 <= n_unique <= 65535, n_rays >= 0");
+  if (n_unique == 0) return ANERF_OK;
+  if (!bones || !rest_pose || !pose_idx || (n_rays > 0 && !inverse)) return set_error(ANERF_E_NULL, "pose_batch_forward: NULL pointer");
+  const int C = n_rays > 0 ? (n_rays + RPB - 1) / RPB : 1;
+  hipLaunchKernelGGL(k_pose_batch_fwd, dim3(C, n_unique), dim3(PBT), 0, (hipStream_t)stream, bones, (int)rot_dim, pelvis, rest_pose,
+                     reinterpret_cast<const long long*>(pose_idx), reinterpret_cast<const int*>(inverse), (int)n_rays, u_kp, u_bones, u_rots,
+                     r_kp, r_bones, r_skts, r_l2ws, r_rots);
+  return check_launch("k_pose_batch_fwd");
+}
+
+int64_t anerf_pose_batch_scratch_size(int32_t n_unique, int32_t n_rays) {
+  if (n_unique < 0 || n_rays < 0) return set_error(ANERF_E_SHAPE, "pose_batch_scratch_size: negative sizes");
+  const int64_t C = n_rays > 0 ? (n_rays + RPB - 1) / RPB : 1;
+  return (int64_t)n_unique * C * (PW + 1) * 4;
+}
+
+int anerf_pose_batch_backward(const float* bones, int32_t rot_dim, const float* pelvis, const float* rest_pose, const int64_t* pose_idx,
+                              int32_t n_unique, const int32_t* inverse, int32_t n_rays, const float* g_r_kp, const float* g_r_bones,
+                              const float* g_r_skts, const float* g_r_l2ws, const float* g_r_rots, const float* g_u_kp,
+                              const float* g_u_bones, const float* g_u_rots, float* g_bones, float* g_pelvis, int32_t accumulate,
+                              void* scratch, int64_t scratch_bytes, void* stream) {
+  if (rot_dim != 3 && rot_dim != 6) return set_error(ANERF_E_CONFIG, "pose_batch_backward: rot_dim must be 3 (axis-angle) or 6 (rot6d)");
+  if (n_unique < 0 || n_rays < 0 || n_unique > 65535) return set_error(ANERF_E_SHAPE, "pose_batch_backward: 0 <= n_unique <= 65535, n_rays >= 0");
+  if (n_unique == 0) return ANERF_OK;
+  if (!bones || !rest_pose || !pose_idx || !g_bones || (n_rays > 0 && !inverse)) return set_error(ANERF_E_NULL, "pose_batch_backward: NULL pointer");
+  const bool any_ray = n_rays > 0 && (g_r_kp || g_r_bones || g_r_skts || g_r_l2ws || g_r_rots);
+  const int C = n_rays > 0 ? (n_rays + RPB - 1) / RPB : 1;
+  float* partial = nullptr;
+  int* count = nullptr;
+  if (any_ray) {
+    if (!scratch || scratch_bytes < anerf_pose_batch_scratch_size(n_unique, n_rays) || ((uintptr_t)scratch & 15))
+      return set_error(ANERF_E_WORKSPACE, "pose_batch_backward: scratch of anerf_pose_batch_scratch_size bytes, 16-byte aligned");
+    partial = reinterpret_cast<float*>(scratch);
+    count = reinterpret_cast<int*>(partial + (int64_t)n_unique * C * PW);
+    hipLaunchKernelGGL(k_pose_partial, dim3(C, n_unique), dim3(PBT), 0, (hipStream_t)stream, reinterpret_cast<const int*>(inverse),
+                       (int)n_rays, (int)rot_dim, g_r_kp, g_r_bones, g_r_skts, g_r_l2ws, g_r_rots, partial, count);
+    const int rc = check_launch("k_pose_partial");
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_pose_batch_bwd, dim3(n_unique), dim3(PBT), 0, (hipStream_t)stream, bones, (int)rot_dim, pelvis, rest_pose,
+                     reinterpret_cast<const long long*>(pose_idx), C, partial, count, g_u_kp, g_u_bones, g_u_rots, g_bones, g_pelvis,
+                     (int)(accumulate != 0));
+  return check_launch("k_pose_batch_bwd");
 }
 
 }  // extern "C"

@@ -426,6 +426,47 @@ def fk_backward(bones, rest_pose, pelvis, g_skts=None, g_l2ws=None, g_kp=None, g
     return gb, gp
 
 
+def pose_batch_forward(bones, pelvis, rest_pose, pose_idx, inverse, want_rays=("kp", "bones", "skts", "l2ws", "rots")):
+    """anerf_pose_batch_forward: the pose layer's forward for one batch in ONE launch.  bones [P,24,3|6] / pelvis [P,3] = the
+    layer's full parameters, pose_idx [U] int64 (distinct poses of the batch), inverse [N] int32 (ray -> slot), rest_pose [24,3].
+    Returns (unique dict: kp / bones / rots [U, ...], per-ray dict of the requested rows [N, ...])."""
+    bones, pelvis, rest = _f32c(bones, "bones"), _f32c(pelvis, "pelvis"), _f32c(rest_pose, "rest_pose").reshape(-1, 24, 3)
+    if rest.shape[0] != 1:
+        raise ValueError("pose_batch_forward: one rest pose shared by all poses")
+    if pose_idx.dtype != torch.int64 or inverse.dtype != torch.int32 or not pose_idx.is_contiguous() or not inverse.is_contiguous():
+        raise TypeError("pose_batch_forward: pose_idx int64 / inverse int32, contiguous")
+    u, n, rd, dev = pose_idx.numel(), inverse.numel(), bones.shape[-1], bones.device
+    E = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+    uniq = {"kp": E(u, 24, 3), "bones": E(u, 24, rd), "rots": E(u, 24, 3, 3)}
+    shapes = {"kp": (n, 24, 3), "bones": (n, 24, rd), "skts": (n, 24, 4, 4), "l2ws": (n, 24, 4, 4), "rots": (n, 24, 3, 3)}
+    rays = {k: E(*shapes[k]) for k in want_rays}
+    _lib.check(_lib.load().anerf_pose_batch_forward(_p(bones), rd, _p(pelvis), _p(rest), _p(pose_idx), u, _p(inverse), n, _p(uniq["kp"]),
+                                                    _p(uniq["bones"]), _p(uniq["rots"]), _p(rays.get("kp")), _p(rays.get("bones")),
+                                                    _p(rays.get("skts")), _p(rays.get("l2ws")), _p(rays.get("rots")), _stream()),
+               "anerf_pose_batch_forward")
+    return uniq, rays
+
+
+def pose_batch_backward(bones, pelvis, rest_pose, pose_idx, inverse, g_rays, g_uniq, g_bones, g_pelvis, accumulate):
+    """anerf_pose_batch_backward.  g_rays / g_uniq: dicts of gradients (missing or None = none) w.r.t. the per-ray rows (kp, bones,
+    skts, l2ws, rots) and the unique-level outputs (kp, bones, rots); g_bones [P,24,rd] / g_pelvis [P,3]: the full-size
+    parameter gradients, rows pose_idx written (accumulate False; other rows untouched) or added to (True)."""
+    bones, pelvis, rest = _f32c(bones, "bones"), _f32c(pelvis, "pelvis"), _f32c(rest_pose, "rest_pose").reshape(-1, 24, 3)
+    f = lambda d, k: _f32c(d.get(k), k)
+    gr = {k: f(g_rays, k) for k in ("kp", "bones", "skts", "l2ws", "rots")}
+    gu = {k: f(g_uniq, k) for k in ("kp", "bones", "rots")}
+    lib = _lib.load()
+    scratch, sbytes = None, 0
+    if any(v is not None for v in gr.values()):
+        scratch, sbytes = _workspace(lib.anerf_pose_batch_scratch_size, "anerf_pose_batch_scratch_size", bones.device, pose_idx.numel(),
+                                     inverse.numel())
+    _lib.check(lib.anerf_pose_batch_backward(_p(bones), bones.shape[-1], _p(pelvis), _p(rest), _p(pose_idx), pose_idx.numel(),
+                                             _p(inverse), inverse.numel(), _p(gr["kp"]), _p(gr["bones"]), _p(gr["skts"]),
+                                             _p(gr["l2ws"]), _p(gr["rots"]), _p(gu["kp"]), _p(gu["bones"]), _p(gu["rots"]),
+                                             _p(g_bones), _p(g_pelvis), int(bool(accumulate)), _p(scratch), sbytes, _stream()),
+               "anerf_pose_batch_backward")
+
+
 class Profile:
     """Caller-owned HIP timing events for AnerfProfile (ABI revision 3): created with hipEventCreate through the HIP
     runtime already loaded in the process, recorded by the library around the MFMA kernels of the one-call training step,
@@ -591,7 +632,7 @@ def train_forward(cfg, net_c, net_f, rays, skts, cyls, n_samples, n_importance=0
 
 
 def backward(state, g, packed_t_c, packed_t_f, perm, shapes_c, shapes_f, packed_i_c=None, packed_i_f=None, want_skts=False,
-             want_codes_c=False, want_codes_f=False, accumulate_into=None, after_fine=None):
+             want_codes_c=False, want_codes_f=False, accumulate_into=None, after_fine=None, codes_into=None):
     """anerf_backward.  g: dict of gradients of the rendered maps (keys as the output dict; rgb_map and, when hierarchical,
     rgb0 are required -- missing ones are taken as zero).  shapes_*: parameter shapes in AnerfNetGrads order (w0, b0, ...).
     accumulate_into: optional (list_c, list_f) of existing gradient tensors the parameter gradients are ADDED to in place
@@ -639,8 +680,17 @@ def backward(state, g, packed_t_c, packed_t_f, perm, shapes_c, shapes_f, packed_
         if hier:
             b.grads_f.w[i], b.grads_f.b[i] = grads_f[2 * i].data_ptr(), grads_f[2 * i + 1].data_ptr()
     g_skts = E((n, cfg.n_joints, 4, 4)) if want_skts else None
-    g_codes_c = E((io.n_codes, 16)) if want_codes_c else None
-    g_codes_f = E((io.n_codes, 16)) if (want_codes_f and hier) else None
+    # codes_into (only with accumulate_into): the frame-code tables' gradient tensors, added to in place like the parameters'
+    if codes_into is not None and accumulate_into is None:
+        raise ValueError("backward: codes_into needs accumulate_into (one `accumulate` flag covers both)")
+    if accumulate_into is not None and codes_into is None and (want_codes_c or want_codes_f):
+        codes_into = (torch.zeros((io.n_codes, 16), dtype=torch.float32, device=dev) if want_codes_c else None,
+                      torch.zeros((io.n_codes, 16), dtype=torch.float32, device=dev) if (want_codes_f and hier) else None)
+    if codes_into is not None:
+        g_codes_c, g_codes_f = (codes_into[0] if want_codes_c else None), (codes_into[1] if (want_codes_f and hier) else None)
+    else:
+        g_codes_c = E((io.n_codes, 16)) if want_codes_c else None
+        g_codes_f = E((io.n_codes, 16)) if (want_codes_f and hier) else None
     b.g_skts, b.g_codes_c, b.g_codes_f = _p(g_skts), _p(g_codes_c), _p(g_codes_f)
     lib, cc = _lib.load(), cfg.c()
     if _active_profile is not None:

@@ -130,14 +130,19 @@ class FusedAdam:
             self.load_state_dict(sd)
 
     # ---- in-place gradient accumulation (opt-in) --------------------------------------------------------------
-    def attach(self, caster):
+    def attach(self, caster, pose_layer=None):
         """Opt in to in-place gradient accumulation: the caster's one-call backward adds the parameter gradients straight
         into this optimiser's flat bucket and reports none to autograd (no 48 AccumulateGrad launches per step).  While
         attached, `torch.autograd.grad(loss, params)` on these parameters yields None -- call `detach()` (or never attach)
-        when the gradients are wanted as autograd results.  `caster` may be the RayParallel wrapper."""
+        when the gradients are wanted as autograd results.  `caster` may be the RayParallel wrapper.
+        pose_layer: a PoseOptLayer whose `pelvis` / `bones` are parameters of this optimiser: its fused backward then adds
+        their gradients in place too (same contract)."""
         caster = getattr(caster, "module", caster)
         caster._anerf_grad_sink = weakref.ref(self)
         self._attached = weakref.ref(caster)
+        if pose_layer is not None:
+            pose_layer._anerf_grad_sink = weakref.ref(self)
+            self._attached_pose = weakref.ref(pose_layer)
         if self.params[0].is_cuda:
             self.materialize()           # the bucket must exist before the first backward for that one to land in it
         return self
@@ -147,6 +152,10 @@ class FusedAdam:
         if caster is not None and getattr(caster, "_anerf_grad_sink", None) is not None and caster._anerf_grad_sink() is self:
             caster._anerf_grad_sink = None
         self._attached = None
+        layer = self._attached_pose() if getattr(self, "_attached_pose", None) is not None else None
+        if layer is not None and getattr(layer, "_anerf_grad_sink", None) is not None and layer._anerf_grad_sink() is self:
+            layer._anerf_grad_sink = None
+        self._attached_pose = None
 
     def __del__(self):
         try:

@@ -10,6 +10,8 @@ shared body bones, pose_opt.py:293-296,318-331).
 `skts` returned here feed RayCaster.render_rays(skts=...); their gradient (the hot path's dskts) flows back to
 `bones` / `pelvis` through one backward kernel.  No CPU fallback.
 """
+import weakref
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -29,6 +31,40 @@ class _FkFn(torch.autograd.Function):
         bones, pelvis, rest_pose = ctx.saved_tensors
         gb, gp = ops.fk_backward(bones, rest_pose, pelvis, g_skts=g_skts, g_l2ws=g_l2ws, g_kp=g_kp, g_rots=g_rots)
         return gb, gp, None
+
+
+class _PoseBatchFn(torch.autograd.Function):
+    """PoseOptLayer.forward for one batch (parameter lookup -> FK per distinct pose -> per-ray rows) as ONE launch each way
+    (anerf_pose_batch_forward / _backward; core/pose_opt.py:318-331,372-445 and its autograd).  Outputs: the five per-ray
+    tensors of the reference's layer, then the unique-level kp / bones / rots the pose regulariser reads.
+    Gradients reach the parameters either as dense tensors through autograd (rows of the batch's poses written into zeros), or
+    -- when the layer is attached to a FusedAdam whose flat bucket owns `pelvis.grad` / `bones.grad` -- added in place by the
+    kernel (no zero fill, no AccumulateGrad add), and autograd is told there is nothing to accumulate."""
+
+    @staticmethod
+    def forward(ctx, pelvis, bones, rest, pose_idx, inverse, layer_ref):
+        uniq, rays = ops.pose_batch_forward(bones, pelvis, rest, pose_idx, inverse)
+        ctx.save_for_backward(pelvis, bones, rest, pose_idx, inverse)
+        ctx.layer_ref = layer_ref
+        ctx.set_materialize_grads(False)
+        return rays["kp"], rays["bones"], rays["skts"], rays["l2ws"], rays["rots"], uniq["kp"], uniq["bones"], uniq["rots"]
+
+    @staticmethod
+    def backward(ctx, g_kp, g_bones, g_skts, g_l2ws, g_rots, gu_kp, gu_bones, gu_rots):
+        pelvis, bones, rest, pose_idx, inverse = ctx.saved_tensors
+        layer = ctx.layer_ref() if ctx.layer_ref is not None else None
+        sink = getattr(layer, "_anerf_grad_sink", None) if layer is not None else None
+        sink = sink() if sink is not None else None
+        # (saved tensors come back as new Python objects: compare storage, not identity)
+        direct = sink is not None and layer.pelvis.data_ptr() == pelvis.data_ptr() and layer.bones.data_ptr() == bones.data_ptr() and \
+            sink.owns_grads([layer.pelvis, layer.bones], bones.device)
+        if direct:
+            gb, gp = layer.bones.grad, layer.pelvis.grad
+        else:
+            gb, gp = torch.zeros_like(bones), torch.zeros_like(pelvis)
+        ops.pose_batch_backward(bones, pelvis, rest, pose_idx, inverse, dict(kp=g_kp, bones=g_bones, skts=g_skts, l2ws=g_l2ws, rots=g_rots),
+                                dict(kp=gu_kp, bones=gu_bones, rots=gu_rots), gb, gp, accumulate=direct)
+        return (None, None, None, None, None, None) if direct else (gp, gb, None, None, None, None)
 
 
 class _RepeatPoses(torch.autograd.Function):
@@ -239,10 +275,33 @@ class PoseOptLayer(nn.Module):
     def to_bones3d(self, bones):
         return bones if bones.shape[-1] == 3 else rot6d_to_axisang(bones)
 
+    def _batch_index(self, idxs):
+        """(unique pose rows int64 [U], inverse int32 [N]) on the device + the host arrays; uploaded once per distinct batch layout
+        (a blocking copy of pageable memory per step would be a host sync per step)"""
+        arr = np.ascontiguousarray(np.asarray(idxs).reshape(-1).astype(np.int64))
+        cache = self.__dict__.setdefault("_batch_cache", {})
+        key = (arr.tobytes(), str(self.pelvis.device))
+        hit = cache.get(key)
+        if hit is None:
+            if len(cache) > 256:
+                cache.clear()
+            uniq, inv = np.unique(arr, return_inverse=True)
+            dev = self.pelvis.device
+            hit = cache[key] = (torch.as_tensor(uniq.astype(np.int64), device=dev), torch.as_tensor(inv.astype(np.int32), device=dev), uniq,
+                                np.bincount(inv, minlength=len(uniq)))
+        return hit
+
     def calculate_kinematic(self, idxs, rest_pose_idxs=None):
         if idxs is None:
             idxs = np.arange(len(self.pelvis))
         idxs = np.atleast_1d(np.asarray(idxs.cpu() if torch.is_tensor(idxs) else idxs))
+        if self.kp_map is None and len(self.rest_pose) == 1 and self.pelvis.is_cuda and getattr(self, "fused_batch", True):
+            # single-view layer with one rest pose (surreal / mixamo / perfcap): the whole call is one launch each way
+            pose_idx, inverse, uniq_host, counts = self._batch_index(idxs)
+            kp, bone, skts, l2ws, rots, kp_u, bone_u, rots_u = _PoseBatchFn.apply(self.pelvis, self.bones, self.rest_pose, pose_idx, inverse,
+                                                                                  weakref.ref(self))
+            self.last_unique = {"idxs": uniq_host, "counts": counts, "rots": rots_u, "bones": bone_u, "kp": kp_u}
+            return kp, bone, skts, l2ws, rots
         unique_idxs, inverse_idxs = np.unique(idxs, return_inverse=True)       # FK once per distinct pose
         rest = self.get_rest_pose(unique_idxs, rest_pose_idxs)
         pelvis, bone = self.idx_to_params(unique_idxs)

@@ -770,7 +770,7 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
         if mixamo:
             groups.append({"params": list(popt.parameters()), "lr": 5e-4, "step_every": args.opt_pose_step})
         opt = optim.FusedAdam(groups, betas=(0.9, 0.999))
-        opt.attach(caster)               # opt in: the backward accumulates into the bucket in place
+        opt.attach(caster, pose_layer=popt)      # opt in: the backwards accumulate into the bucket in place
         if dist is not None and N_rand % world == 0:
             opt.enable_overlap()         # the fine network's all-reduce runs under the coarse half of the backward
     else:

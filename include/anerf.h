@@ -376,7 +376,8 @@ typedef struct AnerfBackwardIO {
   const int32_t *perm_x, *perm_u;
   AnerfNetGrads grads_c, grads_f;
   float *g_skts, *g_codes_c, *g_codes_f;
-  int32_t accumulate;   /* 0: grads_c / grads_f are written; 1: added to their current contents (param.grad in place) */
+  int32_t accumulate;   /* 0: grads_c / grads_f are written; 1: added to their current contents (param.grad in place) -- and so are
+                         * g_codes_c / g_codes_f (ABI revision 4: no zero fill of them inside) */
   int32_t passes;       /* ABI revision 2.  0 or 3: both network passes (fine, then coarse).  1: the fine pass only; 2: the
                          * coarse pass only -- the two halves of one backward, enqueued as two calls so that the caller can
                          * start reducing the fine network's gradients (complete after the first call) over RCCL while the
@@ -391,6 +392,28 @@ int64_t anerf_backward_scratch_size(const AnerfConfig* cfg, int32_t n_rays, int3
 int anerf_train_forward(const AnerfConfig* cfg, const AnerfForwardIO* io, void* workspace, int64_t ws_bytes, void* stream);
 int anerf_backward(const AnerfConfig* cfg, const AnerfForwardIO* io, const AnerfBackwardIO* b, void* workspace,
                    int64_t ws_bytes, void* scratch, int64_t scratch_bytes, void* stream);
+
+/* ABI revision 4: the pose layer's per-iteration work as ONE launch each way (PoseOptLayer.forward, core/pose_opt.py:318-331,
+ * 372-445: parameter lookup for the batch's poses, forward kinematics once per DISTINCT pose, per-ray expansion `x[inverse]` of
+ * the five outputs; and its autograd).  bones [P,24,rot_dim] / pelvis [P,3] (may be NULL) are the layer's FULL parameter tensors,
+ * pose_idx [U] (int64, device) the distinct pose rows of the batch, inverse [N] (int32, device) each ray's slot in 0..U-1, rest_pose
+ * [24,3] one rest pose shared by all poses.  Outputs, any may be NULL: per distinct pose u_kp [U,24,3], u_bones [U,24,rot_dim] (the
+ * gathered parameters), u_rots [U,24,3,3]; per ray r_kp [N,24,3], r_bones [N,24,rot_dim], r_skts / r_l2ws [N,24,4,4], r_rots
+ * [N,24,3,3].
+ * backward: gradients w.r.t. any of those outputs (NULL = none) -> g_bones [P,24,rot_dim], g_pelvis [P,3] (may be NULL) at the rows
+ * pose_idx[u] only (other rows untouched): written, or with accumulate != 0 ADDED to their contents (the parameters' .grad in
+ * place).  Per-ray gradients of a pose are summed in ray order inside 64-ray chunks and the chunks in chunk order: bit-reproducible.
+ * scratch: anerf_pose_batch_scratch_size(n_unique, n_rays) bytes (only read when a per-ray gradient is given).  Launches: one
+ * forward; backward one (no per-ray gradients) or two. */
+int anerf_pose_batch_forward(const float* bones, int32_t rot_dim, const float* pelvis, const float* rest_pose, const int64_t* pose_idx,
+                             int32_t n_unique, const int32_t* inverse, int32_t n_rays, float* u_kp, float* u_bones, float* u_rots,
+                             float* r_kp, float* r_bones, float* r_skts, float* r_l2ws, float* r_rots, void* stream);
+int anerf_pose_batch_backward(const float* bones, int32_t rot_dim, const float* pelvis, const float* rest_pose, const int64_t* pose_idx,
+                              int32_t n_unique, const int32_t* inverse, int32_t n_rays, const float* g_r_kp, const float* g_r_bones,
+                              const float* g_r_skts, const float* g_r_l2ws, const float* g_r_rots, const float* g_u_kp,
+                              const float* g_u_bones, const float* g_u_rots, float* g_bones, float* g_pelvis, int32_t accumulate,
+                              void* scratch, int64_t scratch_bytes, void* stream);
+int64_t anerf_pose_batch_scratch_size(int32_t n_unique, int32_t n_rays);
 
 /* Pose regulariser of the pose-refinement step (Trainer._compute_kp_loss, core/trainer.py:382-403) and its gradient in one
  * launch:  loss = coef * sum_u w_u / 23 * sum_{j >= 1, c} max-thresholded (anchor - value)^2  ("d > tol ? d - tol : 0"),

@@ -321,3 +321,83 @@ def test_fused_kp_loss_equals_the_reference_expression(rot6d):
     np.testing.assert_allclose(layer.bones.grad.cpu().numpy(), 3.0 * g_ref.cpu().numpy(), rtol=2e-5,
                                atol=2e-6 * float(g_ref.abs().max()) * 3.0)
     assert float(layer.bones.grad[1].abs().max()) == 0.0          # pose 1 is not in the batch
+
+
+def _pose_layer(n_poses, rot6d, seed=5):
+    po = importlib.import_module("a-nerf_amd.pose_opt")
+    rng = np.random.RandomState(seed)
+    bones = (rng.randn(n_poses, 24, 3) * 0.4).astype(np.float32)
+    kps = np.repeat((rng.randn(n_poses, 1, 3) * 0.5).astype(np.float32), 24, 1)
+    rest = (synth.SMPL_REST_POSE * synth.SURREAL_SCALE).astype(np.float32)
+    layer = po.PoseOptLayer(kps, bones, rest[None], use_rot6d=rot6d).cuda()
+    if rot6d:
+        with torch.no_grad():      # off the rotation manifold, as optimisation steps leave the parameters
+            layer.bones.add_(torch.tensor((rng.randn(*layer.bones.shape) * 0.1).astype(np.float32), device="cuda"))
+    return layer
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rot6d", [False, True])
+@pytest.mark.parametrize("n_rays, n_poses, layout", [(3072, 8, "blocks"), (384, 1, "blocks"), (777, 5, "random"), (9001, 2, "random")])
+def test_one_launch_pose_batch_equals_the_composed_layer(rot6d, n_rays, n_poses, layout):
+    """PoseOptLayer's fused path (anerf_pose_batch_forward / _backward: lookup + FK per distinct pose + per-ray rows in one launch
+    each way) against the composed one (index_select -> anerf_fk -> expansion; its autograd): forward bit-equal, parameter
+    gradients equal up to the summation order of a pose's rays (ray order here, torch's reduction tree there).  Layouts: the
+    sampler's blocks of consecutive rays per pose, arbitrary per-ray poses, and more rays of one pose (4 500) than one pass of the
+    backward's ray list holds (4 096)."""
+    layer = _pose_layer(11, rot6d)
+    rng = np.random.RandomState(n_rays)
+    pool = rng.choice(11, n_poses, replace=False)
+    idx = np.repeat(pool, n_rays // n_poses + 1)[:n_rays] if layout == "blocks" else pool[rng.randint(0, n_poses, n_rays)]
+    names = ("kp", "bones", "skts", "l2ws", "rots")
+    w = {k: None for k in names}
+    res = {}
+    for fused in (True, False):
+        layer.fused_batch = fused
+        layer.zero_grad(set_to_none=True)
+        out = dict(zip(names, layer(idx)))
+        if w["kp"] is None:
+            g = torch.Generator(device="cuda").manual_seed(1)
+            w = {k: torch.randn(out[k].shape, device="cuda", generator=g) for k in names}
+            wu = torch.randn(layer.last_unique["rots"].shape, device="cuda", generator=g)
+        loss = sum((out[k] * w[k]).sum() for k in names) + (layer.last_unique["rots"] * wu).sum()
+        loss.backward()
+        res[fused] = ({k: v.detach().clone() for k, v in out.items()}, layer.bones.grad.clone(), layer.pelvis.grad.clone(),
+                      {k: layer.last_unique[k].detach().clone() for k in ("kp", "bones", "rots")}, layer.last_unique["counts"].copy())
+    for k in names:
+        assert torch.equal(res[True][0][k], res[False][0][k]), k
+    for k in ("kp", "bones", "rots"):
+        assert torch.equal(res[True][3][k], res[False][3][k]), k
+    assert np.array_equal(res[True][4], res[False][4]) and res[True][4].sum() == n_rays
+    for a, b, nm in ((res[True][1], res[False][1], "bones"), (res[True][2], res[False][2], "pelvis")):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 2e-5 * scale, (nm, float((a - b).abs().max()), scale)
+        untouched = np.setdiff1d(np.arange(11), pool)
+        assert float(a[torch.tensor(untouched, device="cuda")].abs().max()) == 0.0 if len(untouched) else True
+
+
+@pytest.mark.gpu
+def test_pose_batch_backward_accumulates_in_place_when_the_layer_is_attached():
+    """FusedAdam.attach(caster, pose_layer=layer): the fused backward ADDS into pelvis.grad / bones.grad (views of the flat
+    bucket) and reports nothing to autograd; equal bit for bit to the dense route (zeros + rows, then AccumulateGrad's add),
+    also on top of gradients accumulated by an earlier backward (the pose cadence), and bitwise repeatable."""
+    optim = importlib.import_module("a-nerf_amd.optim")
+    idx = np.repeat(np.array([6, 2, 9]), 40)
+    grads = {}
+    for attached in (False, True):
+        layer = _pose_layer(11, True)
+        opt = optim.FusedAdam([{"params": list(layer.parameters()), "lr": 1e-3}])
+        opt.materialize()
+        if attached:
+            class _C:           # stands in for the caster of attach(): only the pose layer matters here
+                pass
+            opt.attach(_C(), pose_layer=layer)
+        for rep in range(2):    # second backward: accumulation on top of the first
+            kp, bones, skts, l2ws, rots = layer(idx)
+            g = torch.Generator(device="cuda").manual_seed(rep)
+            loss = (skts * torch.randn(skts.shape, device="cuda", generator=g)).sum() + (layer.last_unique["rots"] ** 2).sum()
+            loss.backward()
+        assert layer.bones.grad.data_ptr() == opt._views(opt.flat_grad)[1].data_ptr()      # still the bucket's view
+        grads[attached] = (layer.bones.grad.clone(), layer.pelvis.grad.clone())
+    assert torch.equal(grads[True][0], grads[False][0]) and torch.equal(grads[True][1], grads[False][1])
+    assert float(grads[True][0].abs().max()) > 0

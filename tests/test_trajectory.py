@@ -108,7 +108,7 @@ def test_five_training_iterations_follow_the_reference_trajectory(name, tail):
         groups = [{"params": grad_vars, "lr": args.lrate}]
         if case["mixamo"]:
             groups.append({"params": list(layer.parameters()), "lr": args.opt_pose_lrate, "step_every": args.opt_pose_step})
-        fused = optim.FusedAdam(groups, betas=(0.9, 0.999)).attach(caster)
+        fused = optim.FusedAdam(groups, betas=(0.9, 0.999)).attach(caster, pose_layer=layer)     # networks, frame codes, pose: all in place
         opt, popt = fused.group_optimizer(0), (fused.group_optimizer(1) if case["mixamo"] else None)
     else:
         opt, popt = torch_opt, pose_torch_opt
