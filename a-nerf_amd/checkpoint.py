@@ -40,6 +40,9 @@ def nerf_state(global_step, ray_caster, optimizer, popt_layer=None, pose_optimiz
             "poseopt_layer_state_dict": None if popt_layer is None else popt_layer.state_dict(),
             "pose_optimizer_state_dict": psd,
             "poseopt_anchors": popt_anchors,
+            # ours only (ignored by the reference's loaders): where the caster's counter-based generator stands, so that a resumed
+            # run continues the random stream instead of replaying it
+            "anerf_rng_state": _unwrap(ray_caster).rng_state() if hasattr(_unwrap(ray_caster), "rng_state") else None,
             **_unwrap(ray_caster).state_dict()}
 
 
@@ -68,6 +71,8 @@ def load_nerf(path_or_ckpt, ray_caster, optimizer=None, popt_layer=None, pose_op
         raise KeyError(f"not an A-NeRF checkpoint: missing {missing}")
     caster = _unwrap(ray_caster)
     caster.load_state_dict(ckpt)
+    if not finetune and ckpt.get("anerf_rng_state") is not None and hasattr(caster, "set_rng_state"):
+        caster.set_rng_state(ckpt["anerf_rng_state"])
     start = 0 if finetune else ckpt["global_step"]
     if optimizer is not None and not finetune and ckpt.get("optimizer_state_dict") is not None:
         if isinstance(optimizer, FusedAdam) and len(optimizer.param_groups) > 1:

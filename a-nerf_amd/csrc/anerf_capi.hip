@@ -628,9 +628,12 @@ static int weight_grads_impl(const AnerfConfig* cfg, const AnerfSaved* sv, const
   gemm_plan_rows(pp, P.nheavy, &P.rows_h, &P.chunks_h);
   long long ws_pos = 0, out_pos = 0;
   int np = 0, nmat = 0;
+  bool plan_overflow = false;          // an operand / tile table would have been written past its end: reported after planning
+  constexpr int MAX_MAT = (int)(sizeof(P.mat) / sizeof(P.mat[0]));
   auto mat = [&](const float* ptr, int ld) {
     for (int i = 0; i < nmat; ++i)
       if (P.mat[i].ptr == ptr) return i;
+    if (nmat >= MAX_MAT) { plan_overflow = true; return 0; }     // bounds-checked HERE: the table lives on this stack frame
     P.mat[nmat].ptr = ptr; P.mat[nmat].ld = ld; P.mat[nmat].ncols = ld;
     return nmat++;
   };
@@ -680,6 +683,7 @@ static int weight_grads_impl(const AnerfConfig* cfg, const AnerfSaved* sv, const
   auto tile_of = [&](GemmBlock& B, int m, int col0) {
     for (int i = 0; i < B.ntiles; ++i)
       if (B.t[i].mat == m && B.t[i].col0 == col0) return i;
+    if (B.ntiles >= (int)(sizeof(B.t) / sizeof(B.t[0]))) { plan_overflow = true; return 0; }
     B.t[B.ntiles].mat = m; B.t[B.ntiles].col0 = col0;
     return B.ntiles++;
   };
@@ -688,6 +692,7 @@ static int weight_grads_impl(const AnerfConfig* cfg, const AnerfSaved* sv, const
     for (size_t i0 = 0; i0 < list.size(); i0 += per_block) {
       if (!list.empty() && list[i0].prob == p_alpha_host) P.head[0].blk = nb;
       if (!list.empty() && list[i0].prob == p_rgb_host) P.head[1].blk = nb;
+      if (nb >= (int)(sizeof(P.blk) / sizeof(P.blk[0]))) { plan_overflow = true; return; }
       GemmBlock& B = P.blk[nb++];
       B.ntiles = 0; B.pad_ = 0;
       for (int w = 0; w < 4; ++w) B.w[w].a_tile = -1;
@@ -716,13 +721,22 @@ static int weight_grads_impl(const AnerfConfig* cfg, const AnerfSaved* sv, const
     }
   }
   emit(wide, 4);          // views layer: one A tile (dzv) x up to 4 column tiles of f / U'
-  if (nb != P.nheavy || nb > 16 || nmat > 24) return set_error(ANERF_E_CONFIG, "weight_grads: block plan mismatch");
+  if (plan_overflow || nb != P.nheavy) return set_error(ANERF_E_CONFIG, "weight_grads: block plan mismatch (operand / tile / block table full)");
   // head hosts: the feature layer's block (its two B tiles ARE the h7 rows) and layer 7's block + the g rows as a fifth tile
   if (P.head[0].blk < 0 || P.head[1].blk < 0 || P.blk[P.head[0].blk].ntiles != 4 || P.blk[P.head[1].blk].ntiles != 4)
     return set_error(ANERF_E_CONFIG, "weight_grads: head host blocks");
   P.head[0].tile = -1;    // (each wave's own b_tile)
   P.head[0].part_off = (int)G.p[p_alpha].part_off; P.head[0].bias_off = (int)G.p[p_alpha].bias_off;
   P.head[1].tile = tile_of(P.blk[P.head[1].blk], mat(sv->g, 128), 0);
+  if (plan_overflow) return set_error(ANERF_E_CONFIG, "weight_grads: no room for the rgb head's fifth tile");
+  // the hosted head FMAs (HeadWork, anerf_gemm.hip) take wave & 1 as the row tile and wave >> 1 as the column tile of a 2 x 2 block:
+  // that is the order `emit` filled the host blocks' waves in (n-major, both m tiles adjacent) -- checked, not assumed
+  for (int hb = 0; hb < 2; ++hb) {
+    const GemmBlock& B = P.blk[P.head[hb].blk];
+    for (int w = 0; w < 4; ++w)
+      if (B.w[w].a_tile < 0 || B.w[w].m0 != 128 * (w & 1) || B.w[w].n0 != B.w[w & 2].n0)
+        return set_error(ANERF_E_CONFIG, "weight_grads: head host block is not in (row tile = wave & 1, column tile = wave >> 1) order");
+  }
   P.head[1].part_off = (int)G.p[p_rgb].part_off; P.head[1].bias_off = (int)G.p[p_rgb].bias_off;
   return launch_weight_grads(P, G, workspace, b3, (hipStream_t)stream);
 }

@@ -147,18 +147,72 @@ def pack_params_multi(jobs):
         _lib.check(lib.anerf_pack_params_multi(carr, len(chunk), _stream()), "anerf_pack_params_multi")
 
 
-class DeviceRng:
-    """Counter-based generator behind anerf_rand_fill: (seed, offset) on the host, one launch per `fill`.  Stands where the
-    reference calls torch.rand / torch.randn on the device (ray_utils.py:171-180,240-246; nerf.py:176-182;
-    raycasters.py:660,674): same distributions, its own stream (as torch's CPU and GPU generators differ from each other)."""
+_rng_instances = [0]
 
-    def __init__(self, seed=None):
-        self.seed = int(torch.initial_seed() if seed is None else seed) & (2 ** 64 - 1)
+
+class DeviceRng:
+    """Counter-based generator behind anerf_rand_fill: (key, offset) on the host, one launch per `fill`.  Stands where the
+    reference calls torch.rand / torch.randn on the device (ray_utils.py:171-180,240-246; nerf.py:176-182;
+    raycasters.py:660,674): same distributions, its own stream (as torch's CPU and GPU generators differ from each other).
+
+    Seeding follows torch's: the key derives from `torch.initial_seed()` and is RE-derived (offset back to 0) whenever that
+    seed changes, so `torch.manual_seed(k)` before a run reproduces its jitter / noise draws like it does for the torch.rand
+    path this replaces.  The key also mixes a stream id -- the process's rank (RANK / torch.distributed) and a per-instance
+    counter -- so data-parallel ranks and deep-copied casters with the same seed draw DIFFERENT numbers for their shards.
+    `manual_seed(seed)` pins an explicit seed (no longer follows torch's); `state_dict()` / `load_state_dict()` carry (seed,
+    stream id, offset, pinned) for checkpoints (checkpoint.save_nerf stores it under "anerf_rng_state")."""
+
+    def __init__(self, seed=None, stream_id=None):
+        if stream_id is None:
+            rank = 0
+            try:
+                import torch.distributed as dist
+                rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else int(__import__("os").environ.get("RANK", 0))
+            except Exception:
+                pass
+            stream_id = (rank << 20) | (_rng_instances[0] & 0xFFFFF)
+            _rng_instances[0] += 1
+        self.stream_id = int(stream_id)
+        self.pinned = seed is not None
+        self._torch_seed = None
         self.offset = 0
+        self._set(int(torch.initial_seed() if seed is None else seed))
+
+    def _set(self, seed):
+        self._torch_seed = int(seed) & (2 ** 64 - 1)
+        # splitmix-style mix of the stream id into the Philox key (a plain xor would map (seed, id) pairs onto each other)
+        z = (self._torch_seed + 0x9E3779B97F4A7C15 * (self.stream_id + 1)) & (2 ** 64 - 1)
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & (2 ** 64 - 1)
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & (2 ** 64 - 1)
+        self.seed = (z ^ (z >> 31)) & (2 ** 64 - 1)
+        self.offset = 0
+
+    def manual_seed(self, seed):
+        self.pinned = True
+        self._set(seed)
+        return self
+
+    def follow_torch_seed(self):
+        """torch.manual_seed() was called since the last draw (and no explicit seed is pinned): re-derive the key, offset 0"""
+        if not self.pinned and int(torch.initial_seed()) & (2 ** 64 - 1) != self._torch_seed:
+            self._set(torch.initial_seed())
+
+    def __deepcopy__(self, memo):
+        """a copied caster draws its own stream: same seed policy, fresh stream id"""
+        return DeviceRng(seed=self._torch_seed if self.pinned else None)
+
+    def state_dict(self):
+        return {"seed": self._torch_seed, "stream_id": self.stream_id, "offset": self.offset, "pinned": self.pinned}
+
+    def load_state_dict(self, sd):
+        self.stream_id, self.pinned = int(sd["stream_id"]), bool(sd["pinned"])
+        self._set(int(sd["seed"]))
+        self.offset = int(sd["offset"])
 
     def fill(self, specs, device):
         """specs: list of (shape, kind, scale) with kind "uniform" | "normal" (None entries are skipped and returned as None).
         Returns the tensors, all filled by ONE launch."""
+        self.follow_torch_seed()
         outs, jobs = [], []
         for sp in specs:
             if sp is None:

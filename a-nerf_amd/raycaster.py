@@ -120,10 +120,8 @@ class RayCaster(nn.Module):
             # every random input of the call in ONE launch (ops.DeviceRng / anerf_rand_fill): uniforms for the stratified
             # jitter and the inverse-CDF draws, N(0,1) * raw_noise_std * B for the density logits (nerf.py:176-177), N(0,1) *
             # ray_noise_std for the sample-point offsets (raycasters.py:660,674: coarse and importance samples)
-            if getattr(self, "_rng", None) is None:
-                self._rng = ops.DeviceRng()
             sd = raw_noise_std * B
-            t_rand, u_imp, noise, noise_f, pts_noise, pts_noise_is = self._rng.fill([
+            t_rand, u_imp, noise, noise_f, pts_noise, pts_noise_is = self.rng().fill([
                 ((n, N_samples), "uniform", 1.0) if perturb > 0. else None,
                 ((n, N_importance), "uniform", 1.0) if perturb > 0. and hier else None,
                 ((n, N_samples), "normal", sd) if raw_noise_std > 0. else None,
@@ -205,6 +203,23 @@ class RayCaster(nn.Module):
                     m.load_state_dict(ok, strict=False)
                 else:
                     print(f"Error occurred when loading state dict for {key}. The entity is not in the state dict?")
+
+    # ---- the device generator behind perturb / raw_noise_std / ray_noise_std (ops.DeviceRng): seeding and checkpointing
+    def rng(self):
+        if getattr(self, "_rng", None) is None:
+            self._rng = ops.DeviceRng()
+        return self._rng
+
+    def manual_seed(self, seed):
+        """pin this caster's random stream to `seed` (otherwise it follows torch.manual_seed / torch.initial_seed)"""
+        self.rng().manual_seed(seed)
+        return self
+
+    def rng_state(self):
+        return self.rng().state_dict()
+
+    def set_rng_state(self, sd):
+        self.rng().load_state_dict(sd)
 
     def get_embed_fns(self):
         return self.embed_fn, self.embedbones_fn, self.embeddirs_fn

@@ -117,3 +117,35 @@ def test_shared_cylinder_matches_per_ray_cylinders_incl_nan_fallback():
     one_row = ops.forward(cfg, net, None, rb, skt, cyl[:1], c["S"], 0)
     for k in per_ray:
         assert torch.equal(per_ray[k], shared[k]) and torch.equal(per_ray[k], one_row[k]), k
+
+
+def test_render_staticcam_and_tensor_near_far():
+    """render(c2w_staticcam=...) (trainer.py:118-122: the second camera's origins / directions for the full H x W image, the given
+    rays only as view directions -- which the path slices off, raycasters.py:415) equals rendering the second camera's rays
+    directly; near / far given as tensors (the reference multiplies them into ones_like, trainer.py:131) equal the scalar form."""
+    caster = make_caster(build("eval_s32")).eval()
+    H = W = 24
+    focal = 30.0
+    sc = synth.make_scene(0, H, W, focal)
+    c2w_a = dev(synth.default_c2w())
+    c2w_b = c2w_a.clone()
+    c2w_b[0, 3] += 0.3                      # a second camera, shifted sideways
+    rb_a, _ = ops.gen_rays(H, W, focal, c2w_a, (0, 0, W, H))
+    rb_b, _ = ops.gen_rays(H, W, focal, c2w_b, (0, 0, W, H))
+    n = H * W
+    reuse = lambda x, *sh: dev(x)[None].clone().expand(n, *sh)
+    batch = dict(kp_batch=reuse(sc["pose"]["kp"], 24, 3), skts=reuse(sc["pose"]["skts"], 24, 4, 4), cyls=reuse(sc["cyl"], 5),
+                 bones=reuse(sc["pose"]["bones"], 24, 3))
+    rk = dict(RK, N_importance=0, N_samples=32)
+    with torch.no_grad():
+        direct = render_mod.render(H, W, focal, rays=(rb_b[:, 0:3], rb_b[:, 3:6]), chunk=256, ray_caster=caster, cams=None, subject_idxs=None,
+                                   **batch, **rk)
+        static = render_mod.render(H, W, focal, rays=(rb_a[:, 0:3].reshape(H, W, 3), rb_a[:, 3:6].reshape(H, W, 3)), chunk=256,
+                                   c2w_staticcam=c2w_b[:3, :4], ray_caster=caster, cams=None, subject_idxs=None, **batch, **rk)
+        tens = render_mod.render(H, W, focal, rays=(rb_b[:, 0:3], rb_b[:, 3:6]), chunk=256, near=torch.zeros(n, 1, device="cuda"),
+                                 far=torch.ones(1, device="cuda"), ray_caster=caster, cams=None, subject_idxs=None, **batch, **rk)
+    assert static["rgb_map"].shape == (H, W, 3) and static["alpha"].shape == (H, W, 32)
+    for k in direct:
+        assert torch.equal(static[k].reshape(direct[k].shape), direct[k]), k
+        assert torch.equal(tens[k], direct[k]), k
+    assert float(direct["acc_map"].max()) > 0.1

@@ -161,3 +161,35 @@ def test_fused_adam_overlap_refuses_a_second_backward_and_pending_group_state():
     assert torch.equal(g1["state"][0]["exp_avg"], sd["state"][2]["exp_avg"]) and g1["param_groups"][0]["params"] == [0]
     assert torch.equal(g0["state"][1]["exp_avg_sq"], sd["state"][1]["exp_avg_sq"])
     torch.optim.Adam(pose, lr=1.0).load_state_dict(g1)                     # what the reference's pose optimiser would load
+
+
+def test_device_rng_follows_torch_seed_and_separates_streams():
+    """ops.DeviceRng (host logic; the draws themselves are pinned against Philox known answers in test_step_glue.py): the key
+    follows torch.manual_seed like the torch.rand path it replaces, ranks / instances / deep copies get their own streams, an
+    explicit seed pins it, and the state round-trips."""
+    import copy
+    ops = importlib.import_module("a-nerf_amd.ops")
+    torch.manual_seed(1234)
+    a, b = ops.DeviceRng(), ops.DeviceRng()
+    assert a.seed != b.seed and a.stream_id != b.stream_id            # two instances, same torch seed: different streams
+    k0 = a.seed
+    a.offset = 17
+    torch.manual_seed(99)
+    a.follow_torch_seed()
+    assert a.seed != k0 and a.offset == 0                             # torch.manual_seed() re-derives the key and restarts the counter
+    torch.manual_seed(1234)
+    a.follow_torch_seed()
+    assert a.seed == k0 and a.offset == 0                             # ... and the same seed reproduces the same stream
+    r0, r1 = ops.DeviceRng(stream_id=(0 << 20) | 5), ops.DeviceRng(stream_id=(1 << 20) | 5)
+    assert r0.seed != r1.seed                                         # same seed on two ranks: different shards draw different numbers
+    c = copy.deepcopy(a)
+    assert c.seed != a.seed and c.stream_id != a.stream_id            # a copied caster does not replay its original
+    p = ops.DeviceRng().manual_seed(7)
+    torch.manual_seed(5)
+    kp = p.seed
+    p.follow_torch_seed()
+    assert p.seed == kp and p.pinned                                  # pinned: no longer follows torch
+    p.offset = 3
+    q = ops.DeviceRng()
+    q.load_state_dict(p.state_dict())
+    assert (q.seed, q.offset, q.stream_id, q.pinned) == (p.seed, 3, p.stream_id, True)

@@ -75,7 +75,7 @@ def test_rand_fill_is_philox_and_one_launch_per_call():
             ctr[:, 0] = np.arange(q)
             ctr[:, 2] = j
             ctr[:, 3] = call
-            r = philox4x32_10(ctr, (0x90ABCDEF, 0x12345678))
+            r = philox4x32_10(ctr, (rng.seed & 0xFFFFFFFF, rng.seed >> 32))      # the key = the generator's derived 64-bit key
             if sp[1] == "uniform":
                 want = ((r >> 8).astype(np.float32) * np.float32(2.0 ** -24)).reshape(-1)[:n]
                 assert np.array_equal(t.cpu().numpy().reshape(-1), want)          # bit-exact
@@ -91,12 +91,15 @@ def test_rand_fill_is_philox_and_one_launch_per_call():
     u, z = ops.DeviceRng(7).fill([((3072, 80), "uniform", 1.0), ((3072, 80), "normal", 1.0)], torch.device("cuda"))
     assert abs(float(u.mean()) - 0.5) < 2e-3 and abs(float(u.var()) - 1 / 12) < 1e-3
     assert abs(float(z.mean())) < 5e-3 and abs(float(z.var()) - 1.0) < 1e-2 and abs(float((z ** 4).mean()) - 3.0) < 0.1
-    # two generators with the same seed agree; consecutive calls differ
-    a = ops.DeviceRng(5).fill([((64, 64), "uniform", 1.0)], torch.device("cuda"))[0]
-    g = ops.DeviceRng(5)
+    # two generators with the same seed AND stream id agree; consecutive calls differ; another stream id (another rank, another
+    # caster instance: the default) differs
+    a = ops.DeviceRng(5, stream_id=3).fill([((64, 64), "uniform", 1.0)], torch.device("cuda"))[0]
+    g = ops.DeviceRng(5, stream_id=3)
     b = g.fill([((64, 64), "uniform", 1.0)], torch.device("cuda"))[0]
     c = g.fill([((64, 64), "uniform", 1.0)], torch.device("cuda"))[0]
-    assert torch.equal(a, b) and not torch.equal(b, c)
+    d = ops.DeviceRng(5).fill([((64, 64), "uniform", 1.0)], torch.device("cuda"))[0]
+    e = ops.DeviceRng(5).fill([((64, 64), "uniform", 1.0)], torch.device("cuda"))[0]
+    assert torch.equal(a, b) and not torch.equal(b, c) and not torch.equal(d, e) and not torch.equal(a, d)
 
 
 @pytest.mark.gpu
