@@ -304,7 +304,7 @@ def test_caster_draws_its_randomness_from_the_device_rng():
 
     def run(seed, ray_noise=0.05, perturb=1.0, raw_noise=1.0):
         if seed is not None:
-            caster._rng = ops.DeviceRng(seed)
+            caster.manual_seed(seed)          # pins the caster's stream to `seed` (same stream id: re-seeding replays it)
         for p in caster.parameters():
             p.grad = None
         out = render_mod.render(64, 64, 75.0, chunk=4096, rays=(d(ro), d(rd)), use_viewdirs=True, ray_caster=caster, kp_batch=d(kp),
