@@ -183,6 +183,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
                            "(make -C a-nerf_amd/csrc).  There is no CPU fallback for the hot path.")
+    # torch first: it ships its own HIP runtime, and the one mapped FIRST is the one both sides must share -- loading this library
+    # before torch maps the system runtime for it and torch's own next to it, and the library's launches then fail with "no
+    # ROCm-capable device is detected" (seen when build() and smoke() ran in one process)
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
