@@ -167,6 +167,16 @@ class Trainer:
             f.all_reduce_grads(i=i)                       # no-op in a single process; ONE collective over what is due otherwise
             norms = f.step(zero_grad=True, want_norms=True, i=i)
             return {"total_norm": norms[0], "avg_norm": norms[1]}
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            # one process per GPU: average the ranks' gradients with ONE all-reduce of a flat bucket (RayParallel.sync_gradients;
+            # the pose layer's parameters ride in a second bucket) -- what nn.DataParallel's reduce-add did inside one process
+            if hasattr(caster, "sync_gradients"):
+                caster.sync_gradients()
+            if not popt_detach and self.popt_kwargs is not None and self.popt_kwargs.get("popt_layer") is not None:
+                if getattr(self, "_pose_bucket", None) is None:
+                    from .parallel import GradBucket
+                    self._pose_bucket = GradBucket(list(self.popt_kwargs["popt_layer"].parameters()))
+                self._pose_bucket.all_reduce_mean()
         total_norm, avg_norm = get_gradnorm(caster)
         self.optimizer.step()
         self.optimizer.zero_grad()
