@@ -306,7 +306,11 @@ class FusedAdam:
         seg = self._segments()
         for gi in self._due(i, only_group):
             grp = self.param_groups[gi]
-            for p, g in zip(grp["params"], self._views(self.flat_grad, gi)):
+            # the group's gradient views of the flat bucket: built once (48 slice + view calls per step were 0.17 ms of host time)
+            gv = self.__dict__.setdefault("_grad_views", {})
+            if gi not in gv or gv[gi][0] != self.flat_grad.data_ptr():
+                gv[gi] = (self.flat_grad.data_ptr(), self._views(self.flat_grad, gi))
+            for p, g in zip(grp["params"], gv[gi][1]):
                 if p.grad is None:
                     g.zero_()                                    # someone called zero_grad(set_to_none=True) elsewhere:
                     p.grad = g                                   # no gradient this step; the view goes back for the next

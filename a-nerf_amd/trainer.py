@@ -20,7 +20,6 @@ Differences from the reference, all in what is REPORTED, none in what is compute
     get_gradnorm after `zero_grad()` (trainer.py:466-472), i.e. reports zeros under torch 1.x and divides by zero under
     torch >= 2.0.
 """
-import numpy as np
 import torch
 
 from . import optim, pose_opt
