@@ -608,7 +608,9 @@ int anerf_mlp_backward(const AnerfConfig* cfg, const float* packed_t, const floa
 static int weight_grads_impl(const AnerfConfig* cfg, const AnerfSaved* sv, const float* dz, const float* df, const float* dzv,
                              const float* draw, int64_t n_points, const int32_t* perm_x, const int32_t* perm_u,
                              const AnerfNetGrads* gr, float* workspace, int64_t ws_floats, bool b3, bool accumulate,
-                             void* stream) {
+                             void* stream, GemmBatch* defer = nullptr) {
+  // defer != NULL: only the GEMM is enqueued and its reduction descriptor is handed back (anerf_backward reduces both passes of a
+  // step with ONE k_reduce_dw2 launch)
   AnerfTrainLayout T;
   const int rc = anerf_train_layout(cfg, n_points, &T);
   if (rc) return rc;
@@ -738,7 +740,8 @@ static int weight_grads_impl(const AnerfConfig* cfg, const AnerfSaved* sv, const
         return set_error(ANERF_E_CONFIG, "weight_grads: head host block is not in (row tile = wave & 1, column tile = wave >> 1) order");
   }
   P.head[1].part_off = (int)G.p[p_rgb].part_off; P.head[1].bias_off = (int)G.p[p_rgb].bias_off;
-  return launch_weight_grads(P, G, workspace, b3, (hipStream_t)stream);
+  if (defer) *defer = G;
+  return launch_weight_grads(P, G, workspace, b3, (hipStream_t)stream, defer == nullptr);
 }
 
 int anerf_mlp_backward_b3(const AnerfConfig* cfg, const float* packed_t, const float* aux, const float* draw,
@@ -1059,7 +1062,11 @@ int64_t anerf_train_workspace_size(const AnerfConfig* cfg, int32_t n_rays, int32
 int64_t anerf_backward_scratch_size(const AnerfConfig* cfg, int32_t n_rays, int32_t n_samples, int32_t n_importance,
                                     int32_t input_grads) {
   if (!config_ok(cfg) || n_rays < 0 || n_samples < 1 || n_importance < 0) return set_error(ANERF_E_SHAPE, "backward_scratch_size: bad sizes");
-  return bwd_ws(cfg, (int64_t)n_rays * (n_samples + n_importance), input_grads != 0).total;
+  // + a second home for the fine pass's GEMM partials: when both passes run in one call they wait there for the merged reduction
+  const BwdWs f = bwd_ws(cfg, (int64_t)n_rays * (n_samples + n_importance), input_grads != 0);
+  AnerfTrainLayout T;
+  anerf_train_layout(cfg, (int64_t)n_rays * (n_samples + n_importance) > 0 ? (int64_t)n_rays * (n_samples + n_importance) : 1, &T);
+  return f.total + (n_importance > 0 ? (T.gemm_ws_floats * 4 + 255) / 256 * 256 : 0);
 }
 
 int anerf_train_forward(const AnerfConfig* cfg, const AnerfForwardIO* io, void* workspace, int64_t ws_bytes, void* stream) {
@@ -1090,8 +1097,15 @@ int anerf_backward(const AnerfConfig* cfg, const AnerfForwardIO* io, const Anerf
   const bool want_in = b->g_skts || b->g_codes_c || b->g_codes_f;
   const TrainWs t = train_ws(cfg, n, S, Ni);
   if (!workspace || ws_bytes < t.total || ((uintptr_t)workspace & 15)) return set_error(ANERF_E_WORKSPACE, "backward: workspace");
-  if (!scratch || ((uintptr_t)scratch & 15) || scratch_bytes < bwd_ws(cfg, n * (S + Ni), want_in).total)
-    return set_error(ANERF_E_WORKSPACE, "backward: scratch");
+  const int64_t fine_total = bwd_ws(cfg, n * (S + Ni), want_in).total;
+  if (!scratch || ((uintptr_t)scratch & 15) || scratch_bytes < fine_total) return set_error(ANERF_E_WORKSPACE, "backward: scratch");
+  // one k_reduce_dw2 for both passes when they run in this call, no per-kernel timing is asked for and the scratch has the extra
+  // region (anerf_backward_scratch_size): the fine pass's GEMM partials are written THERE, out of the coarse pass's way
+  AnerfTrainLayout Tf;
+  anerf_train_layout(cfg, n * (S + Ni), &Tf);
+  const int64_t gemm_f_bytes = (Tf.gemm_ws_floats * 4 + 255) / 256 * 256;
+  const bool merge_reduce = hier && b->passes == 0 && !b->profile && scratch_bytes >= fine_total + gemm_f_bytes;
+  GemmBatch G_fine;
   if (!b->g_rgb || !b->perm_x || !b->perm_u || !b->packed_t_c || (hier && (!b->packed_t_f || !b->g_rgb0)))
     return set_error(ANERF_E_NULL, "backward: NULL pointer");
   if (want_in && (!b->packed_i_c || (hier && !b->packed_i_f))) return set_error(ANERF_E_NULL, "backward: input-gradient weight image");
@@ -1131,8 +1145,18 @@ int anerf_backward(const AnerfConfig* cfg, const AnerfForwardIO* io, const Anerf
     AnerfTrainLayout T;
     anerf_train_layout(cfg, P, &T);
     prof_rec(b->profile, ANERF_PROF_GEMM(which_pass), stream);
-    r = weight_grads_impl(cfg, &sv, B(w.dz), B(w.df), B(w.dzv), B(w.draw), P, b->perm_x, b->perm_u, gr, B(w.gemm),
-                          T.gemm_ws_floats, b3, b->accumulate != 0, stream);
+    if (merge_reduce && which_pass == 1) {
+      r = weight_grads_impl(cfg, &sv, B(w.dz), B(w.df), B(w.dzv), B(w.draw), P, b->perm_x, b->perm_u, gr, B(fine_total),
+                            T.gemm_ws_floats, b3, b->accumulate != 0, stream, &G_fine);
+    } else if (merge_reduce) {
+      GemmBatch G_coarse;
+      r = weight_grads_impl(cfg, &sv, B(w.dz), B(w.df), B(w.dzv), B(w.draw), P, b->perm_x, b->perm_u, gr, B(w.gemm),
+                            T.gemm_ws_floats, b3, b->accumulate != 0, stream, &G_coarse);
+      if (!r) r = launch_reduce_dw2(G_fine, B(fine_total), G_coarse, B(w.gemm), st);
+    } else {
+      r = weight_grads_impl(cfg, &sv, B(w.dz), B(w.df), B(w.dzv), B(w.draw), P, b->perm_x, b->perm_u, gr, B(w.gemm),
+                            T.gemm_ws_floats, b3, b->accumulate != 0, stream);
+    }
     prof_rec(b->profile, ANERF_PROF_GEMM(which_pass) + 1, stream);
     if (r || !want_in) return r;
     prof_rec(b->profile, ANERF_PROF_BWD_IN(which_pass), stream);

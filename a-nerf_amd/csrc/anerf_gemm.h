@@ -70,6 +70,9 @@ constexpr int GEMM_ROWS = 16;   // sample rows per LDS stage
 // rows-per-block search shared by anerf_train_layout (workspace size) and anerf_weight_grads
 void gemm_plan_rows(long long p_pad, int nheavy, int* rows_h, int* chunks_h);
 
-int launch_weight_grads(const GemmPlan& P, const GemmBatch& G, float* ws, bool b3, hipStream_t st);
+// reduce = false: only the GEMM is enqueued; the caller reduces later (launch_reduce_dw2: both passes of a step in ONE launch)
+int launch_weight_grads(const GemmPlan& P, const GemmBatch& G, float* ws, bool b3, hipStream_t st, bool reduce = true);
+int launch_reduce_dw2(const GemmBatch& G1, const float* ws1, const GemmBatch& G2, const float* ws2, hipStream_t st);
+static_assert(2 * sizeof(GemmBatch) + 32 <= 4096, "two batches by value in one kernel-argument block");
 
 }  // namespace anerf

@@ -552,9 +552,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const GemmPlan G, float* __rest
 }
 
 // Sum the chunk partials in index order and scatter into the gradient tensors.
-__global__ void k_reduce_dw(const GemmBatch G, const float* __restrict__ ws) {
-  const long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (gid >= G.total_out) return;
+__device__ __forceinline__ void reduce_dw_one(const GemmBatch& G, const float* __restrict__ ws, long long gid) {
   int pi = 0;
 #pragma unroll 1
   for (int i = 1; i < G.nprob; ++i)
@@ -592,8 +590,26 @@ __global__ void k_reduce_dw(const GemmBatch G, const float* __restrict__ ws) {
     }
   }
 }
+__global__ void k_reduce_dw(const GemmBatch G, const float* __restrict__ ws) {
+  const long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (gid >= G.total_out) return;
+  reduce_dw_one(G, ws, gid);
+}
+// both network passes of a training step in one launch (the fine pass's partials wait in their own workspace region until the
+// coarse pass's GEMM is done): the same per-element additions, one launch of 27 us instead of two
+__global__ void k_reduce_dw2(const GemmBatch G1, const float* __restrict__ ws1, const GemmBatch G2, const float* __restrict__ ws2) {
+  const long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (gid < G1.total_out) reduce_dw_one(G1, ws1, gid);
+  else if (gid - G1.total_out < G2.total_out) reduce_dw_one(G2, ws2, gid - G1.total_out);
+}
 
-int launch_weight_grads(const GemmPlan& P, const GemmBatch& G, float* ws, bool b3, hipStream_t st) {
+int launch_reduce_dw2(const GemmBatch& G1, const float* ws1, const GemmBatch& G2, const float* ws2, hipStream_t st) {
+  const long long tot = G1.total_out + G2.total_out;
+  hipLaunchKernelGGL(k_reduce_dw2, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, G1, ws1, G2, ws2);
+  return check_launch("k_reduce_dw2");
+}
+
+int launch_weight_grads(const GemmPlan& P, const GemmBatch& G, float* ws, bool b3, hipStream_t st, bool reduce) {
   static unsigned long long lds_set[2] = {};   // per-device bits, see ensure_dynamic_lds
   ensure_dynamic_lds(reinterpret_cast<const void*>(k_gemm_tn<false>), GLDS_BYTES, &lds_set[0]);
   ensure_dynamic_lds(reinterpret_cast<const void*>(k_gemm_tn<true>), GLDS3_BYTES, &lds_set[1]);
@@ -601,7 +617,7 @@ int launch_weight_grads(const GemmPlan& P, const GemmBatch& G, float* ws, bool b
   if (b3) hipLaunchKernelGGL(k_gemm_tn<true>, dim3((unsigned)grid), dim3(256), GLDS3_BYTES, st, P, ws);
   else hipLaunchKernelGGL(k_gemm_tn<false>, dim3((unsigned)grid), dim3(256), GLDS_BYTES, st, P, ws);
   int rc = check_launch("k_gemm_tn");
-  if (rc) return rc;
+  if (rc || !reduce) return rc;
   hipLaunchKernelGGL(k_reduce_dw, dim3((unsigned)((G.total_out + 255) / 256)), dim3(256), 0, st, G, (const float*)ws);
   return check_launch("k_reduce_dw");
 }

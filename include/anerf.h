@@ -366,7 +366,9 @@ int anerf_forward(const AnerfConfig* cfg, const AnerfForwardIO* io, void* worksp
  * inside, both passes summed) and d(loss)/d(frame codes) [n_codes,16] per network (zero-filled inside).
  * packed_t_*: which = 1 (fp32) / 4 (bf16x3) images; packed_i_*: which = 2 / 5, only read when g_skts or g_codes_* is
  * given; perm_x / perm_u: DEVICE copies of anerf_build_perm_tables (fp32) / anerf_build_perm_tables_b3 (bf16x3).
- * scratch: anerf_backward_scratch_size(...) bytes (input_grads != 0 when g_skts / g_codes_* will be requested), free
+ * scratch: anerf_backward_scratch_size(...) bytes (input_grads != 0 when g_skts / g_codes_* will be requested; the size includes
+ * a second region for the fine pass's GEMM partials: when both passes run in one call, without per-kernel timing, they are reduced
+ * together with the coarse pass's by ONE k_reduce_dw2 launch -- a smaller scratch of the first region only still works), free
  * to reuse after the call is enqueued and executed.  Same kernels, same order, same results as the staged sequence
  * composite_backward -> mlp_backward -> weight_grads (-> input_grads -> encode_backward / code_grads) per pass. */
 typedef struct AnerfBackwardIO {
