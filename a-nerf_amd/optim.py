@@ -431,6 +431,30 @@ class _GroupView:
         self.opt.load_state_dict(sd, group=self.gi)
 
 
+_UNIT_SEED = {}
+
+
+def unit_seed(device):
+    """the cached scalar 1.0 `backward()` below seeds the graph with, one per device"""
+    k = str(device)
+    if k not in _UNIT_SEED:
+        _UNIT_SEED[k] = torch.ones((), dtype=torch.float32, device=device)
+    return _UNIT_SEED[k]
+
+
+def is_unit_seed(go):
+    """True when an upstream gradient IS that cached 1.0 (same storage): the fused losses then hand their gradients on unscaled"""
+    s = _UNIT_SEED.get(str(go.device))
+    return s is not None and go.dim() == 0 and go.data_ptr() == s.data_ptr()
+
+
+def backward(loss):
+    """`loss.backward()` for a scalar loss built from fused_nerf_loss (+ pose_opt.kp_loss): seeds the graph with a CACHED 1.0 instead
+    of a fresh ones_like (one fill launch per step), and the fused losses recognise that seed and skip their `gradient * 1.0`
+    launches -- three small launches per training step (four with the pose regulariser).  Same gradients, bit for bit."""
+    torch.autograd.backward(loss, grad_tensors=unit_seed(loss.device))
+
+
 class _LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rgb, acc, rgb0, acc0, target, bgs, loss_type, coarse_weight, beta):
@@ -444,7 +468,8 @@ class _LossFn(torch.autograd.Function):
     def backward(ctx, go, _):
         g = ctx.g
         flat = g["flat"]
-        scaled = flat * go                                  # ONE launch for the four maps (they are views of one buffer)
+        scaled = flat if is_unit_seed(go) else flat * go    # ONE launch for the four maps (they are views of one buffer); none when
+                                                            # the graph was seeded by optim.backward()
         base = flat.data_ptr()
 
         def sc(t):

@@ -160,7 +160,10 @@ class Trainer:
     def optimize(self, loss, i, popt_detach=False):
         args = self.args
         caster = self.render_kwargs_train["ray_caster"]
-        loss.backward()
+        if loss.is_cuda:
+            optim.backward(loss)          # = loss.backward() seeded with a cached 1.0 (no fill, no `grad * 1` launches)
+        else:
+            loss.backward()
         if self._fused is not None:
             f = self._fused
             f.all_reduce_grads(i=i)                       # no-op in a single process; ONE collective over what is due otherwise

@@ -819,7 +819,7 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
                                                                               loss_fn="L1" if mixamo else "MSE")
         if mixamo:   # _compute_kp_loss (trainer.py:382-403; opt_pose_tol 0.01, opt_pose_coef 2.0, mixamo.txt:45,54), one launch
             loss = loss + pose_opt.kp_loss(popt.last_unique["rots"], anchor_u, w_u, True, 0.01, 2.0)
-        loss.backward()
+        (optim.backward if fused else torch.autograd.backward)(loss)      # fused tail: cached unit seed, no `grad * 1` launches
         if i is not None:
             ev[i][1].record()
         it[0] += 1

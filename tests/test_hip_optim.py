@@ -224,3 +224,30 @@ def test_fused_adam_groups_cadence_and_checkpoint_round_trip(tmp_path):
         drive(opt, net_p + pose_p, i)
         drive(opt2, net2 + pose2, i)
     assert torch.equal(opt.flat, opt2.flat) and opt._steps == opt2._steps == [7, 2]
+
+
+@pytest.mark.gpu
+def test_backward_with_the_cached_unit_seed_equals_plain_backward():
+    """optim.backward(loss) seeds the graph with a cached 1.0 and the fused losses skip their `gradient * 1` launches: the
+    gradients w.r.t. the rendered maps (and through the pose regulariser) are bit-identical to loss.backward()'s, also when the
+    loss is a sum of both and when it is scaled afterwards (then the seed is not what reaches the losses, and they scale)."""
+    pose_opt = importlib.import_module("a-nerf_amd.pose_opt")
+    g = torch.Generator(device="cuda").manual_seed(3)
+    n = 257
+    mk = lambda *sh: torch.rand(*sh, device="cuda", generator=g)
+    target = mk(n, 3)
+    vals0, anchors, w = torch.randn(5, 24, 3, 3, device="cuda", generator=g), torch.randn(5, 24, 6, device="cuda", generator=g), mk(5)
+    base = {k: (mk(n, 3) if "rgb" in k else mk(n)) for k in ("rgb_map", "acc_map", "rgb0", "acc0")}
+    res = {}
+    for mode in ("plain", "seeded", "scaled_plain", "scaled_seeded"):
+        preds = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        vals = vals0.clone().requires_grad_(True)
+        loss, _ = optim.fused_nerf_loss(preds, target, bgs=1.0, loss_fn="L1")
+        loss = loss + pose_opt.kp_loss(vals, anchors, w / w.sum(), True, 0.01, 2.0)
+        if mode.startswith("scaled"):
+            loss = loss * 0.37
+        (optim.backward if mode.endswith("seeded") else torch.autograd.backward)(loss)
+        res[mode] = [preds[k].grad.clone() for k in sorted(preds)] + [vals.grad.clone()]
+    for a, b in (("plain", "seeded"), ("scaled_plain", "scaled_seeded")):
+        assert all(torch.equal(x, y) for x, y in zip(res[a], res[b])), (a, b)
+    assert not torch.equal(res["plain"][0], res["scaled_plain"][0])
