@@ -20,7 +20,9 @@ class AnerfConfig(C.Structure):
 
 
 class AnerfNetParams(C.Structure):
-    _fields_ = [("w", C.c_void_p * 12), ("b", C.c_void_p * 12), ("codes", C.c_void_p), ("n_codes", C.c_int32)]
+    _fields_ = [("w", C.c_void_p * 12), ("b", C.c_void_p * 12), ("codes", C.c_void_p), ("n_codes", C.c_int32),
+                ("sched_dim_x", C.c_int32), ("sched_dim_u", C.c_int32), ("reserved_", C.c_int32),
+                ("sched_x", C.c_void_p), ("sched_u", C.c_void_p)]
 
 
 class AnerfLayout(C.Structure):
@@ -33,7 +35,7 @@ class AnerfSaved(C.Structure):
                 ("p_pad", C.c_int64)]
 
 
-ABI_VERSION = 4        # revision of include/anerf.h these structures were written for (checked against anerf_version())
+ABI_VERSION = 5        # revision of include/anerf.h these structures were written for (checked against anerf_version())
 PROF_SLOTS = 16
 
 
@@ -64,7 +66,7 @@ class AnerfForwardIO(C.Structure):
 
 
 class AnerfNetGrads(C.Structure):
-    _fields_ = [("w", C.c_void_p * 12), ("b", C.c_void_p * 12)]
+    _fields_ = [("w", C.c_void_p * 12), ("b", C.c_void_p * 12), ("sched_x", C.c_void_p), ("sched_u", C.c_void_p)]
 
 
 class AnerfBackwardIO(C.Structure):

@@ -100,6 +100,8 @@ class _MlpRawFn(torch.autograd.Function):
         for i in range(12):
             gs.w[i] = grads[2 * i].data_ptr()
             gs.b[i] = grads[2 * i + 1].data_ptr()
+        if meta.get("sched") is not None:
+            meta["sched"].fill(gs)
         ws = torch.empty(T.gemm_ws_floats, dtype=torch.float32, device=dev)
         px, pu = perm_tables(cfg, dev, b3=b3)
         _lib.check((lib.anerf_weight_grads_b3 if b3 else lib.anerf_weight_grads)(C.byref(cc), C.byref(st), _p(dz), _p(df), _p(dzv), _p(draw), P, _p(px), _p(pu),
@@ -221,7 +223,8 @@ class _RenderRaysFn(torch.autograd.Function):
         grads_c, grads_f, g_skts, g_cc, g_cf = ops.backward(
             state, dict(zip(ctx.keys, gs)), meta["packed_t_c"], meta["packed_t_f"], perm_tables(meta["kw"]["cfg"], dev, b3=b3),
             ctx.shapes[:24], ctx.shapes[24:], pi[0], pi[1], want_skts, want_cc, want_cf,
-            accumulate_into=(into[:24], into[24:]) if direct else None, after_fine=hook, codes_into=codes_into)
+            accumulate_into=(into[:24], into[24:]) if direct else None, after_fine=hook, codes_into=codes_into,
+            sched=meta.get("sched"))
         ctx.state = None
         if direct:
             if codes_into is not None:
@@ -249,6 +252,7 @@ def _render_rays_one_node(caster, kw, prec):
                 packed_i=lambda: tuple(n.packed(5 if b3 else 2)[0] for n in nets) + ((None,) if not hier else ()))
     params = [p for n in nets for p in _net_params(n)]
     meta["params"] = params
+    meta["sched"] = net_c.input_schedule()     # what the images above were packed with (set by RayCaster.render_rays)
     # the embedding weights behind codes_c / codes_f when the kernels index them directly (training mode), else None
     code_w = lambda n: n.framecodes.codes.weight if (n is not None and n.use_framecode and n.training) else None
     meta["code_params"] = (code_w(net_c), code_w(net_f) if hier else None)
@@ -300,7 +304,7 @@ def render_rays_train(caster, kw):
         meta = dict(cfg=cfg, rays=rays, z=zz, skts=skts_c.detach(), tau_v=kw["tau_v"], tau_d=kw["tau_d"],
                     cut_v=kw["cut_v"], cut_d=kw["cut_d"], cam=cam, codes=None if codes is None else codes.detach(),
                     packed=net.packed(0) if prec == "fp32" else None, packed_t=net.packed(4 if prec == "bf16x3" else 1), packed_i=lambda: net.packed(5 if prec == "bf16x3" else 2),
-                    precision=prec, packed_b3=net.packed(3) if prec == "bf16x3" else None)
+                    precision=prec, packed_b3=net.packed(3) if prec == "bf16x3" else None, sched=net.input_schedule())
         return _MlpRawFn.apply(meta, skts_c, codes, *_net_params(net))
 
     def comp(raw, zz, noise):

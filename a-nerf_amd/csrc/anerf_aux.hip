@@ -28,7 +28,7 @@ __global__ void k_pack(AnerfNetParams P, const int32_t* __restrict__ table, long
 #pragma unroll
       for (int k = 0; k < 24; ++k)
         if (id == k) src = tens[k];
-      val = src[off];
+      val = src[off] * sched_scale(P, id, off);
     }
     out[i] = val;
   }

@@ -207,7 +207,7 @@ using namespace anerf;
 extern "C" {
 
 const char* anerf_last_error(void) { return g_err; }
-int anerf_version(void) { return 4; }
+int anerf_version(void) { return 5; }
 
 int anerf_layout(const AnerfConfig* cfg, int which, AnerfLayout* out) {
   if (!out) return set_error(ANERF_E_NULL, "out is NULL");
@@ -363,6 +363,7 @@ int anerf_pack_params(const AnerfNetParams* params, const int32_t* table, int64_
   if (!params || !table || !out) return set_error(ANERF_E_NULL, "pack: NULL pointer");
   for (int i = 0; i < 12; ++i)
     if (!params->w[i] || !params->b[i]) return set_error(ANERF_E_NULL, "pack: NULL tensor");
+  if (!sched_ok(*params)) return set_error(ANERF_E_SHAPE, "pack: sched_x / sched_u without sched_dim_x / sched_dim_u");
   return launch_pack(params, table, n, out, (hipStream_t)stream);
 }
 
@@ -371,6 +372,7 @@ int anerf_pack_params_b3(const AnerfNetParams* params, const int32_t* table, int
   if (!params || !table || !out) return set_error(ANERF_E_NULL, "pack_b3: NULL pointer");
   for (int i = 0; i < 12; ++i)
     if (!params->w[i] || !params->b[i]) return set_error(ANERF_E_NULL, "pack_b3: NULL tensor");
+  if (!sched_ok(*params)) return set_error(ANERF_E_SHAPE, "pack_b3: sched_x / sched_u without sched_dim_x / sched_dim_u");
   int rc = launch_pack_b3(params, table, 2 * stream_floats, out, (hipStream_t)stream);
   if (rc) return rc;
   return launch_pack(params, table + 2 * stream_floats, aux_floats, out + stream_floats, (hipStream_t)stream);
@@ -663,15 +665,18 @@ static int weight_grads_impl(const AnerfConfig* cfg, const AnerfSaved* sv, const
   };
   auto DZ = [&](int l) { return dz + (long long)l * pp * 256; };
   auto H = [&](int l) { return sv->h + (long long)l * pp * 256; };
-  add(DZ(0), 256, 256, sv->x, DX, DX, gr->w[0], DX, 0, perm_x, 0, 256, gr->b[0], 0, 256);
+  const int p_x0 = add(DZ(0), 256, 256, sv->x, DX, DX, gr->w[0], DX, 0, perm_x, 0, 256, gr->b[0], 0, 256);
   for (int l = 1; l <= 4; ++l) add(DZ(l), 256, 256, H(l - 1), 256, 256, gr->w[l], 256, 0, nullptr, 0, 256, gr->b[l], 0, 256);
-  add(DZ(5), 256, 256, sv->x, DX, DX, gr->w[5], DX + 256, 0, perm_x, 0, 256, gr->b[5], 0, 256);
+  const int p_x5 = add(DZ(5), 256, 256, sv->x, DX, DX, gr->w[5], DX + 256, 0, perm_x, 0, 256, gr->b[5], 0, 256);
   add(DZ(5), 256, 256, H(4), 256, 256, gr->w[5], DX + 256, DX, nullptr, 0, 256, nullptr, 0, 0);
   add(DZ(6), 256, 256, H(5), 256, 256, gr->w[6], 256, 0, nullptr, 0, 256, gr->b[6], 0, 256);
   const int p_rgb_host = add(DZ(7), 256, 256, H(6), 256, 256, gr->w[7], 256, 0, nullptr, 0, 256, gr->b[7], 0, 256);
   const int p_alpha_host = add(df, 256, 256, H(7), 256, 256, gr->w[9], 256, 0, nullptr, 0, 256, gr->b[9], 0, 256);
   add(dzv, 128, 128, sv->f, 256, 256, gr->w[10], KV, 0, nullptr, 0, 128, gr->b[10], 0, 128);
-  add(dzv, 128, 128, sv->u, UW, UW, gr->w[10], KV, 256, perm_u, 0, 128, nullptr, 0, 0);
+  const int p_u = add(dzv, 128, 128, sv->u, UW, UW, gr->w[10], KV, 256, perm_u, 0, 128, nullptr, 0, 0);
+  // frequency schedule (ABI 5): the images were packed as W diag(s); the gradient of W is the image's gradient times diag(s)
+  G.p[p_x0].colscale = G.p[p_x5].colscale = gr->sched_x;
+  G.p[p_u].colscale = gr->sched_u;
   // heads: rgb_linear <- draw[:, 0:3]^T g (4 row slots), alpha_linear <- draw[:, 3]^T h7 (2 row slots)
   const int p_rgb = add(draw, 4, 3, sv->g, 128, 128, gr->w[11], 128, 0, nullptr, 0, 3, gr->b[11], 0, 3, 4);
   const int p_alpha = add(draw, 4, 1, H(7), 256, 256, gr->w[8], 256, 0, nullptr, 0, 1, gr->b[8], 0, 1, 2);

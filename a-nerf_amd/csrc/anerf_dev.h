@@ -47,6 +47,11 @@ inline void ensure_dynamic_lds(const void* kernel, int bytes, unsigned long long
   __atomic_fetch_or(done, bit, __ATOMIC_RELAXED);
 }
 
+// a schedule vector comes with its length (the pack kernels take the column of an element modulo the layer's input width)
+inline bool sched_ok(const AnerfNetParams& p) {
+  return (!p.sched_x || p.sched_dim_x > 0) && (!p.sched_u || p.sched_dim_u > 0);
+}
+
 #if defined(__HIPCC__)
 // sin and cos of x for |x| < ~1e4: Cody-Waite reduction by pi/2 (3 constants, exact products for |k| < 2^16)
 // + cephes-style minimax polynomials on [-pi/4, pi/4]; max abs error ~1e-7 (covers 2^6 * distance, 2^3 * unit dir).
@@ -70,6 +75,25 @@ __device__ __forceinline__ void sincos_f32(float x, float& s, float& c) {
   const float cc = (q & 1) ? sr : cr;
   s = (q & 2) ? -ss : ss;
   c = ((q + 1) & 2) ? -cc : cc;
+}
+
+// ABI revision 5, frequency schedule folded into the weight images: factor of element `off` of parameter tensor `id` (0..11 weights,
+// 12..23 biases; torch Linear [out][in] row-major).  Only pts_linears.0 (id 0, in = dim_x), the input columns of the skip layer
+// pts_linears.5 (id 5, in = dim_x + 256, encoded input first: nerf.py:139-141) and the columns of views_linears.0 behind its 256
+// feature columns (id 10, in = 256 + u_width) consume the encoding.
+__device__ __forceinline__ float sched_scale(const AnerfNetParams& P, int id, int off) {
+  if (P.sched_x) {
+    if (id == 0) return P.sched_x[off % P.sched_dim_x];
+    if (id == 5) {
+      const int c = off % (P.sched_dim_x + 256);
+      return c < P.sched_dim_x ? P.sched_x[c] : 1.f;
+    }
+  }
+  if (P.sched_u && id == 10) {
+    const int c = off % (256 + P.sched_dim_u) - 256;
+    return c >= 0 ? P.sched_u[c] : 1.f;
+  }
+  return 1.f;
 }
 
 // sample index -> ray index.  P < 2^32 is checked by the launchers (mlp_dispatch): one 32-bit division (~25 instructions)

@@ -10,6 +10,7 @@ struct GemmProb {
   float* dst;            // gradient tensor rows m_first.. -> dst[(m - m_first) * dst_ld + dst_col0 + colmap[n]]
   float* bias_dst;       // bias gradient (column sums of A) or nullptr
   const int* colmap;     // output-column permutation (stream order -> torch order) or nullptr
+  const float* colscale; // per torch column (relative to dst_col0) factor of the gradient, or nullptr (frequency schedule, ABI 5)
   long long part_off;    // float offset of the [chunks][M][N] partials in the workspace
   long long bias_off;    // float offset of the [chunks][M] bias partials, -1 if none
   long long out_base;    // prefix of (M*N + (bias ? M : 0)) over the problems, for k_reduce_dw

@@ -577,6 +577,7 @@ __device__ __forceinline__ void reduce_dw_one(const GemmBatch& G, const float* _
     if (mrow >= pr.m_first && mrow < pr.m_first + pr.m_count) {
       const int col = pr.colmap ? pr.colmap[n] : n;
       float* d = pr.dst + (long long)(mrow - pr.m_first) * pr.dst_ld + pr.dst_col0 + col;
+      if (pr.colscale) s *= pr.colscale[col];
       *d = G.accumulate ? *d + s : s;
     }
   } else {

@@ -130,32 +130,48 @@ class NeRF(nn.Module):
             self.__dict__.pop("_npp_cache", None)
         super().__setattr__(name, value)
 
-    def packed(self, which=0):
-        """(stream, aux) weight images for the kernels; re-gathered only when a parameter changed."""
+    def set_input_schedule(self, sched):
+        """sched = None, or ops.InputSchedule: the embedders' --freq_schedule factors of this network's encoded input columns.  The
+        kernels produce the UNSCALED encoding; the factors are folded into the weight images the fused paths consume (W diag(s)) and
+        into the weight gradients (AnerfNetParams / AnerfNetGrads.sched_x, sched_u).  Set by the caster at every entry (the
+        embedders are its children, not this module's)."""
+        self.__dict__["_sched"] = sched
+
+    def input_schedule(self):
+        return self.__dict__.get("_sched")
+
+    def _image_version(self, P, fold):
+        sched = self.__dict__.get("_sched") if fold else None
+        return tuple((p.data_ptr(), p._version) for p in P.values()) + ((sched.serial,) if sched is not None else ()), sched
+
+    def packed(self, which=0, fold=True):
+        """(stream, aux) weight images for the kernels; re-gathered only when a parameter (or the frequency schedule) changed.
+        fold=False: the plain weights -- for callers that bring their own encoded input (NeRF.forward), whose rows already carry
+        the schedule."""
         P = self.named_path_params()
-        ver = tuple((p.data_ptr(), p._version) for p in P.values())
+        ver, sched = self._image_version(P, fold)
         sf, af, _, _ = ops.layout(self.path_cfg, which)
         hit = self._packed.get(which)
         if hit is None or hit[0] != ver:
             dev = next(iter(P.values())).device
             flat = hit[1] if hit is not None and hit[1].device == dev else torch.empty(sf + af, dtype=torch.float32, device=dev)
             with torch.no_grad():
-                ops.pack_params(self.path_cfg, {k: v.detach() for k, v in P.items()}, which, out=flat)
+                ops.pack_params(self.path_cfg, {k: v.detach() for k, v in P.items()}, which, out=flat, sched=sched)
             self._packed[which] = (ver, flat)
         flat = self._packed[which][1]
         return flat[:sf], flat[sf:]
 
     def _stale(self, which):
-        """(version key, flat buffer to (re)fill) when image `which` is out of date, else None"""
+        """(version key, flat buffer to (re)fill, parameters, schedule) when image `which` is out of date, else None"""
         P = self.named_path_params()
-        ver = tuple((p.data_ptr(), p._version) for p in P.values())
+        ver, sched = self._image_version(P, True)
         hit = self._packed.get(which)
         if hit is not None and hit[0] == ver:
             return None
         sf, af, _, _ = ops.layout(self.path_cfg, which)
         dev = next(iter(P.values())).device
         flat = hit[1] if hit is not None and hit[1].device == dev else torch.empty(sf + af, dtype=torch.float32, device=dev)
-        return ver, flat, P
+        return ver, flat, P, sched
 
     def codes_table(self, cam_idx):
         if not self.use_framecode:
@@ -164,7 +180,7 @@ class NeRF(nn.Module):
 
     def forward(self, x):
         """x [..., input_ch+input_ch_bones+input_ch_views(+1)] -> [..., 4]   (nerf.py:133-148)."""
-        stream, aux = self.packed()
+        stream, aux = self.packed(fold=False)
         codes = self.framecodes.codes.weight if self.use_framecode else None
         if self.use_framecode and not self.training:
             codes, idx = self.framecodes.table_for(x[..., -1], False)
@@ -220,6 +236,18 @@ class Embedder(nn.Module):
     def get_tau(self):
         return 0.0
 
+    def schedule_weights(self):
+        """per-band factors of the frequency schedule, or None (the plain embedder has none)"""
+        return None
+
+    def column_scale(self):
+        """[out_dim] CPU fp32 factors of this embedder's output columns under the frequency schedule (1 for the raw input block)"""
+        d, nf = self.kwargs["input_dims"], self.kwargs["num_freqs"]
+        w = self.schedule_weights()
+        if w is None:
+            return torch.ones(self.out_dim)
+        return torch.cat([torch.ones(d if self.kwargs["include_input"] else 0), w.repeat_interleave(2).repeat_interleave(d)])
+
 
 class CutoffEmbedder(Embedder):
     """Cutoff PE state (core/cutoff_embedder.py:61-197): cutoff_dist [cutoff_dim] parameter (frozen), tau buffer,
@@ -229,14 +257,26 @@ class CutoffEmbedder(Embedder):
                  opt_cutoff=False, cutoff_dim=24, freq_schedule=False, init_alpha=0., cut_to_cutoff=False,
                  shift_inputs=False, **kwargs):
         super().__init__(**kwargs)
-        if normalize or opt_cutoff or freq_schedule or cut_to_cutoff or shift_inputs or not cutoff_inputs:
-            raise NotImplementedError("HIP path implements the shipped configs: cutoff_inputs=True, no normalize/"
-                                      "opt_cutoff/freq_schedule/cut_to_dist/cutoff_shift")
+        if normalize or cut_to_cutoff or shift_inputs or not cutoff_inputs:
+            raise NotImplementedError("HIP path: cutoff_inputs=True, no normalize / cut_to_dist / cutoff_shift (these change the "
+                                      "encoding arithmetic inside the fused kernel; no shipped config uses them)")
+        # opt_cutoff is accepted: the reference stores the flag and nothing reads it -- cutoff_dist stays requires_grad=False
+        # (cutoff_embedder.py:83,93-94), so the path is the same with or without it
+        self.opt_cutoff = opt_cutoff
         self.dist_inputs, self.cutoff_inputs, self.cutoff_dim = dist_inputs, cutoff_inputs, cutoff_dim
         self.cutoff_dist = nn.Parameter(torch.ones(cutoff_dim) * cutoff_dist, requires_grad=False)
         self.init_tau = 20.
         self.register_buffer("tau", torch.tensor(self.init_tau))
         self._tau_host = (None, None, 0.0)     # (tensor identity, version, value): host copy of the device buffer
+        # --freq_schedule (cutoff_embedder.py:96-98,185-197): alpha opens the bands one after the other; its factors reach the
+        # network folded into the weight images (NeRF.set_input_schedule), the kernel's encoding is unchanged
+        self.freq_schedule = freq_schedule
+        nf = self.kwargs["num_freqs"]
+        self.freq_k = torch.arange(nf, dtype=torch.float32)          # log2 of the bands 2^0 .. 2^(nf-1)
+        if freq_schedule:
+            self.init_alpha = init_alpha
+            self.register_buffer("sched_alpha", torch.tensor(self.init_alpha))
+            self._alpha_host = (None, None, 0.0)
 
     def get_tau(self):
         """tau as a host float (a kernel argument).  The device buffer is only read back when it changed
@@ -251,6 +291,35 @@ class CutoffEmbedder(Embedder):
 
     def update_threshold(self, global_step, tau_step, tau_rate, alpha_step, alpha_target):
         self.update_tau(global_step, tau_step, tau_rate)
+        self.update_alpha(global_step, alpha_step, alpha_target)
+
+    def get_alpha(self):
+        """sched_alpha as a host float, read back from the buffer only when it changed (as get_tau)"""
+        key = (id(self.sched_alpha), self.sched_alpha._version)
+        if self._alpha_host[:2] != key:
+            self._alpha_host = key + (float(self.sched_alpha.item()),)
+        return self._alpha_host[2]
+
+    def update_alpha(self, global_step, step, target=None):
+        # cutoff_embedder.py:185-189 (target None -> the highest band)
+        if not self.freq_schedule:
+            return
+        if target is None:
+            target = float(self.freq_k.max())
+        val = torch.tensor(self.init_alpha + (target - self.init_alpha) * global_step / float(step * 1000))
+        self.sched_alpha = val.to(self.sched_alpha.device)
+        self._alpha_host = (id(self.sched_alpha), self.sched_alpha._version, float(val))
+
+    def schedule_weights(self):
+        """cutoff_embedder.py:191-197: w_k = (1 - cos(pi * clamp(alpha - k, 0, 1))) / 2 per band k, on the host in fp32"""
+        if not self.freq_schedule:
+            return None
+        diff = torch.clamp(torch.tensor(self.get_alpha(), dtype=torch.float32) - self.freq_k, 0, 1)
+        return 0.5 * (1. - torch.cos(np.pi * diff))
+
+    def get_schedule_w(self):
+        w = self.schedule_weights()
+        return 1. if w is None else w.repeat_interleave(2).view(1, -1, 1)
 
     def update_tau(self, global_step, step, rate):
         # cutoff_embedder.py:181-183
@@ -271,8 +340,8 @@ def prepack(pairs):
         st = net._stale(which)
         if st is None:
             continue
-        ver, flat, P = st
-        jobs.append((net.path_cfg, {k: v.detach() for k, v in P.items()}, which, flat))
+        ver, flat, P, sched = st
+        jobs.append((net.path_cfg, {k: v.detach() for k, v in P.items()}, which, flat, sched))
         done.append((net, which, ver, flat))
     if jobs:
         with torch.no_grad():

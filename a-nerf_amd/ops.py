@@ -90,10 +90,33 @@ def pack_table(cfg, device, which=0):
     return _table_cache[k]
 
 
-def net_params_struct(params, codes=None):
-    """params: dict name -> CUDA tensor with the reference's state_dict names."""
+_sched_serial = [0]
+
+
+class InputSchedule:
+    """The --freq_schedule factors of a network's encoded input columns as the library takes them (AnerfNetParams.sched_x / sched_u,
+    ABI revision 5): sx [dim_x] for the distance + bone block, su [u_width] for the view (+ frame code) block, device fp32.
+    `serial` identifies the VALUES (weight images are cached against it: tensor addresses get reused)."""
+
+    def __init__(self, sx, su):
+        self.sx, self.su = _f32c(sx, "sched_x"), _f32c(su, "sched_u")
+        _sched_serial[0] += 1
+        self.serial = _sched_serial[0]
+
+    def fill(self, st):
+        """into an AnerfNetParams / AnerfNetGrads"""
+        st.sched_x, st.sched_u = self.sx.data_ptr(), self.su.data_ptr()
+        if hasattr(st, "sched_dim_x"):
+            st.sched_dim_x, st.sched_dim_u = self.sx.numel(), self.su.numel()
+
+
+def net_params_struct(params, codes=None, sched=None):
+    """params: dict name -> CUDA tensor with the reference's state_dict names.  sched: InputSchedule or None."""
     st = _lib.AnerfNetParams()
     keep = []
+    if sched is not None:
+        sched.fill(st)
+        keep.append(sched)
     for i, n in enumerate(PARAM_ORDER):
         w = _f32c(params[n + ".weight"], n + ".weight")
         b = _f32c(params[n + ".bias"], n + ".bias")
@@ -108,14 +131,22 @@ def net_params_struct(params, codes=None):
     return st, keep
 
 
-def pack_params(cfg, params, which=0, out=None):
-    """Gather one network's parameters into the packed (stream, aux) images the MLP kernels consume."""
+def _check_sched(cfg, sched):
+    if sched is not None and (sched.sx.numel() != cfg.dim_x or sched.su.numel() != cfg.dim_d + cfg.framecode_ch):
+        raise ValueError(f"InputSchedule of {sched.sx.numel()} / {sched.su.numel()} columns for a network with "
+                         f"{cfg.dim_x} / {cfg.dim_d + cfg.framecode_ch}")
+
+
+def pack_params(cfg, params, which=0, out=None, sched=None):
+    """Gather one network's parameters into the packed (stream, aux) images the MLP kernels consume.  sched: InputSchedule
+    folded into the columns that consume the encoding, or None."""
     dev = params[PARAM_ORDER[0] + ".weight"].device
     sf, af, _, _ = layout(cfg, which)
     table = pack_table(cfg, dev, which)
     if out is None:
         out = torch.empty(sf + af, dtype=torch.float32, device=dev)
-    st, keep = net_params_struct(params)
+    _check_sched(cfg, sched)
+    st, keep = net_params_struct(params, sched=sched)
     if which >= 3:   # 3: bf16x3 W (forward), 4: bf16x3 W^T (backward-data)
         _lib.check(_lib.load().anerf_pack_params_b3(C.byref(st), _p(table), sf, af, _p(out), _stream()), "anerf_pack_params_b3")
     else:
@@ -125,16 +156,19 @@ def pack_params(cfg, params, which=0, out=None):
 
 def pack_params_multi(jobs):
     """Gather several weight images in ONE launch (anerf_pack_params_multi).  jobs: list of (cfg, params dict, which, out flat
-    tensor of layout(cfg, which) floats).  Replaces one k_pack / k_pack_b3 launch per image (4 per fp32 training step)."""
+    tensor of layout(cfg, which) floats[, InputSchedule or None]).  Replaces one k_pack / k_pack_b3 launch per image (4 per fp32
+    training step)."""
     if not jobs:
         return
     lib = _lib.load()
     arr, keep = [], []
-    for cfg, params, which, out in jobs:
+    for cfg, params, which, out, *rest in jobs:
         dev = out.device
         sf, af, _, _ = layout(cfg, which)
         table = pack_table(cfg, dev, which)
-        st, k = net_params_struct(params)
+        sched = rest[0] if rest else None
+        _check_sched(cfg, sched)
+        st, k = net_params_struct(params, sched=sched)
         keep += k + [table]
         if which >= 3:     # bf16x3 image: hi/lo-split stream part (one table entry per bf16 element) + fp32 aux part
             arr.append(_lib.AnerfPackJob(st, table.data_ptr(), 2 * sf, out.data_ptr(), 1))
@@ -686,7 +720,7 @@ def train_forward(cfg, net_c, net_f, rays, skts, cyls, n_samples, n_importance=0
 
 
 def backward(state, g, packed_t_c, packed_t_f, perm, shapes_c, shapes_f, packed_i_c=None, packed_i_f=None, want_skts=False,
-             want_codes_c=False, want_codes_f=False, accumulate_into=None, after_fine=None, codes_into=None):
+             want_codes_c=False, want_codes_f=False, accumulate_into=None, after_fine=None, codes_into=None, sched=None):
     """anerf_backward.  g: dict of gradients of the rendered maps (keys as the output dict; rgb_map and, when hierarchical,
     rgb0 are required -- missing ones are taken as zero).  shapes_*: parameter shapes in AnerfNetGrads order (w0, b0, ...).
     accumulate_into: optional (list_c, list_f) of existing gradient tensors the parameter gradients are ADDED to in place
@@ -694,6 +728,7 @@ def backward(state, g, packed_t_c, packed_t_f, perm, shapes_c, shapes_f, packed_
     after_fine: optional callable; hierarchical calls are then enqueued as two halves (AnerfBackwardIO.passes = 1, then 2)
     and `after_fine()` runs in between, when everything that produces the FINE network's parameter gradients is on the
     stream -- the data-parallel path starts their all-reduce there, under the coarse pass.
+    sched: the InputSchedule the weight images were packed with (its factors multiply the same gradient columns), or None.
     Returns (grads_c, grads_f, g_skts, g_codes_c, g_codes_f)."""
     cfg, io = state["cfg"], state["io"]
     n, S, Ni = io.n_rays, io.n_samples, io.n_importance
@@ -733,6 +768,10 @@ def backward(state, g, packed_t_c, packed_t_f, perm, shapes_c, shapes_f, packed_
         b.grads_c.w[i], b.grads_c.b[i] = grads_c[2 * i].data_ptr(), grads_c[2 * i + 1].data_ptr()
         if hier:
             b.grads_f.w[i], b.grads_f.b[i] = grads_f[2 * i].data_ptr(), grads_f[2 * i + 1].data_ptr()
+    if sched is not None:
+        _check_sched(cfg, sched)
+        sched.fill(b.grads_c)
+        sched.fill(b.grads_f)
     g_skts = E((n, cfg.n_joints, 4, 4)) if want_skts else None
     # codes_into (only with accumulate_into): the frame-code tables' gradient tensors, added to in place like the parameters'
     if codes_into is not None and accumulate_into is None:

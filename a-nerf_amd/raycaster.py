@@ -95,9 +95,46 @@ class RayCaster(nn.Module):
         super().__setattr__(name, value)
 
     def _taus(self):
-        tv = self.embed_fn.get_tau() if hasattr(self.embed_fn, "cutoff_dist") else 0.0
-        td = self.embeddirs_fn.get_tau() if hasattr(self.embeddirs_fn, "cutoff_dist") else 0.0
+        """(tau_v, tau_d) as the kernels take them.  A plain Embedder has no temperature (its get_tau() reports 0.0, as the
+        reference's does); its gate is switched off through the cutoff (_cutoffs), for which any POSITIVE tau will do."""
+        tv = self.embed_fn.get_tau() if hasattr(self.embed_fn, "cutoff_dist") else 1.0
+        td = self.embeddirs_fn.get_tau() if hasattr(self.embeddirs_fn, "cutoff_dist") else 1.0
         return tv, td
+
+    def _cutoffs(self, dev):
+        """(cut_v, cut_d) [24] device tensors for the kernels' gates w = 1 - sigmoid(tau * (dist - cutoff)).  A plain Embedder
+        (use_cutoff / cutoff_viewdir = False: core/raycasters.py:29-31,66-71; same channels, no gate) is the gate with its cutoff
+        at +1e30: tau * (dist - 1e30) underflows exp() to 0, so w = 1 and dw = 0 EXACTLY."""
+        out = []
+        for f in (self.embed_fn, self.embeddirs_fn):
+            if hasattr(f, "cutoff_dist"):
+                out.append(f.cutoff_dist.detach())
+            else:
+                c = self.__dict__.get("_no_cutoff")
+                if c is None or c.device != dev:
+                    c = self.__dict__["_no_cutoff"] = torch.full((self.network.N_joints,), 1e30, dtype=torch.float32, device=dev)
+                out.append(c)
+        return out
+
+    def _apply_input_schedule(self, dev):
+        """--freq_schedule: hand the embedders' current band factors to the networks (folded into their weight images and weight
+        gradients, NeRF.set_input_schedule); rebuilt only when an alpha changed."""
+        fv, fd = self.embed_fn, self.embeddirs_fn
+        sched = None
+        if getattr(fv, "freq_schedule", False) or getattr(fd, "freq_schedule", False):
+            key = (fv.get_alpha() if getattr(fv, "freq_schedule", False) else None,
+                   fd.get_alpha() if getattr(fd, "freq_schedule", False) else None, str(dev))
+            c = self.__dict__.get("_sched_cache")
+            if c is None or c[0] != key:
+                net = self.network
+                sx = torch.cat([fv.column_scale(), torch.ones(net.input_ch_bones)])
+                su = torch.cat([fd.column_scale(), torch.ones(net.framecode_ch if net.use_framecode else 0)])
+                c = self.__dict__["_sched_cache"] = (key, ops.InputSchedule(sx.to(dev), su.to(dev)))
+            sched = c[1]
+        for net in (self.network, self.network_fine):
+            if net is not None:
+                net.set_input_schedule(sched)
+        return sched
 
     def render_rays(self, ray_batch, N_samples, kp_batch, skts=None, cyls=None, bones=None, cams=None,
                     subject_idxs=None, retraw=False, lindisp=False, perturb=0., N_importance=0, network_fine=None,
@@ -146,8 +183,8 @@ class RayCaster(nn.Module):
                 ((n, N_samples, 3), "normal", ray_noise_std) if ray_noise_std > 0. else None,
                 ((n, N_importance, 3), "normal", ray_noise_std) if ray_noise_std > 0. and hier else None], dev)
         tau_v, tau_d = self._taus()
-        cut_v = self.embed_fn.cutoff_dist.detach()
-        cut_d = self.embeddirs_fn.cutoff_dist.detach() if hasattr(self.embeddirs_fn, "cutoff_dist") else cut_v
+        cut_v, cut_d = self._cutoffs(dev)
+        self._apply_input_schedule(dev)
         cam_idx = None if cams is None else cams.reshape(-1).float()
         codes_c, cam_c = net_c.codes_table(cam_idx)
         codes_f, cam_f = (net_f.codes_table(cam_idx) if net_f is not None else (None, None))
@@ -171,9 +208,12 @@ class RayCaster(nn.Module):
         if color or v is not None or subject_idxs is not None:
             raise NotImplementedError("color / precomputed v / subject_idxs are not used by the shipped configs")
         net = network if network is not None else (self.network_fine if self.network_fine is not None else self.network)
+        self._apply_input_schedule(pts.device)
+        if network is not None:
+            network.set_input_schedule(self.network.input_schedule())
         stream, aux = net.packed()
         tau_v, _ = self._taus()
-        return ops.density(net.path_cfg, stream, aux, pts, skts, tau_v, self.embed_fn.cutoff_dist.detach())
+        return ops.density(net.path_cfg, stream, aux, pts, skts, tau_v, self._cutoffs(pts.device)[0])
 
     @torch.no_grad()
     def render_mesh_density(self, kps, skts, bones, subject_idxs=None, radius=1.0, res=64, render_kwargs=None,
@@ -296,15 +336,19 @@ def create_raycaster(args, data_attrs, device=None):
     for k, v in SUPPORTED.items():
         if getattr(args, k) != v:
             raise NotImplementedError(f"{k}={getattr(args, k)!r}: the HIP path fuses {SUPPORTED} (all shipped configs)")
-    if not (args.use_cutoff and args.cutoff_viewdir and args.cutoff_inputs and args.use_viewdirs) or args.cutoff_bones:
-        raise NotImplementedError("HIP path needs use_cutoff, cutoff_viewdir, cutoff_inputs, use_viewdirs, no cutoff_bones")
+    if not args.use_viewdirs or args.cutoff_bones:
+        raise NotImplementedError("HIP path needs use_viewdirs and no cutoff_bones")
+    if args.use_cutoff and not args.cutoff_inputs:
+        raise NotImplementedError("use_cutoff without cutoff_inputs (raw input ungated, bands gated) is not in the fused encoder")
     if args.multires_bones != 0:
         raise NotImplementedError("multires_bones must be 0 (identity bone embedding)")
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     skel_type = data_attrs["skel_type"]
     n_j = len(skel_type.joint_names)
     n_framecodes = data_attrs["n_views"] if args.n_framecodes is None else args.n_framecodes
-    cutoff_kwargs = {"cutoff": True, "normalize_cutoff": args.normalize_cutoff, "cutoff_dist": args.cutoff_mm * args.ext_scale,
+    # normalize_cutoff: the reference hands it over under a key its CutoffEmbedder does not read ("normalize_cutoff" vs the
+    # constructor's `normalize`, core/raycasters.py:32 / cutoff_embedder.py:64,77): the flag changes nothing there, nor here
+    cutoff_kwargs = {"cutoff": args.use_cutoff, "normalize_cutoff": args.normalize_cutoff, "cutoff_dist": args.cutoff_mm * args.ext_scale,
                      "cutoff_inputs": args.cutoff_inputs, "opt_cutoff": args.opt_cutoff, "cutoff_dim": n_j,
                      "freq_schedule": args.freq_schedule, "init_alpha": args.init_freq}
     embed_fn, input_ch = get_embedder(args.multires, args.i_embed, input_dims=n_j, skel_type=skel_type,
@@ -313,7 +357,8 @@ def create_raycaster(args, data_attrs, device=None):
     embedbones_fn, input_ch_bones = get_embedder(0, args.i_embed, input_dims=3 * n_j, skel_type=skel_type,
                                                  cutoff_kwargs={"cutoff": False})
     embeddirs_fn, input_ch_views = get_embedder(args.multires_views, args.i_embed, input_dims=3 * n_j, skel_type=skel_type,
-                                                cutoff_kwargs=dict(cutoff_kwargs, dist_inputs=True))
+                                                cutoff_kwargs=dict(cutoff_kwargs, dist_inputs=True) if args.cutoff_viewdir
+                                                else {"cutoff": False})
     nerf_kwargs = dict(D=args.netdepth, W=args.netwidth, input_ch=input_ch, input_ch_bones=input_ch_bones,
                        input_ch_views=input_ch_views, output_ch=5 if args.N_importance > 0 else 4, skips=[4],
                        use_viewdirs=args.use_viewdirs, use_framecode=args.opt_framecode, framecode_ch=args.framecode_size,

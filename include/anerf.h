@@ -58,6 +58,15 @@ typedef struct AnerfNetParams {
   const float* b[12];
   const float* codes;
   int32_t n_codes;
+  /* ABI revision 5: the embedders' frequency schedule (--freq_schedule; CutoffEmbedder.get_schedule_w, core/cutoff_embedder.py:
+   * 159,191-197: every sin / cos band k of the encoding is multiplied by w_k(alpha) = (1 - cos(pi * clamp(alpha - k, 0, 1))) / 2
+   * before it reaches the network) as per-column factors FOLDED INTO THE WEIGHT IMAGES: W (s * e) = (W diag(s)) e, so the kernels
+   * keep producing the unscaled encoding e and the pack kernels multiply the columns that consume it -- sched_x [sched_dim_x =
+   * distance block + bone block, torch column order of pts_linears.0's input] for pts_linears.0 and the input columns of the skip
+   * layer pts_linears.5, sched_u [sched_dim_u = view block (+ frame-code columns)] for the columns of views_linears.0 behind its
+   * 256 feature columns.  DEVICE pointers, NULL (with dim 0) = no schedule: every factor 1, the images of revisions <= 4. */
+  int32_t sched_dim_x, sched_dim_u, reserved_;
+  const float *sched_x, *sched_u;
 } AnerfNetParams;
 
 /* Sizes of the packed weight images the kernels consume (see DESIGN.md "weight stream"). */
@@ -143,6 +152,9 @@ typedef struct AnerfSaved {
 typedef struct AnerfNetGrads {
   float* w[12];
   float* b[12];
+  /* ABI revision 5: the factors the weight images were packed with (AnerfNetParams.sched_x / sched_u; [dim_x] / [u_width] DEVICE
+   * floats or NULL).  d loss / d W = (d loss / d (W diag(s))) diag(s): the reduction multiplies the same gradient columns. */
+  const float *sched_x, *sched_u;
 } AnerfNetGrads;
 
 typedef struct AnerfTrainLayout {

@@ -108,27 +108,49 @@ def bone_features(pts, rays_d, skts):
 # ------------------------------------------------------------------------------------------------
 # A6: positional encoding with sigmoid cutoff        (core/cutoff_embedder.py:111-174)
 # ------------------------------------------------------------------------------------------------
-def cutoff_pe(x, dist, n_freq, tau, cutoff, per_joint):
+def schedule_w(alpha, n_freq):
+    """--freq_schedule (CutoffEmbedder.get_schedule_w, core/cutoff_embedder.py:191-197): weight of band k = 0..n_freq-1,
+    w_k = (1 - cos(pi * clamp(alpha - k, 0, 1))) / 2, the same for its sin and its cos channel; alpha follows
+    update_alpha (:185-189).  [n_freq] fp32."""
+    k = torch.arange(n_freq, dtype=torch.float32)
+    diff = torch.clamp(torch.tensor(alpha, dtype=torch.float32) - k, 0, 1)
+    return 0.5 * (1. - torch.cos(np.pi * diff))
+
+
+def schedule_alpha(global_step, step, target, init_alpha=0.):
+    """CutoffEmbedder.update_alpha (core/cutoff_embedder.py:185-189); RayCaster.update_embed_fns passes target = multires - 1 to
+    BOTH embedders (raycasters.py:731-748)."""
+    return float(torch.tensor(init_alpha + (target - init_alpha) * global_step / float(step * 1000)))
+
+
+def cutoff_pe(x, dist, n_freq, tau, cutoff, per_joint, sched_alpha=None, gated=True):
     """x [...,C] with C = 24*per_joint (per_joint=1 for v, 3 for ray dirs); dist [...,24].
     Returns [..., C*(1+2*n_freq)], channel = k*C + c with k=0 raw, 1+2f sin(2^f x), 2+2f cos(2^f x);
-    every band (raw input included: cutoff_inputs=True) is gated by w_j = 1 - sigmoid(tau*(dist_j - c_j))."""
-    w = 1.0 - torch.sigmoid(tau * (dist - cutoff))
-    w = w.repeat_interleave(per_joint, dim=-1)
+    every band (raw input included: cutoff_inputs=True) is gated by w_j = 1 - sigmoid(tau*(dist_j - c_j)).
+    sched_alpha: the frequency schedule's alpha (sin / cos bands times schedule_w, the raw input untouched:
+    cutoff_embedder.py:159-163) or None.  gated=False: the plain Embedder of use_cutoff / cutoff_viewdir = False
+    (cutoff_embedder.py:9-45: same channels, no gate)."""
     bands = [x]
+    sw = None if sched_alpha is None else schedule_w(sched_alpha, n_freq)
     for f in range(n_freq):
-        bands.append(torch.sin(x * (2.0 ** f)))
-        bands.append(torch.cos(x * (2.0 ** f)))
-    out = torch.stack(bands, dim=-2) * w[..., None, :]
+        m = 1.0 if sw is None else sw[f]
+        bands.append(torch.sin(x * (2.0 ** f)) * m)
+        bands.append(torch.cos(x * (2.0 ** f)) * m)
+    out = torch.stack(bands, dim=-2)
+    if gated:
+        w = 1.0 - torch.sigmoid(tau * (dist - cutoff))
+        w = w.repeat_interleave(per_joint, dim=-1)
+        out = out * w[..., None, :]
     return out.flatten(start_dim=-2)
 
 
-def encode(cfg, pts, rays_d, skts, tau_v, tau_d, cut_v, cut_d, cam_idx=None):
+def encode(cfg, pts, rays_d, skts, tau_v, tau_d, cut_v, cut_d, cam_idx=None, sched_alpha=None, gate_v=True, gate_d=True):
     """MLP input X [N,S,dim_x + dim_d (+1)]  (RayCaster.encode_inputs + run_network cat,
     raycasters.py:476-577).  embedbones_fn is the identity (multires_bones=0)."""
     v, r, e = bone_features(pts, rays_d, skts)
-    V = cutoff_pe(v, v, cfg.multires, tau_v, cut_v, 1)
+    V = cutoff_pe(v, v, cfg.multires, tau_v, cut_v, 1, sched_alpha, gate_v)
     eS = e[:, None, :].expand(-1, pts.shape[1], -1)
-    Dv = cutoff_pe(eS, v, cfg.multires_views, tau_d, cut_d, 3)
+    Dv = cutoff_pe(eS, v, cfg.multires_views, tau_d, cut_d, 3, sched_alpha, gate_d)
     parts = [V, r, Dv]
     if cam_idx is not None:
         parts.append(cam_idx.view(-1, 1, 1).expand(-1, pts.shape[1], 1))
@@ -252,7 +274,8 @@ def importance_z(z, weights, n_imp, u=None, single_net=False):
 def render_rays(cfg, P, P_fine, ray_batch, skts, cyls, n_samples, n_importance=0,
                 tau_v=20.0, tau_d=20.0, cut_v=None, cut_d=None, cam_idx=None,
                 t_rand=None, u_imp=None, noise=None, noise_fine=None, lindisp=False,
-                single_net=False, eval_mean_code=False, return_extras=False, pts_noise=None, pts_noise_is=None):
+                single_net=False, eval_mean_code=False, return_extras=False, pts_noise=None, pts_noise_is=None,
+                sched_alpha=None, gate_v=True, gate_d=True):
     """ray_batch [N,>=8] = (o3,d3,near,far[,viewdirs3]); returns the reference's output dict.
     pts_noise [N,S,3] / pts_noise_is [N,Ni,3]: `pts + randn_like(pts) * ray_noise_std` of RayCaster.sample_pts /
     sample_pts_is (raycasters.py:650-677), the random part passed in; the merged samples of the fine pass keep their own
@@ -265,7 +288,8 @@ def render_rays(cfg, P, P_fine, ray_batch, skts, cyls, n_samples, n_importance=0
     pts = o[:, None] + d[:, None] * z[..., None]
     if pts_noise is not None:
         pts = pts + pts_noise
-    X = encode(cfg, pts, d, skts, tau_v, tau_d, cut_v, cut_d, cam_idx)
+    enc_kw = dict(sched_alpha=sched_alpha, gate_v=gate_v, gate_d=gate_d)
+    X = encode(cfg, pts, d, skts, tau_v, tau_d, cut_v, cut_d, cam_idx, **enc_kw)
     raw = mlp(cfg, P, X, eval_mean_code)
     out = composite(cfg, raw, z, d, noise)
     extras = {"near": near, "far": far, "z_vals": z, "X": X, "raw": raw, "weights": out["weights"]}
@@ -277,10 +301,10 @@ def render_rays(cfg, P, P_fine, ray_batch, skts, cyls, n_samples, n_importance=0
         if pts_noise is not None:
             pts_n = pts_n + pts_noise_is
             pts_f = pts_f + torch.gather(torch.cat([pts_noise, pts_noise_is], 1), 1, idx[..., None].expand(-1, -1, 3))
-        Xf = encode(cfg, pts_f, d, skts, tau_v, tau_d, cut_v, cut_d, cam_idx)
+        Xf = encode(cfg, pts_f, d, skts, tau_v, tau_d, cut_v, cut_d, cam_idx, **enc_kw)
         if single_net:
             # only the new samples go through the (shared) net; raw outputs are merged (raycasters.py:462-469)
-            Xn = encode(cfg, pts_n, d, skts, tau_v, tau_d, cut_v, cut_d, cam_idx)
+            Xn = encode(cfg, pts_n, d, skts, tau_v, tau_d, cut_v, cut_d, cam_idx, **enc_kw)
             raw_n = mlp(cfg, P_fine, Xn, eval_mean_code)
             raw_f = torch.gather(torch.cat([raw, raw_n], 1), 1, idx[..., None].expand(-1, -1, 4))
         else:

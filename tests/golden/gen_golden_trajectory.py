@@ -25,7 +25,7 @@ Schedules are made visible inside five iterations by flags, not by code changes:
 learning rate falls by 10^(-1/5) per iteration), global_step = 50 000 * i (tau = 20 * 10^(global_step / 250 000)),
 `--opt_pose_step 2` (pose parameters step at i = 2, 4 and accumulate in between).
 
-Run:  python tests/golden/gen_golden_trajectory.py      (writes tests/golden/trajectory_{surreal,mixamo}.npz)
+Run:  python tests/golden/gen_golden_trajectory.py [case ...]      (writes tests/golden/trajectory_{surreal,mixamo,surreal_freq}.npz)
 """
 import importlib
 import os
@@ -70,6 +70,10 @@ CASES = {
     "surreal": dict(cfg="configs/surreal/surreal.txt", seeds=(11, 12), n=64, poses=[0, 1, 2, 3], ray_seed=21, target_seed=5, mixamo=False),
     "mixamo": dict(cfg="configs/mixamo/mixamo.txt", seeds=(21, 22), n=64, poses=[0, 1, 2, 3, 4, 5, 6, 7], ray_seed=22, target_seed=6,
                    mixamo=True),
+    # --freq_schedule (outside the shipped configs): alpha = 6 * global_step / 500 000 = 0.6 i, so the bands open while the
+    # trajectory runs (band 0 partly at i = 1, bands 0..2 at i = 5) and the closed ones must not move at all
+    "surreal_freq": dict(cfg="configs/surreal/surreal.txt", seeds=(11, 12), n=64, poses=[0, 1, 2, 3], ray_seed=23, target_seed=7,
+                         mixamo=False, extra=["--freq_schedule", "--freq_schedule_step", "500"]),
 }
 
 
@@ -77,7 +81,7 @@ def run_case(cp, name, case):
     from core.raycasters import create_raycaster
     from core.trainer import Trainer
     from core.utils.skeleton_utils import SMPLSkeleton, get_per_joint_coords, smpl_rest_pose
-    extra = list(EXTRA) + (["--opt_pose_step", "2"] if case["mixamo"] else [])
+    extra = list(EXTRA) + (["--opt_pose_step", "2"] if case["mixamo"] else []) + list(case.get("extra", []))
     args = gen_golden.make_args(cp, case["cfg"], extra)
     rest = (smpl_rest_pose * synth.SURREAL_SCALE).astype(np.float32)
     data_attrs = {"skel_type": SMPLSkeleton, "near": 0.0, "far": 1.0, "n_views": N_POSES, "hwf": (512, 512, 600.0),
@@ -120,6 +124,8 @@ def run_case(cp, name, case):
                "alpha_mean": stats["alpha"]}
         if case["mixamo"]:
             rec.update(kp_loss=loss_dict["kp_loss"].item(), mpjpc=stats["MPJPC"])
+        if args.freq_schedule:
+            rec.update(sched_alpha=caster.embed_fn.sched_alpha.item(), sched_alpha_d=caster.embeddirs_fn.sched_alpha.item())
         for k, v in rec.items():
             out[f"it{i}.{k}"] = np.array(v, dtype=np.float64)
         for tag, net in (("c", caster.network), ("f", caster.network_fine)):
@@ -146,7 +152,8 @@ def main():
     import core.utils.skeleton_utils as su
     su.p3dr.axis_angle_to_matrix = oracle.axis_angle_to_matrix
     for name, case in CASES.items():
-        run_case(cp, name, case)
+        if len(sys.argv) < 2 or name in sys.argv[1:]:
+            run_case(cp, name, case)
 
 
 if __name__ == "__main__":

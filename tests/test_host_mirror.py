@@ -92,14 +92,14 @@ def test_tau_schedule_matches_reference_formula():
 
 def test_unsupported_configurations_fail_loudly():
     for bad in [dict(kp_dist_type="relpos"), dict(view_type="rayangle"), dict(bone_type="axisang"), dict(cutoff_bones=True),
-                dict(multires_bones=2), dict(use_cutoff=False)]:
+                dict(multires_bones=2), dict(cutoff_inputs=False), dict(cut_to_dist=True), dict(cutoff_shift=True)]:
         with pytest.raises(NotImplementedError):
             raycaster.create_raycaster(surreal_args(**bad), data_attrs(), device="cpu")
     with pytest.raises(NotImplementedError):
         networks.NeRF(input_ch=360, input_ch_bones=72, input_ch_views=648, use_viewdirs=False)
     with pytest.raises(NotImplementedError):
         networks.get_embedder(7, input_dims=24, cutoff_kwargs={"cutoff": True, "cutoff_inputs": True, "cutoff_dim": 24,
-                                                               "dist_inputs": False, "freq_schedule": True})[0]
+                                                               "dist_inputs": False, "normalize": True})[0]
 
 
 def test_fused_adam_host_contract():

@@ -32,6 +32,9 @@ WATCH = ["pts_linears.0.weight", "pts_linears.5.bias", "alpha_linear.weight", "v
 CASES = {
     "surreal": dict(args="surreal", seeds=(11, 12), n=64, poses=[0, 1, 2, 3], ray_seed=21, target_seed=5, mixamo=False),
     "mixamo": dict(args="mixamo", seeds=(21, 22), n=64, poses=list(range(8)), ray_seed=22, target_seed=6, mixamo=True),
+    # --freq_schedule: alpha = 0.6 i -- the weight images are re-folded every iteration, closed bands must not move
+    "surreal_freq": dict(args="surreal", seeds=(11, 12), n=64, poses=[0, 1, 2, 3], ray_seed=23, target_seed=7, mixamo=False,
+                         over=dict(freq_schedule=True, freq_schedule_step=500)),
 }
 
 
@@ -77,13 +80,13 @@ def _batch(case, dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["surreal", "mixamo"])
+@pytest.mark.parametrize("name", ["surreal", "mixamo", "surreal_freq"])
 @pytest.mark.parametrize("tail", ["fused", "torch"])
 def test_five_training_iterations_follow_the_reference_trajectory(name, tail):
     case = CASES[name]
     g = dict(np.load(os.path.join(GOLDEN, f"trajectory_{name}.npz")))
     dev = torch.device("cuda")
-    args = ref_args(case["args"], **({"opt_pose_step": 2} if case["mixamo"] else {}))
+    args = ref_args(case["args"], **({"opt_pose_step": 2} if case["mixamo"] else {}), **case.get("over", {}))
     assert int(g["opt_pose_step"]) == args.opt_pose_step and int(g["N_samples"]) == args.N_samples
     data_attrs = {"skel_type": Skel, "near": 0.0, "far": 1.0, "n_views": N_POSES, "hwf": (512, 512, 600.0),
                   "joint_coords": np.tile(np.eye(3, dtype=np.float32), (24, 1, 1))}
@@ -129,6 +132,12 @@ def test_five_training_iterations_follow_the_reference_trajectory(name, tail):
         assert float(stats["cutoff"]) == pytest.approx(G("tau"), rel=1e-6)
         assert caster.embeddirs_fn.get_tau() == pytest.approx(G("tau_d"), rel=1e-6)
         assert float(stats["alpha"]) == pytest.approx(G("alpha_mean"), abs=1e-5)
+        if args.freq_schedule:
+            assert caster.embed_fn.get_alpha() == G("sched_alpha") and caster.embeddirs_fn.get_alpha() == G("sched_alpha_d")
+            # bands >= 3 never opened in these five iterations (alpha <= 3.0 is reached AFTER the last step): their columns of
+            # pts_linears.0 saw zero gradients only, so Adam left them exactly where they started
+            w0 = synth.make_net_params(case["seeds"][0], args.multires, args.multires_views, fc, N_POSES)["pts_linears.0.weight"]
+            assert np.array_equal(caster.network.pts_linears[0].weight.detach().cpu().numpy()[:, 24 + 48 * 3:24 + 48 * 7], w0[:, 24 + 48 * 3:24 + 48 * 7])
         if not case["mixamo"]:     # get_gradnorm before the step (the reference's pose branch reports it after zero_grad: zeros)
             assert float(stats["total_norm"]) == pytest.approx(G("total_norm"), rel=2e-3)
             assert float(stats["avg_norm"]) == pytest.approx(G("avg_norm"), rel=2e-3)

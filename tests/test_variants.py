@@ -1,0 +1,260 @@
+"""Embedder variants OUTSIDE the shipped configs, against vectors from the reference itself (tests/golden/gen_golden_variants.py):
+
+  --freq_schedule            band schedule (core/cutoff_embedder.py:185-197), folded into the weight images + weight gradients
+  use_cutoff off             plain Embedder for distances and views (run_nerf.py's argparse default)
+  cutoff_viewdir off         plain Embedder for the view directions only
+  --opt_cutoff / --normalize_cutoff   stored / mis-keyed by the reference, never read: bit-identical outputs there
+
+CPU: the oracle restatement vs those vectors.  GPU: create_raycaster(<reference-parsed args + the flag>) -> render() vs the
+same vectors (forward 1e-4, loss 2e-6, gradients 2e-3 of the norm / 5e-4 (bf16x3: 1.5e-3; ungated variants 5e-3) of the rows' max, dskts 2e-3 of its max).
+"""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from cases import pytest_rand
+from test_reference_args import ref_args, data_attrs, dev
+
+raycaster = importlib.import_module("a-nerf_amd.raycaster")
+render_mod = importlib.import_module("a-nerf_amd.render")
+synth = importlib.import_module("a-nerf_amd.synth")
+
+# name -> (poses of the eval batch, poses of the training batch, ray seed, argument overrides, oracle keywords)
+VARIANTS = {
+    "freq_schedule": ([3], [4, 5], 21, dict(freq_schedule=True), {}),
+    "no_cutoff": ([6], [7, 8], 23, dict(use_cutoff=False, cutoff_viewdir=False, cutoff_inputs=False), dict(gate_v=False, gate_d=False)),
+    "no_view_cutoff": ([9], [10, 11], 25, dict(cutoff_viewdir=False), dict(gate_d=False)),
+}
+STEP = 2750        # global_step the schedule vectors were taken at
+OUT8 = ["rgb_map", "disp_map", "acc_map", "alpha", "rgb0", "disp0", "acc0", "alpha0"]
+
+
+def t(x):
+    return torch.tensor(np.asarray(x), dtype=torch.float32)
+
+
+def batches(name):
+    pe, pt, seed, _, _ = VARIANTS[name]
+    ev = synth.scene_batch(48, pe, ray_seed=seed)
+    tr = synth.scene_batch(40, pt, ray_seed=seed + 1, per_ray_pose=True)
+    return ev, tr, t(np.random.default_rng(seed).random((40, 3)))
+
+
+def params():
+    return synth.make_net_params(11, 7, 4, 0, 8), synth.make_net_params(12, 7, 4, 0, 8)
+
+
+# ------------------------------------------------------------------------------------------------ CPU: oracle vs reference
+def test_schedule_weights_restate_the_reference(oracle, golden):
+    g = golden("variants_freq_schedule")
+    alpha = oracle.schedule_alpha(STEP, 5, 7 - 1)
+    assert alpha == float(g["alpha_v"]) == float(g["alpha_d"])       # both embedders get target = multires - 1
+    np.testing.assert_array_equal(oracle.schedule_w(alpha, 7).repeat_interleave(2).numpy(), g["sched_w_v"])
+    np.testing.assert_array_equal(oracle.schedule_w(alpha, 4).repeat_interleave(2).numpy(), g["sched_w_d"])
+    assert 0 < g["sched_w_v"][6] < 1 and g["sched_w_v"][8] == 0      # the vectors sit mid-schedule: band 3 partly open, 4.. closed
+
+
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_oracle_matches_the_reference_variant(oracle, golden, name):
+    g = golden("variants_" + name)
+    (ev, tr, target), okw = batches(name), dict(VARIANTS[name][4])
+    tau = 20.0
+    if name == "freq_schedule":
+        okw["sched_alpha"] = float(g["alpha_v"])
+        tau = float(g["tau"])
+    cfg = oracle.OracleConfig()
+    Pc, Pf = (oracle.params_from_numpy(p, True) for p in params())
+    ro, rd, kp, skts, bones, cyls, _ = ev
+    with torch.no_grad():
+        out = oracle.render_rays(cfg, Pc, Pf, oracle.make_ray_batch(t(ro), t(rd)), t(skts), t(cyls), 64, 16, tau_v=tau, tau_d=tau, **okw)
+    for k in OUT8:
+        np.testing.assert_allclose(out[k].numpy(), g["eval_" + k], rtol=1e-4, atol=1e-5, err_msg=k)
+    ro, rd, kp, skts, bones, cyls, _ = tr
+    sk = t(skts).requires_grad_(True)
+    out = oracle.render_rays(cfg, Pc, Pf, oracle.make_ray_batch(t(ro), t(rd)), sk, t(cyls), 64, 16, tau_v=tau, tau_d=tau,
+                             t_rand=t(pytest_rand((40, 64))), u_imp=t(pytest_rand((40, 16))), noise=t(pytest_rand((40, 64))),
+                             noise_fine=t(pytest_rand((40, 80))), **okw)
+    for k in OUT8:
+        np.testing.assert_allclose(out[k].detach().numpy(), g["train_" + k], rtol=1e-4, atol=1e-5, err_msg=k)
+    loss, _ = oracle.nerf_loss(out, target, torch.ones(40, 3))
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-6
+    loss.backward()
+    np.testing.assert_allclose(sk.grad.numpy(), g["dskts"], rtol=2e-3, atol=2e-8)
+    for tag, P in [("c", Pc), ("f", Pf)]:
+        for n, p in P.items():
+            ref = float(g[f"gnorm_{tag}.{n}"])
+            assert abs(float(p.grad.norm()) - ref) <= 1e-3 * ref + 1e-9, (tag, n)
+        for n in ("pts_linears.0.weight", "pts_linears.5.weight", "views_linears.0.weight"):
+            r = g[f"grows_{tag}.{n}"]
+            np.testing.assert_allclose(P[n].grad[:24].numpy(), r, rtol=2e-3, atol=1e-4 * np.abs(r).max(), err_msg=n)
+    if name == "freq_schedule":        # closed bands get exactly no gradient: columns 24 + 48 k .. of band k >= 4
+        assert np.all(g["grows_f.pts_linears.0.weight"][:, 24 + 48 * 4:24 + 48 * 7] == 0)
+        assert np.all(P["pts_linears.0.weight"].grad[:, 24 + 48 * 4:24 + 48 * 7].numpy() == 0)
+
+
+def test_host_mirror_schedule_and_flags():
+    """create_raycaster on the CPU: the mirror's embedders follow the reference's schedule arithmetic; the no-op flags build the
+    shipped caster; what is still refused says so."""
+    args = ref_args("surreal", freq_schedule=True)
+    _, rk_test, *_ = raycaster.create_raycaster(args, data_attrs(), device="cpu")
+    caster = rk_test["ray_caster"]
+    assert "sched_alpha" in caster.state_dict()["embed_state_dict"] and "sched_alpha" in caster.state_dict()["embeddirs_state_dict"]
+    caster.update_embed_fns(STEP, args)
+    g = dict(np.load(importlib.import_module("conftest").GOLDEN + "/variants_freq_schedule.npz"))
+    assert caster.embed_fn.get_alpha() == float(g["alpha_v"]) and caster.embeddirs_fn.get_alpha() == float(g["alpha_d"])
+    assert caster.embed_fn.get_tau() == pytest.approx(float(g["tau"]), rel=1e-7)
+    np.testing.assert_array_equal(caster.embed_fn.get_schedule_w().reshape(-1).numpy(), g["sched_w_v"])
+    np.testing.assert_array_equal(caster.embeddirs_fn.get_schedule_w().reshape(-1).numpy(), g["sched_w_d"])
+    sx = caster.embed_fn.column_scale()
+    assert sx.shape == (360,) and torch.all(sx[:24] == 1) and torch.all(sx[24 + 48 * 3:24 + 48 * 4] == float(g["sched_w_v"][6]))
+    su = caster.embeddirs_fn.column_scale()
+    assert su.shape == (648,) and torch.all(su[:72] == 1) and torch.all(su[72 + 144 * 3:] == float(g["sched_w_d"][6]))
+    # a checkpoint carries alpha (as the reference's buffer does) and restores it
+    sd = caster.state_dict()
+    _, rk2, *_ = raycaster.create_raycaster(args, data_attrs(), device="cpu")
+    rk2["ray_caster"].load_state_dict(sd)
+    assert rk2["ray_caster"].embed_fn.get_alpha() == caster.embed_fn.get_alpha()
+    # stored-never-read flags: same caster as surreal.txt
+    _, rk3, *_ = raycaster.create_raycaster(ref_args("surreal", opt_cutoff=True, normalize_cutoff=True), data_attrs(), device="cpu")
+    assert not any(p.requires_grad for p in rk3["ray_caster"].embed_fn.parameters())
+    # argparse defaults: plain embedders, no parameters, tau 0
+    _, rk4, *_ = raycaster.create_raycaster(ref_args("surreal", use_cutoff=False, cutoff_viewdir=False, cutoff_inputs=False),
+                                            data_attrs(), device="cpu")
+    c4 = rk4["ray_caster"]
+    assert c4.state_dict()["embed_state_dict"] == {} and c4.embed_fn.get_tau() == 0.0 and c4._taus() == (1.0, 1.0)
+    for bad in (dict(cut_to_dist=True), dict(cutoff_shift=True), dict(cutoff_inputs=False), dict(cutoff_bones=True),
+                dict(multires_bones=2), dict(kp_dist_type="relpos"), dict(view_type="world"), dict(bone_type="axisang")):
+        with pytest.raises(NotImplementedError):
+            raycaster.create_raycaster(ref_args("surreal", **bad), data_attrs(), device="cpu")
+
+
+# ------------------------------------------------------------------------------------------------ GPU: HIP path vs reference
+def _caster(over):
+    args = ref_args("surreal", **over)
+    rk_train, rk_test, *_ = raycaster.create_raycaster(args, data_attrs(), device="cuda")
+    caster = rk_test["ray_caster"]
+    Pc, Pf = params()
+    caster.network.load_state_dict({k: torch.tensor(v) for k, v in Pc.items()})
+    caster.network_fine.load_state_dict({k: torch.tensor(v) for k, v in Pf.items()})
+    return args, caster, rk_train, rk_test
+
+
+def _render(rk, args, b, skts=None, **over):
+    ro, rd, kp, sk, bones, cyls, _ = b
+    kw = dict(rk)
+    kw.update(over)
+    return render_mod.render(64, 64, 75.0, chunk=args.chunk, rays=(dev(ro), dev(rd)), kp_batch=dev(kp),
+                             skts=dev(sk) if skts is None else skts, cyls=dev(cyls), bones=dev(bones), cams=None, subject_idxs=None, **kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("route", ["one_call", "staged"])
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_hip_path_matches_the_reference_variant(golden, name, route, precision):
+    g = golden("variants_" + name)
+    ev, tr, target = batches(name)
+    args, caster, rk_train, rk_test = _caster(VARIANTS[name][3])
+    if name == "freq_schedule":
+        caster.update_embed_fns(STEP, args)
+    caster.render_precision = caster.train_precision = precision
+    caster.train_route = route
+    caster.eval()
+    with torch.no_grad():
+        out = _render(rk_test, args, ev)
+    assert set(out) == set(OUT8)
+    for k in OUT8:
+        np.testing.assert_allclose(out[k].cpu().numpy(), g["eval_" + k], atol=1e-4, rtol=1e-4, err_msg=k)
+    rk_train["ray_caster"].train()
+    skts = dev(tr[3]).requires_grad_(True)
+    out = _render(rk_train, args, tr, skts=skts, pytest=True)
+    for k in OUT8:
+        np.testing.assert_allclose(out[k].detach().cpu().numpy(), g["train_" + k], atol=1e-4, rtol=1e-4, err_msg=k)
+    loss, _ = render_mod.nerf_loss(out, target.cuda(), bgs=torch.ones(40, 3, device="cuda"), loss_fn=args.loss_fn,
+                                   coarse_weight=args.coarse_weight)
+    assert abs(float(loss.detach()) - float(g["loss"])) < 2e-6
+    loss.backward()
+    for tag, net in [("c", caster.network), ("f", caster.network_fine)]:
+        for pname, p in net.named_parameters():
+            ref_n = float(g[f"gnorm_{tag}.{pname}"])
+            assert abs(float(p.grad.norm()) - ref_n) <= 2e-3 * ref_n + 1e-9, (tag, pname)
+        for pname in ("pts_linears.0.weight", "pts_linears.5.weight", "views_linears.0.weight"):
+            r = g[f"grows_{tag}.{pname}"]
+            got = dict(net.named_parameters())[pname].grad[:24].cpu().numpy()
+            # (bf16x3 observed 5.8e-4 of the rows' max on pts_linears.5; a wrong or missing column factor is an O(1) error.
+            # Without the gate every sample of a ray reaches every joint's columns with a large input: the row sums cancel
+            # heavily, and the reference's OWN fp32 rows sit 7e-4 of their max away from the float64 value of the same
+            # expression (single samples flipping a ReLU move a whole row; measured with the oracle in float64).  Observed here:
+            # 2.0e-3 fp32, 2.7e-3 bf16x3.)
+            bar = (5e-4 if precision == "fp32" else 1.5e-3) if name == "freq_schedule" else 5e-3
+            np.testing.assert_allclose(got, r, rtol=0, atol=bar * np.abs(r).max(), err_msg=pname)
+        if name == "freq_schedule":
+            assert torch.all(net.pts_linears[0].weight.grad[:, 24 + 48 * 4:24 + 48 * 7] == 0)
+    ref = g["dskts"]
+    np.testing.assert_allclose(skts.grad.cpu().numpy(), ref, rtol=5e-3, atol=2e-3 * np.abs(ref).max())
+
+
+@pytest.mark.gpu
+def test_noop_flags_render_the_reference_vectors(golden):
+    """--opt_cutoff --normalize_cutoff: the reference's output with the flags (= without them, asserted by the generator)"""
+    g = golden("variants_noop_flags")
+    args, caster, rk_train, rk_test = _caster(dict(opt_cutoff=True, normalize_cutoff=True))
+    caster.eval()
+    with torch.no_grad():
+        out = _render(rk_test, args, synth.scene_batch(48, [12], ray_seed=27))
+    np.testing.assert_allclose(out["rgb_map"].cpu().numpy(), g["eval_rgb_map"], atol=1e-4)
+    np.testing.assert_allclose(out["acc_map"].cpu().numpy(), g["eval_acc_map"], atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_schedule_follows_alpha_and_attached_optimizer_path(golden):
+    """The weight images are rebuilt when alpha moves (and only then), and the in-place gradient route of an attached FusedAdam
+    applies the same column factors as the autograd route."""
+    optim = importlib.import_module("a-nerf_amd.optim")
+    ev, tr, target = batches("freq_schedule")
+    args, caster, rk_train, rk_test = _caster(dict(freq_schedule=True))
+    caster.eval()
+    with torch.no_grad():
+        caster.update_embed_fns(0, args)                 # alpha 0: only the raw inputs reach the network
+        a0 = _render(rk_test, args, ev)["rgb_map"].clone()
+        caster.update_embed_fns(STEP, args)
+        a1 = _render(rk_test, args, ev)["rgb_map"].clone()
+        img = caster.network._packed[0][1]
+        ver = caster.network._packed[0][0]
+        a1b = _render(rk_test, args, ev)["rgb_map"]
+        assert caster.network._packed[0][0] == ver and caster.network._packed[0][1] is img     # cache hit, no repack
+        caster.update_embed_fns(10 ** 6, args)           # alpha beyond every band: the shipped (unscheduled) encoding
+        a2 = _render(rk_test, args, ev)["rgb_map"].clone()
+    np.testing.assert_allclose(a1.cpu().numpy(), golden("variants_freq_schedule")["eval_rgb_map"], atol=1e-4)
+    assert torch.equal(a1, a1b) and (a0 - a1).abs().max() > 1e-3 and (a2 - a1).abs().max() > 1e-3
+    args_p, plain, _, rk_plain = _caster({})
+    plain.embed_fn.update_tau(10 ** 6, args.cutoff_step, args.cutoff_rate)
+    plain.embeddirs_fn.update_tau(10 ** 6, args.cutoff_step, args.cutoff_rate)
+    plain.eval()
+    with torch.no_grad():
+        ref = _render(rk_plain, args_p, ev)["rgb_map"]
+    assert torch.equal(a2, ref)                          # every factor exactly 1 -> the same image, bit for bit
+    # in-place accumulation (FusedAdam.attach) vs autograd
+    caster.update_embed_fns(STEP, args)
+    rk_train["ray_caster"].train()
+
+    def grads(attach):
+        for p in caster.parameters():
+            p.grad = None
+        opt = optim.FusedAdam([p for p in caster.parameters() if p.requires_grad], lr=0.0) if attach else None
+        if attach:
+            opt.attach(caster)
+        out = _render(rk_train, args, tr, pytest=True)
+        loss, _ = render_mod.nerf_loss(out, target.cuda(), bgs=torch.ones(40, 3, device="cuda"), loss_fn=args.loss_fn,
+                                       coarse_weight=args.coarse_weight)
+        loss.backward()
+        res = {n: p.grad.clone() for n, p in caster.named_parameters() if p.grad is not None}
+        if attach:
+            opt.detach()
+        return res
+    ga, gb = grads(False), grads(True)
+    assert set(ga) == set(gb)
+    for n in ga:
+        assert torch.equal(ga[n], gb[n]), n
