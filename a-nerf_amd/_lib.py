@@ -16,7 +16,7 @@ class AnerfConfig(C.Structure):
     _fields_ = [("n_joints", C.c_int32), ("multires", C.c_int32), ("multires_views", C.c_int32),
                 ("framecode_ch", C.c_int32), ("netdepth", C.c_int32), ("netwidth", C.c_int32),
                 ("skip", C.c_int32), ("density_act", C.c_int32), ("density_scale", C.c_float),
-                ("softplus_shift", C.c_float)]
+                ("softplus_shift", C.c_float), ("cutoff_bones", C.c_int32)]
 
 
 class AnerfNetParams(C.Structure):

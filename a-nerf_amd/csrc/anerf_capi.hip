@@ -53,7 +53,7 @@ int mlp_b3_entry(const AnerfConfig* cfg, const float* packed, const float* aux, 
                  float* raw, const AnerfSaved* sv, hipStream_t st, const float* pnoise = nullptr);
 int launch_pack_b3(const AnerfNetParams* P, const int32_t* table, long long n, void* out, hipStream_t st);
 int mlp_density_entry(const float* packed, const float* aux, const float* pts, const float* skts, float tau_v,
-                      const float* cut_v, long long P, int nstages_trunk, float* sigma, hipStream_t st);
+                      const float* cut_v, long long P, int nstages_trunk, float* sigma, hipStream_t st, int gate_bones);
 int launch_gen_rays(int W, int x0, int y0, int bw, int bh, float fx, float fy, float cx, float cy, const float* c2w,
                     float near, float far, float* ray_batch, long long* valid_idx, hipStream_t st);
 int launch_assemble(const float* rgb, const float* acc, const float* disp, const long long* valid_idx, int n, float* rgb_img,
@@ -63,7 +63,7 @@ int mlp_bwd_in_entry(const float* packed_i, const float* dz, const float* dzv, f
 int launch_encode_bwd(int ld, const float* dx, const float* du, int uw, const float* rays, int ray_stride, const float* z,
                       const float* skts, long long skt_stride, float tau_v, float tau_d, const float* cut_v,
                       const float* cut_d, int n, int S, float* dY, float* dQ, float* dskts, bool accumulate, hipStream_t st,
-                      const float* pnoise = nullptr);
+                      const float* pnoise = nullptr, int gate_bones = 0);
 int launch_gather_rows3(const float* a, const float* b, const long long* idx, int n, int S, int Ni, float* out, hipStream_t st);
 int launch_code_reduce(const float* du, int uw, const float* cam, int n, int S, int n_codes, float* rowsum, float* dcodes,
                        hipStream_t st);
@@ -801,7 +801,8 @@ int anerf_encode_backward(const AnerfConfig* cfg, const float* dx, const float* 
   if (skt_ray_stride != 384) return set_error(ANERF_E_SHAPE, "encode_backward: skts must be per ray (stride 384)");
   if (n_rays == 0) return ANERF_OK;
   return launch_encode_bwd(cfg->multires_views, dx, du, u_width(cfg), rays, ray_stride, z_vals, skts, skt_ray_stride, tau_v,
-                           tau_d, cutoff_v, cutoff_d, n_rays, n_samples, dy_ws, dq_ws, dskts, false, (hipStream_t)stream);
+                           tau_d, cutoff_v, cutoff_d, n_rays, n_samples, dy_ws, dq_ws, dskts, false, (hipStream_t)stream, nullptr,
+                           cfg->cutoff_bones);
 }
 
 int anerf_code_grads(const AnerfConfig* cfg, const float* du, const float* cam_idx, int32_t n_rays, int32_t n_samples,
@@ -823,7 +824,8 @@ int anerf_density(const AnerfConfig* cfg, const float* packed, const float* aux,
     if (k++ == 8) break;                 // segments 0..7 = pts_linears.0..7
     stages += seg_stages(s);
   }
-  return mlp_density_entry(packed, aux, pts, skts, tau_v, cutoff_v, n_points, stages, sigma_raw, (hipStream_t)stream);
+  return mlp_density_entry(packed, aux, pts, skts, tau_v, cutoff_v, n_points, stages, sigma_raw, (hipStream_t)stream,
+                           cfg->cutoff_bones);
 }
 
 int anerf_gen_rays(int32_t H, int32_t W, float focal_x, float focal_y, float center_x, float center_y, const float* c2w,
@@ -1170,7 +1172,8 @@ int anerf_backward(const AnerfConfig* cfg, const AnerfForwardIO* io, const Anerf
     prof_rec(b->profile, ANERF_PROF_BWD_IN(which_pass) + 1, stream);
     if (b->g_skts) {
       r = launch_encode_bwd(cfg->multires_views, B(w.dx), B(w.du), uw, io->rays, io->ray_stride, zz, io->skts, io->skt_ray_stride,
-                            io->tau_v, io->tau_d, io->cutoff_v, io->cutoff_d, (int)n, ns, B(w.dy), B(w.dq), b->g_skts, skts_written, st, pn);
+                            io->tau_v, io->tau_d, io->cutoff_v, io->cutoff_d, (int)n, ns, B(w.dy), B(w.dq), b->g_skts, skts_written, st, pn,
+                            cfg->cutoff_bones);
       if (r) return r;
       skts_written = true;
     }

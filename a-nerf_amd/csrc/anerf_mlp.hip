@@ -285,10 +285,11 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
       const float n = sqrtf(y0 * y0 + y1 * y1 + y2 * y2);
       const float inv = rcp_nr(fmaxf(n, 1e-12f));
       v[a] = n;
-      rh[3 * a + 0] = y0 * inv;
-      rh[3 * a + 1] = y1 * inv;
-      rh[3 * a + 2] = y2 * inv;
       wv[a] = cutoff_gate(A.tau_v, n, A.cut_v[j]);
+      const float gb = A.gate_bones ? inv * wv[a] : inv;      // cutoff_bones: r_j * w_j (bone embedder = the distance gate)
+      rh[3 * a + 0] = y0 * gb;
+      rh[3 * a + 1] = y1 * gb;
+      rh[3 * a + 2] = y2 * gb;
     }
   }
 
@@ -543,11 +544,11 @@ int mlp_dispatch(const AnerfConfig* cfg, const MlpArgs& a, bool pre, bool train,
 
 // density query: pts [P,3] under one pose -> sigma logit [P]
 int mlp_density_entry(const float* packed, const float* aux, const float* pts, const float* skts, float tau_v,
-                      const float* cut_v, long long P, int nstages_trunk, float* sigma, hipStream_t st) {
+                      const float* cut_v, long long P, int nstages_trunk, float* sigma, hipStream_t st, int gate_bones) {
   MlpArgs a;
   memset(&a, 0, sizeof(a));   // (pnoise = nullptr)
   a.packed = packed; a.aux = aux; a.z = pts; a.skts = skts; a.cut_v = cut_v; a.cut_d = cut_v; a.raw = sigma;
-  a.P = P; a.Ppad = P; a.skt_stride = 0; a.S = 1; a.N = 1; a.nstages = nstages_trunk; a.tau_v = tau_v; a.tau_d = tau_v;
+  a.P = P; a.Ppad = P; a.skt_stride = 0; a.S = 1; a.N = 1; a.nstages = nstages_trunk; a.tau_v = tau_v; a.tau_d = tau_v; a.gate_bones = gate_bones;
   const long long nblk = (P + TILE - 1) / TILE;
   if (nblk <= 0) return ANERF_OK;
   if (P > 0xFFFFFF00ll) return set_error(ANERF_E_SHAPE, "more than 2^32 - 256 points in one call");
@@ -569,7 +570,7 @@ int mlp_raw_entry(const AnerfConfig* cfg, const float* packed, const float* aux,
   a.packed = packed; a.aux = aux; a.rays = rays; a.z = z; a.skts = skts; a.cam = cam; a.codes = codes;
   a.cut_v = cut_v; a.cut_d = cut_d; a.x = x; a.raw = raw; a.P = P; a.skt_stride = skt_stride;
   a.S = S; a.N = N; a.ray_stride = ray_stride; a.n_codes = n_codes; a.x_width = x_width; a.nstages = nstages;
-  a.tau_v = tau_v; a.tau_d = tau_d;
+  a.tau_v = tau_v; a.tau_d = tau_d; a.gate_bones = cfg->cutoff_bones;
   a.save_h = a.save_f = a.save_g = a.save_x = a.save_u = nullptr;
 #if defined(ANERF_EXP_TILE_TIMING)
   a.save_u = g_tile_timing_buf;

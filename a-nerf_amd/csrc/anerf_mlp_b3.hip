@@ -334,10 +334,11 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
       const float n = sqrtf(y0 * y0 + y1 * y1 + y2 * y2);
       const float inv = rcp_nr(fmaxf(n, 1e-12f));
       v[a] = n;
-      rh[3 * a + 0] = y0 * inv;
-      rh[3 * a + 1] = y1 * inv;
-      rh[3 * a + 2] = y2 * inv;
       wv[a] = cutoff_gate(A.tau_v, n, A.cut_v[j]);
+      const float gb = A.gate_bones ? inv * wv[a] : inv;      // cutoff_bones: r_j * w_j
+      rh[3 * a + 0] = y0 * gb;
+      rh[3 * a + 1] = y1 * gb;
+      rh[3 * a + 2] = y2 * gb;
     }
   };
 
@@ -534,7 +535,7 @@ int mlp_b3_entry(const AnerfConfig* cfg, const float* packed, const float* aux, 
   a.packed = packed; a.aux = aux; a.rays = rays; a.z = z; a.skts = skts; a.cam = cam; a.codes = codes;
   a.cut_v = cut_v; a.cut_d = cut_d; a.x = nullptr; a.raw = raw; a.P = P; a.Ppad = P; a.skt_stride = skt_stride;
   a.S = S; a.N = N; a.ray_stride = ray_stride; a.n_codes = n_codes; a.x_width = 0; a.nstages = nstages;
-  a.tau_v = tau_v; a.tau_d = tau_d;
+  a.tau_v = tau_v; a.tau_d = tau_d; a.gate_bones = cfg->cutoff_bones;
   a.save_h = a.save_f = a.save_g = a.save_x = a.save_u = nullptr;
 #ifdef ANERF_EXP_STAGE_TIMING
   a.tbuf = reinterpret_cast<unsigned long long*>(g_tile_timing_buf);

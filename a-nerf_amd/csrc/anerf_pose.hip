@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void k_encode_bwd(const float* __restrict__ dx
                                                     long long skt_stride, float tau_v, float tau_d,
                                                     const float* __restrict__ cut_v, const float* __restrict__ cut_d,
                                                     long long P, int S, float* __restrict__ dY, float* __restrict__ dQ,
-                                                    const float* __restrict__ pnoise) {
+                                                    const float* __restrict__ pnoise, int gate_bones) {
   constexpr int LV = 7;
   const long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   const long long p = gid / 6;
@@ -127,7 +127,12 @@ __global__ __launch_bounds__(256) void k_encode_bwd(const float* __restrict__ dx
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int j = 8 * G + 4 * h + t;
-    const float dot = dr[3 * t] * rh[3 * t] + dr[3 * t + 1] * rh[3 * t + 1] + dr[3 * t + 2] * rh[3 * t + 2];
+    float dot = dr[3 * t] * rh[3 * t] + dr[3 * t + 1] * rh[3 * t + 1] + dr[3 * t + 2] * rh[3 * t + 2];
+    if (gate_bones) {   // cutoff_bones: the network saw r * w(v) -- d r = w * d(r w), and the gate's slope adds (d(r w) . r) w' to d v
+      dv[t] += dot * wvp[t];
+      dot *= wv[t];
+      dr[3 * t] *= wv[t]; dr[3 * t + 1] *= wv[t]; dr[3 * t + 2] *= wv[t];
+    }
     const float iv = 1.f / fmaxf(v[t], 1e-12f);
     const float dote = de[3 * t] * e[3 * t] + de[3 * t + 1] * e[3 * t + 1] + de[3 * t + 2] * e[3 * t + 2];
     const float iq = 1.f / fmaxf(qn[t], 1e-12f);
@@ -222,15 +227,15 @@ __global__ __launch_bounds__(16 * CODE_SLOTS) void k_code_reduce(const float* __
 int launch_encode_bwd(int ld, const float* dx, const float* du, int uw, const float* rays, int ray_stride, const float* z,
                       const float* skts, long long skt_stride, float tau_v, float tau_d, const float* cut_v,
                       const float* cut_d, int n, int S, float* dY, float* dQ, float* dskts, bool accumulate, hipStream_t st,
-                      const float* pnoise) {
+                      const float* pnoise, int gate_bones) {
   const long long P = (long long)n * S;
   const unsigned blocks = (unsigned)((6 * P + 255) / 256);
   if (ld == 4)
     hipLaunchKernelGGL(k_encode_bwd<4>, dim3(blocks), dim3(256), 0, st, dx, du, uw, rays, ray_stride, z, skts, skt_stride,
-                       tau_v, tau_d, cut_v, cut_d, P, S, dY, dQ, pnoise);
+                       tau_v, tau_d, cut_v, cut_d, P, S, dY, dQ, pnoise, gate_bones);
   else
     hipLaunchKernelGGL(k_encode_bwd<0>, dim3(blocks), dim3(256), 0, st, dx, du, uw, rays, ray_stride, z, skts, skt_stride,
-                       tau_v, tau_d, cut_v, cut_d, P, S, dY, dQ, pnoise);
+                       tau_v, tau_d, cut_v, cut_d, P, S, dY, dQ, pnoise, gate_bones);
   int rc = check_launch("k_encode_bwd");
   if (rc) return rc;
   hipLaunchKernelGGL(k_pose_reduce, dim3(n), dim3(128), 0, st, (const float*)dY, (const float*)dQ, rays, ray_stride, z, n, S,

@@ -16,8 +16,9 @@ class PathConfig:
     """Static configuration of the path (reference: create_raycaster, core/raycasters.py:17-184)."""
 
     def __init__(self, multires=7, multires_views=4, framecode_ch=0, density_scale=1.0, softplus_shift=None,
-                 n_joints=24, netdepth=8, netwidth=256, skip=4):
+                 n_joints=24, netdepth=8, netwidth=256, skip=4, cutoff_bones=False):
         self.multires, self.multires_views, self.framecode_ch = multires, multires_views, framecode_ch
+        self.cutoff_bones = bool(cutoff_bones)     # --cutoff_bones: the bone-direction block is gated by the distance gate too
         self.density_scale, self.softplus_shift = float(density_scale), softplus_shift
         self.n_joints, self.netdepth, self.netwidth, self.skip = n_joints, netdepth, netwidth, skip
         self.dim_v = n_joints * (1 + 2 * multires)
@@ -31,7 +32,7 @@ class PathConfig:
     def c(self):
         return _lib.AnerfConfig(self.n_joints, self.multires, self.multires_views, self.framecode_ch, self.netdepth,
                                 self.netwidth, self.skip, 0 if self.softplus_shift is None else 1, self.density_scale,
-                                0.0 if self.softplus_shift is None else float(self.softplus_shift))
+                                0.0 if self.softplus_shift is None else float(self.softplus_shift), int(self.cutoff_bones))
 
 
 def _stream():

@@ -101,6 +101,22 @@ class RayCaster(nn.Module):
         td = self.embeddirs_fn.get_tau() if hasattr(self.embeddirs_fn, "cutoff_dist") else 1.0
         return tv, td
 
+    def _bones_gated(self):
+        """--cutoff_bones (core/raycasters.py:54-57): the bone embedder is a CutoffEmbedder fed the joint distances -- the bone
+        directions are multiplied by the same gate as the distance encoding.  The kernels take ONE distance gate (tau_v, cut_v):
+        the two embedders are built from the same arguments and stepped by the same update_embed_fns call, and a checkpoint that
+        makes them differ is refused here rather than rendered wrongly."""
+        fb, fv = self.embedbones_fn, self.embed_fn
+        if fb is None or not hasattr(fb, "cutoff_dist"):
+            return False
+        key = (fb.get_tau(), fv.get_tau() if hasattr(fv, "cutoff_dist") else None, fb.cutoff_dist._version, id(fb.cutoff_dist),
+               getattr(getattr(fv, "cutoff_dist", None), "_version", None))
+        if self.__dict__.get("_bones_gate_ok") != key:
+            if not hasattr(fv, "cutoff_dist") or fb.get_tau() != fv.get_tau() or not torch.equal(fb.cutoff_dist, fv.cutoff_dist):
+                raise NotImplementedError("cutoff_bones: the bone embedder's tau / cutoff_dist differ from the distance embedder's")
+            self.__dict__["_bones_gate_ok"] = key
+        return True
+
     def _cutoffs(self, dev):
         """(cut_v, cut_d) [24] device tensors for the kernels' gates w = 1 - sigmoid(tau * (dist - cutoff)).  A plain Embedder
         (use_cutoff / cutoff_viewdir = False: core/raycasters.py:29-31,66-71; same channels, no gate) is the gate with its cutoff
@@ -153,7 +169,8 @@ class RayCaster(nn.Module):
         cfg = net_c.path_cfg
         B = preproc_kwargs.get("density_scale", net_c.density_scale)
         shift = density_shift_of(preproc_kwargs.get("density_fn", F.relu))
-        cfg = ops.PathConfig(cfg.multires, cfg.multires_views, cfg.framecode_ch, density_scale=B, softplus_shift=shift)
+        cfg = ops.PathConfig(cfg.multires, cfg.multires_views, cfg.framecode_ch, density_scale=B, softplus_shift=shift,
+                             cutoff_bones=self._bones_gated())
         # randomness is generated here (device tensors) and handed to the kernels as inputs
         t_rand = u_imp = noise = noise_f = pts_noise = pts_noise_is = None
         hier = N_importance > 0
@@ -213,7 +230,9 @@ class RayCaster(nn.Module):
             network.set_input_schedule(self.network.input_schedule())
         stream, aux = net.packed()
         tau_v, _ = self._taus()
-        return ops.density(net.path_cfg, stream, aux, pts, skts, tau_v, self._cutoffs(pts.device)[0])
+        c = net.path_cfg
+        cfg = ops.PathConfig(c.multires, c.multires_views, c.framecode_ch, density_scale=c.density_scale, cutoff_bones=self._bones_gated())
+        return ops.density(cfg, stream, aux, pts, skts, tau_v, self._cutoffs(pts.device)[0])
 
     @torch.no_grad()
     def render_mesh_density(self, kps, skts, bones, subject_idxs=None, radius=1.0, res=64, render_kwargs=None,
@@ -336,8 +355,8 @@ def create_raycaster(args, data_attrs, device=None):
     for k, v in SUPPORTED.items():
         if getattr(args, k) != v:
             raise NotImplementedError(f"{k}={getattr(args, k)!r}: the HIP path fuses {SUPPORTED} (all shipped configs)")
-    if not args.use_viewdirs or args.cutoff_bones:
-        raise NotImplementedError("HIP path needs use_viewdirs and no cutoff_bones")
+    if not args.use_viewdirs:
+        raise NotImplementedError("HIP path needs use_viewdirs")
     if args.use_cutoff and not args.cutoff_inputs:
         raise NotImplementedError("use_cutoff without cutoff_inputs (raw input ungated, bands gated) is not in the fused encoder")
     if args.multires_bones != 0:
@@ -355,7 +374,8 @@ def create_raycaster(args, data_attrs, device=None):
                                       cutoff_kwargs=dict(cutoff_kwargs, dist_inputs=False, cut_to_cutoff=args.cut_to_dist,
                                                          shift_inputs=args.cutoff_shift))
     embedbones_fn, input_ch_bones = get_embedder(0, args.i_embed, input_dims=3 * n_j, skel_type=skel_type,
-                                                 cutoff_kwargs={"cutoff": False})
+                                                 cutoff_kwargs=dict(cutoff_kwargs, dist_inputs=True) if args.cutoff_bones
+                                                 else {"cutoff": False})
     embeddirs_fn, input_ch_views = get_embedder(args.multires_views, args.i_embed, input_dims=3 * n_j, skel_type=skel_type,
                                                 cutoff_kwargs=dict(cutoff_kwargs, dist_inputs=True) if args.cutoff_viewdir
                                                 else {"cutoff": False})

@@ -47,6 +47,9 @@ typedef struct AnerfConfig {
   int32_t density_act;     /* 0 = relu, 1 = softplus(x - softplus_shift)  raycasters.py:230 */
   float density_scale;     /* B in raw2outputs, nerf.py:150                               */
   float softplus_shift;
+  int32_t cutoff_bones;    /* ABI revision 5.  != 0: --cutoff_bones (raycasters.py:54-57 with multires_bones = 0): the bone-direction
+                            * block r [72] is gated too, r_j * w_j with the distance gate w_j = 1 - sigmoid(tau_v * (v_j - cutoff_v[j]))
+                            * (the bone embedder is a CutoffEmbedder fed the same distances, with the same tau and cutoff) */
 } AnerfConfig;
 
 /* One network's parameters in the reference's state_dict order (torch Linear [out,in] row-major):

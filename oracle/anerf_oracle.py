@@ -144,10 +144,14 @@ def cutoff_pe(x, dist, n_freq, tau, cutoff, per_joint, sched_alpha=None, gated=T
     return out.flatten(start_dim=-2)
 
 
-def encode(cfg, pts, rays_d, skts, tau_v, tau_d, cut_v, cut_d, cam_idx=None, sched_alpha=None, gate_v=True, gate_d=True):
+def encode(cfg, pts, rays_d, skts, tau_v, tau_d, cut_v, cut_d, cam_idx=None, sched_alpha=None, gate_v=True, gate_d=True,
+           gate_r=False):
     """MLP input X [N,S,dim_x + dim_d (+1)]  (RayCaster.encode_inputs + run_network cat,
-    raycasters.py:476-577).  embedbones_fn is the identity (multires_bones=0)."""
+    raycasters.py:476-577).  embedbones_fn is the identity (multires_bones=0), or with gate_r (--cutoff_bones,
+    raycasters.py:54-57) a CutoffEmbedder without bands fed the joint distances: r_j * w_j."""
     v, r, e = bone_features(pts, rays_d, skts)
+    if gate_r:
+        r = cutoff_pe(r, v, 0, tau_v, cut_v, 3)
     V = cutoff_pe(v, v, cfg.multires, tau_v, cut_v, 1, sched_alpha, gate_v)
     eS = e[:, None, :].expand(-1, pts.shape[1], -1)
     Dv = cutoff_pe(eS, v, cfg.multires_views, tau_d, cut_d, 3, sched_alpha, gate_d)
@@ -275,7 +279,7 @@ def render_rays(cfg, P, P_fine, ray_batch, skts, cyls, n_samples, n_importance=0
                 tau_v=20.0, tau_d=20.0, cut_v=None, cut_d=None, cam_idx=None,
                 t_rand=None, u_imp=None, noise=None, noise_fine=None, lindisp=False,
                 single_net=False, eval_mean_code=False, return_extras=False, pts_noise=None, pts_noise_is=None,
-                sched_alpha=None, gate_v=True, gate_d=True):
+                sched_alpha=None, gate_v=True, gate_d=True, gate_r=False):
     """ray_batch [N,>=8] = (o3,d3,near,far[,viewdirs3]); returns the reference's output dict.
     pts_noise [N,S,3] / pts_noise_is [N,Ni,3]: `pts + randn_like(pts) * ray_noise_std` of RayCaster.sample_pts /
     sample_pts_is (raycasters.py:650-677), the random part passed in; the merged samples of the fine pass keep their own
@@ -288,7 +292,7 @@ def render_rays(cfg, P, P_fine, ray_batch, skts, cyls, n_samples, n_importance=0
     pts = o[:, None] + d[:, None] * z[..., None]
     if pts_noise is not None:
         pts = pts + pts_noise
-    enc_kw = dict(sched_alpha=sched_alpha, gate_v=gate_v, gate_d=gate_d)
+    enc_kw = dict(sched_alpha=sched_alpha, gate_v=gate_v, gate_d=gate_d, gate_r=gate_r)
     X = encode(cfg, pts, d, skts, tau_v, tau_d, cut_v, cut_d, cam_idx, **enc_kw)
     raw = mlp(cfg, P, X, eval_mean_code)
     out = composite(cfg, raw, z, d, noise)

@@ -6,6 +6,8 @@
                                parameter gradients and d loss / d skts
   variants_no_cutoff.npz       use_cutoff off (the argparse DEFAULT of run_nerf.py: plain Embedder for distances and views)
   variants_no_view_cutoff.npz  use_cutoff on, cutoff_viewdir off (plain Embedder for the view directions only)
+  variants_cutoff_bones.npz    --cutoff_bones (multires_bones = 0): the bone directions gated by the distance gate, at global_step
+                               60 000 (tau = 34.8: a gate sharp enough to matter)
   variants_noop_flags.npz      --opt_cutoff --normalize_cutoff: the reference's outputs are BIT-IDENTICAL to the run without them
                                (asserted here; the flags are stored / mis-keyed and never read)
 
@@ -118,6 +120,16 @@ def main():
     g = eval_and_train(caster, rk_train, rk_test, [9], [10, 11], ray_seed=25)
     np.savez_compressed(os.path.join(OUT, "variants_no_view_cutoff.npz"), **g)
     print("no_view_cutoff loss", g["loss"])
+
+    # ---- gated bone directions
+    args, caster, rk_train, rk_test = build(cp, extra=["--cutoff_bones"])
+    assert type(caster.embedbones_fn).__name__ == "CutoffEmbedder" and caster.embedbones_fn.out_dim == 72
+    caster.update_embed_fns(60000, args)
+    g = eval_and_train(caster, rk_train, rk_test, [15], [16, 17], ray_seed=29)
+    g["tau"] = np.array(caster.embedbones_fn.get_tau())
+    assert caster.embed_fn.get_tau() == caster.embedbones_fn.get_tau()
+    np.savez_compressed(os.path.join(OUT, "variants_cutoff_bones.npz"), **g)
+    print("cutoff_bones tau", g["tau"], "loss", g["loss"])
 
     # ---- flags the reference stores and never reads
     _, caster0, rk_train0, rk_test0 = build(cp)

@@ -91,7 +91,7 @@ def test_tau_schedule_matches_reference_formula():
 
 
 def test_unsupported_configurations_fail_loudly():
-    for bad in [dict(kp_dist_type="relpos"), dict(view_type="rayangle"), dict(bone_type="axisang"), dict(cutoff_bones=True),
+    for bad in [dict(kp_dist_type="relpos"), dict(view_type="rayangle"), dict(bone_type="axisang"),
                 dict(multires_bones=2), dict(cutoff_inputs=False), dict(cut_to_dist=True), dict(cutoff_shift=True)]:
         with pytest.raises(NotImplementedError):
             raycaster.create_raycaster(surreal_args(**bad), data_attrs(), device="cpu")

@@ -3,6 +3,7 @@
   --freq_schedule            band schedule (core/cutoff_embedder.py:185-197), folded into the weight images + weight gradients
   use_cutoff off             plain Embedder for distances and views (run_nerf.py's argparse default)
   cutoff_viewdir off         plain Embedder for the view directions only
+  --cutoff_bones             bone directions times the distance gate (raycasters.py:54-57), a flag of the fused kernels' prologue
   --opt_cutoff / --normalize_cutoff   stored / mis-keyed by the reference, never read: bit-identical outputs there
 
 CPU: the oracle restatement vs those vectors.  GPU: create_raycaster(<reference-parsed args + the flag>) -> render() vs the
@@ -26,8 +27,10 @@ VARIANTS = {
     "freq_schedule": ([3], [4, 5], 21, dict(freq_schedule=True), {}),
     "no_cutoff": ([6], [7, 8], 23, dict(use_cutoff=False, cutoff_viewdir=False, cutoff_inputs=False), dict(gate_v=False, gate_d=False)),
     "no_view_cutoff": ([9], [10, 11], 25, dict(cutoff_viewdir=False), dict(gate_d=False)),
+    "cutoff_bones": ([15], [16, 17], 29, dict(cutoff_bones=True), dict(gate_r=True)),
 }
 STEP = 2750        # global_step the schedule vectors were taken at
+STEP_OF = {"freq_schedule": STEP, "cutoff_bones": 60000}      # update_embed_fns(global_step) before the vectors were taken
 OUT8 = ["rgb_map", "disp_map", "acc_map", "alpha", "rgb0", "disp0", "acc0", "alpha0"]
 
 
@@ -60,10 +63,9 @@ def test_schedule_weights_restate_the_reference(oracle, golden):
 def test_oracle_matches_the_reference_variant(oracle, golden, name):
     g = golden("variants_" + name)
     (ev, tr, target), okw = batches(name), dict(VARIANTS[name][4])
-    tau = 20.0
+    tau = float(g["tau"]) if "tau" in g else 20.0
     if name == "freq_schedule":
         okw["sched_alpha"] = float(g["alpha_v"])
-        tau = float(g["tau"])
     cfg = oracle.OracleConfig()
     Pc, Pf = (oracle.params_from_numpy(p, True) for p in params())
     ro, rd, kp, skts, bones, cyls, _ = ev
@@ -124,7 +126,15 @@ def test_host_mirror_schedule_and_flags():
                                             data_attrs(), device="cpu")
     c4 = rk4["ray_caster"]
     assert c4.state_dict()["embed_state_dict"] == {} and c4.embed_fn.get_tau() == 0.0 and c4._taus() == (1.0, 1.0)
-    for bad in (dict(cut_to_dist=True), dict(cutoff_shift=True), dict(cutoff_inputs=False), dict(cutoff_bones=True),
+    # --cutoff_bones: the bone embedder becomes a CutoffEmbedder of its own (checkpoint keys as the reference's)
+    _, rk5, *_ = raycaster.create_raycaster(ref_args("surreal", cutoff_bones=True), data_attrs(), device="cpu")
+    c5 = rk5["ray_caster"]
+    assert sorted(c5.state_dict()["embedbones_state_dict"]) == ["cutoff_dist", "tau"] and c5.embedbones_fn.out_dim == 72
+    assert c5._bones_gated() and not caster._bones_gated()
+    c5.embedbones_fn.update_tau(10 ** 5, 250, 10.)          # a checkpoint whose two gates differ is refused, not rendered
+    with pytest.raises(NotImplementedError):
+        c5._bones_gated()
+    for bad in (dict(cut_to_dist=True), dict(cutoff_shift=True), dict(cutoff_inputs=False),
                 dict(multires_bones=2), dict(kp_dist_type="relpos"), dict(view_type="world"), dict(bone_type="axisang")):
         with pytest.raises(NotImplementedError):
             raycaster.create_raycaster(ref_args("surreal", **bad), data_attrs(), device="cpu")
@@ -157,8 +167,9 @@ def test_hip_path_matches_the_reference_variant(golden, name, route, precision):
     g = golden("variants_" + name)
     ev, tr, target = batches(name)
     args, caster, rk_train, rk_test = _caster(VARIANTS[name][3])
-    if name == "freq_schedule":
-        caster.update_embed_fns(STEP, args)
+    if name in STEP_OF:
+        caster.update_embed_fns(STEP_OF[name], args)
+        assert caster.embed_fn.get_tau() == pytest.approx(float(g["tau"]), rel=1e-7)
     caster.render_precision = caster.train_precision = precision
     caster.train_route = route
     caster.eval()
