@@ -269,3 +269,42 @@ def test_schedule_follows_alpha_and_attached_optimizer_path(golden):
     assert set(ga) == set(gb)
     for n in ga:
         assert torch.equal(ga[n], gb[n]), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fc", [0, 16])
+def test_schedule_fold_at_the_abi_is_packing_pre_multiplied_weights(fc):
+    """ABI revision 5 semantics, without the host mirror: anerf_pack_params* with sched_x / sched_u produce, for EVERY image kind
+    (0 W, 1 W^T, 2 input-gradient image; 3 / 4 / 5 their split-bf16 forms), bit for bit the image of a network whose
+    pts_linears.0, skip-layer input block and views_linears.0 view block were multiplied by the factors beforehand -- and the
+    multi-image launch agrees with the single ones."""
+    ops = importlib.import_module("a-nerf_amd.ops")
+    cfg = ops.PathConfig(7, 4, fc)
+    P = {k: torch.tensor(v, device="cuda") for k, v in synth.make_net_params(5, 7, 4, fc, 8).items() if not k.startswith("framecodes")}
+    rng = np.random.default_rng(0)
+    sx = torch.tensor(rng.random(cfg.dim_x).astype(np.float32), device="cuda")
+    su = torch.tensor(rng.random(cfg.dim_d + fc).astype(np.float32), device="cuda")
+    sx[5], su[7] = 0.0, 1.0
+    sched = ops.InputSchedule(sx, su)
+    Q = dict(P)
+    Q["pts_linears.0.weight"] = P["pts_linears.0.weight"] * sx
+    w5 = P["pts_linears.5.weight"].clone()
+    w5[:, :cfg.dim_x] *= sx
+    Q["pts_linears.5.weight"] = w5
+    wv = P["views_linears.0.weight"].clone()
+    wv[:, 256:] *= su
+    Q["views_linears.0.weight"] = wv
+    images = {}
+    for which in range(6):
+        a = torch.cat(ops.pack_params(cfg, P, which, sched=sched))
+        b = torch.cat(ops.pack_params(cfg, Q, which))
+        c = torch.cat(ops.pack_params(cfg, P, which))
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), which
+        assert not torch.equal(a.view(torch.int32), c.view(torch.int32)), which
+        images[which] = a
+    outs = {w: torch.empty_like(images[w]) for w in range(6)}
+    ops.pack_params_multi([(cfg, P, w, outs[w], sched) for w in range(6)])
+    for w in range(6):
+        assert torch.equal(outs[w].view(torch.int32), images[w].view(torch.int32)), w
+    with pytest.raises(ValueError):
+        ops.pack_params(cfg, P, 0, sched=ops.InputSchedule(sx[:-1], su))
