@@ -823,7 +823,8 @@ __global__ void k_pack_b3(AnerfNetParams P, const int32_t* __restrict__ table, l
 #pragma unroll
       for (int k = 0; k < 24; ++k)
         if (id == k) src = tens[k];
-      const float x = src[off] * sched_scale(P, id, off);
+      float x = src[off] * sched_scale(P, id, off);
+      asm volatile("" : "+v"(x));   // the ROUNDED fp32 product is what gets split: no contraction of the multiply into `x - hi` below
       const __bf16 hi = (__bf16)x;
       const __bf16 r = part ? (__bf16)(x - (float)hi) : hi;
       val = __builtin_bit_cast(unsigned short, r);

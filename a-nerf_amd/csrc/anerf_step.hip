@@ -40,6 +40,7 @@ __global__ void k_pack_multi(PackJobs J) {
       for (int k = 0; k < 24; ++k)
         if (id == k) src = tens[k];
       x = src[off] * sched_scale(job.params, id, off);
+      asm volatile("" : "+v"(x));   // the ROUNDED fp32 product is what gets split: no contraction of the multiply into `x - hi` below
     }
     if (job.kind == 0) {
       static_cast<float*>(job.out)[i] = x;

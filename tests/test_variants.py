@@ -300,7 +300,8 @@ def test_schedule_fold_at_the_abi_is_packing_pre_multiplied_weights(fc):
         b = torch.cat(ops.pack_params(cfg, Q, which))
         c = torch.cat(ops.pack_params(cfg, P, which))
         assert torch.equal(a.view(torch.int32), b.view(torch.int32)), which
-        assert not torch.equal(a.view(torch.int32), c.view(torch.int32)), which
+        # the backward-data images (1, 4) hold no column that consumes the encoding (d x comes from image 2 / 5): untouched
+        assert torch.equal(a.view(torch.int32), c.view(torch.int32)) == (which in (1, 4)), which
         images[which] = a
     outs = {w: torch.empty_like(images[w]) for w in range(6)}
     ops.pack_params_multi([(cfg, P, w, outs[w], sched) for w in range(6)])
