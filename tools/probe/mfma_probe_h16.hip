@@ -20,12 +20,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr int STAGE_BYTES = 32768, FRAG = 1024;
 
-template <int VAR>
-__global__ __launch_bounds__(256) void k_h16(const char* __restrict__ wstream, long long stream_bytes, int stages, float* out,
-                                             unsigned long long* clocks) {
+template <int VAR, int NW>
+__global__ __launch_bounds__(64 * NW) void k_h16(const char* __restrict__ wstream, long long stream_bytes, int stages, float* out,
+                                                 unsigned long long* clocks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  for (int i = threadIdx.x; i < 3 * STAGE_BYTES / 4; i += 256) ((float*)smem)[i] = 1e-3f * (i & 31);
+  for (int i = threadIdx.x; i < 3 * STAGE_BYTES / 4; i += 64 * NW) ((float*)smem)[i] = 1e-3f * (i & 31);
   __syncthreads();
   f32x4 acc[16];         // 256 outputs x 16 samples: 16 blocks of 16 outputs
   float hb[64];          // the previous layer's outputs = B operands: 64 k-steps' worth (one float per k-step and lane)
@@ -35,10 +35,11 @@ __global__ __launch_bounds__(256) void k_h16(const char* __restrict__ wstream, l
   for (int r = 0; r < 64; ++r) hb[r] = 1e-2f * (r + 1) + 1e-4f * lane;
   const unsigned lane16 = lane * 16;
   auto issue = [&](long long goff, int sl) __attribute__((always_inline)) {
-    const char* g = wstream + goff + wave * 8 * FRAG;
-    const unsigned lds0 = (unsigned)reinterpret_cast<size_t>((lds_ptr_t)(smem + sl * STAGE_BYTES + wave * 8 * FRAG));
+    constexpr int PER = 32 / NW;              // fragments per wave and stage: 8 (4 waves) or 4 (8 waves)
+    const char* g = wstream + goff + wave * PER * FRAG;
+    const unsigned lds0 = (unsigned)reinterpret_cast<size_t>((lds_ptr_t)(smem + sl * STAGE_BYTES + wave * PER * FRAG));
 #pragma unroll
-    for (int half = 0; half < 2; ++half)
+    for (int half = 0; half < PER / 4; ++half)
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
                    "global_load_lds_dwordx4 %1, %2\n\t"
                    "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void k_h16(const char* __restrict__ wstream, l
   float s = 0.f;
 #pragma unroll
   for (int b = 0; b < 16; ++b) s += acc[b][0] + acc[b][1] + acc[b][2] + acc[b][3];
-  out[blockIdx.x * 256 + threadIdx.x] = s;
+  out[blockIdx.x * 64 * NW + threadIdx.x] = s;
   if (threadIdx.x == 0) { clocks[2 * blockIdx.x] = t1 - t0; clocks[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
@@ -215,17 +216,18 @@ void run_k(K kern, const char* name, const char* w, long long stream_bytes, floa
          hipGetErrorString(hipGetLastError()));
 }
 
-template <int VAR>
+template <int VAR, int NW>
 void run(const char* name, const char* w, long long stream_bytes, float* out, unsigned long long* clocks, int blocks, int stages) {
   const int lds = 3 * STAGE_BYTES;
-  (void)hipFuncSetAttribute((const void*)k_h16<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  auto kern = k_h16<VAR, NW>;
+  (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  hipLaunchKernelGGL((k_h16<VAR>), dim3(blocks), dim3(256), lds, 0, w, stream_bytes, 16, out, clocks);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * NW), lds, 0, w, stream_bytes, 16, out, clocks);
   (void)hipDeviceSynchronize();
   float best = 1e30f; double ghz = 0, cps = 0;
   for (int rep = 0; rep < 3; ++rep) {
     (void)hipEventRecord(e0);
-    hipLaunchKernelGGL((k_h16<VAR>), dim3(blocks), dim3(256), lds, 0, w, stream_bytes, stages, out, clocks);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * NW), lds, 0, w, stream_bytes, stages, out, clocks);
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     std::vector<unsigned long long> h(2 * 1024);
@@ -235,22 +237,27 @@ void run(const char* name, const char* w, long long stream_bytes, float* out, un
     for (int i = 0; i < nb; ++i) { c += (double)h[2 * i]; r += (double)h[2 * i + 1]; }
     if (ms < best) { best = ms; ghz = c / r * 0.1; cps = c / nb / stages; }
   }
-  printf("%-100s %8.3f ms   stage %6.0f clocks (4096 nominal; 128-sample kernels: 8700 per 8192)   %5.3f GHz  [%s]\n", name, best, cps, ghz,
+  printf("%-100s %8.3f ms   stage %6.0f clocks (%d nominal)   %5.3f GHz  [%s]\n", name, best, cps, NW == 4 ? 4096 : 8192, ghz,
          hipGetErrorString(hipGetLastError()));
 }
 
 int main() {
   float* out; unsigned long long* clocks;
-  (void)hipMalloc(&out, 4096 * 256 * 4); (void)hipMalloc(&clocks, 4096 * 16);
+  (void)hipMalloc(&out, 4096 * 512 * 4); (void)hipMalloc(&clocks, 4096 * 16);
   const int blocks = 256 * 4, stages = 856;      // 107 stages = one pass through the network's weight image; 8 of them
   const long long stream_bytes = 107LL * STAGE_BYTES;
   char* w; (void)hipMalloc(&w, stream_bytes + STAGE_BYTES); (void)hipMemset(w, 0, stream_bytes + STAGE_BYTES);
   run_k(k_ref32, "REFERENCE 128-sample stage on this box: 128 x v_mfma_f32_32x32x2_f32, fragment reads, DMA re-issue", w, stream_bytes, out, clocks,
         blocks, stages / 2, 8192);
-  run<0>("half-time stage: 128 x v_mfma_f32_16x16x4_f32 + barrier, operands in registers", w, stream_bytes, out, clocks, blocks, stages);
-  run<1>("+ 32 weight-fragment reads (ds_read_b128) per stage, one k-group ahead", w, stream_bytes, out, clocks, blocks, stages);
-  run<2>("+ LDS-DMA re-issue of the consumed slot behind the barrier (3-slot ring, 32 KiB per stage)", w, stream_bytes, out, clocks, blocks, stages);
-  run<3>("+ layer hand-over every 8th stage (64 v_max, fenced)", w, stream_bytes, out, clocks, blocks, stages);
-  run<2>("VAR 2 again", w, stream_bytes, out, clocks, blocks, stages);
+  run<0, 4>("half-time stage: 128 x v_mfma_f32_16x16x4_f32 + barrier, operands in registers", w, stream_bytes, out, clocks, blocks, stages);
+  run<1, 4>("+ 32 weight-fragment reads (ds_read_b128) per stage, one k-group ahead", w, stream_bytes, out, clocks, blocks, stages);
+  run<2, 4>("+ LDS-DMA re-issue of the consumed slot behind the barrier (3-slot ring, 32 KiB per stage)", w, stream_bytes, out, clocks, blocks, stages);
+  run<3, 4>("+ layer hand-over every 8th stage (64 v_max, fenced)", w, stream_bytes, out, clocks, blocks, stages);
+  // the same 16-sample waves, EIGHT per tile = two per SIMD sharing one ring: a 128-sample tile at occupancy 2 (a stage is now 2 x 4 096
+  // clocks of MFMAs per SIMD; what one wave waits for -- barrier, DMA issue, hand-over -- the other can fill)
+  run<0, 8>("8 x 16-sample waves (2 per SIMD): MFMAs + barrier", w, stream_bytes, out, clocks, blocks, stages / 2);
+  run<1, 8>("8 waves: + fragment reads (every wave reads every fragment: 64 KiB per SIMD and stage)", w, stream_bytes, out, clocks, blocks, stages / 2);
+  run<2, 8>("8 waves: + LDS-DMA re-issue (4 KiB per wave)", w, stream_bytes, out, clocks, blocks, stages / 2);
+  run<3, 8>("8 waves: + layer hand-over every 8th stage", w, stream_bytes, out, clocks, blocks, stages / 2);
   return 0;
 }
