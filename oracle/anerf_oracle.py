@@ -189,12 +189,14 @@ def mlp(cfg, P, X, eval_mean_code=False):
     return torch.cat([rgb, sigma], -1)
 
 
-def density_query(cfg, P, pts, skts, tau_v=20.0, cut_v=None):
+def density_query(cfg, P, pts, skts, tau_v=20.0, cut_v=None, sched_alpha=None, gate_v=True, gate_r=False):
     """RayCaster.render_pts_density (core/raycasters.py:597-648): pts [N,1,3] under one pose -> alpha_linear(
-    forward_density([embed(v), r])) [N,1,1]."""
+    forward_density([embed(v), r])) [N,1,1].  sched_alpha / gate_v / gate_r: the embedder variants of encode()."""
     cut_v = torch.full((N_JOINTS,), 0.5) if cut_v is None else cut_v
     v, r, _ = bone_features(pts, torch.ones(pts.shape[0], 3), skts)
-    x = torch.cat([cutoff_pe(v, v, cfg.multires, tau_v, cut_v, 1), r], -1)
+    if gate_r:
+        r = cutoff_pe(r, v, 0, tau_v, cut_v, 3)
+    x = torch.cat([cutoff_pe(v, v, cfg.multires, tau_v, cut_v, 1, sched_alpha, gate_v), r], -1)
     h = x
     for i in range(cfg.D):
         h = F.relu(F.linear(h, P[f"pts_linears.{i}.weight"], P[f"pts_linears.{i}.bias"]))

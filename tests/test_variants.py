@@ -309,3 +309,32 @@ def test_schedule_fold_at_the_abi_is_packing_pre_multiplied_weights(fc):
         assert torch.equal(outs[w].view(torch.int32), images[w].view(torch.int32)), w
     with pytest.raises(ValueError):
         ops.pack_params(cfg, P, 0, sched=ops.InputSchedule(sx[:-1], su))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_density_query_follows_the_variant(oracle, golden, name):
+    """fwd_type='density' (raycasters.py:597-648) shares the fused kernels' prologue and weight images: under every variant it must
+    agree with the oracle restatement of the same variant (pinned above against the reference's vectors), and differ from the
+    shipped encoding."""
+    g = golden("variants_" + name)
+    args, caster, rk_train, rk_test = _caster(VARIANTS[name][3])
+    if name in STEP_OF:
+        caster.update_embed_fns(STEP_OF[name], args)
+    caster.eval()
+    pose = synth.make_pose(20)
+    kps, skts, bones = dev(pose["kp"])[None], dev(pose["skts"])[None], dev(pose["bones"])[None]
+    q = np.random.default_rng(5).uniform(-0.6, 0.6, (257, 1, 3)).astype(np.float32) + pose["kp"][0]
+    with torch.no_grad():
+        got = caster(dev(q), kps, skts, bones, render_kwargs=rk_test["preproc_kwargs"], fwd_type="density").cpu().numpy()
+    okw = {k: v for k, v in VARIANTS[name][4].items() if k in ("gate_v", "gate_r")}
+    if name == "freq_schedule":
+        okw["sched_alpha"] = float(g["alpha_v"])
+    tau = float(g["tau"]) if "tau" in g else 20.0
+    P = oracle.params_from_numpy(params()[1])          # the fine network answers density queries
+    with torch.no_grad():
+        ref = oracle.density_query(oracle.OracleConfig(), P, t(q), t(pose["skts"])[None], tau_v=tau, **okw).numpy()
+        plain = oracle.density_query(oracle.OracleConfig(), P, t(q), t(pose["skts"])[None], tau_v=tau).numpy()
+    np.testing.assert_allclose(got, ref, atol=5e-5 * max(1.0, np.abs(ref).max()), rtol=1e-4)
+    if name != "no_view_cutoff":          # (the view gate does not reach the density head)
+        assert np.abs(ref - plain).max() > 1e-3
