@@ -59,6 +59,13 @@ def main():
         for part in path.split("."):
             obj = getattr(obj, part)
         res[f"{mod}:{path}"] = describe(obj)
+    # run_nerf.py is a script (its imports start the whole application): render_path's signature is read from its syntax tree
+    import ast
+    tree = ast.parse(open(os.path.join(G.REF, "run_nerf.py")).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "render_path"][0]
+    pos = fn.args.args
+    dfl = [None] * (len(pos) - len(fn.args.defaults)) + [repr(ast.literal_eval(d)) for d in fn.args.defaults]
+    res["run_nerf:render_path"] = [{"name": a.arg, "kind": "POSITIONAL_OR_KEYWORD", "default": d} for a, d in zip(pos, dfl)]
     json.dump(res, open(os.path.join(G.OUT, "api_signatures.json"), "w"), indent=1)
     print(len(res), "signatures;", sum(len(v) for v in res.values()), "parameters")
 

@@ -12,7 +12,7 @@ import pytest
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "api_signatures.json")
 # reference module -> ours
 MODULES = {"core.raycasters": "a-nerf_amd.raycaster", "core.networks.nerf": "a-nerf_amd.networks", "core.cutoff_embedder": "a-nerf_amd.networks",
-           "core.trainer": None, "core.pose_opt": "a-nerf_amd.pose_opt"}
+           "core.trainer": None, "core.pose_opt": "a-nerf_amd.pose_opt", "run_nerf": "a-nerf_amd.render"}
 TRAINER_HOME = {"render": "a-nerf_amd.render", "batchify_rays": "a-nerf_amd.render", "decay_optimizer_lrate": "a-nerf_amd.trainer",
                 "Trainer.__init__": "a-nerf_amd.trainer", "Trainer.train_batch": "a-nerf_amd.trainer"}
 SIGS = json.load(open(GOLDEN))
