@@ -124,6 +124,9 @@ def run_case(cp, name, case):
                "alpha_mean": stats["alpha"]}
         if case["mixamo"]:
             rec.update(kp_loss=loss_dict["kp_loss"].item(), mpjpc=stats["MPJPC"])
+        if i == 1:          # what train_batch hands back, by name (trainer.py:262-277)
+            out["keys_loss_dict"] = np.array(sorted(loss_dict))
+            out["keys_stats"] = np.array(sorted(stats))
         if args.freq_schedule:
             rec.update(sched_alpha=caster.embed_fn.sched_alpha.item(), sched_alpha_d=caster.embeddirs_fn.sched_alpha.item())
         for k, v in rec.items():

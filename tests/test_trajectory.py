@@ -123,6 +123,8 @@ def test_five_training_iterations_follow_the_reference_trajectory(name, tail):
         lr_used = float(g["lrate0"]) if i == 1 else float(g[f"it{i - 1}.lrate"])
         loss_dict, stats = tr.train_batch(batch, i=i, global_step=int(g["global_step_per_iter"]) * i)
         G = lambda k: float(g[f"it{i}.{k}"])
+        if i == 1:      # train_batch hands back the reference's dictionaries, key for key (trainer.py:262-277)
+            assert sorted(loss_dict) == [str(k) for k in g["keys_loss_dict"]] and sorted(stats) == [str(k) for k in g["keys_stats"]]
         d_loss = abs(float(loss_dict["total_loss"]) - G("loss"))
         worst["loss"] = max(worst["loss"], d_loss)
         assert d_loss <= 5e-6, (i, float(loss_dict["total_loss"]), G("loss"))
