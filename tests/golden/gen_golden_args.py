@@ -51,10 +51,23 @@ def manifest(args, n_views=8):
             "single_net_shared": caster.network_fine is caster.network}
 
 
+# embedder variants outside the shipped configs (surreal.txt + flags / minus lines): what the reference builds for them
+VARIANTS = {
+    "surreal_freq_schedule": (["--freq_schedule"], ()),
+    "surreal_cutoff_bones": (["--cutoff_bones"], ()),
+    "surreal_no_cutoff": ([], ("use_cutoff", "cutoff_viewdir", "cutoff_inputs")),
+    "surreal_no_view_cutoff": ([], ("cutoff_viewdir",)),
+    "surreal_noop_flags": (["--opt_cutoff", "--normalize_cutoff"], ()),
+}
+
+
 def main():
     cp = import_reference()
-    for name, path in CONFIGS.items():
-        args = make_args(cp, path)
+    import gen_golden_variants as V
+    jobs = [(name, path, make_args(cp, path)) for name, path in CONFIGS.items()]
+    jobs += [(name, "configs/surreal/surreal.txt + " + " ".join(extra) + (" - " + " ".join(drop) if drop else ""),
+              V.make_args(cp, "configs/surreal/surreal.txt", drop, extra)) for name, (extra, drop) in VARIANTS.items()]
+    for name, path, args in jobs:
         with open(os.path.join(OUT, f"caster_manifest_{name}.json"), "w") as f:
             json.dump(manifest(args), f, indent=1, sort_keys=True, default=str)
         d = dict(vars(args))

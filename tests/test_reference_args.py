@@ -24,6 +24,8 @@ synth = importlib.import_module("a-nerf_amd.synth")
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CONFIGS = ["surreal", "surreal_single", "mixamo", "mixamo_finetune", "h36m_prot2", "h36m_prot2_finetune", "perfcap",
            "perfcap_finetune"]
+# surreal.txt with embedder flags outside the shipped configs (tests/golden/gen_golden_args.py VARIANTS; tests/test_variants.py renders them)
+VARIANT_CONFIGS = ["surreal_freq_schedule", "surreal_cutoff_bones", "surreal_no_cutoff", "surreal_no_view_cutoff", "surreal_noop_flags"]
 
 
 def ref_args(name, **over):
@@ -43,7 +45,7 @@ def data_attrs(n_views=8):
             "joint_coords": np.tile(np.eye(3, dtype=np.float32), (24, 1, 1))}
 
 
-@pytest.mark.parametrize("name", CONFIGS)
+@pytest.mark.parametrize("name", CONFIGS + VARIANT_CONFIGS)
 def test_create_raycaster_reproduces_the_reference_manifest(name):
     m = json.load(open(os.path.join(GOLDEN, f"caster_manifest_{name}.json")))
     rk_train, rk_test, start, grad_vars, optimizer, ckpt = raycaster.create_raycaster(ref_args(name), data_attrs(), device="cpu")
