@@ -363,7 +363,7 @@ int anerf_pack_params(const AnerfNetParams* params, const int32_t* table, int64_
   if (!params || !table || !out) return set_error(ANERF_E_NULL, "pack: NULL pointer");
   for (int i = 0; i < 12; ++i)
     if (!params->w[i] || !params->b[i]) return set_error(ANERF_E_NULL, "pack: NULL tensor");
-  if (!sched_ok(*params)) return set_error(ANERF_E_SHAPE, "pack: sched_x / sched_u without sched_dim_x / sched_dim_u");
+  if (!sched_ok(*params)) return set_error(ANERF_E_SHAPE, "pack: sched_dim_x must be 432 and sched_dim_u 72 / 648 / 664 (the encoded widths of the supported layouts; trunk width 256)");
   return launch_pack(params, table, n, out, (hipStream_t)stream);
 }
 
@@ -372,7 +372,7 @@ int anerf_pack_params_b3(const AnerfNetParams* params, const int32_t* table, int
   if (!params || !table || !out) return set_error(ANERF_E_NULL, "pack_b3: NULL pointer");
   for (int i = 0; i < 12; ++i)
     if (!params->w[i] || !params->b[i]) return set_error(ANERF_E_NULL, "pack_b3: NULL tensor");
-  if (!sched_ok(*params)) return set_error(ANERF_E_SHAPE, "pack_b3: sched_x / sched_u without sched_dim_x / sched_dim_u");
+  if (!sched_ok(*params)) return set_error(ANERF_E_SHAPE, "pack_b3: sched_dim_x must be 432 and sched_dim_u 72 / 648 / 664 (the encoded widths of the supported layouts; trunk width 256)");
   int rc = launch_pack_b3(params, table, 2 * stream_floats, out, (hipStream_t)stream);
   if (rc) return rc;
   return launch_pack(params, table + 2 * stream_floats, aux_floats, out + stream_floats, (hipStream_t)stream);

@@ -47,9 +47,15 @@ inline void ensure_dynamic_lds(const void* kernel, int bytes, unsigned long long
   __atomic_fetch_or(done, bit, __ATOMIC_RELAXED);
 }
 
-// a schedule vector comes with its length (the pack kernels take the column of an element modulo the layer's input width)
+// a schedule vector comes with its length (the pack kernels take the column of an element modulo the layer's input width).
+// sched_scale() below hard-codes the trunk width 256 -- the only width config_ok() admits -- so the lengths must be those of
+// the supported layouts: dim_x = 24 (1 + 2*7) + 72 = 432, u_width = 72 (1 + 2*multires_views) [+ 16 frame-code columns]
+// in {72, 648, 664}.  A direct C caller with another length gets ANERF_E_SHAPE, not silently mis-scaled weight columns; the
+// entry points that know the configuration compare with it exactly (sched_matches).
 inline bool sched_ok(const AnerfNetParams& p) {
-  return (!p.sched_x || p.sched_dim_x > 0) && (!p.sched_u || p.sched_dim_u > 0);
+  const bool x_ok = p.sched_x ? p.sched_dim_x == 432 : true;
+  const bool u_ok = p.sched_u ? (p.sched_dim_u == 72 || p.sched_dim_u == 648 || p.sched_dim_u == 664) : true;
+  return x_ok && u_ok;
 }
 
 #if defined(__HIPCC__)

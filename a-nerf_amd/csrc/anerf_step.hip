@@ -190,7 +190,7 @@ int anerf_pack_params_multi(const AnerfPackJob* jobs, int32_t n_jobs, void* stre
     if (q.kind != 0 && q.kind != 1) return set_error(ANERF_E_CONFIG, "pack_multi: kind must be 0 (float) or 1 (bf16 hi/lo)");
     for (int i = 0; i < 12; ++i)
       if (!q.params.w[i] || !q.params.b[i]) return set_error(ANERF_E_NULL, "pack_multi: NULL tensor");
-    if (!sched_ok(q.params)) return set_error(ANERF_E_SHAPE, "pack_multi: sched_x / sched_u without sched_dim_x / sched_dim_u");
+    if (!sched_ok(q.params)) return set_error(ANERF_E_SHAPE, "pack_multi: sched_dim_x must be 432 and sched_dim_u 72 / 648 / 664 (the encoded widths of the supported layouts; trunk width 256)");
     if (q.n > nmax) nmax = q.n;
   }
   if (nmax == 0) return ANERF_OK;

@@ -199,13 +199,7 @@ class DeviceRng:
 
     def __init__(self, seed=None, stream_id=None):
         if stream_id is None:
-            rank = 0
-            try:
-                import torch.distributed as dist
-                rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else int(__import__("os").environ.get("RANK", 0))
-            except Exception:
-                pass
-            stream_id = (rank << 20) | (_rng_instances[0] & 0xFFFFF)
+            stream_id = (self._rank() << 20) | (_rng_instances[0] & 0xFFFFF)
             _rng_instances[0] += 1
         self.stream_id = int(stream_id)
         self.pinned = seed is not None
@@ -239,10 +233,23 @@ class DeviceRng:
     def state_dict(self):
         return {"seed": self._torch_seed, "stream_id": self.stream_id, "offset": self.offset, "pinned": self.pinned}
 
+    @staticmethod
+    def _rank():
+        try:
+            import torch.distributed as dist
+            return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else int(__import__("os").environ.get("RANK", 0))
+        except Exception:
+            return 0
+
     def load_state_dict(self, sd):
-        self.stream_id, self.pinned = int(sd["stream_id"]), bool(sd["pinned"])
+        """Continue a saved stream.  The checkpoint is written by ONE rank: the instance part of the stream id (low 20 bits)
+        is restored, the rank part is this process's own, so the writing rank resumes its stream exactly and every other
+        data-parallel rank keeps drawing different jitter / noise for its different ray shard.  The restored state is
+        pinned: a torch seed that differs on resume must not reset the offset at the next draw (follow_torch_seed)."""
+        self.stream_id = (self._rank() << 20) | (int(sd["stream_id"]) & 0xFFFFF)
         self._set(int(sd["seed"]))
         self.offset = int(sd["offset"])
+        self.pinned = True
 
     def fill(self, specs, device):
         """specs: list of (shape, kind, scale) with kind "uniform" | "normal" (None entries are skipped and returned as None).

@@ -251,7 +251,7 @@ class FusedAdam:
             work = dist.all_reduce(fg[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True)
         self._async = (work, lo, hi)
 
-    def all_reduce_grads(self, group=None, i=None, weight=None):
+    def all_reduce_grads(self, group=None, i=None, weight=None, only_group=None):
         """Sum the gradient bucket over ranks; the 1/world scale is applied inside step().  ONE collective over the
         contiguous range of the groups due on iteration `i` (see class doc; i=None: every group).
         weight: multiply the local gradients first -- `parallel.shard_weight()` for ragged ray shards, so that the reduced
@@ -260,7 +260,7 @@ class FusedAdam:
         world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         if world <= 1 and not (_force_collectives() and dist.is_available() and dist.is_initialized()):
             return
-        due = self._due(i)
+        due = self._due(i, only_group)                # only_group: just that parameter group (the pose group has stopped)
         seg = self._segments()
         runs = []                                     # maximal runs of consecutive due groups -> one collective each
         for gi in due:

@@ -77,22 +77,17 @@ class Trainer:
             return dict(kp_batch=batch["kp3d"], skts=batch["skts"], bones=batch["bones"], cyls=batch["cyls"]), {}
         kp_idx = batch["kp_idx"]
         if torch.is_tensor(kp_idx):
-            # the layer groups rays by pose on the host (np.unique): a host copy of the index, cached by content inside the
-            # layer, so a repeated batch layout costs no transfer
-            kp_idx = self._host_index(kp_idx)
+            # the layer groups rays by pose on the host (np.unique) and caches that grouping by CONTENT; the host copy itself is
+            # taken afresh every iteration, as the reference does (trainer.py:299 `kp_idx.cpu().numpy()`): a cache keyed on the
+            # tensor's address would hand back a previous batch's indices when the allocator reuses the block.  train_batch
+            # leaves a loader's host-side kp_idx on the host, so this is normally no transfer at all.
+            kp_idx = kp_idx.detach().cpu().numpy()
         kps, bones, skts, _, rots = layer(kp_idx)
         kp_args, extras = dict(kp_batch=kps, skts=skts, bones=bones, cyls=batch["cyls"]), {"rots": rots}
         if detach:
             kp_args = {k: (v.detach() if v is not None else None) for k, v in kp_args.items()}
             extras = {k: v.detach() for k, v in extras.items()}
         return kp_args, extras
-
-    def _host_index(self, idx):
-        key = (idx.data_ptr(), idx._version, tuple(idx.shape))
-        hit = self.__dict__.get("_idx_host")
-        if hit is None or hit[0] != key:
-            hit = self._idx_host = (key, idx.detach().cpu().numpy())
-        return hit[1]
 
     def get_fwd_args(self, batch):
         return {"rays": batch["rays"], "cams": batch["cam_idxs"] if self.args.opt_framecode else None,
@@ -166,8 +161,15 @@ class Trainer:
             loss.backward()
         if self._fused is not None:
             f = self._fused
-            f.all_reduce_grads(i=i)                       # no-op in a single process; ONE collective over what is due otherwise
-            norms = f.step(zero_grad=True, want_norms=True, i=i)
+            # after opt_pose_stop (or without opt_pose) the reference never touches pose_optimizer again (trainer.py:476: the
+            # `not popt_detach` guard): only the network group is reduced and stepped -- Adam with zero gradients would still
+            # move bones / pelvis along their remaining first moments
+            only = 0 if (popt_detach and len(f.param_groups) > 1) else None
+            f.all_reduce_grads(i=i, only_group=only)      # no-op in a single process; ONE collective over what is due otherwise
+            pose_due = only is None and len(f.param_groups) > 1 and 1 in f._due(i)
+            norms = f.step(zero_grad=True, want_norms=True, i=i, only_group=only)
+            if pose_due and getattr(args, "opt_pose_cache", False) and self.popt_kwargs is not None:
+                self.popt_kwargs["popt_layer"].update_cache()             # trainer.py:479-480
             return {"total_norm": norms[0], "avg_norm": norms[1]}
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
             # one process per GPU: average the ranks' gradients with ONE all-reduce of a flat bucket (RayParallel.sync_gradients;
@@ -193,7 +195,9 @@ class Trainer:
     def train_batch(self, batch, i=0, global_step=0):
         args = self.args
         H, W, focal = self.hwf
-        batch = {k: (v.to(self.device) if torch.is_tensor(v) and self.device is not None else v) for k, v in batch.items()}
+        # kp_idx is consumed on the host (the pose layer groups rays by pose there): a loader's host tensor stays where it is
+        batch = {k: (v.to(self.device) if torch.is_tensor(v) and self.device is not None and k != "kp_idx" else v)
+                 for k, v in batch.items()}
         popt_detach = not (args.opt_pose_stop is None or i < args.opt_pose_stop)
         kp_args, extra_args = self.get_kp_args(batch, detach=popt_detach)
         preds = render(H, W, focal, chunk=args.chunk, verbose=i < 10, retraw=False, **kp_args, **self.get_fwd_args(batch),

@@ -64,7 +64,13 @@ def parse():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
                     help="exact fp32 MFMA, or hi/lo-split bf16 MFMAs (3 per product, fp32 accumulate); train workloads: "
                          "bf16x3 applies to the forward kernel only, backward + weight-gradient GEMM stay fp32")
-    return ap.parse_args()
+    ap.add_argument("--detail", default=None, help="where the full record goes (default: bench_detail.json next to this script); "
+                                                   "stdout carries only the <= 4 KB contract line")
+    a = ap.parse_args()
+    if a.detail:
+        global DETAIL_PATH
+        DETAIL_PATH = os.path.abspath(a.detail)
+    return a
 
 
 _JSON_FD = None
@@ -108,10 +114,84 @@ def _flush_c_stdio():
         pass
 
 
+LINE_BUDGET = 4096           # bytes of the ONE stdout line (the driver reads a bounded tail of stdout: BENCH_r04 came back
+                             # unparsed when the line had grown to 20 KB)
+DETAIL_PATH = os.path.join(ROOT, "bench_detail.json")
+
+# the contract keys of the task statement (+ who ran); everything else lives in bench_detail.json
+_LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "dry_run", "config", "roofline", "cpu_baseline", "parity", "ranks", "backend", "devices",
+              "ms_per_step_per_rank", "collective_ms_per_step", "collective_bytes", "collective_alone_ms", "shards", "shard_weights",
+              "all_checks_ok", "graph", "extras_summary", "scaling_model_8gpu", "detail")
+_ROOF_KEYS = ("bound", "kernel", "achieved", "algorithmic", "peak", "unit", "frac", "avg_launch_ms", "flop_per_launch", "traffic")
+_CONFIG_KEYS = ("workload", "rays_per_step", "samples_per_ray", "n_importance", "parallelism", "opt_pose_step", "chunk", "tail", "graph")
+# dropped first (in this order) if a line would still exceed LINE_BUDGET
+_OPTIONAL = ("shard_weights", "shards", "devices", "collective_ms_per_step", "ms_per_step_per_rank", "scaling_model_8gpu", "extras_summary",
+             "parity")
+
+
+def _strict(x, nd=6):
+    """strict-JSON form of a record: no NaN / Infinity tokens (-> null), numpy scalars -> Python, floats to nd significant digits"""
+    if isinstance(x, dict):
+        return {str(k): _strict(v, nd) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_strict(v, nd) for v in x]
+    if isinstance(x, (bool, type(None), str)):
+        return x
+    if isinstance(x, (int, np.integer)):
+        return int(x)
+    if isinstance(x, (float, np.floating)):
+        x = float(x)
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float(f"{x:.{nd}g}") if nd else x
+    return str(x)
+
+
+def compact_line(res):
+    """The ONE stdout line: the contract keys only, <= LINE_BUDGET bytes of strict JSON.  Per-step statistics, per-kernel
+    lists, traffic notes, the full extra-workload records and the scaling model's inputs go to bench_detail.json."""
+    line = {k: res[k] for k in _LINE_KEYS if k in res}
+    if "roofline" in line:
+        line["roofline"] = {k: line["roofline"][k] for k in _ROOF_KEYS if k in line["roofline"]}
+    if "config" in line:
+        line["config"] = {k: line["config"][k] for k in _CONFIG_KEYS if k in line["config"]}
+    if "step_ms" in res and res["step_ms"]:
+        line["step_ms_median"] = res["step_ms"]["median"]
+    if "host_enqueue_ms" in res and res["host_enqueue_ms"]:
+        line["host_enqueue_ms_median"] = res["host_enqueue_ms"]["median"]
+    if "cpu_baseline" in line and isinstance(line["cpu_baseline"], dict):
+        line["cpu_baseline"] = dict(line["cpu_baseline"], sample=str(line["cpu_baseline"].get("sample", ""))[:200])
+    line = _strict(line)
+    enc = lambda d: json.dumps(d, allow_nan=False, separators=(", ", ": "))
+    for k in _OPTIONAL:
+        if len(enc(line).encode()) <= LINE_BUDGET:
+            break
+        line.pop(k, None)
+    out = enc(line)
+    if len(out.encode()) > LINE_BUDGET:          # cannot happen with the keys above; never print an unparsable line
+        line = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                     "vs_baseline", "dtype", "data") if k in line}
+        out = enc(line)
+    return out
+
+
 def emit(res):
-    """The ONE JSON line of the bench contract, written to the process's original stdout."""
+    """The ONE JSON line of the bench contract (compact_line), written to the process's original stdout, nothing after it.
+    The full record goes to bench_detail.json (--detail) and, as one line, to stderr."""
     _flush_c_stdio()
-    line = (json.dumps(res) + "\n").encode()
+    full = _strict(res, nd=0)
+    try:
+        tmp = DETAIL_PATH + f".{os.getpid()}.tmp"
+        with open(tmp, "w") as f:
+            json.dump(full, f, allow_nan=False, indent=1)
+        os.replace(tmp, DETAIL_PATH)
+        res = dict(res, detail=os.path.basename(DETAIL_PATH))
+    except OSError as e:                          # a read-only checkout: the line still goes out
+        sys.stderr.write(f"bench.py: could not write {DETAIL_PATH}: {e}\n")
+    sys.stderr.write("bench_detail: " + json.dumps(full, allow_nan=False) + "\n")
+    sys.stderr.flush()
+    line = (compact_line(res) + "\n").encode()
     if _JSON_FD is None:
         sys.stdout.write(line.decode())
         sys.stdout.flush()
@@ -275,11 +355,20 @@ def main():
             ex = extra_workloads(args, device, synth, ops, pipeline)
             if dist is None:
                 res["scaling_model_8gpu"] = scaling_model(ex, device)
+            summ = []
             for e in ex:
-                e.pop("_key", None)
+                key = e.pop("_key", None)
                 if e.get("workload", "").startswith("reference-shaped") and "value" in e:
                     e["vs_headline_kernel_bench"] = e["value"] / res["value"]
+                # <= ~150 bytes per extra on the stdout line; the full records are bench_detail.json's `extra_workloads`
+                tag = "?" if key is None else "_".join(str(k) for k in key if k is not None)
+                summ.append({"workload": tag, "error": e["error"][:80]} if "error" in e else
+                            {"workload": tag, "value": e["value"], "ms_per_step": e["ms_per_step"], "frac": e["roofline"]["frac"]} |
+                            ({"step_ms": e["step_ms"]["median"]} if e.get("step_ms") else {}) |
+                            ({"host_ms": e["host_enqueue_ms"]["median"]} if e.get("host_enqueue_ms") else {}) |
+                            ({"graph": e["graph"]} if "graph" in e else {}))
             res["extra_workloads"] = ex
+            res["extras_summary"] = summ
         emit(res)
     if dist is not None:
         dist.destroy_process_group()

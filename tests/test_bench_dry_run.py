@@ -9,6 +9,7 @@ import json
 import os
 import subprocess
 import sys
+import tempfile
 
 import pytest
 
@@ -18,16 +19,42 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def run(*flags, env=None, timeout=300):
     e = dict(os.environ, **(env or {}))
     e.pop("WORLD_SIZE", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--steps", "3", "--warmup", "1", *flags], env=e,
-                       capture_output=True, text=True, timeout=timeout)
+    detail = tempfile.NamedTemporaryFile(suffix=".json", delete=False).name
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--steps", "3", "--warmup", "1", "--detail", detail,
+                        *flags], env=e, capture_output=True, text=True, timeout=timeout)
+    r.detail = detail
     return r
 
 
+def _no_constants(tok):
+    raise ValueError(f"non-strict JSON token {tok!r} on the bench line")
+
+
+def strict_line(stdout):
+    """what the driver does with the run: the LAST stdout line, bounded, strict JSON, contract keys present"""
+    line = stdout.rstrip("\n").splitlines()[-1]
+    assert len(line.encode()) <= 4096, len(line.encode())
+    j = json.loads(line, parse_constant=_no_constants)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config"):
+        assert k in j, k
+    assert "workload" in j["config"]
+    return j
+
+
 def record(r):
+    """the stdout line (checked as the driver reads it) merged over the full record of bench_detail.json"""
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout            # ONE JSON line on stdout, whatever gloo prints
-    return json.loads(lines[0])
+    j = strict_line(r.stdout)
+    full = json.load(open(r.detail))
+    os.unlink(r.detail)
+    assert j["detail"] == os.path.basename(r.detail)
+    for k, v in j.items():                      # the line is a subset of the detail record (floats rounded to 6 digits)
+        if k not in ("detail", "step_ms_median", "host_enqueue_ms_median") and not isinstance(v, (dict, list, float)):
+            assert full[k] == v, k
+    return {**full, **{k: v for k, v in j.items() if k not in full}}
 
 
 def test_world8_render_frame_is_sharded_gathered_and_recorded():
@@ -77,5 +104,43 @@ def test_dry_run_bucket_is_the_real_flat_bucket(workload, floats):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--n-rand", "64", "--steps", "2", "--warmup", "1",
                         "--cpu-rays", "0", "--extra", "off"], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    j = json.loads(r.stdout.strip().splitlines()[-1])
+    j = strict_line(r.stdout)
     assert j["collective_bytes"] == 4 * floats and j["backend"].startswith("nccl")
+
+
+def test_line_budget_holds_for_a_full_default_record():
+    """compact_line on a record shaped like the default run's (headline + 8 extras with per-kernel lists, NaN in a statistic):
+    <= 4096 bytes, strict JSON, contract keys + roofline + cpu_baseline + extras_summary survive; detail keys do not."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    stats = {"n": 20, "mean": 19.09467144012451, "median": 19.0357084274292, "p95": 19.1477, "min": 19.01, "max": float("nan"), "over_1p5x_median": 0}
+    roof = {"bound": "mfma", "kernel": "k_mlp_fwd<7,4,0,false,false,0>" + " x" * 40, "achieved": 142.81234567, "algorithmic": 142.8, "peak": 157.3,
+            "unit": "TFLOP/s", "frac": 0.9079123456, "avg_launch_ms": 201.7, "launch_ms": stats, "flop_per_launch": 28805000000000,
+            "traffic": 5.16e8, "traffic_note": "n" * 300, "kernels": [{"kernel": "k", "pass": "fine", "ms": 1.0, "flop": 1, "tflops": 1.0, "frac": float("inf")}] * 8}
+    extra = {"workload": "w" * 200, "value": 1.0e6, "unit": "rays/s", "steps": 20, "ms_per_step": 2.93, "dtype": "f32", "roofline": roof,
+             "step_ms": stats, "period_ms": stats, "host_enqueue_ms": stats, "slow_steps": [], "graph": True}
+    res = {"metric": "rays/sec", "value": 1290000.123456789, "unit": "rays/s", "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 202.4,
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "SURREAL-shaped 512x512 frame, 64 samples/ray, forward render (BASELINE config 2)", "rays_per_step": 261121,
+                      "samples_per_ray": 64, "n_importance": 0, "parallelism": "ray-sharded x1", "weights": "z" * 100},
+           "roofline": roof, "step_ms": stats, "slow_steps": [], "alt_precision": {"x": 1},
+           "cpu_baseline": {"value": 1430.0, "unit": "rays/s", "cores": 16, "kind": "port", "sample": "s" * 400},
+           "parity": {"max_abs_rgb": 1e-6, "psnr_gpu_db": 10.0, "psnr_oracle_db": 10.0}, "ranks": 1, "backend": "none (single process)",
+           "devices": ["cuda:0 AMD Instinct MI355X"], "ms_per_step_per_rank": [202.4], "collective_ms_per_step": [0.0],
+           "scaling_model_8gpu": {"config3": {"predicted_speedup_8gpu": 6.7}, "config4": {"predicted_speedup_8gpu": 6.4}},
+           "extra_workloads": [extra] * 8,
+           "extras_summary": [{"workload": "train_mixamo_384_20", "value": 131000.123, "ms_per_step": 2.93, "frac": 0.632, "step_ms": 2.9,
+                               "host_ms": 0.25, "graph": True}] * 8}
+    line = b.compact_line(res)
+    assert len(line.encode()) <= 4096
+    j = json.loads(line, parse_constant=_no_constants)
+    assert j["value"] == pytest.approx(1290000.123456789, rel=1e-5) and j["roofline"]["frac"] == pytest.approx(0.9079123, rel=1e-5)
+    assert j["cpu_baseline"]["cores"] == 16 and len(j["cpu_baseline"]["sample"]) == 200 and len(j["extras_summary"]) == 8
+    assert "extra_workloads" not in j and "kernels" not in j["roofline"] and "traffic_note" not in j["roofline"] and "launch_ms" not in j["roofline"]
+    assert j["step_ms_median"] == pytest.approx(19.0357, rel=1e-5)
+    # a record too fat even after the whitelist sheds the optional keys, never the contract ones
+    res["extras_summary"] = [{"workload": "x" * 100, "value": 1.0}] * 60
+    j = json.loads(b.compact_line(res), parse_constant=_no_constants)
+    assert "extras_summary" not in j and j["roofline"]["frac"] > 0.9 and j["cpu_baseline"]["kind"] == "port"

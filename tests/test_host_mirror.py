@@ -2,6 +2,7 @@
 tau schedule, configuration guards."""
 import argparse
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -193,3 +194,21 @@ def test_device_rng_follows_torch_seed_and_separates_streams():
     q = ops.DeviceRng()
     q.load_state_dict(p.state_dict())
     assert (q.seed, q.offset, q.stream_id, q.pinned) == (p.seed, 3, p.stream_id, True)
+    # a checkpoint written by rank 0 and loaded on rank 1 keeps rank 1's own stream (different draws for its shard),
+    # continues at the saved offset, and is pinned -- a different torch seed on resume does not restart it
+    u = ops.DeviceRng()
+    u.offset = 9
+    sd = u.state_dict()
+    os.environ["RANK"] = "1"
+    try:
+        v = ops.DeviceRng()
+        v.load_state_dict(sd)
+    finally:
+        os.environ.pop("RANK")
+    assert v.stream_id >> 20 == 1 and v.stream_id & 0xFFFFF == u.stream_id & 0xFFFFF and v.seed != u.seed and v.offset == 9
+    w = ops.DeviceRng()
+    w.load_state_dict(sd)                                             # the writing rank: exact continuation
+    assert (w.seed, w.offset, w.stream_id) == (u.seed, 9, u.stream_id) and w.pinned
+    torch.manual_seed(4321)
+    w.follow_torch_seed()
+    assert (w.seed, w.offset) == (u.seed, 9)

@@ -327,3 +327,38 @@ def test_caster_draws_its_randomness_from_the_device_rng():
     det, _ = run(123, ray_noise=0.0, perturb=0.0, raw_noise=0.0)
     assert caster._rng.offset == 0                    # nothing random asked for: no launch, no draw consumed
     assert float((det["rgb_map"] - a["rgb_map"]).abs().max()) > 1e-4
+
+
+@pytest.mark.gpu
+def test_driver_command_prints_one_bounded_strict_line():
+    """The driver's N = 1 command, verbatim (`python3 bench.py --gpus 1 --steps 20 --warmup 5`): the LAST stdout line is the only
+    one, <= 4096 bytes, strict JSON (no NaN / Infinity tokens), and carries the contract keys with `roofline`, `cpu_baseline` and
+    the per-extra summary; the full record is in bench_detail.json.  (BENCH_r04 came back parsed = null on a 20 KB line.)"""
+    def no_constants(tok):
+        raise ValueError(f"non-strict JSON token {tok!r}")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    detail = os.path.join(ROOT, "bench_detail.json")
+    if os.path.exists(detail):
+        os.unlink(detail)
+    r = subprocess.run(["python3", "bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5"], env=env, capture_output=True, text=True,
+                       timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stdout.endswith("\n") and len(r.stdout.strip().splitlines()) == 1, r.stdout[-500:]
+    line = r.stdout.rstrip("\n").splitlines()[-1]
+    assert len(line.encode()) <= 4096, len(line.encode())
+    j = json.loads(line, parse_constant=no_constants)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "parity", "ranks", "backend", "extras_summary"):
+        assert k in j, k
+    assert j["metric"] == "rays/sec" and j["n_gpus"] == 1 and j["steps"] == 20 and j["warmup"] == 5 and j["dtype"] == "f32"
+    assert "BASELINE config 2" in j["config"]["workload"] and j["config"]["rays_per_step"] == 261121
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "flop_per_launch", "traffic"):
+        assert k in j["roofline"], k
+    assert j["roofline"]["bound"] == "mfma" and 0.5 < j["roofline"]["frac"] < 1.0 and j["roofline"]["peak"] == 157.3
+    assert j["value"] == pytest.approx(261121 / (j["ms_per_step"] * 1e-3), rel=1e-4)
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in j["cpu_baseline"], k
+    assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["value"] > 0
+    assert len(j["extras_summary"]) >= 7 and all("error" not in e and e["frac"] > 0 for e in j["extras_summary"]), j["extras_summary"]
+    full = json.load(open(detail))
+    assert len(full["extra_workloads"]) == len(j["extras_summary"]) and "kernels" in full["extra_workloads"][1]["roofline"]

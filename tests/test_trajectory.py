@@ -168,3 +168,83 @@ def test_five_training_iterations_follow_the_reference_trajectory(name, tail):
     if case["mixamo"]:      # the pose cadence: stepped at i = 2 and 4 only -> Adam step count 2
         steps = (fused._steps[1] if tail == "fused" else int(pose_torch_opt.state[layer.bones]["step"]))
         assert steps == 2
+
+
+def _mixamo_trainer(tail, dev, **over):
+    """the mixamo case of the trajectory test as a reusable set-up: (trainer, caster, pose layer, fused-or-None, pose torch optimiser)"""
+    case = CASES["mixamo"]
+    args = ref_args("mixamo", **over)
+    data_attrs = {"skel_type": Skel, "near": 0.0, "far": 1.0, "n_views": N_POSES, "hwf": (512, 512, 600.0),
+                  "joint_coords": np.tile(np.eye(3, dtype=np.float32), (24, 1, 1))}
+    rk_train, rk_test, _, grad_vars, torch_opt, _ = raycaster.create_raycaster(args, data_attrs, device=dev)
+    caster = rk_test["ray_caster"]
+    for net, seed in ((caster.network, case["seeds"][0]), (caster.network_fine, case["seeds"][1])):
+        net.load_state_dict({k: torch.tensor(v) for k, v in synth.make_net_params(seed, args.multires, args.multires_views, 16, N_POSES).items()})
+    rk_train["pytest"] = True
+    poses = [synth.make_pose(k) for k in range(N_POSES)]
+    kps, bones = np.stack([q["kp"] for q in poses]), np.stack([q["bones"] for q in poses])
+    layer = pose_opt.PoseOptLayer(kps, bones, (synth.SMPL_REST_POSE * synth.SURREAL_SCALE)[None], use_rot6d=args.opt_rot6d).to(dev)
+    anchors = {"kps": torch.tensor(kps), "bones": torch.tensor(bones),
+               "rots": pose_opt.axisang_to_rot(torch.tensor(bones).reshape(-1, 3)).reshape(N_POSES, 24, 3, 3), "beta": None}
+    with torch.no_grad():
+        layer.bones.add_(torch.tensor((np.random.RandomState(77).randn(*layer.bones.shape) * 0.12).astype(np.float32), device=dev))
+    popt_kwargs = {"popt_layer": layer, "popt_anchors": anchors, "skel_type": Skel}
+    pose_torch_opt = torch.optim.Adam(layer.parameters(), lr=args.opt_pose_lrate, betas=(0.9, 0.999))
+    fused = None
+    if tail == "fused":
+        fused = optim.FusedAdam([{"params": grad_vars, "lr": args.lrate},
+                                 {"params": list(layer.parameters()), "lr": args.opt_pose_lrate, "step_every": args.opt_pose_step}],
+                                betas=(0.9, 0.999)).attach(caster, pose_layer=layer)
+        opt, popt = fused.group_optimizer(0), fused.group_optimizer(1)
+    else:
+        opt, popt = torch_opt, pose_torch_opt
+    tr = trainer_mod.Trainer(args, data_attrs, opt, popt, rk_train, rk_test, popt_kwargs=popt_kwargs, device=dev)
+    caster.train()
+    return tr, caster, layer, fused, pose_torch_opt
+
+
+@pytest.mark.gpu
+def test_fresh_batches_reach_the_pose_layer_with_their_own_indices():
+    """a loader yields NEW tensors every iteration, and the allocator hands the freed kp_idx block back at the same
+    address -- the pose layer must still see each batch's own indices (the reference: `kp_idx.cpu().numpy()` per iteration,
+    core/trainer.py:299), whether kp_idx arrives on the host (a DataLoader's batch) or already on the device."""
+    dev = torch.device("cuda")
+    tr, caster, layer, fused, _ = _mixamo_trainer("fused", dev, opt_pose_step=1)
+    case = dict(CASES["mixamo"])
+    base = {k: v.cpu() for k, v in _batch(case, dev).items()}
+    rng = np.random.default_rng(3)
+    for i in range(1, 7):
+        which = np.sort(rng.choice(N_POSES, size=3 + i % 3, replace=False))
+        idx = torch.tensor(which[rng.integers(0, len(which), size=case["n"])], dtype=torch.int64)
+        idx[:len(which)] = torch.tensor(which)
+        batch = dict(base, kp_idx=idx if i % 2 else idx.to(dev), cam_idxs=idx.to(torch.float32))
+        tr.train_batch(batch, i=i, global_step=i)
+        assert np.array_equal(layer.last_unique["idxs"], which), (i, layer.last_unique["idxs"], which)
+        assert int(layer.last_unique["counts"].sum()) == case["n"]
+        del batch, idx
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tail", ["fused", "torch"])
+def test_pose_parameters_freeze_at_opt_pose_stop(tail):
+    """from iteration opt_pose_stop on the reference never steps pose_optimizer again (trainer.py:441-483, the
+    `not popt_detach` guard) -- bones / pelvis and the pose Adam step count stand still although Adam's first moments are not
+    zero, in the fused tail as in the torch tail; the network group keeps training."""
+    dev = torch.device("cuda")
+    tr, caster, layer, fused, pose_torch_opt = _mixamo_trainer(tail, dev, opt_pose_step=1, opt_pose_stop=3)
+    batch = _batch(CASES["mixamo"], dev)
+    snaps, w = [], []
+    for i in range(1, 6):
+        tr.train_batch(batch, i=i, global_step=i)
+        snaps.append((layer.bones.detach().clone(), layer.pelvis.detach().clone()))
+        w.append(caster.network.pts_linears[3].weight.detach().clone())
+    steps = fused._steps[1] if tail == "fused" else int(pose_torch_opt.state[layer.bones]["step"])
+    assert steps == 2                                                       # iterations 1 and 2 only
+    assert not torch.equal(snaps[0][0], snaps[1][0])                       # the pose did move while it was allowed to
+    for s in snaps[2:]:
+        assert torch.equal(s[0], snaps[1][0]) and torch.equal(s[1], snaps[1][1])
+    assert not torch.equal(w[4], w[2])                                      # the networks go on
+    if tail == "fused":
+        assert fused._steps[0] == 5
+        o, n = fused._segments()[1]
+        assert float(fused.exp_avg[o:o + n].abs().max()) > 0                # moments are non-zero: a step would have moved the pose
