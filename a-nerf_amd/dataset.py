@@ -9,16 +9,27 @@ from it through `BaseH5Dataset` + `ray_collate_fn` (`core/dataset.py:20-420, 813
     c2ws [N,4,4]  focals [N] or [N,2]  (centers [N,2], gt_kp3d, kp_idxs / cam_idxs for multi-view sets: optional)
 
 `H5PoseData` reads that layout -- from a real `.h5` when `h5py` is importable (it is not in the build image; the import is
-optional and loud), or from an `.npz` twin holding the same keys with the same shapes and dtypes (`write_npz_twin`; what
-the tests use) -- and `sample_batch()` assembles exactly the batch dict `ray_collate_fn` hands to `Trainer.train_batch`
-(`rays [2,N,3], target_s, kp_idx, kp3d, bones, skts, cyls, cam_idxs, fgs, bgs`, all per-ray replicated), as device tensors.
+optional and loud), or from an `.npz` twin holding the same keys with the same shapes and dtypes (`write_npz_twin`) -- and
+`sample_batch()` assembles exactly the batch dict `ray_collate_fn` hands to `Trainer.train_batch` (`rays [2,N,3], target_s,
+kp_idx, kp3d, bones, skts, cyls, cam_idxs, fgs, bgs`, all per-ray replicated), as device tensors.  `kind` selects the
+index arithmetic of the reference's dataset classes: "base" (BaseH5Dataset), "surreal" (SurrealDataset: images and cameras
+arranged (N_cams, N_kps), poses shared by the cameras; load_surreal.py:302-380), "mixamo" (MixamoDataset: the sorted subset
+named by `*selected.npy`, white background; load_mixamo.py:161-199).
+
+Pinned against the reference itself: tests/golden/dataset_*.npz hold the collated batches, `get_meta()` and sampler output of
+the reference's own classes run over tests/h5shim.py (tests/golden/gen_golden_dataset.py); tests/test_dataset_layout.py
+reproduces them key for key.  The pixel sampler consumes numpy's generator exactly as the reference does (one
+`choice(valid, N, replace=False)` and one `random()` per image, dataset.py:298-318), so a seeded run draws the same pixels.
+One stated difference: ray directions are float32 here; the reference's are float32 under NumPy 1.x and float64 under
+NumPy >= 2 (its `np.int32 * 0.5` image-centre offset becomes a float64 scalar, dataset.py:150-163) -- `render()` casts to
+float32 either way (trainer.py:124-125).
 Host-side I/O only: no arithmetic of the hot path lives here.
 """
 import numpy as np
 import torch
 
 REQUIRED = ("img_shape", "imgs", "masks", "sampling_masks", "kp3d", "bones", "skts", "cyls", "rest_pose", "c2ws", "focals")
-OPTIONAL = ("bkgds", "bkgd_idxs", "betas", "centers", "gt_kp3d", "kp_idxs", "cam_idxs", "ext_scale", "pose_scale")
+OPTIONAL = ("bkgds", "bkgd_idxs", "betas", "centers", "gt_kp3d", "img_paths", "ext_scale", "pose_scale")
 IMAGE_KEYS = ("imgs", "bkgds", "masks", "sampling_masks")
 
 
@@ -44,10 +55,12 @@ def write_npz_twin(path, data, compressed=True):
         if k in ("index", "img_path", "img_shape"):          # `redundants` (process_spin.py:244)
             continue
         v = np.asarray(v)
-        if v.ndim == 0:
+        if v.ndim == 0:                                      # "non-iterable": a scalar dataset of the value's own type
             out[k] = v
         elif k in IMAGE_KEYS:
             out[k] = v.reshape(v.shape[0], h * w, v.shape[-1])
+        elif k == "img_paths":                               # byte strings (process_spin.py:277-280)
+            out[k] = v.astype("S")
         elif np.issubdtype(v.dtype, np.floating):
             out[k] = v.astype(np.float32)
         elif np.issubdtype(v.dtype, np.integer):
@@ -57,11 +70,65 @@ def write_npz_twin(path, data, compressed=True):
     (np.savez_compressed if compressed else np.savez)(path, **out)
 
 
+def per_joint_coords(rest_pose, parents):
+    """skeleton_utils.py:493-539 (get_per_joint_coords / create_local_coord): per joint, the frame whose z axis points from the
+    joint to its parent in the rest pose -- rotate about y, then about x, until z meets that direction"""
+    def rot_y(t):
+        return np.array([[np.cos(t), 0, -np.sin(t)], [0, 1, 0], [np.sin(t), 0, np.cos(t)]], dtype=np.float32)
+
+    def rot_x(t):
+        return np.array([[1, 0, 0], [0, np.cos(t), -np.sin(t)], [0, np.sin(t), np.cos(t)]], dtype=np.float32)
+    acos = lambda a: np.arccos(np.clip(a, -1. + 1e-8, 1. - 1e-8))
+    out = []
+    for i, j in enumerate(parents):
+        vec = rest_pose[j] - rest_pose[i]
+        vec = vec / (np.linalg.norm(vec) + 1e-5)
+        if np.isclose(np.linalg.norm(vec), 0.):
+            out.append(np.eye(3, dtype=np.float32))
+            continue
+        xz = vec[[0, 2]] / np.linalg.norm(vec[[0, 2]])
+        ry = rot_y(acos(xz[-1]) * np.sign(xz[0]))
+        v1 = ry @ vec
+        yz = v1[1:3] / np.linalg.norm(v1[1:3])
+        rx = rot_x(acos(yz[-1]) * np.sign(yz[0]))
+        m = np.eye(4, dtype=np.float32)
+        m[:3, :3] = rx @ ry
+        out.append(np.eye(3, dtype=np.float32) @ np.linalg.inv(m)[:3, :3].T)
+    return np.array(out)
+
+
+def image_batches(n, N_images, n_iter, generator=None):
+    """RayImageSampler over RandIntGenerator (dataset.py:748-811): `n_iter` sorted batches of `N_images` image indices drawn
+    from successive torch.randperm(n) permutations (every image once per epoch), each permutation seeded as the reference
+    seeds it -- from torch's global generator (`torch.empty((), int64).random_()`) unless `generator` is given."""
+    def perm():
+        g = generator
+        if g is None:
+            g = torch.Generator()
+            g.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))
+        return iter(torch.randperm(n, generator=g).tolist())
+    it, batch = perm(), []
+    for _ in range(n_iter):
+        while len(batch) < N_images:
+            try:
+                batch.append(next(it))
+            except StopIteration:
+                it = perm()
+                batch.append(next(it))
+        yield np.sort(batch)
+        batch = []
+
+
 class H5PoseData:
     """BaseH5Dataset's in-memory meta (dataset.py:125-183) + per-image pixel reads + batch assembly."""
 
-    def __init__(self, path, device="cuda"):
-        self.path, self.device = path, torch.device(device)
+    def __init__(self, path, device="cuda", kind="base", mask_img=False, N_cams=None, N_rand_kps=None, idx_map=None, N_nms=0.0,
+                 patch_size=1):
+        if kind not in ("base", "surreal", "mixamo"):
+            raise ValueError(f"H5PoseData: kind {kind!r} (base | surreal | mixamo)")
+        if N_nms != 0 or patch_size != 1 or N_rand_kps is not None:
+            raise NotImplementedError("N_nms > 0 (P_nms), patch_size > 1 and rand_train_kps are used by no shipped config")
+        self.path, self.device, self.kind, self.mask_img = path, torch.device(device), kind, bool(mask_img)
         f = _open(path)
         keys = set(f.keys())
         missing = [k for k in REQUIRED if k not in keys]
@@ -71,17 +138,37 @@ class H5PoseData:
         shp = np.asarray(f["img_shape"][:])
         self.n_images, self.HW = int(shp[0]), (int(shp[1]), int(shp[2]))
         rd = lambda k: np.asarray(f[k][:])
-        self.kp3d, self.bones, self.skts, self.cyls = (rd(k).astype(np.float32) for k in ("kp3d", "bones", "skts", "cyls"))
-        self.rest_pose = rd("rest_pose").astype(np.float32)
-        self.betas = rd("betas").astype(np.float32) if "betas" in keys else None
-        self.c2ws, self.focals = rd("c2ws").astype(np.float32), rd("focals").astype(np.float32)
-        self.centers = rd("centers").astype(np.float32) if "centers" in keys else None
+        # as stored (float32 on disk); the per-item casts of get_pose_data / get_camera_data are no-ops on them
+        self.kp3d, self.bones, self.skts, self.cyls = (rd(k) for k in ("kp3d", "bones", "skts", "cyls"))
+        self.gt_kp3d = rd("gt_kp3d") if "gt_kp3d" in keys else None
+        self.rest_pose = rd("rest_pose")
+        self.betas = rd("betas") if "betas" in keys else None
+        self.c2ws, self.focals = rd("c2ws"), rd("focals")
+        self.centers = rd("centers") if "centers" in keys else None
         self.has_bg = "bkgds" in keys
         if self.has_bg:
             self.bgs = rd("bkgds").reshape(-1, self.HW[0] * self.HW[1], 3)
             self.bg_idxs = rd("bkgd_idxs").astype(np.int64)
-        self.kp_idxs = rd("kp_idxs").astype(np.int64) if "kp_idxs" in keys else np.arange(self.n_images)
-        self.cam_idxs = rd("cam_idxs").astype(np.int64) if "cam_idxs" in keys else np.arange(self.n_images)
+        # ---- which images a queried index means (`_idx_map`) and how it maps to a pose / a camera
+        self._idx_map = None if idx_map is None else np.asarray(idx_map)
+        self._N_kps = self._N_cams = None
+        if kind == "surreal":                       # load_surreal.py:326-364
+            n_kps_total, n_cams_total = len(self.kp3d), len(self.c2ws) // len(self.kp3d)
+            self._N_kps, self._N_cams = n_kps_total, (n_cams_total if N_cams is None else int(N_cams))
+            if self._N_cams != n_cams_total:        # the reference's hard-coded camera subset
+                self._idx_map = np.concatenate([np.arange(n_kps_total) + n_kps_total * c for c in (0, 3, 6)])
+        elif kind == "mixamo":                      # load_mixamo.py:187-199
+            sel = str(path).replace("processed_h5py.h5", "selected.npy").replace("processed_h5py.npz", "selected.npy")
+            if idx_map is None:
+                if sel == str(path):
+                    raise ValueError("H5PoseData(kind='mixamo'): the file name must contain 'processed_h5py' (its subset is read from "
+                                     "'<prefix>selected.npy' next to it), or pass idx_map")
+                self._idx_map = np.array(sorted(np.load(sel)))
+            else:
+                self._idx_map = np.array(sorted(self._idx_map))
+            self.bgs = np.full((1, self.HW[0] * self.HW[1], 3), 255, dtype=np.uint8)      # "set white bkgd manually"
+            self.bg_idxs = np.zeros(self.n_images, dtype=np.int64)
+            self.has_bg = True
         # per-image pixel reads: h5py slices one row from disk per access; numpy's NpzFile is lazy per KEY, not per row -- every
         # `f[key][idx]` would inflate the whole array again (0.2 s per row on a 39 MB `imgs`, three times per sampled image).
         # The .npz twin's image arrays (uint8) are therefore read ONCE here and indexed in memory as the reference indexes its
@@ -94,17 +181,56 @@ class H5PoseData:
         # pre-computed pixel directions (dataset.py:147-163); the first two columns still need the division by focal
         i, j = np.meshgrid(np.arange(self.HW[1], dtype=np.float32), np.arange(self.HW[0], dtype=np.float32), indexing="xy")
         i, j = i.reshape(-1), j.reshape(-1)
-        oy, ox = (self.HW[0] * 0.5, self.HW[1] * 0.5) if self.centers is None else (0.0, 0.0)
+        oy, ox = (np.float32(self.HW[0] * 0.5), np.float32(self.HW[1] * 0.5)) if self.centers is None else (np.float32(0), np.float32(0))
         self._dirs = np.stack([i - ox, -(j - oy), -np.ones_like(i)], -1)
 
     def __len__(self):
-        return self.n_images
+        return self.n_images if self._idx_map is None else len(self._idx_map)
 
-    def data_attrs(self, near=0.0, far=1.0):
-        """what create_raycaster / create_popt read (run_nerf.py:520-560): skeleton-independent part"""
-        return {"near": near, "far": far, "n_views": int(self.cam_idxs.max()) + 1, "hwf": (self.HW[0], self.HW[1], self.focals),
-                "rest_pose": self.rest_pose, "betas": self.betas, "kp3d": self.kp3d, "bones": self.bones,
-                "skts": self.skts, "cyls": self.cyls, "c2ws": self.c2ws, "centers": self.centers}
+    # ---- index arithmetic of the dataset classes (dataset.py:396-412, load_surreal.py:366-382) ------------------------
+    def get_kp_idx(self, idx, q_idx):
+        """(index of the pose data in the file, index the pose is known by -- PoseOptLayer row, `kp_idx` of the batch)"""
+        if self.kind == "surreal":
+            return idx % len(self.kp3d), q_idx % self._N_kps
+        return idx, q_idx
+
+    def get_cam_idx(self, idx, q_idx):
+        """(index of the camera data in the file, index of the per-view code -- `cam_idxs` of the batch)"""
+        if self.kind == "surreal":
+            return idx, q_idx // self._N_kps
+        return idx, q_idx
+
+    def _subset_idxs(self):
+        """dataset.py:414-431 `_get_subset_idxs`: file indices of the poses / cameras / images the dataset serves"""
+        if self._idx_map is not None:
+            i_idxs = _k = _c = self._idx_map
+            _kq = _cq = np.arange(len(self._idx_map))
+        else:
+            i_idxs = np.arange(self.n_images)
+            _k = _kq = np.arange(len(self.kp3d))
+            _c = _cq = np.arange(len(self.c2ws))
+        k_idxs, _ = self.get_kp_idx(_k, _kq)
+        c_idxs, _ = self.get_cam_idx(_c, _cq)
+        return k_idxs, c_idxs, i_idxs
+
+    def data_attrs(self, skel_type=None):
+        """`get_meta()` (dataset.py:433-484, load_surreal.py:384-387): what create_raycaster / create_popt / the trainer read.
+        skel_type: an object with `joint_trees` (parent index per joint); default: the 24-joint SMPL tree."""
+        from . import synth
+        parents = np.asarray(synth.SMPL_PARENTS if skel_type is None else skel_type.joint_trees)
+        k_idxs, c_idxs, _ = self._subset_idxs()
+        H, W = np.int32(self.HW[0]), np.int32(self.HW[1])                  # img_shape is stored as int32
+        hwf = (np.repeat([H], len(c_idxs), 0), np.repeat([W], len(c_idxs), 0), self.focals[c_idxs])
+        betas = self.betas
+        if betas is not None:
+            if len(betas) > 1:
+                betas = betas[k_idxs]
+            betas = betas.mean(0, keepdims=True).repeat(len(betas), 0)
+        return {"hwf": hwf, "center": None if self.centers is None else self.centers[c_idxs].copy(), "c2ws": self.c2ws[c_idxs],
+                "near": 60., "far": 100., "n_views": self._N_cams if self.kind == "surreal" else len(self),
+                "skel_type": skel_type, "joint_coords": per_joint_coords(self.rest_pose, parents), "rest_pose": self.rest_pose,
+                "gt_kp3d": None if self.gt_kp3d is None else self.gt_kp3d[k_idxs], "kp3d": self.kp3d[k_idxs], "skts": self.skts[k_idxs],
+                "bones": self.bones[k_idxs], "betas": betas, "kp_map": None, "kp_uidxs": None}
 
     # ---- per-image pieces, named as in BaseH5Dataset -------------------------------------------------------------
     def get_rays(self, c2w, focal, pixel_idxs, center=None):
@@ -118,41 +244,50 @@ class H5PoseData:
         rays_d = dirs if np.isclose(np.eye(3), c2w[:3, :3]).all() else np.sum(dirs[..., None, :] * c2w[:3, :3], -1)
         return np.broadcast_to(c2w[:3, -1], rays_d.shape).copy(), rays_d.copy()
 
-    def sample_pixels(self, idx, n, rng):
-        """dataset.py:286-327 for patch_size 1, N_nms 0: n distinct pixels of the sampling mask, ascending"""
+    def sample_pixels(self, idx, n, rng=None):
+        """dataset.py:286-327 for patch_size 1 and N_nms = 0.0: n distinct pixels of image `idx`'s sampling mask, ascending.
+        rng: numpy's global generator (None, as the reference), a RandomState, or a Generator.  Consumes it as the reference
+        does: the choice, then the one `random()` its N_nms dice throws even at probability 0 (dataset.py:312-318)."""
+        rng = np.random if rng is None else rng
         mask = np.asarray(self._f["sampling_masks"][idx]).reshape(-1)      # one row (h5py: one read; .npz twin: resident array)
         valid, = np.where(mask > 0)
-        return np.sort(rng.choice(valid, n, replace=False))
+        px = rng.choice(valid, n, replace=False)
+        rng.random()
+        return np.sort(px)
 
-    def get_img_data(self, idx, pixel_idxs, mask_img=False):
+    def get_img_data(self, idx, pixel_idxs, mask_img=None):
         """dataset.py:262-284: (rgb in [0,1], foreground mask, background colour or None) at the sampled pixels"""
-        fg = np.asarray(self._f["masks"][idx])[pixel_idxs].astype(np.float32)
-        img = np.asarray(self._f["imgs"][idx])[pixel_idxs].astype(np.float32) / 255.0
+        mask_img = self.mask_img if mask_img is None else mask_img
+        fg = np.asarray(self._f["masks"][idx, pixel_idxs]).astype(np.float32)
+        img = np.asarray(self._f["imgs"][idx, pixel_idxs]).astype(np.float32) / 255.
         bg = None
         if self.has_bg:
-            bg = self.bgs[self.bg_idxs[idx], pixel_idxs].astype(np.float32) / 255.0
+            bg = self.bgs[self.bg_idxs[idx], pixel_idxs].astype(np.float32) / 255.
             if mask_img:
-                img = img * fg + (1.0 - fg) * bg
+                img = img * fg + (1. - fg) * bg
         return img, fg, bg
 
     # ---- the collated batch ---------------------------------------------------------------------------------------
-    def sample_batch(self, img_idxs, n_per_image, rng=None, mask_img=False):
-        """`ray_collate_fn` over `BaseH5Dataset.__getitem__` for the images `img_idxs` (dataset.py:60-103, 813-820):
-        len(img_idxs) * n_per_image rays, every per-pose / per-camera quantity replicated per ray, on `self.device`."""
-        rng = np.random.default_rng() if rng is None else rng
+    def sample_batch(self, q_idxs, n_per_image, rng=None, mask_img=None):
+        """`ray_collate_fn` over `__getitem__` for the QUERIED indices `q_idxs` (in [0, len(self)); dataset.py:57-103, 813-820):
+        len(q_idxs) * n_per_image rays, every per-pose / per-camera quantity replicated per ray, on `self.device`."""
         cols = {k: [] for k in ("rays_o", "rays_d", "target_s", "kp_idx", "kp3d", "bones", "skts", "cyls", "cam_idxs", "fgs", "bgs")}
-        for idx in np.asarray(img_idxs).reshape(-1):
-            idx = int(idx)
+        for q in np.asarray(q_idxs).reshape(-1):
+            q = int(q)
+            idx = q if self._idx_map is None else int(self._idx_map[q])
+            cam_real, cam_idx = self.get_cam_idx(idx, q)
+            kp_real, kp_idx = self.get_kp_idx(idx, q)
             px = self.sample_pixels(idx, n_per_image, rng)
-            center = None if self.centers is None else self.centers[idx]
-            ro, rd = self.get_rays(self.c2ws[idx], self.focals[idx], px, center)
+            center = None if self.centers is None else self.centers[cam_real]
+            ro, rd = self.get_rays(self.c2ws[cam_real].astype(np.float32), self.focals[cam_real], px, center)
             rgb, fg, bg = self.get_img_data(idx, px, mask_img)
-            kidx = int(self.kp_idxs[idx])
-            rep = lambda a: np.repeat(a[kidx:kidx + 1], n_per_image, 0)
+            rep = lambda a: np.repeat(a[kp_real:kp_real + 1].astype(np.float32), n_per_image, 0)
             cols["rays_o"].append(ro), cols["rays_d"].append(rd), cols["target_s"].append(rgb), cols["fgs"].append(fg)
-            cols["bgs"].append(bg if bg is not None else np.zeros_like(rgb))
-            cols["kp_idx"].append(np.full(n_per_image, kidx, np.int64))
-            cols["cam_idxs"].append(np.full(n_per_image, int(self.cam_idxs[idx]), np.int64))
+            if bg is None:
+                raise KeyError(f"{self.path}: no `bkgds` (the reference's collate fails on a None background too)")
+            cols["bgs"].append(bg)
+            cols["kp_idx"].append(np.full(n_per_image, kp_idx, np.int64))
+            cols["cam_idxs"].append(np.full(n_per_image, cam_idx, np.int64))
             cols["kp3d"].append(rep(self.kp3d)), cols["bones"].append(rep(self.bones)), cols["skts"].append(rep(self.skts))
             cols["cyls"].append(rep(self.cyls))
         batch = {k: torch.as_tensor(np.concatenate(v, 0)).to(self.device) for k, v in cols.items()}

@@ -67,3 +67,52 @@ def build(name):
     if c.get("ray_noise"):
         out["pts_noise"], out["pts_noise_is"] = ray_noise_arrays(c["n"], c["S"], c["Ni"])
     return out
+
+
+# ---- on-disk dataset layout: the dicts the reference's write_to_h5py receives, numpy-seeded ------------------
+DATASET_CASES = {
+    # name: images, poses, (H, W), reference dataset class, its kwargs, image batches (QUERIED indices, sorted as RayImageSampler
+    # yields them), seed of numpy's global generator before each batch
+    "base": dict(n=3, n_poses=3, HW=(24, 32), focal=40.0, cls="BaseH5Dataset", kw={}, batches=[[0, 2], [1, 1, 2]], seed=5),
+    "base_mask_img": dict(n=3, n_poses=3, HW=(24, 32), focal=40.0, cls="BaseH5Dataset", kw=dict(mask_img=True), batches=[[0, 1]], seed=6),
+    "centers": dict(n=3, n_poses=3, HW=(20, 28), focal=35.0, cls="BaseH5Dataset", kw={}, batches=[[0, 1, 2]], seed=7, centers=True,
+                    focal_xy=True),
+    # SURREAL: imgs / c2ws arranged (N_cams, N_kps); kp3d holds N_kps poses (load_surreal.py:302-380)
+    "surreal_full": dict(n=21, n_poses=3, HW=(16, 20), focal=30.0, cls="SurrealDataset", kw={}, batches=[[0, 4, 11, 20]], seed=8),
+    "surreal_3cams": dict(n=21, n_poses=3, HW=(16, 20), focal=30.0, cls="SurrealDataset", kw=dict(N_cams=3), batches=[[1, 3, 8], [0, 5]], seed=9),
+    # Mixamo: a sorted subset of the file (selected.npy), white background whatever the file holds (load_mixamo.py:161-199)
+    "mixamo": dict(n=10, n_poses=10, HW=(16, 20), focal=30.0, cls="MixamoDataset", kw=dict(subject="james"), batches=[[0, 3], [1, 2, 2]], seed=10,
+                   selected=[7, 1, 4, 8], img_paths=True),
+}
+DATASET_N_SAMPLES = 24
+
+
+def dataset_dict(name):
+    """the dict handed to write_to_h5py (images as [N,H,W,C]) for a DATASET_CASES entry; same arrays on every box"""
+    c = DATASET_CASES[name]
+    n, (H, W) = c["n"], c["HW"]
+    rng = np.random.default_rng(100 + sorted(DATASET_CASES).index(name.replace("_mask_img", "")))
+    poses = [synth.make_pose(50 + k) for k in range(c["n_poses"])]
+    c2w = synth.default_c2w()
+    c2ws = np.stack([c2w] * n).astype(np.float64)
+    c2ws[:, :3, 3] += rng.normal(0, 0.05, (n, 3))
+    for k in range(n // 2):                      # half of the cameras rotated (get_rays takes its dot-product branch), half identity-like
+        a = 0.1 * (k + 1)
+        R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        c2ws[2 * k, :3, :3] = R @ c2ws[2 * k, :3, :3]
+    masks = (rng.random((n, H, W, 1)) > 0.4).astype(np.uint8)
+    d = {"imgs": rng.integers(0, 256, (n, H, W, 3), dtype=np.uint8), "masks": masks,
+         "sampling_masks": np.maximum(masks, (rng.random((n, H, W, 1)) > 0.7).astype(np.uint8)),
+         "bkgds": rng.integers(0, 256, (2, H, W, 3), dtype=np.uint8), "bkgd_idxs": (np.arange(n) % 2).astype(np.int32),
+         "kp3d": np.stack([q["kp"] for q in poses]).astype(np.float64), "gt_kp3d": np.stack([q["kp"] for q in poses]).astype(np.float64),
+         "bones": np.stack([q["bones"] for q in poses]), "skts": np.stack([q["skts"] for q in poses]),
+         "cyls": np.stack([synth.bounding_cylinder(q["kp"]) for q in poses]),
+         "rest_pose": (synth.SMPL_REST_POSE * synth.SURREAL_SCALE), "betas": rng.normal(0, 1, (1 if name.startswith("surreal") else c["n_poses"], 10)),
+         "c2ws": c2ws, "focals": (np.stack([np.full(n, c["focal"]), np.full(n, c["focal"] * 1.1)], -1) if c.get("focal_xy")
+                                  else np.full(n, c["focal"]) + np.arange(n) * 0.5),
+         "ext_scale": 0.001, "index": np.arange(n)}
+    if c.get("centers"):
+        d["centers"] = np.stack([np.full(n, W * 0.5) + rng.normal(0, 2, n), np.full(n, H * 0.5) + rng.normal(0, 2, n)], -1)
+    if c.get("img_paths"):
+        d["img_paths"] = np.array([f"seq{k // 4}/Image{k % 4 + (2 if k == 6 else 0):04d}.png" for k in range(n)])
+    return d

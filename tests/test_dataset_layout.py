@@ -1,76 +1,150 @@
-"""CPU: the reference's dataset layout (core/process_spin.py:234-297) through a-nerf_amd/dataset.py.
+"""CPU: the reference's on-disk dataset layout and its reader against the REFERENCE'S OWN writer and dataset
+classes.
 
-A small synthetic dataset is written in that layout (`.npz` twin: same keys, shapes, dtypes as the `.h5`), read back, and
-the collated batch (`BaseH5Dataset.__getitem__` + `ray_collate_fn`, core/dataset.py:60-103,813-820) is checked against
-independent sources: rays against synth.camera_rays (itself pinned against the reference's get_rays, synth_pins.npz),
-pose replication, pixel values, background lookup, dtypes; and the sampled training batch feeds the oracle."""
+tests/golden/gen_golden_dataset.py ran `core.process_spin.write_to_h5py`, `BaseH5Dataset` / `SurrealDataset` / `MixamoDataset`
++ `ray_collate_fn`, `get_meta()` and `RayImageSampler` in the build container (h5py -> tests/h5shim.py) over the numpy-seeded
+dicts of tests/cases.py DATASET_CASES and stored what they produced.  Here a-nerf_amd/dataset.py reproduces it:
+  * write_npz_twin == the reference writer's file, key for key (dtype, shape, bytes);
+  * H5PoseData.sample_batch == the collated batch of the reference's DataLoader iteration, key for key and dtype for dtype,
+    from the .npz twin AND through the `.h5` branch of `_open` (h5py -> the same shim);
+  * data_attrs == get_meta(); image_batches == RayImageSampler.
+"""
 import importlib
+import json
+import os
+import sys
+import zlib
 
 import numpy as np
 import pytest
 import torch
 
+import cases
+
 dataset = importlib.import_module("a-nerf_amd.dataset")
 synth = importlib.import_module("a-nerf_amd.synth")
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+KIND = {"BaseH5Dataset": "base", "SurrealDataset": "surreal", "MixamoDataset": "mixamo"}
 
 
-def make_data(n=3, H=24, W=32, focal=40.0):
-    rng = np.random.default_rng(0)
-    poses = [synth.make_pose(50 + k) for k in range(n)]
-    c2w = synth.default_c2w()
-    c2ws = np.stack([c2w] * n)
-    c2ws[1, :3, 3] += [0.1, -0.05, 0.2]
-    masks = (rng.random((n, H, W, 1)) > 0.4).astype(np.uint8)
-    return {"imgs": rng.integers(0, 256, (n, H, W, 3), dtype=np.uint8), "masks": masks,
-            "sampling_masks": np.maximum(masks, (rng.random((n, H, W, 1)) > 0.7).astype(np.uint8)),
-            "bkgds": rng.integers(0, 256, (2, H, W, 3), dtype=np.uint8), "bkgd_idxs": np.array([0, 1, 0]),
-            "kp3d": np.stack([q["kp"] for q in poses]).astype(np.float64), "bones": np.stack([q["bones"] for q in poses]),
-            "skts": np.stack([q["skts"] for q in poses]), "cyls": np.stack([synth.bounding_cylinder(q["kp"]) for q in poses]),
-            "rest_pose": (synth.SMPL_REST_POSE * synth.SURREAL_SCALE), "betas": np.zeros((1, 10)),
-            "c2ws": c2ws, "focals": np.full(n, focal), "index": np.arange(n)}, (H, W, focal)
+def write_case(name, tmp_path, ext):
+    c = cases.DATASET_CASES[name]
+    stem = "james_processed_h5py" if c["cls"] == "MixamoDataset" else "synthetic_train_h5py"
+    path = str(tmp_path / f"{stem}.{ext}")
+    if ext == "npz":
+        dataset.write_npz_twin(path, cases.dataset_dict(name))
+    else:                                    # an ".h5" whose container is the shim's (.npz inside), written uncompressed
+        dataset.write_npz_twin(path + ".npz", cases.dataset_dict(name), compressed=False)
+        os.replace(path + ".npz", path)
+    if "selected" in c:
+        np.save(str(tmp_path / "james_selected.npy"), np.array(c["selected"]))
+    return path, c
 
 
-def test_layout_round_trip_and_batch(tmp_path, oracle):
-    data, (H, W, focal) = make_data()
-    path = str(tmp_path / "tiny_h5py_layout.npz")
-    dataset.write_npz_twin(path, dict(data))
-    raw = np.load(path)
-    assert list(raw["img_shape"]) == [3, H, W, 3] and raw["img_shape"].dtype == np.int32
-    assert raw["imgs"].shape == (3, H * W, 3) and raw["imgs"].dtype == np.uint8 and raw["masks"].shape == (3, H * W, 1)
-    assert raw["kp3d"].dtype == np.float32 and raw["bkgd_idxs"].dtype == np.int64 and "index" not in raw
+@pytest.mark.parametrize("name", sorted(cases.DATASET_CASES))
+def test_writer_matches_the_reference_writer(name, tmp_path):
+    want = json.load(open(os.path.join(GOLDEN, "dataset_layout_manifest.json")))[name]
+    path, _ = write_case(name, tmp_path, "npz")
+    with np.load(path, allow_pickle=False) as z:
+        got = {k: {"dtype": str(z[k].dtype), "shape": list(z[k].shape), "crc32": zlib.crc32(np.ascontiguousarray(z[k]).tobytes())}
+               for k in sorted(z.files)}
+    assert sorted(got) == sorted(want)
+    for k in want:
+        assert got[k] == want[k], k
+    assert "index" not in got and got["img_shape"]["dtype"] == "int32" and got["imgs"]["dtype"] == "uint8"
+
+
+@pytest.fixture
+def h5py_shim():
+    """`import h5py` -> tests/h5shim.py for the duration of a test (h5py itself is not in the image)"""
+    import h5shim
+    had = sys.modules.get("h5py")
+    h5shim.install()
+    yield h5shim
+    if had is None:
+        sys.modules.pop("h5py", None)
+    else:
+        sys.modules["h5py"] = had
+
+
+@pytest.mark.parametrize("ext", ["npz", "h5"])
+@pytest.mark.parametrize("name", sorted(cases.DATASET_CASES))
+def test_collated_batch_matches_the_reference_dataset(name, ext, tmp_path, h5py_shim):
+    g = dict(np.load(os.path.join(GOLDEN, f"dataset_{name}.npz")))
+    path, c = write_case(name, tmp_path, ext)
+    ds = dataset.H5PoseData(path, device="cpu", kind=KIND[c["cls"]], mask_img=c["kw"].get("mask_img", False), N_cams=c["kw"].get("N_cams"))
+    if ext == "h5":
+        assert isinstance(ds._f, h5py_shim.File)                       # the `.h5` branch of _open ran, rows are read per access
+    assert len(ds) == int(g["len"])
+    n = cases.DATASET_N_SAMPLES
+    for b, q_idxs in enumerate(c["batches"]):
+        np.random.seed(c["seed"] + b)                                  # the reference samples from numpy's global generator
+        got = ds.sample_batch(q_idxs, n)
+        assert sorted(got) == [str(k) for k in g["batch_keys"]]
+        for k in got:
+            want = g[f"b{b}.{k}"]
+            have = got[k].numpy()
+            assert have.shape == want.shape, (k, have.shape, want.shape)
+            if k in ("rays_d", "rays") and want.dtype == np.float64:
+                # the reference under NumPy >= 2: float64 directions (an np.int32 * 0.5 offset promotes them); float32 under
+                # NumPy 1.x and here.  Same numbers to float32 rounding of the few operations involved
+                assert have.dtype == np.float32
+                np.testing.assert_allclose(have, want, rtol=3e-7, atol=3e-7)
+            else:
+                assert have.dtype == want.dtype, (k, have.dtype, want.dtype)
+                np.testing.assert_array_equal(have, want, err_msg=k)
+        assert got["kp_idx"].dtype == torch.int64 and got["rays"].shape == (2, n * len(q_idxs), 3)
+    # seeded another way: a RandomState handed in draws the same pixels as the global generator with that seed
+    np.random.seed(123)
+    a = ds.sample_batch(c["batches"][0], n)
+    b_ = ds.sample_batch(c["batches"][0], n, rng=np.random.RandomState(123))
+    assert all(torch.equal(a[k], b_[k]) for k in a)
+
+
+@pytest.mark.parametrize("name", sorted(cases.DATASET_CASES))
+def test_data_attrs_match_get_meta(name, tmp_path):
+    g = dict(np.load(os.path.join(GOLDEN, f"dataset_{name}.npz")))
+    path, c = write_case(name, tmp_path, "npz")
+    ds = dataset.H5PoseData(path, device="cpu", kind=KIND[c["cls"]], N_cams=c["kw"].get("N_cams"))
+    m = ds.data_attrs()
+    assert sorted(m) == [str(k) for k in g["meta.keys"]]
+    H, W, focals = m["hwf"]
+    for key, have in (("H", H), ("W", W), ("focals", focals), ("c2ws", m["c2ws"]), ("rest_pose", m["rest_pose"]), ("kp3d", m["kp3d"]),
+                      ("skts", m["skts"]), ("bones", m["bones"]), ("betas", m["betas"]), ("joint_coords", m["joint_coords"])):
+        want = g[f"meta.{key}"]
+        assert np.asarray(have).shape == want.shape and np.asarray(have).dtype == want.dtype, (key, np.asarray(have).dtype, want.dtype)
+        np.testing.assert_array_equal(np.asarray(have), want, err_msg=key)
+    assert int(m["n_views"]) == int(g["meta.n_views"]) and [m["near"], m["far"]] == list(g["meta.near_far"])
+    if "meta.center" in g:
+        np.testing.assert_array_equal(m["center"], g["meta.center"])
+    else:
+        assert m["center"] is None
+    if "meta.gt_kp3d" in g:
+        np.testing.assert_array_equal(m["gt_kp3d"], g["meta.gt_kp3d"])
+
+
+def test_image_batches_follow_the_reference_sampler():
+    g = np.load(os.path.join(GOLDEN, "dataset_sampler.npz"))
+    torch.manual_seed(int(g["seed"]))
+    got = np.stack(list(dataset.image_batches(int(g["n"]), int(g["N_images"]), len(g["batches"]))))
+    np.testing.assert_array_equal(got, g["batches"])
+    assert all((np.diff(b) >= 0).all() for b in got)
+    assert len(set(got.reshape(-1)[:int(g["n"])].tolist())) == int(g["n"])     # every image once per permutation
+
+
+def test_batch_feeds_the_path(tmp_path, oracle):
+    """the sampled batch drives the hot path's oracle: finite output on rays of the sampling mask"""
+    path, c = write_case("base", tmp_path, "npz")
     ds = dataset.H5PoseData(path, device="cpu")
-    assert len(ds) == 3 and ds.HW == (H, W) and ds.has_bg
-    # the .npz twin's image arrays are resident (NpzFile would inflate the whole array on every per-row access)
-    assert all(isinstance(ds._f[k], np.ndarray) for k in ("imgs", "masks", "sampling_masks"))
-    rng = np.random.default_rng(5)
-    b = ds.sample_batch([2, 0], 40, rng=rng)
-    assert set(b) == {"rays_o", "rays_d", "target_s", "kp_idx", "kp3d", "bones", "skts", "cyls", "cam_idxs", "fgs", "bgs", "rays"}
-    assert b["rays"].shape == (2, 80, 3) and b["skts"].shape == (80, 24, 4, 4) and b["kp_idx"].dtype == torch.int64
+    b = ds.sample_batch([2, 0], 40, rng=np.random.default_rng(5))
+    assert b["rays"].shape == (2, 80, 3) and b["skts"].shape == (80, 24, 4, 4)
     assert b["kp_idx"][:40].eq(2).all() and b["kp_idx"][40:].eq(0).all() and b["cam_idxs"][:40].eq(2).all()
-    # re-derive the pixel indices the sampler drew and check every column against independent sources
-    rng2 = np.random.default_rng(5)
-    for blk, idx in enumerate([2, 0]):
-        sl = slice(40 * blk, 40 * blk + 40)
-        valid, = np.where(data["sampling_masks"][idx].reshape(-1) > 0)
-        px = np.sort(rng2.choice(valid, 40, replace=False))
-        ro, rd = synth.camera_rays(H, W, focal, data["c2ws"][idx].astype(np.float32))
-        np.testing.assert_allclose(b["rays_d"][sl].numpy(), rd.reshape(-1, 3)[px], rtol=1e-6, atol=1e-7)
-        np.testing.assert_allclose(b["rays_o"][sl].numpy(), ro.reshape(-1, 3)[px], rtol=0, atol=0)
-        np.testing.assert_allclose(b["target_s"][sl].numpy(), data["imgs"][idx].reshape(-1, 3)[px] / 255.0, atol=1e-7)
-        np.testing.assert_array_equal(b["fgs"][sl].numpy(), data["masks"][idx].reshape(-1, 1)[px].astype(np.float32))
-        np.testing.assert_allclose(b["bgs"][sl].numpy(), data["bkgds"][data["bkgd_idxs"][idx]].reshape(-1, 3)[px] / 255.0, atol=1e-7)
-        np.testing.assert_allclose(b["skts"][sl].numpy(), np.repeat(data["skts"][idx:idx + 1], 40, 0).astype(np.float32))
-        np.testing.assert_allclose(b["cyls"][sl].numpy(), np.repeat(data["cyls"][idx:idx + 1], 40, 0).astype(np.float32))
-    # the batch drives the path: oracle render on it is finite (rays of the sampling mask hit the bounding cylinder or
-    # take the NaN-mean fallback)
-    cfg = oracle.OracleConfig()
+    assert all(isinstance(ds._f[k], np.ndarray) for k in ("imgs", "masks", "sampling_masks"))     # the twin's image arrays are resident
     P = oracle.params_from_numpy(synth.make_net_params(11))
     rb = oracle.make_ray_batch(b["rays"][0], b["rays"][1])
     with torch.no_grad():
-        out = oracle.render_rays(cfg, P, None, rb, b["skts"], b["cyls"], 16)
+        out = oracle.render_rays(oracle.OracleConfig(), P, None, rb, b["skts"], b["cyls"], 16)
     assert torch.isfinite(out["rgb_map"]).all()
-    attrs = ds.data_attrs()
-    assert attrs["n_views"] == 3 and attrs["rest_pose"].shape == (24, 3)
 
 
 def test_errors_are_loud(tmp_path):
@@ -83,3 +157,28 @@ def test_errors_are_loud(tmp_path):
     except ImportError:
         with pytest.raises(ImportError, match="h5py"):
             dataset.H5PoseData(str(tmp_path / "x.h5"), device="cpu")
+    path, _ = write_case("base", tmp_path, "npz")
+    with pytest.raises(NotImplementedError, match="shipped config"):
+        dataset.H5PoseData(path, device="cpu", patch_size=4)
+    with pytest.raises(ValueError, match="kind"):
+        dataset.H5PoseData(path, device="cpu", kind="zju")
+
+
+def test_data_attrs_build_the_caster(tmp_path):
+    """run_nerf.py:520-560: `data_attrs = dataset.get_meta()` goes straight into create_raycaster -- ours does too"""
+    import argparse
+    raycaster = importlib.import_module("a-nerf_amd.raycaster")
+    d = json.load(open(os.path.join(GOLDEN, "args_surreal.json")))
+    d.pop("_config_file")
+    d.update(basedir="/nonexistent")
+
+    class Skel:
+        joint_names = ["j%d" % i for i in range(24)]
+        joint_trees = np.asarray(synth.SMPL_PARENTS)
+    path, c = write_case("surreal_3cams", tmp_path, "npz")
+    ds = dataset.H5PoseData(path, device="cpu", kind="surreal", N_cams=3)
+    attrs = ds.data_attrs(skel_type=Skel)
+    rk_train, rk_test, start, grad_vars, opt, _ = raycaster.create_raycaster(argparse.Namespace(**d), attrs, device="cpu")
+    caster = rk_test["ray_caster"]
+    assert attrs["n_views"] == 3 and tuple(caster.joint_coords.shape[-3:]) == (24, 3, 3)
+    np.testing.assert_array_equal(caster.joint_coords.reshape(24, 3, 3).numpy(), attrs["joint_coords"])
