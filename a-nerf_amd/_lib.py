@@ -35,7 +35,7 @@ class AnerfSaved(C.Structure):
                 ("p_pad", C.c_int64)]
 
 
-ABI_VERSION = 5        # revision of include/anerf.h these structures were written for (checked against anerf_version())
+ABI_VERSION = 6        # revision of include/anerf.h these structures were written for (checked against anerf_version())
 PROF_SLOTS = 16
 
 
@@ -51,6 +51,22 @@ class AnerfRandJob(C.Structure):
     _fields_ = [("out", C.c_void_p), ("n", C.c_int64), ("kind", C.c_int32), ("scale", C.c_float)]
 
 
+MAX_ADAM_GROUPS = 4
+
+
+class AnerfStepBlock(C.Structure):        # DEVICE layout (ABI revision 6); on the host only its size and field offsets are used
+    _fields_ = [("rng_seed", C.c_uint64), ("rng_offset", C.c_uint64), ("tau_v", C.c_float), ("tau_d", C.c_float),
+                ("adam_step_size", C.c_float * MAX_ADAM_GROUPS), ("adam_sqrt_bc2", C.c_float * MAX_ADAM_GROUPS),
+                ("adam_grad_scale", C.c_float * MAX_ADAM_GROUPS), ("reserved_", C.c_float * 2)]
+
+
+class AnerfStepValues(C.Structure):
+    _fields_ = [("rng_seed", C.c_uint64), ("rng_offset", C.c_uint64), ("tau_v", C.c_float), ("tau_d", C.c_float),
+                ("n_groups", C.c_int32), ("lr", C.c_float * MAX_ADAM_GROUPS), ("beta1", C.c_float * MAX_ADAM_GROUPS),
+                ("beta2", C.c_float * MAX_ADAM_GROUPS), ("adam_step", C.c_int32 * MAX_ADAM_GROUPS),
+                ("grad_scale", C.c_float * MAX_ADAM_GROUPS)]
+
+
 class AnerfForwardIO(C.Structure):
     _fields_ = [("packed_c", C.c_void_p), ("aux_c", C.c_void_p), ("packed_f", C.c_void_p), ("aux_f", C.c_void_p),
                 ("rays", C.c_void_p), ("ray_stride", C.c_int32),
@@ -62,7 +78,8 @@ class AnerfForwardIO(C.Structure):
                 ("single_net", C.c_int32), ("precision", C.c_int32),
                 ("rgb_map", C.c_void_p), ("disp_map", C.c_void_p), ("acc_map", C.c_void_p), ("alpha", C.c_void_p),
                 ("rgb0", C.c_void_p), ("disp0", C.c_void_p), ("acc0", C.c_void_p), ("alpha0", C.c_void_p),
-                ("pts_noise", C.c_void_p), ("pts_noise_is", C.c_void_p), ("profile", C.POINTER(AnerfProfile)), ("cyl_shared", C.c_int32)]
+                ("pts_noise", C.c_void_p), ("pts_noise_is", C.c_void_p), ("profile", C.POINTER(AnerfProfile)), ("cyl_shared", C.c_int32),
+                ("step", C.c_void_p)]
 
 
 class AnerfNetGrads(C.Structure):
@@ -172,6 +189,10 @@ SIGNATURES = {
     "anerf_adam_blocks": (C.c_int, [C.c_int64]),
     "anerf_adam_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
                                   C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "anerf_step_block_write": (C.c_int, [C.c_void_p, C.POINTER(AnerfStepValues), C.c_void_p]),
+    "anerf_rand_fill_dev": (C.c_int, [C.POINTER(AnerfRandJob), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "anerf_adam_step_dev": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int32, C.c_int32,
+                                      C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

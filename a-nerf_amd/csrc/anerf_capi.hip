@@ -39,7 +39,7 @@ int mlp_raw_entry(const AnerfConfig* cfg, const float* packed, const float* aux,
                   const float* z, const float* skts, long long skt_stride, const float* cam, const float* codes,
                   int n_codes, float tau_v, float tau_d, const float* cut_v, const float* cut_d, const float* x,
                   int x_width, long long P, int N, int S, int nstages, float* raw, bool pre, const AnerfSaved* sv,
-                  hipStream_t st, const float* pnoise = nullptr);
+                  hipStream_t st, const float* pnoise = nullptr, const float* tau_dev = nullptr);
 int mlp_bwd_entry(const float* packed_t, const float* aux, const float* draw, const AnerfSaved* sv, float* dz, float* df,
                   float* dzv, long long P, int nstages, hipStream_t st);
 int launch_gather_raw(const float* raw_c, const float* raw_is, const long long* idx, int n, int S, int Ni, float* out, hipStream_t st);
@@ -50,7 +50,7 @@ int mlp_bwd_b3_entry(const float* packed_t, const float* aux, const float* draw,
 int mlp_b3_entry(const AnerfConfig* cfg, const float* packed, const float* aux, const float* rays, int ray_stride,
                  const float* z, const float* skts, long long skt_stride, const float* cam, const float* codes, int n_codes,
                  float tau_v, float tau_d, const float* cut_v, const float* cut_d, long long P, int N, int S, int nstages,
-                 float* raw, const AnerfSaved* sv, hipStream_t st, const float* pnoise = nullptr);
+                 float* raw, const AnerfSaved* sv, hipStream_t st, const float* pnoise = nullptr, const float* tau_dev = nullptr);
 int launch_pack_b3(const AnerfNetParams* P, const int32_t* table, long long n, void* out, hipStream_t st);
 int mlp_density_entry(const float* packed, const float* aux, const float* pts, const float* skts, float tau_v,
                       const float* cut_v, long long P, int nstages_trunk, float* sigma, hipStream_t st, int gate_bones);
@@ -63,7 +63,7 @@ int mlp_bwd_in_entry(const float* packed_i, const float* dz, const float* dzv, f
 int launch_encode_bwd(int ld, const float* dx, const float* du, int uw, const float* rays, int ray_stride, const float* z,
                       const float* skts, long long skt_stride, float tau_v, float tau_d, const float* cut_v,
                       const float* cut_d, int n, int S, float* dY, float* dQ, float* dskts, bool accumulate, hipStream_t st,
-                      const float* pnoise = nullptr, int gate_bones = 0);
+                      const float* pnoise = nullptr, int gate_bones = 0, const float* tau_dev = nullptr);
 int launch_gather_rows3(const float* a, const float* b, const long long* idx, int n, int S, int Ni, float* out, hipStream_t st);
 int launch_code_reduce(const float* du, int uw, const float* cam, int n, int S, int n_codes, float* rowsum, float* dcodes,
                        hipStream_t st);
@@ -207,7 +207,7 @@ using namespace anerf;
 extern "C" {
 
 const char* anerf_last_error(void) { return g_err; }
-int anerf_version(void) { return 5; }
+int anerf_version(void) { return 6; }
 
 int anerf_layout(const AnerfConfig* cfg, int which, AnerfLayout* out) {
   if (!out) return set_error(ANERF_E_NULL, "out is NULL");
@@ -947,7 +947,9 @@ int forward_impl(const AnerfConfig* cfg, const AnerfForwardIO* io, char* ws, con
     return set_error(ANERF_E_NULL, "forward: pts_noise and pts_noise_is go together when n_importance > 0");
   auto mlp = [&](const float* packed, const float* aux, const float* codes, const float* zz, int ns, float* raw,
                  const AnerfSaved* sv, const float* pn) {
-    if (pn) {   // ray_noise_std > 0: same kernels through the internal entries, which take the point offsets
+    // ABI revision 6: io->step = the device-resident step block; the TRAINING kernels then read {tau_v, tau_d} from it
+    const float* tau_dev = (sv && io->step) ? &io->step->tau_v : nullptr;
+    if (pn || tau_dev) {   // ray_noise_std > 0 / device-resident tau: same kernels through the internal entries, which take both
       AnerfLayout L;
       int r = anerf_layout(cfg, io->precision == 1 ? 3 : 0, &L);
       if (r) return r;
@@ -959,10 +961,10 @@ int forward_impl(const AnerfConfig* cfg, const AnerfForwardIO* io, char* ws, con
       if (io->precision == 1)
         return mlp_b3_entry(cfg, packed, aux, io->rays, io->ray_stride, zz, io->skts, io->skt_ray_stride, io->cam_idx, codes, io->n_codes,
                             io->tau_v, io->tau_d, io->cutoff_v, io->cutoff_d, (long long)n * ns, n, ns, L.n_stages, raw, sv,
-                            (hipStream_t)stream, pn);
+                            (hipStream_t)stream, pn, tau_dev);
       return mlp_raw_entry(cfg, packed, aux, io->rays, io->ray_stride, zz, io->skts, io->skt_ray_stride, io->cam_idx, codes, io->n_codes,
                            io->tau_v, io->tau_d, io->cutoff_v, io->cutoff_d, nullptr, 0, (long long)n * ns, n, ns, L.n_stages, raw, false,
-                           sv, (hipStream_t)stream, pn);
+                           sv, (hipStream_t)stream, pn, tau_dev);
     }
     if (sv)
       return (io->precision == 1 ? anerf_mlp_raw_train_b3 : anerf_mlp_raw_train)(
@@ -1173,7 +1175,7 @@ int anerf_backward(const AnerfConfig* cfg, const AnerfForwardIO* io, const Anerf
     if (b->g_skts) {
       r = launch_encode_bwd(cfg->multires_views, B(w.dx), B(w.du), uw, io->rays, io->ray_stride, zz, io->skts, io->skt_ray_stride,
                             io->tau_v, io->tau_d, io->cutoff_v, io->cutoff_d, (int)n, ns, B(w.dy), B(w.dq), b->g_skts, skts_written, st, pn,
-                            cfg->cutoff_bones);
+                            cfg->cutoff_bones, io->step ? &io->step->tau_v : nullptr);
       if (r) return r;
       skts_written = true;
     }

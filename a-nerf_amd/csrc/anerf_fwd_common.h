@@ -510,6 +510,7 @@ struct MlpArgs {
   long long skt_stride;
   int S, N, ray_stride, n_codes, x_width, nstages;
   float tau_v, tau_d;
+  const float* tau_dev;   // ABI revision 6, TRAIN kernels only: {tau_v, tau_d} in device memory (AnerfStepBlock) or nullptr = the two above
   int gate_bones;   // --cutoff_bones: the bone-direction block r is gated by the distance gate as well (raycasters.py:54-57)
 #ifdef ANERF_EXP_STAGE_TIMING
   unsigned long long* tbuf;   // debug build only: per-stage clocks (tools/stage_timing.py)

@@ -202,6 +202,15 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
   const long long p = (long long)blockIdx.x * TILE + wave * 32 + m;
   const bool valid = p < A.P;
   const long long pc = valid ? p : A.P - 1;
+  // gate temperatures: kernel arguments, or (training step under a captured hipGraph, ABI revision 6) two floats of the
+  // device-resident step block -- wave-uniform scalar loads; the render kernels (TRAIN = false) keep the arguments
+  float tau_v = A.tau_v, tau_d = A.tau_d;
+  if constexpr (TRAIN) {
+    if (A.tau_dev) {
+      tau_v = A.tau_dev[0];
+      tau_d = A.tau_dev[1];
+    }
+  }
   // TRAIN: every lane stores its saved activations unconditionally -- tail lanes (p >= P) computed on the clamped sample
   // pc = P - 1 and so rewrite that row with identical values -- which keeps exec-mask changes out of the MFMA stream.
   const long long ps = pc;
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
       const float n = sqrtf(y0 * y0 + y1 * y1 + y2 * y2);
       const float inv = rcp_nr(fmaxf(n, 1e-12f));
       v[a] = n;
-      wv[a] = cutoff_gate(A.tau_v, n, A.cut_v[j]);
+      wv[a] = cutoff_gate(tau_v, n, A.cut_v[j]);
       const float gb = A.gate_bones ? inv * wv[a] : inv;      // cutoff_bones: r_j * w_j (bone embedder = the distance gate)
       rh[3 * a + 0] = y0 * gb;
       rh[3 * a + 1] = y1 * gb;
@@ -413,7 +422,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd(const MlpArgs A) {
       e[3 * a + 0] = y0 * inv;
       e[3 * a + 1] = y1 * inv;
       e[3 * a + 2] = y2 * inv;
-      wd[a] = cutoff_gate(A.tau_d, v[a], A.cut_d[j]);
+      wd[a] = cutoff_gate(tau_d, v[a], A.cut_d[j]);
     }
     f32x2 wd2[18];   // the gate of every direction component, in operand pairs
 #pragma unroll
@@ -564,9 +573,10 @@ int mlp_raw_entry(const AnerfConfig* cfg, const float* packed, const float* aux,
                   const float* z, const float* skts, long long skt_stride, const float* cam, const float* codes,
                   int n_codes, float tau_v, float tau_d, const float* cut_v, const float* cut_d, const float* x,
                   int x_width, long long P, int N, int S, int nstages, float* raw, bool pre, const AnerfSaved* sv,
-                  hipStream_t st, const float* pnoise) {
+                  hipStream_t st, const float* pnoise, const float* tau_dev) {
   MlpArgs a;
   a.pnoise = pnoise;
+  a.tau_dev = tau_dev;
   a.packed = packed; a.aux = aux; a.rays = rays; a.z = z; a.skts = skts; a.cam = cam; a.codes = codes;
   a.cut_v = cut_v; a.cut_d = cut_d; a.x = x; a.raw = raw; a.P = P; a.skt_stride = skt_stride;
   a.S = S; a.N = N; a.ray_stride = ray_stride; a.n_codes = n_codes; a.x_width = x_width; a.nstages = nstages;

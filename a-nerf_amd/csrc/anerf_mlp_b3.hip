@@ -274,6 +274,13 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
   const long long p = (long long)blockIdx.x * TILE + wave * 32 + m;
   const bool valid = p < A.P;
   const long long pc = valid ? p : A.P - 1;
+  float tau_v = A.tau_v, tau_d = A.tau_d;   // TRAIN: optionally from the device-resident step block (see k_mlp_fwd)
+  if constexpr (TRAIN) {
+    if (A.tau_dev) {
+      tau_v = A.tau_dev[0];
+      tau_d = A.tau_dev[1];
+    }
+  }
 #ifdef ANERF_EXP_B3_NOHSAVE
   const bool save = false;
 #else
@@ -334,7 +341,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
       const float n = sqrtf(y0 * y0 + y1 * y1 + y2 * y2);
       const float inv = rcp_nr(fmaxf(n, 1e-12f));
       v[a] = n;
-      wv[a] = cutoff_gate(A.tau_v, n, A.cut_v[j]);
+      wv[a] = cutoff_gate(tau_v, n, A.cut_v[j]);
       const float gb = A.gate_bones ? inv * wv[a] : inv;      // cutoff_bones: r_j * w_j
       rh[3 * a + 0] = y0 * gb;
       rh[3 * a + 1] = y1 * gb;
@@ -453,7 +460,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_b3(const MlpArgs A) {
     e[3 * a + 0] = y0 * inv;
     e[3 * a + 1] = y1 * inv;
     e[3 * a + 2] = y2 * inv;
-    wd[a] = cutoff_gate(A.tau_d, vn, A.cut_d[j]);
+    wd[a] = cutoff_gate(tau_d, vn, A.cut_d[j]);
   }
   float gse[36], cbe[36];
 #pragma unroll
@@ -529,9 +536,10 @@ static int launch_b3(const MlpArgs& a, hipStream_t st) {
 int mlp_b3_entry(const AnerfConfig* cfg, const float* packed, const float* aux, const float* rays, int ray_stride,
                  const float* z, const float* skts, long long skt_stride, const float* cam, const float* codes, int n_codes,
                  float tau_v, float tau_d, const float* cut_v, const float* cut_d, long long P, int N, int S, int nstages,
-                 float* raw, const AnerfSaved* sv, hipStream_t st, const float* pnoise) {
+                 float* raw, const AnerfSaved* sv, hipStream_t st, const float* pnoise, const float* tau_dev) {
   MlpArgs a;
   a.pnoise = pnoise;
+  a.tau_dev = tau_dev;
   a.packed = packed; a.aux = aux; a.rays = rays; a.z = z; a.skts = skts; a.cam = cam; a.codes = codes;
   a.cut_v = cut_v; a.cut_d = cut_d; a.x = nullptr; a.raw = raw; a.P = P; a.Ppad = P; a.skt_stride = skt_stride;
   a.S = S; a.N = N; a.ray_stride = ray_stride; a.n_codes = n_codes; a.x_width = 0; a.nstages = nstages;

@@ -121,8 +121,13 @@ __global__ __launch_bounds__(RB) void k_loss_final(const float* __restrict__ par
 __global__ __launch_bounds__(RB) void k_adam(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                              float* __restrict__ v, long long n4, long long n, float step_size,
                                              float b1, float b2, float sqrt_bc2, float eps, float gscale, int zero,
-                                             float* __restrict__ partial) {
+                                             float* __restrict__ partial, const AnerfStepBlock* __restrict__ blk, int grp) {
   __shared__ float sh[4];
+  if (blk) {   // ABI revision 6: this group's step size / bias correction / gradient scale from the device-resident step block
+    step_size = blk->adam_step_size[grp];
+    sqrt_bc2 = blk->adam_sqrt_bc2[grp];
+    gscale = blk->adam_grad_scale[grp];
+  }
   float ss = 0.f;
   for (long long i = blockIdx.x * (long long)RB + threadIdx.x; i < n4; i += (long long)gridDim.x * RB) {
     f32x4 pp = reinterpret_cast<f32x4*>(p)[i], gg = reinterpret_cast<f32x4*>(g)[i];
@@ -226,7 +231,26 @@ int anerf_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_
   const int nblk = anerf_adam_blocks(n);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_adam, dim3(nblk), dim3(RB), 0, st, params, grads, exp_avg, exp_avg_sq, (long long)(n / 4), (long long)n,
-                     step_size, beta1, beta2, sqrt_bc2, eps, grad_scale, (int)zero_grads, norms2 ? partials : nullptr);
+                     step_size, beta1, beta2, sqrt_bc2, eps, grad_scale, (int)zero_grads, norms2 ? partials : nullptr,
+                     (const AnerfStepBlock*)nullptr, 0);
+  int rc = check_launch("k_adam");
+  if (rc || !norms2) return rc;
+  hipLaunchKernelGGL(k_sumsq_final, dim3(1), dim3(RB), 0, st, (const float*)partials, nblk, (int)n_tensors, norms2);
+  return check_launch("k_sumsq_final");
+}
+
+int anerf_adam_step_dev(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1, float beta2, float eps,
+                        const AnerfStepBlock* block, int32_t group, int32_t zero_grads, int32_t n_tensors, float* partials,
+                        float* norms2, void* stream) {
+  if (n < 0 || group < 0 || group >= ANERF_MAX_ADAM_GROUPS) return set_error(ANERF_E_SHAPE, "adam_dev: n >= 0, 0 <= group < 4");
+  if (n == 0) return ANERF_OK;
+  if (!block || !params || !grads || !exp_avg || !exp_avg_sq || (norms2 && !partials)) return set_error(ANERF_E_NULL, "adam_dev: NULL pointer");
+  if ((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) != 0)
+    return set_error(ANERF_E_SHAPE, "adam_dev: buffers must be 16-byte aligned");
+  const int nblk = anerf_adam_blocks(n);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_adam, dim3(nblk), dim3(RB), 0, st, params, grads, exp_avg, exp_avg_sq, (long long)(n / 4), (long long)n,
+                     0.f, beta1, beta2, 1.f, eps, 1.f, (int)zero_grads, norms2 ? partials : nullptr, block, (int)group);
   int rc = check_launch("k_adam");
   if (rc || !norms2) return rc;
   hipLaunchKernelGGL(k_sumsq_final, dim3(1), dim3(RB), 0, st, (const float*)partials, nblk, (int)n_tensors, norms2);

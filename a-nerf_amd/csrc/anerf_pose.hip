@@ -23,8 +23,13 @@ __global__ __launch_bounds__(256) void k_encode_bwd(const float* __restrict__ dx
                                                     long long skt_stride, float tau_v, float tau_d,
                                                     const float* __restrict__ cut_v, const float* __restrict__ cut_d,
                                                     long long P, int S, float* __restrict__ dY, float* __restrict__ dQ,
-                                                    const float* __restrict__ pnoise, int gate_bones) {
+                                                    const float* __restrict__ pnoise, int gate_bones,
+                                                    const float* __restrict__ tau_dev) {
   constexpr int LV = 7;
+  if (tau_dev) {   // ABI revision 6: the step block's {tau_v, tau_d} (a captured training step), else the arguments
+    tau_v = tau_dev[0];
+    tau_d = tau_dev[1];
+  }
   const long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   const long long p = gid / 6;
   const int sub = (int)(gid - p * 6);
@@ -227,15 +232,15 @@ __global__ __launch_bounds__(16 * CODE_SLOTS) void k_code_reduce(const float* __
 int launch_encode_bwd(int ld, const float* dx, const float* du, int uw, const float* rays, int ray_stride, const float* z,
                       const float* skts, long long skt_stride, float tau_v, float tau_d, const float* cut_v,
                       const float* cut_d, int n, int S, float* dY, float* dQ, float* dskts, bool accumulate, hipStream_t st,
-                      const float* pnoise, int gate_bones) {
+                      const float* pnoise, int gate_bones, const float* tau_dev) {
   const long long P = (long long)n * S;
   const unsigned blocks = (unsigned)((6 * P + 255) / 256);
   if (ld == 4)
     hipLaunchKernelGGL(k_encode_bwd<4>, dim3(blocks), dim3(256), 0, st, dx, du, uw, rays, ray_stride, z, skts, skt_stride,
-                       tau_v, tau_d, cut_v, cut_d, P, S, dY, dQ, pnoise, gate_bones);
+                       tau_v, tau_d, cut_v, cut_d, P, S, dY, dQ, pnoise, gate_bones, tau_dev);
   else
     hipLaunchKernelGGL(k_encode_bwd<0>, dim3(blocks), dim3(256), 0, st, dx, du, uw, rays, ray_stride, z, skts, skt_stride,
-                       tau_v, tau_d, cut_v, cut_d, P, S, dY, dQ, pnoise, gate_bones);
+                       tau_v, tau_d, cut_v, cut_d, P, S, dY, dQ, pnoise, gate_bones, tau_dev);
   int rc = check_launch("k_encode_bwd");
   if (rc) return rc;
   hipLaunchKernelGGL(k_pose_reduce, dim3(n), dim3(128), 0, st, (const float*)dY, (const float*)dQ, rays, ray_stride, z, n, S,

@@ -7,6 +7,8 @@
 // HBM / latency-bound byte movers; at 384 rays per rank (the 8-GPU shard of the 3072-ray batch) the launches they replace
 // were ~0.3 ms of a 2.6 ms step.
 #include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
 #include <stdint.h>
 #include "anerf.h"
 #include "anerf_dev.h"
@@ -71,7 +73,11 @@ struct RandJobs {
 };
 
 // thread t of job blockIdx.y produces elements 4t .. 4t+3: counter = (t lo, t hi, job, offset lo), key = seed ^ (offset hi)
-__global__ void k_rand_fill(RandJobs J, uint64_t seed, uint64_t offset) {
+__global__ void k_rand_fill(RandJobs J, uint64_t seed, uint64_t offset, const AnerfStepBlock* __restrict__ blk) {
+  if (blk) {   // ABI revision 6: (seed, offset) of a captured training step live in the device-resident step block
+    seed = blk->rng_seed;
+    offset += blk->rng_offset;   // `offset` carries the index of this fill inside the iteration (0, 1, ...: one per caster call)
+  }
   const AnerfRandJob& job = J.j[blockIdx.y];
   const long long quads = (job.n + 3) / 4;
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < quads; t += (long long)gridDim.x * blockDim.x) {
@@ -170,6 +176,23 @@ __global__ __launch_bounds__(128) void k_cyl_bbox(const double* __restrict__ cyl
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ABI revision 6: the step block is written by ONE thread from a by-value copy of its new contents (kernel arguments: no
+// staging buffer the host could overwrite while an earlier write is still queued).  mask bit g = Adam group g is (re)written.
+__global__ void k_step_block_write(AnerfStepBlock* __restrict__ dst, AnerfStepBlock v, unsigned mask) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  dst->rng_seed = v.rng_seed;
+  dst->rng_offset = v.rng_offset;
+  dst->tau_v = v.tau_v;
+  dst->tau_d = v.tau_d;
+  for (int g = 0; g < ANERF_MAX_ADAM_GROUPS; ++g)
+    if (mask & (1u << g)) {
+      dst->adam_step_size[g] = v.adam_step_size[g];
+      dst->adam_sqrt_bc2[g] = v.adam_sqrt_bc2[g];
+      dst->adam_grad_scale[g] = v.adam_grad_scale[g];
+    }
+}
+
 }  // namespace anerf
 
 using namespace anerf;
@@ -199,7 +222,8 @@ int anerf_pack_params_multi(const AnerfPackJob* jobs, int32_t n_jobs, void* stre
   return check_launch("k_pack_multi");
 }
 
-int anerf_rand_fill(const AnerfRandJob* jobs, int32_t n_jobs, uint64_t seed, uint64_t offset, void* stream) {
+static int rand_fill_impl(const AnerfRandJob* jobs, int32_t n_jobs, uint64_t seed, uint64_t offset, const AnerfStepBlock* blk,
+                          void* stream) {
   if (n_jobs == 0) return ANERF_OK;
   if (!jobs) return set_error(ANERF_E_NULL, "rand_fill: jobs is NULL");
   if (n_jobs < 0 || n_jobs > ANERF_MAX_RAND_JOBS) return set_error(ANERF_E_SHAPE, "rand_fill: 0 <= n_jobs <= 6");
@@ -215,8 +239,43 @@ int anerf_rand_fill(const AnerfRandJob* jobs, int32_t n_jobs, uint64_t seed, uin
   if (nmax == 0) return ANERF_OK;
   const long long quads = (nmax + 3) / 4;
   const int blocks = (int)((quads + 255) / 256 < 2048 ? (quads + 255) / 256 : 2048);
-  hipLaunchKernelGGL(k_rand_fill, dim3(blocks, n_jobs), dim3(256), 0, (hipStream_t)stream, J, seed, offset);
+  hipLaunchKernelGGL(k_rand_fill, dim3(blocks, n_jobs), dim3(256), 0, (hipStream_t)stream, J, seed, offset, blk);
   return check_launch("k_rand_fill");
+}
+
+int anerf_rand_fill(const AnerfRandJob* jobs, int32_t n_jobs, uint64_t seed, uint64_t offset, void* stream) {
+  return rand_fill_impl(jobs, n_jobs, seed, offset, nullptr, stream);
+}
+
+int anerf_rand_fill_dev(const AnerfRandJob* jobs, int32_t n_jobs, const AnerfStepBlock* block, int32_t call_index, void* stream) {
+  if (!block) return set_error(ANERF_E_NULL, "rand_fill_dev: block is NULL");
+  if (call_index < 0) return set_error(ANERF_E_SHAPE, "rand_fill_dev: call_index >= 0");
+  return rand_fill_impl(jobs, n_jobs, 0, (uint64_t)call_index, block, stream);
+}
+
+int anerf_step_block_write(AnerfStepBlock* block, const AnerfStepValues* v, void* stream) {
+  if (!block || !v) return set_error(ANERF_E_NULL, "step_block_write: NULL pointer");
+  if (((uintptr_t)block & 15) != 0) return set_error(ANERF_E_SHAPE, "step_block_write: the block must be 16-byte aligned");
+  if (v->n_groups < 0 || v->n_groups > ANERF_MAX_ADAM_GROUPS) return set_error(ANERF_E_SHAPE, "step_block_write: 0 <= n_groups <= 4");
+  AnerfStepBlock b;
+  memset(&b, 0, sizeof(b));
+  b.rng_seed = v->rng_seed;
+  b.rng_offset = v->rng_offset;
+  b.tau_v = v->tau_v;
+  b.tau_d = v->tau_d;
+  unsigned mask = 0;
+  for (int g = 0; g < v->n_groups; ++g) {
+    if (v->adam_step[g] <= 0) continue;            // this group does not step this iteration
+    // bias corrections in double, exactly as anerf_adam_step computes them from (lr, step)
+    const double bc1 = 1.0 - pow((double)v->beta1[g], (double)v->adam_step[g]);
+    const double bc2 = 1.0 - pow((double)v->beta2[g], (double)v->adam_step[g]);
+    b.adam_step_size[g] = (float)((double)v->lr[g] / bc1);
+    b.adam_sqrt_bc2[g] = (float)sqrt(bc2);
+    b.adam_grad_scale[g] = v->grad_scale[g];
+    mask |= 1u << g;
+  }
+  hipLaunchKernelGGL(k_step_block_write, dim3(1), dim3(64), 0, (hipStream_t)stream, block, b, mask);
+  return check_launch("k_step_block_write");
 }
 
 int anerf_make_ray_batch(const float* rays_o, const float* rays_d, int32_t n_rays, float near, float far, int32_t out_stride,

@@ -185,6 +185,67 @@ def pack_params_multi(jobs):
 _rng_instances = [0]
 
 
+class StepBlock:
+    """The device-resident AnerfStepBlock of a captured training step (ABI revision 6) and the host-side AnerfStepValues it
+    is written from: `write()` is ONE launch whose kernel arguments carry the values (stream-ordered; nothing the host could
+    overwrite while an earlier write is still queued).  Inside `with ops.step_block(blk):` every DeviceRng.fill,
+    train_forward / backward and adam_step reads its per-step scalars from the block instead of taking them as kernel
+    arguments -- same kernels, same arithmetic, so the results are bit-identical; what changes is that a captured hipGraph
+    of the step can be replayed without node updates (graph_step.GraphedTrainStep)."""
+
+    def __init__(self, device):
+        self.buf = torch.zeros(C.sizeof(_lib.AnerfStepBlock) // 4, dtype=torch.float32, device=device)
+        self.values = _lib.AnerfStepValues()
+        self.fills = 0            # index of the next DeviceRng.fill inside the current iteration
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr()
+
+    def set_rng(self, seed, offset):
+        self.values.rng_seed, self.values.rng_offset = int(seed), int(offset)
+
+    def set_tau(self, tau_v, tau_d):
+        self.values.tau_v, self.values.tau_d = float(tau_v), float(tau_d)
+
+    def set_adam(self, groups):
+        """groups: per optimiser group (lr, beta1, beta2, step, grad_scale); step <= 0 = the group does not step this iteration"""
+        if len(groups) > _lib.MAX_ADAM_GROUPS:
+            raise ValueError(f"StepBlock: at most {_lib.MAX_ADAM_GROUPS} optimiser groups")
+        v = self.values
+        v.n_groups = len(groups)
+        for g, (lr, b1, b2, step, gs) in enumerate(groups):
+            v.lr[g], v.beta1[g], v.beta2[g], v.adam_step[g], v.grad_scale[g] = float(lr), float(b1), float(b2), int(step), float(gs)
+
+    def write(self):
+        self.fills = 0
+        _lib.check(_lib.load().anerf_step_block_write(C.c_void_p(self.ptr), C.byref(self.values), _stream()), "anerf_step_block_write")
+
+    def read(self):
+        """host copy of the device block (a synchronising D2H copy: tests only)"""
+        raw = self.buf.cpu().numpy().tobytes()
+        return _lib.AnerfStepBlock.from_buffer_copy(raw)
+
+
+_active_step = None
+
+
+class step_block:
+    """route the per-step scalars of the calls inside through `blk` (see StepBlock)"""
+
+    def __init__(self, blk):
+        self.blk = blk
+
+    def __enter__(self):
+        global _active_step
+        self.prev, _active_step = _active_step, self.blk
+        return self.blk
+
+    def __exit__(self, *a):
+        global _active_step
+        _active_step = self.prev
+
+
 class DeviceRng:
     """Counter-based generator behind anerf_rand_fill: (key, offset) on the host, one launch per `fill`.  Stands where the
     reference calls torch.rand / torch.randn on the device (ray_utils.py:171-180,240-246; nerf.py:176-182;
@@ -266,7 +327,12 @@ class DeviceRng:
             jobs.append(_lib.AnerfRandJob(t.data_ptr(), t.numel(), 0 if kind == "uniform" else 1, float(scale)))
         if jobs:
             carr = (_lib.AnerfRandJob * len(jobs))(*jobs)
-            _lib.check(_lib.load().anerf_rand_fill(carr, len(jobs), self.seed, self.offset, _stream()), "anerf_rand_fill")
+            blk = _active_step
+            if blk is not None:       # (seed, offset) from the device-resident step block: the owner writes them per iteration
+                _lib.check(_lib.load().anerf_rand_fill_dev(carr, len(jobs), C.c_void_p(blk.ptr), blk.fills, _stream()), "anerf_rand_fill_dev")
+                blk.fills += 1
+            else:
+                _lib.check(_lib.load().anerf_rand_fill(carr, len(jobs), self.seed, self.offset, _stream()), "anerf_rand_fill")
             self.offset += 1
         return outs
 
@@ -475,15 +541,21 @@ def loss(rgb, acc, target, rgb0=None, acc0=None, bgs=None, loss_type=0, coarse_w
 
 
 def adam_step(params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_scale=1.0, zero_grads=False,
-              n_tensors=0, norms2=None):
+              n_tensors=0, norms2=None, group=0):
     """torch.optim.Adam's update over one flat fp32 buffer (anerf_adam_step).  norms2: optional [2] tensor that
-    receives get_gradnorm's (total_norm, avg_norm)."""
+    receives get_gradnorm's (total_norm, avg_norm).  Inside `with step_block(blk)`: lr / step / grad_scale of optimiser group
+    `group` are read from the device-resident block (anerf_adam_step_dev); the arguments given here are ignored."""
     for t, nm in ((params, "params"), (grads, "grads"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
         if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != params.numel():
             raise ValueError(f"adam_step: {nm} must be contiguous float32 with {params.numel()} elements")
     lib = _lib.load()
     n = params.numel()
     part = torch.empty(lib.anerf_adam_blocks(n), dtype=torch.float32, device=params.device) if norms2 is not None else None
+    if _active_step is not None:
+        _lib.check(lib.anerf_adam_step_dev(_p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), n, float(beta1), float(beta2), float(eps),
+                                           C.c_void_p(_active_step.ptr), int(group), int(bool(zero_grads)), int(n_tensors), _p(part),
+                                           _p(norms2), _stream()), "anerf_adam_step_dev")
+        return
     _lib.check(lib.anerf_adam_step(_p(params), _p(grads), _p(exp_avg), _p(exp_avg_sq), n, float(lr), float(beta1), float(beta2),
                                    float(eps), int(step), float(grad_scale), int(bool(zero_grads)), int(n_tensors), _p(part),
                                    _p(norms2), _stream()), "anerf_adam_step")
@@ -686,6 +758,9 @@ def _forward_io(cfg, net_c, net_f, rays, skts, cyls, n_samples, n_importance, ta
     if _active_profile is not None:
         io.profile = C.pointer(_active_profile.st)
         keep.append(_active_profile)
+    if _active_step is not None:      # the training kernels read tau_v / tau_d from the device-resident step block
+        io.step = _active_step.ptr
+        keep.append(_active_step)
     return io, out, keep
 
 

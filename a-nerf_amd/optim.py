@@ -322,7 +322,7 @@ class FusedAdam:
             norms = self.norms if (want_norms and gi == 0) else None
             ops.adam_step(self.flat[o:o + n], self.flat_grad[o:o + n], self.exp_avg[o:o + n], self.exp_avg_sq[o:o + n],
                           grp["lr"], grp["betas"][0], grp["betas"][1], grp["eps"], self._steps[gi], self._grad_scale[gi],
-                          zero_grad, len(grp["params"]), norms)
+                          zero_grad, len(grp["params"]), norms, group=gi)
             self._grad_scale[gi] = 1.0
             for p in grp["params"]:
                 torch.autograd.graph.increment_version(p)        # parameters changed behind torch's back

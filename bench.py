@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--extra", default="auto", choices=["auto", "on", "off"],
                     help="append `extra_workloads` (5 steps each of train N_rand=3072, train 384 rays, 64+128 bf16x3 render, each "
                          "with its own roofline) to the record; auto = only for the default invocation (render64, fp32, 1 GPU)")
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="train workloads: replay the iteration as ONE captured hipGraph (a-nerf_amd/graph_step.py).  auto = on in a single "
+                         "process with the fused tail, off for multi-rank runs")
     ap.add_argument("--dry-run", action="store_true",
                     help="multi-rank plumbing without a GPU: rendezvous (gloo), the real shard arithmetic of the workload, the "
                          "collectives with their real shapes (frame all-gather / gradient-bucket all-reduce), record assembly and "
@@ -366,7 +369,7 @@ def main():
                             {"workload": tag, "value": e["value"], "ms_per_step": e["ms_per_step"], "frac": e["roofline"]["frac"]} |
                             ({"step_ms": e["step_ms"]["median"]} if e.get("step_ms") else {}) |
                             ({"host_ms": e["host_enqueue_ms"]["median"]} if e.get("host_enqueue_ms") else {}) |
-                            ({"graph": e["graph"]} if "graph" in e else {}))
+                            ({"graph": bool(e["graph"])} if "graph" in e else {}))
             res["extra_workloads"] = ex
             res["extras_summary"] = summ
         emit(res)
@@ -501,10 +504,12 @@ def extra_workloads(args, device, synth, ops, pipeline):
                    "value": r["value"], "unit": r["unit"], "steps": a.steps,
                    "ms_per_step": r["ms_per_step"], "dtype": r["dtype"], "roofline": r["roofline"]}
             for k in ("step_ms", "period_ms", "host_enqueue_ms", "slow_steps", "allocator_in_timed_region",
-                      "gc_collections_in_timed_region", "vs_headline_kernel_bench"):
+                      "gc_collections_in_timed_region", "vs_headline_kernel_bench", "graph"):
                 if k in r:
                     rec[k] = r[k]
-            rec["_key"] = (a.workload, getattr(a, "n_rand", None), getattr(a, "opt_pose_step", None))
+            train = a.workload in ("train", "train_mixamo")
+            rec["_key"] = (a.workload + ("_bf16x3" if a.precision == "bf16x3" else ""), a.n_rand if train else None,
+                           a.opt_pose_step if a.workload == "train_mixamo" else (1 if train else None))
             out.append(rec)
         except Exception as e:       # an extra must never take the headline record down with it
             out.append({"workload": str(over), "error": f"{type(e).__name__}: {e}"})
@@ -893,10 +898,9 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
 
     it = [0]                     # global iteration counter (the reference's `i`, trainer.py:451)
 
-    def step(i=None):
-        if i is not None:
-            host_t[i] = time.perf_counter()
-            ev[i][0].record()
+    def iteration(k, mark=None):
+        """one training iteration (the reference's loop body, trainer.py:228-277) with iteration counter k; `mark(name)` lets the
+        eager path record HIP events between its phases (a captured graph has no such points)"""
         b = batch
         if mixamo:   # per-ray pose indices, as the reference calls its layer (kp_idx of the batch): FK once per distinct pose
             kp_r, bones_r, skts_r, _, rots_r = popt(pose_idx_host)
@@ -909,25 +913,52 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
         if mixamo:   # _compute_kp_loss (trainer.py:382-403; opt_pose_tol 0.01, opt_pose_coef 2.0, mixamo.txt:45,54), one launch
             loss = loss + pose_opt.kp_loss(popt.last_unique["rots"], anchor_u, w_u, True, 0.01, 2.0)
         (optim.backward if fused else torch.autograd.backward)(loss)      # fused tail: cached unit seed, no `grad * 1` launches
-        if i is not None:
-            ev[i][1].record()
-        it[0] += 1
-        if i is not None and dist is not None:
-            ev_c[i][0].record()
+        if mark:
+            mark("bwd_done")
         if fused:
-            opt.all_reduce_grads(i=it[0])     # ONE RCCL all-reduce over whatever is due (networks [+ pose]); 1/world folded into Adam
+            opt.all_reduce_grads(i=k)     # ONE RCCL all-reduce over whatever is due (networks [+ pose]); 1/world folded into Adam
         else:
             bucket.all_reduce_mean()
-        if i is not None and dist is not None:
-            ev_c[i][1].record()
+        if mark:
+            mark("reduced")
         if fused:
-            opt.step(zero_grad=True, i=it[0])
+            opt.step(zero_grad=True, i=k)
         else:
             opt.step()
             opt.zero_grad()
             if mixamo:
                 popt_opt.step()
                 popt_opt.zero_grad()
+        return {"loss": loss}
+
+    # --graph: the iteration as ONE hipGraph launch (a-nerf_amd/graph_step.py; per-step scalars in a device-resident block, ABI
+    # revision 6).  auto = single process with the fused tail; multi-rank runs keep the eager step (the RCCL collectives of the
+    # overlap path have never run under capture -- there is no second GPU to try them on)
+    use_graph = fused and (args.graph == "on" or (args.graph == "auto" and dist is None))
+    gs = None
+    if use_graph:
+        graph_step = importlib.import_module("a-nerf_amd.graph_step")
+        gs = graph_step.GraphedTrainStep(iteration, caster, opt, eager_steps=0)
+
+    def step(i=None, eager=False):
+        if i is not None:
+            host_t[i] = time.perf_counter()
+            ev[i][0].record()
+        it[0] += 1
+        if gs is not None and not eager:
+            loss = gs.step(it[0])["loss"]
+            if i is not None:
+                ev[i][1].record()         # (a captured step has no point between backward and optimiser to put an event at)
+        else:
+            def mark(name):
+                if i is not None:
+                    if name == "bwd_done":
+                        ev[i][1].record()
+                        if dist is not None:
+                            ev_c[i][0].record()
+                    elif dist is not None:
+                        ev_c[i][1].record()
+            loss = iteration(it[0], mark)["loss"]
         if i is not None:
             ev_e[i].record()
         return loss
@@ -940,8 +971,10 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
     # the W warm-up steps, preceded by a few untimed priming steps: the first ~10 steps of a fresh process still hit
     # one-off runtime stalls (allocator pool growth, lazy code-object loads; a single 40 ms hiccup was seen as late as
     # step 6), which would dominate a short timed window of 3-20 ms steps
-    for _ in range(8 + args.warmup):
-        step()
+    for _ in range(8):
+        step(eager=True)
+    for _ in range(args.warmup):
+        step()                   # graph mode: the first of these captures
     import gc
     gc.collect()
     gc.freeze()
@@ -992,7 +1025,7 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
         from torch.profiler import profile, ProfilerActivity
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
             for _ in range(3):
-                step()
+                step(eager=True)
             torch.cuda.synchronize()
         sys.stderr.write(prof.key_averages(group_by_stack_n=8).table(sort_by="self_cuda_time_total", row_limit=60,
                                                                       max_name_column_width=60, max_src_column_width=110) + "\n")
@@ -1020,7 +1053,7 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
         with ops.profiling(prof):
             for _ in range(n_prof):
                 prof.reset()             # fresh events: a pair this step does not record reads as None, not as last step's value
-                step()
+                step(eager=True)         # per-kernel events are recorded by the library at enqueue time: the eager form of the step
                 torch.cuda.synchronize()
                 for kind in ("fwd", "bwd", "gemm") + (("bwd_in",) if mixamo else ()):
                     for ps in (0, 1):
@@ -1058,7 +1091,8 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
                # [+ input gradients] MFLOP per sample) against the HIP-event time of forward + backward; `survey_3x` keeps SURVEY
                # 8(d)'s "training = 3 x forward" convention next to it (it over-counts the backward-data kernel)
                "roofline": {"bound": "mfma", "kernel": "k_mlp_fwd<train> + k_mlp_bwd + k_gemm_tn" + (" + k_mlp_bwd_in" if mixamo else "") +
-                                                       " (both nets), HIP-event time of fwd+bwd",
+                                                       (" (both nets), HIP-event time of the whole captured step (hipGraph: loss + optimiser included)"
+                                                        if gs is not None else " (both nets), HIP-event time of fwd+bwd"),
                             # bf16x3: every algorithmic FLOP is issued as 3 bf16 MFMA FLOPs, priced against the bf16 peak
                             "achieved": (3 if b3 else 1) * achieved / 1e12, "algorithmic": achieved / 1e12,
                             "peak": (PEAK_BF16_MFMA if b3 else PEAK_FP32_MFMA) / 1e12, "unit": "TFLOP/s",
@@ -1073,7 +1107,11 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
                "step_ms": step_stats(step_all), "period_ms": step_stats(period_all), "host_enqueue_ms": step_stats(host_all),
                "slow_steps": outliers(step_all, host_all),
                "allocator_in_timed_region": {k: alloc1[k] - alloc0[k] for k in alloc0},
-               "gc_collections_in_timed_region": [b - a for a, b in zip(gc0, gc1)]}
+               "gc_collections_in_timed_region": [b - a for a, b in zip(gc0, gc1)],
+               # True: every timed step was ONE hipGraphLaunch (+ the step-block write); captures / replays counted by the wrapper
+               "graph": False if gs is None else {"replays": gs.replays, "captures": gs.captures, "eager_calls": gs.eager_calls,
+                                                  "graphs": [list(k) for k in gs.graphs]}}
+        res["config"]["graph"] = gs is not None
         if trace is not None:
             res["alloc_trace"] = [{"step": i, "new_segments": trace[i][0] - (trace[i - 1][0] if i else alloc0["num_device_alloc"]),
                                    "reserved_MB": trace[i][1] / 2 ** 20, "grew_MB": (trace[i][1] - trace[i - 1][1]) / 2 ** 20 if i else None,

@@ -347,6 +347,46 @@ typedef struct AnerfProfile {
   void* ev[ANERF_PROF_SLOTS];
 } AnerfProfile;
 
+/* ---- ABI revision 6: the per-step scalars of a training iteration in DEVICE memory -----------------------------------------
+ * Every entry point is stream-only (no allocation, no synchronisation), so a whole training iteration -- anerf_rand_fill,
+ * anerf_pack_params_multi, anerf_train_forward, anerf_loss, anerf_backward, anerf_adam_step, the pose layer -- can be captured
+ * ONCE into a hipGraph and replayed.  What changes from one iteration to the next besides the buffers' contents are a few scalars
+ * that are kernel ARGUMENTS in the calls above, i.e. frozen into a captured graph: the Philox offset of the random inputs, the gate
+ * temperatures tau (CutoffEmbedder.update_tau, core/cutoff_embedder.py:181-183: a new value every global step), Adam's step
+ * count / learning rate (decay_optimizer_lrate, core/trainer.py:173-183) and the 1/world gradient scale.  They live in an
+ * AnerfStepBlock instead; the *_dev forms below and AnerfForwardIO.step read it, so a replay needs no node update:
+ *   per iteration:  anerf_step_block_write(block, &values, stream)      one launch, the values travel as kernel arguments
+ *                   hipGraphLaunch(exec, stream)
+ * The arithmetic is that of the by-value forms (the bias corrections are computed on the host in double by both), so a captured
+ * step is bit-identical to the same step issued call by call (tests/test_graph_step.py). */
+#define ANERF_MAX_ADAM_GROUPS 4
+typedef struct AnerfStepBlock {          /* DEVICE memory, 16-byte aligned; written only by anerf_step_block_write */
+  uint64_t rng_seed, rng_offset;         /* anerf_rand_fill_dev                                                     */
+  float tau_v, tau_d;                    /* AnerfForwardIO.step (adjacent: the kernels read them as a pair)         */
+  float adam_step_size[ANERF_MAX_ADAM_GROUPS];    /* lr / (1 - beta1^step)                                          */
+  float adam_sqrt_bc2[ANERF_MAX_ADAM_GROUPS];     /* sqrt(1 - beta2^step)                                           */
+  float adam_grad_scale[ANERF_MAX_ADAM_GROUPS];   /* 1/world after a summed all-reduce, else 1                      */
+  float reserved_[2];
+} AnerfStepBlock;
+typedef struct AnerfStepValues {         /* HOST: what the host mirror knows before it enqueues iteration i         */
+  uint64_t rng_seed, rng_offset;
+  float tau_v, tau_d;
+  int32_t n_groups;                      /* optimiser groups in use, <= ANERF_MAX_ADAM_GROUPS                       */
+  float lr[ANERF_MAX_ADAM_GROUPS], beta1[ANERF_MAX_ADAM_GROUPS], beta2[ANERF_MAX_ADAM_GROUPS];
+  int32_t adam_step[ANERF_MAX_ADAM_GROUPS];       /* 1-based step count this iteration applies; <= 0: group not stepped, its
+                                                   * block entries are left as they are                             */
+  float grad_scale[ANERF_MAX_ADAM_GROUPS];
+} AnerfStepValues;
+int anerf_step_block_write(AnerfStepBlock* block, const AnerfStepValues* values_host, void* stream);
+/* anerf_rand_fill / anerf_adam_step with (seed, offset) / (lr, step, grad_scale) taken from the block (group = optimiser group).
+ * call_index: the fill's index inside the iteration (one fill per caster call: 0 for the first chunk, 1 for the second ...);
+ * it draws what anerf_rand_fill(jobs, n_jobs, block->rng_seed, block->rng_offset + call_index) draws. */
+struct AnerfRandJob;
+int anerf_rand_fill_dev(const struct AnerfRandJob* jobs, int32_t n_jobs, const AnerfStepBlock* block, int32_t call_index, void* stream);
+int anerf_adam_step_dev(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float beta1, float beta2, float eps,
+                        const AnerfStepBlock* block, int32_t group, int32_t zero_grads, int32_t n_tensors, float* partials,
+                        float* norms2, void* stream);
+
 typedef struct AnerfForwardIO {
   const float *packed_c, *aux_c, *packed_f, *aux_f;
   const float *rays; int32_t ray_stride;
@@ -365,6 +405,10 @@ typedef struct AnerfForwardIO {
   /* ABI revision 4: != 0 = `cyls` holds ONE cylinder [5] shared by every ray of the call -- what run_nerf.render_path's
    * `reuse_input(cyls, expand)` (run_nerf.py:62-72: a stride-0 expand of the frame's cylinder) means; 0 = per-ray [N,5]. */
   int32_t cyl_shared;
+  /* ABI revision 6 (DEVICE pointer, may be NULL): the step block of a captured training step.  When given, the TRAINING kernels
+   * (anerf_train_forward, and anerf_backward's pose-gradient kernel) read tau_v / tau_d from it instead of from the two fields
+   * above; anerf_forward (rendering) ignores it. */
+  const struct AnerfStepBlock* step;
 } AnerfForwardIO;
 int64_t anerf_workspace_size(const AnerfConfig* cfg, int32_t n_rays, int32_t n_samples, int32_t n_importance);
 int anerf_forward(const AnerfConfig* cfg, const AnerfForwardIO* io, void* workspace, int64_t ws_bytes, void* stream);

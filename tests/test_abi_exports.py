@@ -18,7 +18,25 @@ def test_every_declared_symbol_is_exported_and_bound():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in anerf.h but not exported"
     assert declared == set(lib_mod.SIGNATURES), (declared ^ set(lib_mod.SIGNATURES))
-    assert lib.anerf_version() == lib_mod.ABI_VERSION == 5
+    assert lib.anerf_version() == lib_mod.ABI_VERSION == 6
+
+
+def test_step_block_structs_match_the_compiled_header(tmp_path):
+    """ABI revision 6: sizes and field offsets of AnerfStepBlock / AnerfStepValues / AnerfForwardIO as a C compiler lays out
+    include/anerf.h, against the ctypes mirrors the host side fills"""
+    import subprocess
+    lib_mod = importlib.import_module("a-nerf_amd._lib")
+    src = tmp_path / "sz.c"
+    src.write_text('#include "anerf.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", '
+                   'sizeof(AnerfStepBlock), sizeof(AnerfStepValues), sizeof(AnerfForwardIO), offsetof(AnerfStepBlock, tau_v), '
+                   'offsetof(AnerfStepBlock, adam_grad_scale), offsetof(AnerfStepValues, adam_step), offsetof(AnerfStepValues, grad_scale), '
+                   'offsetof(AnerfForwardIO, step));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    B, V, F = lib_mod.AnerfStepBlock, lib_mod.AnerfStepValues, lib_mod.AnerfForwardIO
+    assert got == [ctypes.sizeof(B), ctypes.sizeof(V), ctypes.sizeof(F), B.tau_v.offset, B.adam_grad_scale.offset, V.adam_step.offset,
+                   V.grad_scale.offset, F.step.offset]
 
 
 def test_layout_and_pack_table_host_side():

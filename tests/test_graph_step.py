@@ -1,0 +1,190 @@
+"""The training iteration as one captured hipGraph (a-nerf_amd/graph_step.py, ABI revision 6) against the same iteration issued
+call by call: BIT-identical losses, parameters, Adam moments and random draws over a run that crosses the pose cadence
+(opt_pose_step) and changes tau and the learning rate every iteration, as the reference's schedules do
+(core/cutoff_embedder.py:181-183, core/trainer.py:173-183, 476-478).  CPU part: the step block's layout and the host mirror.
+"""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+_lib = importlib.import_module("a-nerf_amd._lib")
+ops = importlib.import_module("a-nerf_amd.ops")
+synth = importlib.import_module("a-nerf_amd.synth")
+
+
+def test_step_block_layout_matches_the_header():
+    """the ctypes mirrors of include/anerf.h's AnerfStepBlock / AnerfStepValues (sizes cross-checked against the compiled header
+    in tests/test_abi_exports.py); tau_v / tau_d adjacent -- the kernels read them as a pair through one pointer"""
+    B, V = _lib.AnerfStepBlock, _lib.AnerfStepValues
+    assert C.sizeof(B) == 80 and C.sizeof(B) % 16 == 0 and C.sizeof(V) == 112
+    assert B.rng_seed.offset == 0 and B.rng_offset.offset == 8 and B.tau_v.offset == 16 and B.tau_d.offset == 20
+    assert B.adam_step_size.offset == 24 and B.adam_sqrt_bc2.offset == 40 and B.adam_grad_scale.offset == 56
+    assert _lib.AnerfForwardIO.step.offset == C.sizeof(_lib.AnerfForwardIO) - 8
+
+
+def _setup(mixamo, n_rays, dev, opt_pose_step=3, seed=0):
+    networks = importlib.import_module("a-nerf_amd.networks")
+    raycaster = importlib.import_module("a-nerf_amd.raycaster")
+    optim = importlib.import_module("a-nerf_amd.optim")
+    pose_opt = importlib.import_module("a-nerf_amd.pose_opt")
+    n_poses = 8
+    d = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32, device=dev)
+    kw = dict(D=8, W=256, input_ch=360, input_ch_bones=72, input_ch_views=648, use_viewdirs=True)
+    mk = {}
+    if mixamo:
+        kw.update(use_framecode=True, framecode_ch=16, n_framecodes=n_poses)
+        mk = dict(framecode_ch=16, n_codes=n_poses)
+    net_c, net_f = networks.NeRF(**kw), networks.NeRF(**kw)
+    net_c.load_state_dict({k: torch.tensor(v) for k, v in synth.make_net_params(11, **mk).items()})
+    net_f.load_state_dict({k: torch.tensor(v) for k, v in synth.make_net_params(12, **mk).items()})
+    ck = {"cutoff": True, "cutoff_dist": 0.5, "cutoff_inputs": True, "cutoff_dim": 24}
+    e_v, _ = networks.get_embedder(7, input_dims=24, cutoff_kwargs=dict(ck, dist_inputs=False))
+    e_b, _ = networks.get_embedder(0, input_dims=72, cutoff_kwargs={"cutoff": False})
+    e_d, _ = networks.get_embedder(4, input_dims=72, cutoff_kwargs=dict(ck, dist_inputs=True))
+    caster = raycaster.RayCaster(net_c, e_v, e_b, e_d, network_fine=net_f).to(dev)
+    caster.train()
+    caster._rng = ops.DeviceRng(seed=1234 + seed, stream_id=5)      # same Philox key in both runs (instance counters differ)
+    popt = None
+    groups = [{"params": [p for p in caster.parameters() if p.requires_grad], "lr": 5e-4}]
+    if mixamo:
+        poses = [synth.make_pose(k) for k in range(n_poses)]
+        popt = pose_opt.PoseOptLayer(np.stack([q["kp"] for q in poses]), np.stack([q["bones"] for q in poses]),
+                                     (synth.SMPL_REST_POSE * synth.SURREAL_SCALE)[None], use_rot6d=True).to(dev)
+        groups.append({"params": list(popt.parameters()), "lr": 5e-4, "step_every": opt_pose_step})
+    opt = optim.FusedAdam(groups, betas=(0.9, 0.999))
+    opt.attach(caster, pose_layer=popt)
+    ro, rd, kp, skts, bones, cyls, pidx = synth.scene_batch(n_rays, list(range(n_poses)), H=512, W=512, focal=600.0, ray_seed=3,
+                                                            per_ray_pose=True)
+    static = dict(rays=(d(ro), d(rd)), batch=dict(kp_batch=d(kp), skts=d(skts), cyls=d(cyls), bones=d(bones)),
+                  target=d(np.random.default_rng(1).random((n_rays, 3))), pidx=np.asarray(pidx))
+    return caster, opt, popt, static
+
+
+def _make_iteration(caster, opt, popt, st, mixamo):
+    render_mod = importlib.import_module("a-nerf_amd.render")
+    optim = importlib.import_module("a-nerf_amd.optim")
+    pose_opt = importlib.import_module("a-nerf_amd.pose_opt")
+    dev = st["target"].device
+    cams = anchor_u = w_u = None
+    if mixamo:
+        uniq, counts = np.unique(st["pidx"], return_counts=True)
+        anchor_u = popt.bones.detach().clone()[torch.tensor(uniq, device=dev)].contiguous()
+        w_u = torch.tensor(counts / float(len(st["pidx"])), dtype=torch.float32, device=dev)
+        cams = torch.tensor(st["pidx"], device=dev).to(torch.float32)
+    pk = {"density_scale": 1.0, "density_fn": torch.nn.functional.relu}
+
+    def iteration(k):
+        b = st["batch"]
+        if mixamo:
+            kp_r, bones_r, skts_r, _, _ = popt(st["pidx"])
+            b = dict(b, kp_batch=kp_r, skts=skts_r, bones=bones_r)
+        out = render_mod.render(512, 512, 600.0, chunk=4096, rays=st["rays"], use_viewdirs=True, ray_caster=caster, cams=cams,
+                                subject_idxs=None, N_samples=64, N_importance=16, perturb=1.0, raw_noise_std=1.0, preproc_kwargs=pk, **b)
+        loss, stats = optim.fused_nerf_loss(out, st["target"], bgs=1.0, loss_fn="L1" if mixamo else "MSE")
+        if mixamo:
+            loss = loss + pose_opt.kp_loss(popt.last_unique["rots"], anchor_u, w_u, True, 0.01, 2.0)
+        optim.backward(loss)
+        opt.all_reduce_grads(i=k)
+        norms = opt.step(zero_grad=True, want_norms=True, i=k)
+        return {"loss": loss, "stats": stats, "norms": norms, "rgb": out["rgb_map"]}
+    return iteration
+
+
+def _schedule(caster, opt, k):
+    """what the trainer does between iterations: a new tau and a new learning rate every step (update_embed_fns /
+    decay_optimizer_lrate), values that are kernel ARGUMENTS in the eager calls and step-block entries under the graph"""
+    for f in (caster.embed_fn, caster.embeddirs_fn):
+        f.update_tau(k, 0.01, 1.5)                              # tau = init_tau * 1.5 ** (k / 10)
+    for gi, g in enumerate(opt.param_groups):
+        g["lr"] = 5e-4 * (0.9 ** (k / 3.0)) * (1.0 if gi == 0 else 0.5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mixamo", [False, True])
+def test_captured_step_is_bit_identical_to_the_eager_step(mixamo):
+    graph_step = importlib.import_module("a-nerf_amd.graph_step")
+    dev = torch.device("cuda")
+    n_iter, n_rays = 9, 192
+    runs = []
+    for mode in ("eager", "graph"):
+        torch.manual_seed(7)
+        caster, opt, popt, st = _setup(mixamo, n_rays, dev)
+        iteration = _make_iteration(caster, opt, popt, st, mixamo)
+        gs = graph_step.GraphedTrainStep(iteration, caster, opt, eager_steps=2, enabled=mode == "graph")
+        trace = []
+        for k in range(1, n_iter + 1):
+            _schedule(caster, opt, k)
+            out = gs.step(k)
+            trace.append((out["loss"].detach().clone(), out["stats"].detach().clone(), out["norms"].detach().clone(), out["rgb"].detach().clone()))
+        torch.cuda.synchronize()
+        runs.append(dict(trace=trace, flat=opt.flat.clone(), m=opt.exp_avg.clone(), v=opt.exp_avg_sq.clone(), steps=list(opt._steps),
+                         offset=caster.rng().offset, gs=gs, caster=caster, opt=opt, popt=popt, st=st))
+    e, g = runs
+    assert g["gs"].eager_calls == 2 and g["gs"].replays == n_iter - 2
+    # the pose cadence (step_every = 3): one graph per set of due groups, iterations 3 / 6 / 9 step both groups
+    assert sorted(g["gs"].graphs) == ([(0,), (0, 1)] if mixamo else [(0,)]) and g["gs"].captures == (2 if mixamo else 1)
+    assert e["steps"] == g["steps"] == ([n_iter, 3] if mixamo else [n_iter]) and e["offset"] == g["offset"] == n_iter
+    for k, (a, b) in enumerate(zip(e["trace"], g["trace"])):
+        for x, y, what in zip(a, b, ("loss", "stats", "norms", "rgb_map")):
+            assert torch.equal(x, y), (k + 1, what, float((x - y).abs().max()))
+    assert torch.equal(e["flat"], g["flat"]) and torch.equal(e["m"], g["m"]) and torch.equal(e["v"], g["v"])
+    assert len({float(t[0]) for t in g["trace"]}) == n_iter                 # the iterations differ (fresh draws, moving parameters)
+    # the device block holds what the last iteration ran with
+    blk, gs = g["gs"].block.read(), g["gs"]
+    assert blk.rng_offset == n_iter - 1 and blk.rng_seed == g["caster"].rng().seed
+    assert blk.tau_v == np.float32(g["caster"].embed_fn.get_tau()) and blk.tau_v > 1.2 * e["caster"].embed_fn.init_tau
+    # after graph steps the eager world sees the new parameters: an eval render re-gathers its weight images (versions were bumped)
+    caster, st = g["caster"], g["st"]
+    render_mod = importlib.import_module("a-nerf_amd.render")
+    kw = dict(chunk=4096, rays=st["rays"], use_viewdirs=True, ray_caster=caster, subject_idxs=None, N_samples=64, N_importance=16,
+              perturb=0.0, raw_noise_std=0.0, preproc_kwargs={"density_scale": 1.0, "density_fn": torch.nn.functional.relu}, **st["batch"])
+    cams = torch.tensor(st["pidx"], device=dev).to(torch.float32) if mixamo else None
+    caster.eval(), e["caster"].eval()
+    with torch.no_grad():
+        img_g = render_mod.render(512, 512, 600.0, cams=cams, **kw)["rgb_map"]
+        kw["ray_caster"] = e["caster"]
+        img_e = render_mod.render(512, 512, 600.0, cams=cams, **kw)["rgb_map"]
+    assert torch.equal(img_g, img_e)
+
+
+@pytest.mark.gpu
+def test_dev_forms_equal_the_by_value_forms():
+    """anerf_rand_fill_dev / anerf_adam_step_dev against anerf_rand_fill / anerf_adam_step on the same inputs, bit for bit; a group
+    with step <= 0 keeps its block entries"""
+    dev = torch.device("cuda")
+    blk = ops.StepBlock(dev)
+    rng = ops.DeviceRng(5, stream_id=3)
+    specs = [((64, 33), "uniform", 1.0), ((1000,), "normal", 0.3)]
+    for call in range(3):
+        ref = ops.DeviceRng(5, stream_id=3)
+        ref.offset = 40 + call
+        want = ref.fill(specs, dev)
+        blk.set_rng(rng.seed, 40)
+        blk.set_tau(1.0, 2.0)
+        blk.set_adam([])
+        blk.write()
+        with ops.step_block(blk):
+            for _ in range(call):                                   # the call-th fill of the iteration
+                rng.fill(specs, dev)
+            got = rng.fill(specs, dev)
+        assert all(torch.equal(a, b) for a, b in zip(want, got)), call
+    n = 1003
+    g0 = torch.Generator(device="cpu").manual_seed(1)
+    mk = lambda: [torch.randn(n + 1, generator=g0).to(dev)[:n + 1] for _ in range(4)]
+    base = mk()
+    for step, lr, gs in ((1, 1e-3, 1.0), (7, 3e-4, 0.125)):
+        a = [t.clone() for t in base]
+        b = [t.clone() for t in base]
+        a[3].abs_(), b[3].abs_()
+        na, nb = torch.zeros(2, device=dev), torch.zeros(2, device=dev)
+        ops.adam_step(a[0][:1000], a[1][:1000], a[2][:1000], a[3][:1000], lr, 0.9, 0.999, 1e-8, step, gs, True, 5, na)
+        blk.set_adam([(9.0, 0.5, 0.5, 0, 3.0), (lr, 0.9, 0.999, step, gs)])     # group 0 does not step: its entries stay
+        blk.write()
+        with ops.step_block(blk):
+            ops.adam_step(b[0][:1000], b[1][:1000], b[2][:1000], b[3][:1000], -1.0, 0.9, 0.999, 1e-8, -1, -1.0, True, 5, nb, group=1)
+        assert all(torch.equal(x, y) for x, y in zip(a, b)) and torch.equal(na, nb)
+    r = blk.read()
+    assert r.adam_grad_scale[1] == 0.125 and r.adam_step_size[0] == 0.0 and r.tau_d == 2.0
