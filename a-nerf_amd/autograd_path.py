@@ -203,14 +203,6 @@ class _RenderRaysFn(torch.autograd.Function):
         sink = meta.get("grad_sink")
         into = [p.grad for p in meta["params"]]
         direct = sink is not None and sink.owns_grads(meta["params"], dev)
-        # data-parallel overlap (opt-in on the attached optimiser): the fine network's path gradients are complete when the
-        # first half of the backward is enqueued; their all-reduce starts there and runs under the coarse pass
-        hook = None
-        if direct and getattr(sink, "overlap", False):
-            sink.check_one_backward()        # raises on a second backward of the same step (nothing is enqueued yet)
-        if direct and hier and getattr(sink, "overlap", False):
-            fine_params = meta["params"][24:]
-            hook = lambda: sink.begin_async_all_reduce(fine_params)
         # frame codes ride along: when the tables handed to the kernels ARE the embedding weights (training mode) and their .grad
         # lives in the same bucket, the code gradients are added in place as well (no zero fill, no AccumulateGrad add)
         codes_into = None
@@ -220,11 +212,26 @@ class _RenderRaysFn(torch.autograd.Function):
                 (not want_cc or cp[0] is not None) and (not want_cf or cp[1] is not None)
             if ok:
                 codes_into = (cp[0].grad if cp[0] is not None else None, cp[1].grad if cp[1] is not None else None)
+        # data-parallel overlap (opt-in on the attached optimiser): the fine network's path gradients are complete when the
+        # first half of the backward is enqueued; their all-reduce starts there and runs under the coarse pass
+        hook = hook_c = None
+        if direct and getattr(sink, "overlap", False):
+            sink.check_one_backward()        # raises on a second backward of the same step (nothing is enqueued yet)
+        if direct and hier and getattr(sink, "overlap", False):
+            # each network's bucket range = its 24 path tensors + its frame-code table right behind them (NeRF registers
+            # `framecodes` last); a table whose gradient is not added in place stays out (it reaches the bucket later, through autograd)
+            cp = meta.get("code_params", (None, None))
+            fine_params = meta["params"][24:] + ([cp[1]] if (codes_into is not None and want_cf) else [])
+            coarse_params = meta["params"][:24] + ([cp[0]] if (codes_into is not None and want_cc) else [])
+            hook = lambda: sink.begin_async_all_reduce(fine_params)
+            # ... and the coarse network's, once ITS parameter gradients are enqueued: under the pose-gradient tail of the coarse
+            # pass and the pose layer's backward when there is one (Mixamo-type configurations), else at the end of the pass
+            hook_c = lambda: sink.begin_async_all_reduce(coarse_params)
         grads_c, grads_f, g_skts, g_cc, g_cf = ops.backward(
             state, dict(zip(ctx.keys, gs)), meta["packed_t_c"], meta["packed_t_f"], perm_tables(meta["kw"]["cfg"], dev, b3=b3),
             ctx.shapes[:24], ctx.shapes[24:], pi[0], pi[1], want_skts, want_cc, want_cf,
             accumulate_into=(into[:24], into[24:]) if direct else None, after_fine=hook, codes_into=codes_into,
-            sched=meta.get("sched"))
+            sched=meta.get("sched"), after_coarse_params=hook_c)
         ctx.state = None
         if direct:
             if codes_into is not None:

@@ -1124,9 +1124,14 @@ int anerf_backward(const AnerfConfig* cfg, const AnerfForwardIO* io, const Anerf
   hipStream_t st = (hipStream_t)stream;
   auto F = [&](int64_t off) { return reinterpret_cast<float*>(ws + off); };
   const int uw = u_width(cfg);
-  if (b->passes < 0 || b->passes > 3) return set_error(ANERF_E_CONFIG, "backward: passes must be 0..3");
-  const bool do_fine = hier && (b->passes == 0 || (b->passes & 1));
-  const bool do_coarse = !hier || b->passes == 0 || (b->passes & 2);
+  if (b->passes < 0 || (b->passes > 3 && b->passes != 4 && b->passes != 8)) return set_error(ANERF_E_CONFIG, "backward: passes must be 0..3, 4 or 8");
+  // ABI revision 6: passes = 4 / 8 split the COARSE pass once more -- 4 = everything that ends in PARAMETER gradients (weights, biases,
+  // frame codes: complete when this call is enqueued, so their all-reduce can start), 8 = its pose-gradient tail (k_encode_bwd +
+  // k_pose_reduce into g_skts), which reads dx / du of the preceding passes = 4 call from the SAME scratch
+  const int coarse_part = b->passes == 4 ? 1 : (b->passes == 8 ? 2 : 0);
+  if (coarse_part && (!hier || !b->g_skts)) return set_error(ANERF_E_CONFIG, "backward: passes = 4 / 8 need n_importance > 0 and g_skts");
+  const bool do_fine = hier && (b->passes == 0 || (b->passes <= 3 && (b->passes & 1)));
+  const bool do_coarse = !hier || b->passes == 0 || (b->passes & 2) || coarse_part;
   const bool coarse_only = hier && !do_fine;              // second half of a split backward: g_skts already holds the fine pass
   if (b->g_skts && !coarse_only && hipMemsetAsync(b->g_skts, 0, (size_t)n * 24 * 16 * 4, st) != hipSuccess)
     return set_error(ANERF_E_LAUNCH, "backward: hipMemsetAsync");
@@ -1134,11 +1139,19 @@ int anerf_backward(const AnerfConfig* cfg, const AnerfForwardIO* io, const Anerf
   // one network pass: composite backward -> dz chain -> weight gradients (-> input gradients -> pose / code gradients)
   auto pass = [&](int which_pass, const AnerfSaved& sv, const float* raw, const float* zz, int ns, const float* noise, const float* g_rgb,
                   const float* g_acc, const float* g_disp, const float* g_alpha, const float* packed_t, const float* aux,
-                  const float* packed_i, const AnerfNetGrads* gr, float* g_codes, const float* pn) {
+                  const float* packed_i, const AnerfNetGrads* gr, float* g_codes, const float* pn, int part) {
     const int64_t P = n * ns;
     const BwdWs w = bwd_ws(cfg, P, want_in);
     auto B = [&](int64_t off) { return reinterpret_cast<float*>(sb + off); };
     const int64_t pp = sv.p_pad;
+    auto pose_tail = [&]() {
+      int r2 = launch_encode_bwd(cfg->multires_views, B(w.dx), B(w.du), uw, io->rays, io->ray_stride, zz, io->skts, io->skt_ray_stride,
+                                 io->tau_v, io->tau_d, io->cutoff_v, io->cutoff_d, (int)n, ns, B(w.dy), B(w.dq), b->g_skts, skts_written, st, pn,
+                                 cfg->cutoff_bones, io->step ? &io->step->tau_v : nullptr);
+      if (!r2) skts_written = true;
+      return r2;
+    };
+    if (part == 2) return pose_tail();       // passes = 8: dx / du are where the passes = 4 call left them
     int r = zero_pad_rows(B(w.draw), 1, pp, P, 4, st);
     if (!r) r = zero_pad_rows(B(w.dz), 8, pp, P, 256, st);
     if (!r) r = zero_pad_rows(B(w.df), 1, pp, P, 256, st);
@@ -1172,31 +1185,28 @@ int anerf_backward(const AnerfConfig* cfg, const AnerfForwardIO* io, const Anerf
     r = (b3 ? anerf_input_grads_b3 : anerf_input_grads)(cfg, packed_i, B(w.dz), B(w.dzv), pp, P, B(w.dx), B(w.du), stream);
     if (r) return r;
     prof_rec(b->profile, ANERF_PROF_BWD_IN(which_pass) + 1, stream);
-    if (b->g_skts) {
-      r = launch_encode_bwd(cfg->multires_views, B(w.dx), B(w.du), uw, io->rays, io->ray_stride, zz, io->skts, io->skt_ray_stride,
-                            io->tau_v, io->tau_d, io->cutoff_v, io->cutoff_d, (int)n, ns, B(w.dy), B(w.dq), b->g_skts, skts_written, st, pn,
-                            cfg->cutoff_bones, io->step ? &io->step->tau_v : nullptr);
-      if (r) return r;
-      skts_written = true;
-    }
+    // frame-code gradients first: they are PARAMETER gradients (all-reduced), the pose gradients behind them are not
+    // (independent kernels: both only read dx / du)
     if (g_codes) {
       // accumulate = 1: the frame-code gradients are ADDED to the caller's tensor too (k_code_reduce adds; no zero fill)
       if (!b->accumulate && hipMemsetAsync(g_codes, 0, (size_t)io->n_codes * 16 * 4, st) != hipSuccess) return set_error(ANERF_E_LAUNCH, "backward: hipMemsetAsync");
       r = anerf_code_grads(cfg, B(w.du), io->cam_idx, (int)n, ns, g_codes, io->n_codes, B(w.rowsum), stream);
+      if (r) return r;
     }
+    if (b->g_skts && part != 1) r = pose_tail();
     return r;
   };
   if (do_fine) {   // the fine pass first, as autograd runs it
     const AnerfSaved sf = saved_at(ws + t.off_f, t.sf);
     rc = pass(1, sf, F(t.fwd.raw_f), F(t.fwd.zm), (int)(S + Ni), io->noise_fine, b->g_rgb, b->g_acc, b->g_disp, b->g_alpha,
-              b->packed_t_f, io->aux_f, b->packed_i_f, &b->grads_f, b->g_codes_f, io->pts_noise ? F(t.fwd.pn_f) : nullptr);
+              b->packed_t_f, io->aux_f, b->packed_i_f, &b->grads_f, b->g_codes_f, io->pts_noise ? F(t.fwd.pn_f) : nullptr, 0);
     if (rc) return rc;
   }
   if (!do_coarse) return ANERF_OK;
   const AnerfSaved sc = saved_at(ws + t.off_c, t.sc);
   return pass(0, sc, F(t.fwd.raw), F(t.fwd.z), (int)S, io->noise, hier ? b->g_rgb0 : b->g_rgb, hier ? b->g_acc0 : b->g_acc,
               hier ? b->g_disp0 : b->g_disp, hier ? b->g_alpha0 : b->g_alpha, b->packed_t_c, io->aux_c, b->packed_i_c, &b->grads_c,
-              b->g_codes_c, io->pts_noise);
+              b->g_codes_c, io->pts_noise, coarse_part);
 }
 
 }  // extern "C"

@@ -37,17 +37,16 @@ class StaticBatch:
         self.device, self.buf = torch.device(device), {}
 
     def load(self, batch):
+        """one persistent tensor per (key, shape, dtype): a batch of another size gets its own set (and its own graph)"""
         out = {}
         for k, v in batch.items():
             if not torch.is_tensor(v):
                 out[k] = v
                 continue
-            b = self.buf.get(k)
-            if b is None or b.shape != v.shape or b.dtype != v.dtype:
-                if b is not None:
-                    raise ValueError(f"StaticBatch: '{k}' changed from {tuple(b.shape)} {b.dtype} to {tuple(v.shape)} {v.dtype}; "
-                                     "a captured step needs static shapes")
-                b = self.buf[k] = torch.empty(v.shape, dtype=v.dtype, device=self.device)
+            slot = (k, tuple(v.shape), v.dtype)
+            b = self.buf.get(slot)
+            if b is None:
+                b = self.buf[slot] = torch.empty(v.shape, dtype=v.dtype, device=self.device)
             if v.data_ptr() != b.data_ptr():
                 b.copy_(v, non_blocking=True)
             out[k] = b
@@ -62,7 +61,7 @@ class GraphedTrainStep:
         self.step_fn, self.caster, self.opt = step_fn, getattr(caster, "module", caster), optimizer
         self.eager_left, self.enabled = int(eager_steps), bool(enabled)
         self.block = None
-        self.graphs = {}            # due-groups tuple -> (CUDAGraph, outputs, fills per step)
+        self.graphs = {}            # (due-groups tuple, caller's key) -> (CUDAGraph, outputs, fills per step)
         self.pool = None
         self.replays = self.captures = self.eager_calls = 0
         self.why_eager = None
@@ -117,7 +116,24 @@ class GraphedTrainStep:
         self.captures += 1
         return g, out, fills
 
-    def step(self, i):
+    def prepare(self, i, key=None, due=None):
+        """capture the graph iteration i would replay, now (nothing runs, no counter moves): keeps the capture -- milliseconds of
+        host time -- out of a timed or latency-sensitive stretch.  The step must have run eagerly before (warm caches)."""
+        why = self._capturable()
+        if not self.enabled or why is not None:
+            return False
+        if self.block is None:
+            self.block = ops.StepBlock(next(iter(self.opt.params)).device)
+        due = tuple(self.opt._due(i)) if due is None else tuple(due)
+        gk = due if key is None else (due, key)
+        if gk not in self.graphs:
+            self.graphs[gk] = self._capture(i, due)
+        return True
+
+    def step(self, i, key=None, due=None):
+        """iteration i.  key: anything hashable that selects among captured variants of step_fn (batch size, pose layout, a mode
+        flag): each (due groups, key) pair gets its own graph.  due: the optimiser groups this iteration steps (default: the
+        optimiser's own cadence, FusedAdam._due(i))."""
         why = None if self.enabled else "disabled"
         if why is None and self.eager_left > 0:
             self.eager_left -= 1
@@ -133,10 +149,11 @@ class GraphedTrainStep:
             return self.step_fn(i)
         if self.block is None:
             self.block = ops.StepBlock(next(iter(self.opt.params)).device)
-        due = tuple(self.opt._due(i))
-        hit = self.graphs.get(due)
+        due = tuple(self.opt._due(i)) if due is None else tuple(due)
+        gk = due if key is None else (due, key)
+        hit = self.graphs.get(gk)
         if hit is None:
-            hit = self.graphs[due] = self._capture(i, due)
+            hit = self.graphs[gk] = self._capture(i, due)
         g, out, fills = hit
         self._fill_block(i, due)
         self.block.write()

@@ -803,7 +803,8 @@ def train_forward(cfg, net_c, net_f, rays, skts, cyls, n_samples, n_importance=0
 
 
 def backward(state, g, packed_t_c, packed_t_f, perm, shapes_c, shapes_f, packed_i_c=None, packed_i_f=None, want_skts=False,
-             want_codes_c=False, want_codes_f=False, accumulate_into=None, after_fine=None, codes_into=None, sched=None):
+             want_codes_c=False, want_codes_f=False, accumulate_into=None, after_fine=None, codes_into=None, sched=None,
+             after_coarse_params=None):
     """anerf_backward.  g: dict of gradients of the rendered maps (keys as the output dict; rgb_map and, when hierarchical,
     rgb0 are required -- missing ones are taken as zero).  shapes_*: parameter shapes in AnerfNetGrads order (w0, b0, ...).
     accumulate_into: optional (list_c, list_f) of existing gradient tensors the parameter gradients are ADDED to in place
@@ -811,6 +812,11 @@ def backward(state, g, packed_t_c, packed_t_f, perm, shapes_c, shapes_f, packed_
     after_fine: optional callable; hierarchical calls are then enqueued as two halves (AnerfBackwardIO.passes = 1, then 2)
     and `after_fine()` runs in between, when everything that produces the FINE network's parameter gradients is on the
     stream -- the data-parallel path starts their all-reduce there, under the coarse pass.
+    after_coarse_params: optional callable (with after_fine); runs when everything that produces the COARSE network's parameter
+    gradients (weights, biases, frame codes) is on the stream.  With pose gradients requested the coarse pass is enqueued as two
+    calls (passes = 4, then 8) and the callable runs in between: the coarse network's all-reduce then runs under the
+    pose-gradient tail (k_encode_bwd, k_pose_reduce and the pose layer's own backward), none of which is all-reduced on an
+    iteration that does not step the pose group.
     sched: the InputSchedule the weight images were packed with (its factors multiply the same gradient columns), or None.
     Returns (grads_c, grads_f, g_skts, g_codes_c, g_codes_f)."""
     cfg, io = state["cfg"], state["io"]
@@ -873,10 +879,14 @@ def backward(state, g, packed_t_c, packed_t_f, perm, shapes_c, shapes_f, packed_
         b.profile = C.pointer(_active_profile.st)
     want_in = int(want_skts or want_codes_c or want_codes_f)
     scratch, sbytes = _workspace(lib.anerf_backward_scratch_size, "anerf_backward_scratch_size", dev, C.byref(cc), n, S, Ni, want_in)
-    for passes in ((1, 2) if (after_fine is not None and hier) else (0,)):
+    split = after_fine is not None and hier
+    plan = (0,) if not split else ((1, 4, 8) if (after_coarse_params is not None and want_skts) else (1, 2))
+    for passes in plan:
         b.passes = passes
         _lib.check(lib.anerf_backward(C.byref(cc), C.byref(io), C.byref(b), _p(state["ws"]), state["ws_bytes"], _p(scratch), sbytes,
                                       _stream()), "anerf_backward")
         if passes == 1:
             after_fine()
+        elif passes in (2, 4) and after_coarse_params is not None:
+            after_coarse_params()
     return grads_c, grads_f, g_skts, g_codes_c, g_codes_f

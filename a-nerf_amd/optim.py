@@ -54,7 +54,10 @@ class FusedAdam:
         self.norms = None
         self._pending = None              # optimizer state loaded before the buffers exist
         self.overlap = False              # see enable_overlap()
-        self._async = None                # (work handle, lo, hi) of an all-reduce started during the backward
+        self.split_adam = True            # overlap: Adam of the first-reduced network runs while the second one's collective is in flight
+        self.overlap_stats = {"early_collectives": 0, "main_collectives": 0, "split_adam_steps": 0}     # counters (tests, bench record)
+        self._async = []                  # [(work handle, lo, hi)]: all-reduces started during the backward, in launch order
+        self._early = []                  # bucket ranges whose Adam may run before the rest is reduced (see all_reduce_grads)
         self._side = None
         self._defaults = {"lr": lr, "betas": tuple(betas), "eps": eps, "weight_decay": 0, "amsgrad": False, "step_every": 1}
         if params and isinstance(params[0], dict):
@@ -215,25 +218,36 @@ class FusedAdam:
     def check_one_backward(self):
         """Called by the caster's backward BEFORE it enqueues anything: with overlap on, an early all-reduce that has not been
         consumed by all_reduce_grads() means this is a second backward of the same step."""
-        if self.overlap and self._async is not None:
+        if self.overlap and self._async:
             raise RuntimeError("FusedAdam overlap: a second backward arrived before all_reduce_grads() consumed the early "
                                "all-reduce of the first; its gradients would be added to an already-reduced bucket range. "
                                "Use enable_overlap(False) for gradient accumulation, or call all_reduce_grads() between backwards.")
 
     def _drop_async(self):
-        """forget an early all-reduce nobody consumed (all_reduce_grads() was skipped after a backward): join it first so that
-        nothing is in flight on the bucket, then clear the handle -- it must not be mistaken for the next step's."""
-        if self._async is not None:
-            work, _, _ = self._async
-            self._async = None
-            work.wait()
+        """forget early all-reduces nobody consumed (all_reduce_grads() was skipped after a backward): join them first so that
+        nothing is in flight on the bucket, then clear the handles -- they must not be mistaken for the next step's."""
+        if self._async:
+            pend, self._async = self._async, []
+            for work, _, _ in pend:
+                work.wait()
             if self._side is not None and self.flat_grad is not None:
                 torch.cuda.current_stream(self.flat_grad.device).wait_stream(self._side)
+        self._join_early()
+
+    def _join_early(self):
+        """join the collectives all_reduce_grads() left in flight for step()'s split Adam (see there)"""
+        early, self._early = self._early, []
+        for _, _, rest in early:
+            for work in rest:
+                work.wait()
+        if early and self._side is not None and self.flat_grad is not None:
+            torch.cuda.current_stream(self.flat_grad.device).wait_stream(self._side)
 
     def begin_async_all_reduce(self, params, group=None):
-        """Called by the caster's backward between its two halves: all-reduce (sum) the flat-bucket range that holds
-        `params` (they must be contiguous in the bucket) asynchronously.  No-op without a process group."""
-        if not (dist.is_available() and dist.is_initialized()) or self._async is not None:
+        """Called by the caster's backward at the points where a network's parameter gradients are complete (after the fine pass;
+        after the parameter part of the coarse pass): all-reduce (sum) the flat-bucket range that holds `params` (they must be
+        contiguous in the bucket) asynchronously on the side stream.  No-op without a process group."""
+        if not (dist.is_available() and dist.is_initialized()):
             return
         if dist.get_world_size(group) <= 1 and not _force_collectives():
             return
@@ -244,12 +258,15 @@ class FusedAdam:
         if lo < 0 or hi > fg.numel() * 4 or (hi - lo) != 4 * sum(p.numel() for p in params):
             return                                   # not one contiguous run of the bucket: leave it to the main collective
         lo, hi = lo // 4, hi // 4
+        if any(not (hi <= alo or lo >= ahi) for _, alo, ahi in self._async):
+            return                                   # overlaps a range already in flight (same hook twice): the main collective's job
         if self._side is None:
             self._side = torch.cuda.Stream(device=fg.device)
-        self._side.wait_stream(torch.cuda.current_stream(fg.device))      # everything enqueued so far = the fine pass
+        self._side.wait_stream(torch.cuda.current_stream(fg.device))      # everything enqueued so far produced these gradients
         with torch.cuda.stream(self._side):
             work = dist.all_reduce(fg[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True)
-        self._async = (work, lo, hi)
+        self._async.append((work, lo, hi))
+        self.overlap_stats["early_collectives"] += 1
 
     def all_reduce_grads(self, group=None, i=None, weight=None, only_group=None):
         """Sum the gradient bucket over ranks; the 1/world scale is applied inside step().  ONE collective over the
@@ -269,29 +286,40 @@ class FusedAdam:
             else:
                 runs.append([gi])
         pieces = [(seg[run[0]][0], seg[run[-1]][0] + seg[run[-1]][1]) for run in runs]
-        if self._async is not None:                   # a range was already reduced under the backward: reduce around it
-            work, alo, ahi = self._async
-            self._async = None
+        self._early = []
+        if self._async:                               # ranges already (being) reduced under the backward: reduce around them
+            pend, self._async = self._async, []
             if weight is not None and float(weight) != 1.0:
-                raise RuntimeError("FusedAdam: overlap needs an even ray split (the early all-reduce was not weighted)")
-            cut = []
-            for lo, hi in pieces:
-                if ahi <= lo or alo >= hi:
-                    cut.append((lo, hi))
-                else:
-                    if lo < alo:
-                        cut.append((lo, alo))
-                    if ahi < hi:
-                        cut.append((ahi, hi))
-            pieces = cut
-            work.wait()                               # the current stream now waits for the early collective
-            if self._side is not None:
-                torch.cuda.current_stream(self.flat_grad.device).wait_stream(self._side)
+                raise RuntimeError("FusedAdam: overlap needs an even ray split (the early all-reduces were not weighted)")
+            for _, alo, ahi in pend:
+                cut = []
+                for lo, hi in pieces:
+                    if ahi <= lo or alo >= hi:
+                        cut.append((lo, hi))
+                    else:
+                        if lo < alo:
+                            cut.append((lo, alo))
+                        if ahi < hi:
+                            cut.append((ahi, hi))
+                pieces = cut
+            main = torch.cuda.current_stream(self.flat_grad.device)
+            if len(pend) > 1 and not pieces and self.split_adam:
+                # nothing left to reduce here and more than one collective in flight: join only the FIRST now -- step() runs the
+                # Adam of its range while the later ones are still on the wire, and joins those before it touches their ranges
+                work, alo, ahi = pend[0]
+                work.wait()
+                self._early = [(alo, ahi, [w for w, _, _ in pend[1:]])]
+            else:
+                for work, _, _ in pend:
+                    work.wait()                       # the current stream now waits for the early collectives
+                if self._side is not None:
+                    main.wait_stream(self._side)
         for lo, hi in pieces:
             buf = self.flat_grad[lo:hi]
             if weight is not None and float(weight) != 1.0:
                 buf.mul_(float(weight))
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+            self.overlap_stats["main_collectives"] += 1
         for gi in due:
             self._grad_scale[gi] = 1.0 / world
 
@@ -302,6 +330,7 @@ class FusedAdam:
         want_norms: returns a [2] device tensor (total_norm, avg_norm) of group 0's gradients at this step
         (`get_gradnorm(ray_caster)`, trainer.py:192-203) -- read it when convenient."""
         self.materialize()
+        early, self._early = self._early, []      # keep it from _drop_async: step() joins these itself, behind the first Adam
         self._drop_async()                # only set here if all_reduce_grads() was skipped after an overlapped backward
         seg = self._segments()
         for gi in self._due(i, only_group):
@@ -320,12 +349,37 @@ class FusedAdam:
             self._steps[gi] += 1
             o, n = seg[gi]
             norms = self.norms if (want_norms and gi == 0) else None
-            ops.adam_step(self.flat[o:o + n], self.flat_grad[o:o + n], self.exp_avg[o:o + n], self.exp_avg_sq[o:o + n],
-                          grp["lr"], grp["betas"][0], grp["betas"][1], grp["eps"], self._steps[gi], self._grad_scale[gi],
-                          zero_grad, len(grp["params"]), norms, group=gi)
+
+            def adam(lo, hi, nm=None):
+                ops.adam_step(self.flat[lo:hi], self.flat_grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi],
+                              grp["lr"], grp["betas"][0], grp["betas"][1], grp["eps"], self._steps[gi], self._grad_scale[gi],
+                              zero_grad, len(grp["params"]), nm, group=gi)
+            if early and gi == 0:
+                # data-parallel overlap: the first-reduced network's range is final, the other network's collective is still in
+                # flight on the side stream -- update the former now, join, update the rest.  Adam is element-wise: the same
+                # numbers as one launch over the group.  (Not with want_norms -- one fixed-order sum over the group -- nor when a
+                # range boundary is not 16-byte aligned: then join first and take the single launch.)
+                alo, ahi, rest = early[0]
+                ok = norms is None and o <= alo and ahi <= o + n and alo % 4 == 0 and ahi % 4 == 0
+                if ok:
+                    adam(alo, ahi)
+                    self.overlap_stats["split_adam_steps"] += 1
+                self._early, early = early, []
+                self._join_early()
+                if ok:
+                    for lo, hi in ((o, alo), (ahi, o + n)):
+                        if hi > lo:
+                            adam(lo, hi)
+                else:
+                    adam(o, o + n, norms)
+            else:
+                adam(o, o + n, norms)
             self._grad_scale[gi] = 1.0
             for p in grp["params"]:
                 torch.autograd.graph.increment_version(p)        # parameters changed behind torch's back
+        if early:                          # (group 0 did not step: nothing consumed them)
+            self._early = early
+            self._join_early()
         return self.norms if want_norms else None
 
     def zero_grad(self, set_to_none=False, only_group=None):

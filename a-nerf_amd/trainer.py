@@ -61,6 +61,7 @@ class Trainer:
         self.hwf, self.data_attrs = data_attrs["hwf"], data_attrs
         self._fused = self._fused_of(optimizer)
         self._anchor_cache = {}
+        self._gs = self._static = None          # enable_graph()
 
     @staticmethod
     def _fused_of(optimizer):
@@ -69,6 +70,67 @@ class Trainer:
         if isinstance(optimizer, optim._GroupView):
             return optimizer.opt
         return None
+
+    # ---- the iteration as one hipGraph launch (opt-in) ------------------------------------------------------------------
+    def enable_graph(self, on=True, eager_steps=2):
+        """Replay the device side of train_batch -- pose layer, render, losses, backward, optimiser -- from a captured hipGraph
+        (graph_step.GraphedTrainStep): one launch per iteration instead of ~45, same kernels and bit-identical results.  Needs the
+        fused tail (a FusedAdam).  The loader's batch is copied into persistent device tensors before each replay; the pose
+        layer's grouping of the rays is staged the same way; learning rate, tau, Adam's step count and the random offset travel
+        through the device-resident step block.  Each (batch size, number of distinct poses, pose-optimisation phase) gets its
+        own graph on first use; `--freq_schedule` runs stay eager (with a warning)."""
+        if not on:
+            self._gs = self._static = None
+            return self
+        if self._fused is None:
+            raise ValueError("Trainer.enable_graph needs the fused tail: pass a FusedAdam (or its group_optimizer views) as the optimizers")
+        from . import graph_step
+        caster = self.render_kwargs_train["ray_caster"]
+        self._static = graph_step.StaticBatch(self.device if self.device is not None else next(caster.parameters()).device)
+        self._gs = graph_step.GraphedTrainStep(self._graph_body, caster, self._fused, eager_steps=eager_steps)
+        return self
+
+    def _graph_body(self, i):
+        """the capturable part of train_batch (no host read of device data, static shapes, inputs at static addresses)"""
+        sb, kp_idx, popt_detach, no_pose = self._cur
+        args = self.args
+        H, W, focal = self.hwf
+        kp_args, extra_args = self.get_kp_args(dict(sb, kp_idx=kp_idx), detach=popt_detach)
+        preds = render(H, W, focal, chunk=args.chunk, verbose=False, retraw=False, **kp_args, **self.get_fwd_args(sb),
+                       **self.render_kwargs_train)
+        loss_dict, stats = self.compute_loss(sb, preds, kp_opts={**kp_args, **extra_args}, popt_detach=no_pose)
+        optim_stats = self.optimize(loss_dict["total_loss"], i, no_pose)
+        return {"loss_dict": loss_dict, "stats": stats, "optim": optim_stats, "alpha": preds["acc_map"].detach().mean()}
+
+    def _train_batch_graphed(self, batch, i, global_step):
+        args, f = self.args, self._fused
+        kp_idx = batch.get("kp_idx")
+        if torch.is_tensor(kp_idx):
+            kp_idx = kp_idx.detach().cpu().numpy()
+        sb = self._static.load({k: v for k, v in batch.items() if k != "kp_idx"})
+        popt_detach = not (args.opt_pose_stop is None or i < args.opt_pose_stop)
+        no_pose = popt_detach or not args.opt_pose
+        layer = None if self.popt_kwargs is None else self.popt_kwargs.get("popt_layer")
+        n_rays = int(batch["target_s"].shape[0])
+        key = (n_rays, popt_detach, no_pose) + (layer.stage_batch(kp_idx) if layer is not None else ())
+        only = 0 if (no_pose and len(f.param_groups) > 1) else None
+        self._cur = (sb, kp_idx, popt_detach, no_pose)
+        out = self._gs.step(i, key=key, due=f._due(i, only))
+        self._cur = None
+        return self._finish_iteration(out["loss_dict"], out["stats"], out["optim"], out["alpha"], global_step)
+
+    def _finish_iteration(self, loss_dict, stats, optim_stats, alpha, global_step):
+        """the host-side tail of an iteration (trainer.py:262-277): learning-rate decay, tau / alpha schedules, the stats dict"""
+        args = self.args
+        net_opt = self._fused.group_optimizer(0) if self._fused is not None else self.optimizer
+        new_lrate, _ = decay_optimizer_lrate(args.lrate, args.lrate_decay, decay_rate=args.lrate_decay_rate, optimizer=net_opt,
+                                             global_step=global_step, decay_unit=args.decay_unit)
+        caster = self.render_kwargs_train["ray_caster"]
+        caster = getattr(caster, "module", caster)
+        if not args.finetune:
+            caster.update_embed_fns(global_step, args)
+        stats = {"lrate": new_lrate, "alpha": alpha, "cutoff": caster.embed_fn.get_tau(), **stats, **optim_stats}
+        return loss_dict, stats
 
     # ---- step 1: pose data of the batch (trainer.py:290-317) ---------------------------------------------------------
     def get_kp_args(self, batch, detach=False):
@@ -131,6 +193,20 @@ class Trainer:
         layer, anchors = self.popt_kwargs["popt_layer"], self.popt_kwargs["popt_anchors"]
         lu = layer.last_unique
         dev = lu["rots"].device
+        if "idx_dev" in lu:
+            # staged batch (PoseOptLayer.stage_batch, the captured step): the distinct pose rows and their ray shares are device
+            # tensors at static addresses -- gather the anchors with them on the device (the same rows, the same values)
+            full = self.__dict__.get("_anchors_dev")
+            if full is None or full[0] != (id(anchors), str(dev), bool(args.opt_rot6d)):
+                a = anchors["rots"].to(dev)[..., :3, :2].flatten(start_dim=-2) if args.opt_rot6d else anchors["bones"].to(dev)
+                full = self._anchors_dev = ((id(anchors), str(dev), bool(args.opt_rot6d)), a.contiguous(), anchors["kps"].to(dev).contiguous())
+            anc, w, anc_kps = full[1].index_select(0, lu["idx_dev"]), lu["w_dev"], full[2].index_select(0, lu["idx_dev"])
+            values = lu["rots"] if args.opt_rot6d else lu["bones"]
+            loss = pose_opt.kp_loss(values, anc, w, bool(args.opt_rot6d), args.opt_pose_tol, args.opt_pose_coef)
+            with torch.no_grad():
+                pj = (anc_kps - lu["kp"].detach()).pow(2.).sum(-1).pow(0.5)
+                mpjpc = (pj.mean(-1) * w).sum() / args.ext_scale
+            return {"kp_loss": loss}, {"MPJPC": mpjpc}
         key = (lu["idxs"].tobytes(), lu["counts"].tobytes(), bool(args.opt_rot6d))
         hit = self._anchor_cache.get(key)
         if hit is None:
@@ -195,6 +271,13 @@ class Trainer:
     def train_batch(self, batch, i=0, global_step=0):
         args = self.args
         H, W, focal = self.hwf
+        if self._gs is not None and self.device is not None and torch.device(self.device).type == "cuda":
+            if not self.render_kwargs_train.get("pytest", False):
+                return self._train_batch_graphed(batch, i, global_step)
+            if not self.__dict__.get("_warned_pytest"):       # pytest = True: numpy-seeded random inputs are uploaded per call
+                self._warned_pytest = True
+                import warnings
+                warnings.warn("Trainer.enable_graph: render_kwargs_train['pytest'] uploads host random numbers every call; running eagerly")
         # kp_idx is consumed on the host (the pose layer groups rays by pose there): a loader's host tensor stays where it is
         batch = {k: (v.to(self.device) if torch.is_tensor(v) and self.device is not None and k != "kp_idx" else v)
                  for k, v in batch.items()}
@@ -205,16 +288,7 @@ class Trainer:
         no_pose = popt_detach or not args.opt_pose
         loss_dict, stats = self.compute_loss(batch, preds, kp_opts={**kp_args, **extra_args}, popt_detach=no_pose)
         optim_stats = self.optimize(loss_dict["total_loss"], i, no_pose)
-        net_opt = self._fused.group_optimizer(0) if self._fused is not None else self.optimizer
-        new_lrate, _ = decay_optimizer_lrate(args.lrate, args.lrate_decay, decay_rate=args.lrate_decay_rate, optimizer=net_opt,
-                                             global_step=global_step, decay_unit=args.decay_unit)
-        caster = self.render_kwargs_train["ray_caster"]
-        caster = getattr(caster, "module", caster)
-        if not args.finetune:
-            caster.update_embed_fns(global_step, args)
-        stats = {"lrate": new_lrate, "alpha": preds["acc_map"].detach().mean(), "cutoff": caster.embed_fn.get_tau(), **stats,
-                 **optim_stats}
-        return loss_dict, stats
+        return self._finish_iteration(loss_dict, stats, optim_stats, preds["acc_map"].detach().mean(), global_step)
 
     # ---- checkpoints (trainer.py:485-517) ------------------------------------------------------------------------------
     def save_nerf(self, path, global_step):

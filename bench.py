@@ -100,6 +100,68 @@ def outliers(gpu_ms, host_ms=None):
             for i in np.nonzero(a > 1.5 * med)[0]]
 
 
+class ClockSampler:
+    """GPU shader clock (sclk, MHz) and socket power (W) sampled by a HOST thread through amdsmi while a workload runs
+    (the bf16x3 kernel moves 9 % between leases under power management; a slow lease must be
+    distinguishable from a regression).  Reads sysfs-backed counters only: nothing is enqueued on any stream.  Absent /
+    failing amdsmi -> every field None."""
+
+    def __init__(self, device_index=0, period_s=0.05):
+        self.idx, self.period, self.samples, self._stop, self._th, self.err = device_index, period_s, [], None, None, None
+
+    def _read(self, smi, h):
+        clk = pw = None
+        try:
+            ci = smi.amdsmi_get_clock_info(h, smi.AmdSmiClkType.GFX)
+            clk = float(ci.get("clk", ci.get("cur_clk")))
+        except Exception as e:
+            self.err = self.err or f"clock: {type(e).__name__}: {e}"
+        try:
+            pi = smi.amdsmi_get_power_info(h)
+            for k in ("current_socket_power", "average_socket_power", "socket_power"):
+                v = pi.get(k)
+                if isinstance(v, (int, float)) and v > 0:
+                    pw = float(v)
+                    break
+        except Exception as e:
+            self.err = self.err or f"power: {type(e).__name__}: {e}"
+        return clk, pw
+
+    def __enter__(self):
+        import threading
+        try:
+            import amdsmi as smi
+            try:
+                smi.amdsmi_init()
+            except Exception:
+                pass                                   # torch may have initialised it already
+            h = smi.amdsmi_get_processor_handles()[self.idx]
+        except Exception as e:
+            self.err = f"amdsmi unavailable: {type(e).__name__}: {e}"
+            return self
+        self._stop = threading.Event()
+
+        def run():
+            while not self._stop.is_set():
+                self.samples.append(self._read(smi, h))
+                self._stop.wait(self.period)
+        self._th = threading.Thread(target=run, daemon=True)
+        self._th.start()
+        return self
+
+    def __exit__(self, *a):
+        if self._th is not None:
+            self._stop.set()
+            self._th.join(timeout=2.0)
+
+    def summary(self):
+        clk = [c for c, _ in self.samples if c]
+        pw = [p for _, p in self.samples if p]
+        f = lambda xs, fn: float(fn(xs)) if xs else None
+        return {"samples": len(self.samples), "sclk_mhz_min": f(clk, min), "sclk_mhz_max": f(clk, max), "sclk_mhz_mean": f(clk, np.mean),
+                "power_w_mean": f(pw, np.mean), "power_w_max": f(pw, max), "error": self.err}
+
+
 _ALLOC_KEYS = ("num_device_alloc", "num_device_free", "num_alloc_retries", "num_sync_all_streams")
 
 
@@ -125,12 +187,13 @@ DETAIL_PATH = os.path.join(ROOT, "bench_detail.json")
 _LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "dry_run", "config", "roofline", "cpu_baseline", "parity", "ranks", "backend", "devices",
               "ms_per_step_per_rank", "collective_ms_per_step", "collective_bytes", "collective_alone_ms", "shards", "shard_weights",
-              "all_checks_ok", "graph", "extras_summary", "scaling_model_8gpu", "detail")
-_ROOF_KEYS = ("bound", "kernel", "achieved", "algorithmic", "peak", "unit", "frac", "avg_launch_ms", "flop_per_launch", "traffic")
+              "all_checks_ok", "graph", "alt_precision", "clocks", "extras_summary", "scaling_model_8gpu", "detail")
+_ROOF_KEYS = ("bound", "kernel", "achieved", "algorithmic", "peak", "unit", "frac", "frac_at_observed_clock", "avg_launch_ms", "flop_per_launch",
+              "traffic")
 _CONFIG_KEYS = ("workload", "rays_per_step", "samples_per_ray", "n_importance", "parallelism", "opt_pose_step", "chunk", "tail", "graph")
 # dropped first (in this order) if a line would still exceed LINE_BUDGET
-_OPTIONAL = ("shard_weights", "shards", "devices", "collective_ms_per_step", "ms_per_step_per_rank", "scaling_model_8gpu", "extras_summary",
-             "parity")
+_OPTIONAL = ("shard_weights", "shards", "devices", "collective_ms_per_step", "ms_per_step_per_rank", "clocks", "alt_precision",
+             "scaling_model_8gpu", "extras_summary", "parity")
 
 
 def _strict(x, nd=6):
@@ -163,6 +226,19 @@ def compact_line(res):
         line["step_ms_median"] = res["step_ms"]["median"]
     if "host_enqueue_ms" in res and res["host_enqueue_ms"]:
         line["host_enqueue_ms_median"] = res["host_enqueue_ms"]["median"]
+    if isinstance(line.get("alt_precision"), dict):              # the same frame through the split-bf16 kernels (never `value`)
+        ap = line["alt_precision"]
+        line["alt_precision"] = {"precision": "bf16x3", "value": ap.get("value"), "ms_per_step": ap.get("ms_per_step"),
+                                 "max_abs_rgb_vs_f32": ap.get("max_abs_rgb_vs_f32")}
+    if isinstance(line.get("clocks"), dict):
+        line["clocks"] = {k: line["clocks"].get(k) for k in ("sclk_mhz_min", "sclk_mhz_max", "sclk_mhz_mean", "power_w_mean")}
+    if isinstance(line.get("scaling_model_8gpu"), dict):         # the predictions only; terms and inputs are in the detail file
+        sm = line["scaling_model_8gpu"]
+        line["scaling_model_8gpu"] = {"note": "model, not a measurement: N = 1 timings + ring terms", "t_hop_us_assumed": sm.get("t_hop_us_assumed")} | {
+            k: {"speedup_no_latency_no_skew": v["without_latency_and_skew"]["speedup_8gpu"], "speedup_with_latency": v["with_latency"]["speedup_8gpu"],
+                "speedup_with_latency_and_skew": v["with_latency_and_skew"]["speedup_8gpu"], "exposed_collective_ms": v["exposed_collective_ms"],
+                "skew_ms": v["skew_ms_p95_minus_median"]}
+            for k, v in sm.items() if isinstance(v, dict) and "with_latency" in v}
     if "cpu_baseline" in line and isinstance(line["cpu_baseline"], dict):
         line["cpu_baseline"] = dict(line["cpu_baseline"], sample=str(line["cpu_baseline"].get("sample", ""))[:200])
     line = _strict(line)
@@ -369,7 +445,8 @@ def main():
                             {"workload": tag, "value": e["value"], "ms_per_step": e["ms_per_step"], "frac": e["roofline"]["frac"]} |
                             ({"step_ms": e["step_ms"]["median"]} if e.get("step_ms") else {}) |
                             ({"host_ms": e["host_enqueue_ms"]["median"]} if e.get("host_enqueue_ms") else {}) |
-                            ({"graph": bool(e["graph"])} if "graph" in e else {}))
+                            ({"graph": bool(e["graph"])} if "graph" in e else {}) |
+                            ({"sclk_mhz": [e["clocks"]["sclk_mhz_min"], e["clocks"]["sclk_mhz_max"]]} if (e.get("clocks") or {}).get("sclk_mhz_min") else {}))
             res["extra_workloads"] = ex
             res["extras_summary"] = summ
         emit(res)
@@ -504,7 +581,7 @@ def extra_workloads(args, device, synth, ops, pipeline):
                    "value": r["value"], "unit": r["unit"], "steps": a.steps,
                    "ms_per_step": r["ms_per_step"], "dtype": r["dtype"], "roofline": r["roofline"]}
             for k in ("step_ms", "period_ms", "host_enqueue_ms", "slow_steps", "allocator_in_timed_region",
-                      "gc_collections_in_timed_region", "vs_headline_kernel_bench", "graph"):
+                      "gc_collections_in_timed_region", "vs_headline_kernel_bench", "graph", "clocks"):
                 if k in r:
                     rec[k] = r[k]
             train = a.workload in ("train", "train_mixamo")
@@ -521,8 +598,8 @@ def scaling_model(extras, device):
     """What the N = 1 run can say about the 8-GPU strong-scaling target before a SCALE run exists: the 384-ray shard step
     measured here (= each rank's compute at N = 8), the gradient bucket's all-reduce on a ONE-rank RCCL communicator (the fixed
     launch + kernel cost of the collective; no xGMI traffic) and a ring model for the wire time (2 (G-1)/G x bytes over one
-    xGMI link at ~153 GB/s -- RCCL's rings over the 7-link mesh can only be faster), with the fine network's half of it hidden
-    under the coarse backward (FusedAdam.enable_overlap).  A model on file, not a measurement."""
+    xGMI link at ~153 GB/s -- RCCL's rings over the 7-link mesh can only be faster), a per-hop latency term, a rank-skew term and
+    what this round's schedule hides of each network's collective.  A model on file, not a measurement."""
     by = {tuple(e["_key"]): e for e in extras if "_key" in e}
     out = {"note": "prediction from single-GPU measurements + a ring model; the measured curve is the driver's SCALE_rNN.json"}
     bucket_bytes = 2 * 864260 * 4
@@ -553,18 +630,43 @@ def scaling_model(extras, device):
         _flush_c_stdio()
     except Exception as e:
         out["collective_world1_error"] = f"{type(e).__name__}: {e}"
-    G, link = 8, 153e9
-    wire_ms = 2 * (G - 1) / G * bucket_bytes / link * 1e3
-    out.update({"collective_bytes": bucket_bytes, "collective_world1_ms": coll1, "ring_wire_ms_8gpu": wire_ms,
-                "xgmi_link_GBps_assumed": link / 1e9})
-    exposed = (coll1 or 0.0) + 0.5 * wire_ms          # the fine network's half runs under the coarse backward
-    for name, full, shard, n in (("config3", ("train", 3072, 1), ("train", 384, 1), 3072),
-                                 ("config4_opt_pose_step20", ("train_mixamo", 3072, 20), ("train_mixamo", 384, 20), 3072)):
+    # ---- the terms.  Per NETWORK (the bucket is reduced as two halves, see FusedAdam.enable_overlap):
+    #   launch   the collective on a ONE-rank communicator, measured above (enqueue + kernel, no wire)
+    #   latency  2 (G-1) ring steps x t_hop.  t_hop = 3 us ASSUMED: RCCL's LL / LL128 protocols move a small chunk per step with a
+    #            flag-polling handshake; public rccl-tests all_reduce_perf figures for 8 x MI300X put the small-message (<= 64 KiB)
+    #            all-reduce at 25-45 us = 14 steps x 1.8-3.2 us.  Nothing here can measure it (one GPU)
+    #   wire     2 (G-1)/G x bytes over ONE xGMI link at 153 GB/s (a ring uses one link per direction; the 7-link mesh is idle otherwise)
+    #   skew     p95 - median of the step period at the shard size, measured in this run: with 8 ranks in lockstep each step waits
+    #            for the slowest one (the max of 8 draws sits near the p90 of one rank's distribution)
+    # What is hidden: the FINE network's collective runs under the coarse backward (>= 1 ms: hidden whatever the terms).  The COARSE
+    # network's starts when its parameter gradients are enqueued (AnerfBackwardIO.passes = 4): in config 4 the pose-gradient tail
+    # (k_encode_bwd + k_pose_reduce of the coarse pass, the pose layer's backward; 115 us at 384 rays in
+    # profiles/r04_mix384_step_timeline.txt) runs on beside it and is not reduced on the 19 of 20 iterations that do not step the
+    # pose group; in config 3 there is no tail, only the first network's share of k_adam (~5 us) runs under it.
+    G, link, t_hop_ms = 8, 153e9, 3.0e-3
+    net_bytes = bucket_bytes // 2
+    wire_ms = 2 * (G - 1) / G * net_bytes / link * 1e3
+    lat_ms = 2 * (G - 1) * t_hop_ms
+    launch_ms = coll1 or 0.0
+    coll_net_ms = launch_ms + lat_ms + wire_ms
+    out.update({"collective_bytes": bucket_bytes, "collective_world1_ms": coll1, "xgmi_link_GBps_assumed": link / 1e9, "t_hop_us_assumed": t_hop_ms * 1e3,
+                "per_network_collective_ms": {"launch": launch_ms, "latency_2(G-1)_hops": lat_ms, "ring_wire": wire_ms, "total": coll_net_ms}})
+    for name, full, shard, n, window_ms, pose_every in (("config3", ("train", 3072, 1), ("train", 384, 1), 3072, 0.005, 0),
+                                                        ("config4_opt_pose_step20", ("train_mixamo", 3072, 20), ("train_mixamo", 384, 20), 3072, 0.115, 20)):
         if full in by and shard in by:
             t1, t8 = by[full]["step_ms"]["median"], by[shard]["step_ms"]["median"]
+            per = by[shard].get("period_ms") or by[shard]["step_ms"]
+            skew = max(0.0, per["p95"] - per["median"])
+            small = (launch_ms + lat_ms) / pose_every if pose_every else 0.0      # the pose group's own collective, on the iterations it is due
+            exp_old = launch_ms + wire_ms                                         # round-4 model: no latency, no skew, coarse half exposed
+            exp_lat_seq = coll_net_ms                                             # + latency, the coarse collective behind the backward (round 4's schedule)
+            exp_lat = max(0.0, coll_net_ms - window_ms) + small                   # + latency, this round's schedule
+            mk = lambda e: {"step_ms_8gpu": t8 + e, "speedup_8gpu": t1 / (t8 + e), "rays_per_s_8gpu": n / ((t8 + e) * 1e-3)}
             out[name] = {"step_ms_1gpu": t1, "shard_step_ms": t8, "speedup_before_allreduce": t1 / t8,
-                         "predicted_step_ms_8gpu": t8 + exposed, "predicted_speedup_8gpu": t1 / (t8 + exposed),
-                         "predicted_rays_per_s_8gpu": n / ((t8 + exposed) * 1e-3)}
+                         "hidden_window_ms": window_ms, "skew_ms_p95_minus_median": skew, "exposed_collective_ms": exp_lat,
+                         "without_latency_and_skew": mk(exp_old), "with_latency_coarse_collective_after_backward": mk(exp_lat_seq),
+                         "with_latency": mk(exp_lat), "with_latency_and_skew": mk(exp_lat + skew),
+                         "predicted_speedup_8gpu": t1 / (t8 + exp_lat + skew)}
     return out
 
 
@@ -648,11 +750,13 @@ def bench_render(args, rank, world, device, dist, synth, ops, pipeline):
         out = step()
     barrier()
     alloc0 = alloc_counters(device)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(i)
-    barrier()
-    dt = dt_local = time.perf_counter() - t0
+    clocks = ClockSampler(device.index or 0)
+    with clocks:                                         # host thread, sysfs reads: nothing on the timed stream
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = step(i)
+        barrier()
+        dt = dt_local = time.perf_counter() - t0
     alloc1 = alloc_counters(device)
     tt = torch.tensor([dt], device=device)
     if dist is not None:
@@ -711,7 +815,13 @@ def bench_render(args, rank, world, device, dist, synth, ops, pipeline):
                          "avg_launch_ms": mlp_ms, "launch_ms": step_stats(mlp_all), "flop_per_launch": flops_launch, "traffic": None},
             "step_ms": step_stats(step_all), "slow_steps": outliers(step_all),
             "allocator_in_timed_region": {k: alloc1[k] - alloc0[k] for k in alloc0},
+            # shader clock / socket power DURING the timed steps (amdsmi, host thread); frac_at_observed_clock rescales the MFMA
+            # peak (quoted at 2400 MHz, MI355X_MICROARCH.md) to the mean clock the kernel actually ran at
+            "clocks": clocks.summary(),
         }
+        ck = res["clocks"]
+        if ck.get("sclk_mhz_mean"):
+            res["roofline"]["frac_at_observed_clock"] = res["roofline"]["frac"] * 2400.0 / ck["sclk_mhz_mean"]
         attach_traffic(res, args.workload + ("_bf16x3" if b3 else ""), world)
         if alt is not None:
             res["alt_precision"] = alt
@@ -973,8 +1083,12 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
     # step 6), which would dominate a short timed window of 3-20 ms steps
     for _ in range(8):
         step(eager=True)
+    if gs is not None:           # capture both cadence phases now (nothing runs): no capture inside the timed steps
+        gs.prepare(1)
+        if mixamo and args.opt_pose_step > 1:
+            gs.prepare(args.opt_pose_step)
     for _ in range(args.warmup):
-        step()                   # graph mode: the first of these captures
+        step()
     import gc
     gc.collect()
     gc.freeze()
@@ -1116,6 +1230,8 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
             res["alloc_trace"] = [{"step": i, "new_segments": trace[i][0] - (trace[i - 1][0] if i else alloc0["num_device_alloc"]),
                                    "reserved_MB": trace[i][1] / 2 ** 20, "grew_MB": (trace[i][1] - trace[i - 1][1]) / 2 ** 20 if i else None,
                                    "step_ms": step_all[i], "host_ms": host_all[i]} for i in range(len(trace))]
+        if fused and dist is not None:
+            res["overlap"] = dict(opt.overlap_stats, enabled=bool(opt.overlap))
         if coll_alone_ms is not None:
             res["collective_alone_ms"] = coll_alone_ms
             res["collective_bytes"] = int(opt.flat_grad.numel() * 4)

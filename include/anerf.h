@@ -444,7 +444,12 @@ typedef struct AnerfBackwardIO {
                          * start reducing the fine network's gradients (complete after the first call) over RCCL while the
                          * coarse pass runs (replaces nn.DataParallel's reduce-add, core/raycasters.py:157).  g_skts is
                          * zero-filled by the call that runs the fine pass; a coarse-only call ADDS to it.  Ignored (both
-                         * passes = the one pass) when n_importance == 0. */
+                         * passes = the one pass) when n_importance == 0.
+                         * ABI revision 6 -- the coarse pass in two calls (n_importance > 0 and g_skts only): 4 = everything that ends
+                         * in PARAMETER gradients (weights, biases, frame codes), 8 = its pose-gradient tail into g_skts, reading the
+                         * input gradients the passes = 4 call left in the SAME scratch.  On iterations where the pose group is not
+                         * stepped the tail produces nothing that is all-reduced, so the coarse network's collective (started after
+                         * the passes = 4 call) runs under it instead of after the backward. */
   const AnerfProfile* profile;   /* ABI revision 3 (HOST pointer, may be NULL): see AnerfProfile */
 } AnerfBackwardIO;
 int64_t anerf_train_workspace_size(const AnerfConfig* cfg, int32_t n_rays, int32_t n_samples, int32_t n_importance);

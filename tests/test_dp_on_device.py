@@ -121,7 +121,16 @@ def _worker(rank, world, port, mixamo, n_rays, q):
             for i in iters:
                 _step(args_o, rk_o, popt_o, opt_o, batch_o, slice(lo, hi), i, reduce=True)
                 started += 1
-            overlap_same = bool(torch.equal(opt_o.flat.detach().cpu(), flat_dp)) and opt_o._async is None and opt_o._side is not None
+            overlap_same = bool(torch.equal(opt_o.flat.detach().cpu(), flat_dp)) and opt_o._async == [] and opt_o._early == [] and \
+                opt_o._side is not None
+            st_o = dict(opt_o.overlap_stats)
+            # both networks' collectives start inside the backward (fine: after its pass; coarse: after the parameter part of its
+            # pass, i.e. under the pose-gradient tail in the Mixamo configuration); what is left for all_reduce_grads() is the pose
+            # group on the iterations it is due (3 of 1..4 -> one main collective); the first-reduced network's Adam runs early
+            want = {"early_collectives": 2 * len(iters), "main_collectives": 1 if mixamo else 0, "split_adam_steps": len(iters) - (1 if mixamo else 0)}    # (not on the iteration whose pose group is still to reduce)
+            overlap_same = overlap_same and st_o == want
+            if st_o != want:
+                print("overlap stats", st_o, "expected", want, flush=True)
         else:
             overlap_same = None
         # both ranks must hold bit-identical parameters

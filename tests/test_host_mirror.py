@@ -139,16 +139,16 @@ def test_fused_adam_overlap_refuses_a_second_backward_and_pending_group_state():
     opt = optim.FusedAdam([{"params": ps}, {"params": pose, "step_every": 20}], lr=5e-4)
     opt.enable_overlap()
     opt.check_one_backward()                           # nothing pending: fine
-    opt._async = (Work(), 0, 12)
+    opt._async = [(Work(), 0, 12), (Work(), 12, 18)]   # the fine network's early all-reduce, then the coarse network's
     with pytest.raises(RuntimeError, match="second backward"):
         opt.check_one_backward()
-    opt.zero_grad()                                    # a skipped all_reduce_grads(): the stale handle is joined and dropped
-    assert opt._async is None and Work.waited == 1
+    opt.zero_grad()                                    # a skipped all_reduce_grads(): the stale handles are joined and dropped
+    assert opt._async == [] and Work.waited == 2
     opt.check_one_backward()
     opt.enable_overlap(False)
-    opt._async = (Work(), 0, 12)
+    opt._async = [(Work(), 0, 12)]
     opt.check_one_backward()                           # overlap off: accumulation over several backwards is allowed
-    opt._async = None
+    opt._async = []
     # (b) torch-format state for all three parameters, loaded before the buffers exist
     ref = torch.optim.Adam([{"params": ps}, {"params": pose}], lr=5e-4)
     for p in ps + pose:

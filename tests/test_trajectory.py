@@ -248,3 +248,64 @@ def test_pose_parameters_freeze_at_opt_pose_stop(tail):
         assert fused._steps[0] == 5
         o, n = fused._segments()[1]
         assert float(fused.exp_avg[o:o + n].abs().max()) > 0                # moments are non-zero: a step would have moved the pose
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["surreal", "mixamo"])
+def test_graphed_trainer_is_bit_identical_to_the_eager_trainer(name):
+    """Trainer.enable_graph(): train_batch replays the device side of the iteration from a captured hipGraph.  Eight iterations on
+    FRESH batches (new rays, new targets, a different set of poses with a different number of distinct poses) with the device
+    generator's randomness, the reference's schedules moving tau and the learning rate every iteration, the pose cadence
+    (opt_pose_step = 2) and the pose-optimisation stop (opt_pose_stop = 6): the same losses, statistics and parameters, bit for
+    bit, as the eager trainer."""
+    ops = importlib.import_module("a-nerf_amd.ops")
+    dev = torch.device("cuda")
+    case = CASES[name]
+    n_iter, n = 8, 64
+    runs = []
+    for graph in (False, True):
+        torch.manual_seed(3)
+        if name == "mixamo":
+            tr, caster, layer, fused, _ = _mixamo_trainer("fused", dev, opt_pose_step=2, opt_pose_stop=6)
+        else:
+            args = ref_args("surreal")
+            data_attrs = {"skel_type": Skel, "near": 0.0, "far": 1.0, "n_views": N_POSES, "hwf": (512, 512, 600.0),
+                          "joint_coords": np.tile(np.eye(3, dtype=np.float32), (24, 1, 1))}
+            rk_train, rk_test, _, grad_vars, _, _ = raycaster.create_raycaster(args, data_attrs, device=dev)
+            caster, layer = rk_test["ray_caster"], None
+            for net, seed in ((caster.network, 11), (caster.network_fine, 12)):
+                net.load_state_dict({k: torch.tensor(v) for k, v in synth.make_net_params(seed).items()})
+            fused = optim.FusedAdam([{"params": grad_vars, "lr": args.lrate}], betas=(0.9, 0.999)).attach(caster)
+            tr = trainer_mod.Trainer(args, data_attrs, fused.group_optimizer(0), None, rk_train, rk_test, popt_kwargs=None, device=dev)
+            caster.train()
+        tr.render_kwargs_train["pytest"] = False
+        caster._rng = ops.DeviceRng(seed=99, stream_id=7)
+        if graph:
+            tr.enable_graph(eager_steps=1)
+        trace = []
+        rng = np.random.default_rng(5)
+        for i in range(1, n_iter + 1):
+            poses = sorted(rng.choice(N_POSES, size=2 + i % 3, replace=False).tolist())
+            ro, rd, kp, skts, bones, cyls, which = synth.scene_batch(n, poses, ray_seed=100 + i, per_ray_pose=True)
+            t = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32)
+            which = np.asarray(poses)[np.asarray(which)]                  # scene_batch numbers the rays' poses 0..len(poses)-1
+            batch = dict(rays=t(np.stack([ro, rd])), target_s=t(np.random.default_rng(200 + i).random((n, 3))),
+                         kp_idx=torch.tensor(which, dtype=torch.int64), kp3d=t(kp), bones=t(bones), skts=t(skts), cyls=t(cyls),
+                         cam_idxs=t(np.asarray(which, dtype=np.float32)), fgs=torch.ones(n, 1), bgs=torch.ones(n, 3))
+            loss_dict, stats = tr.train_batch(batch, i=i, global_step=500 * i)
+            trace.append({**{k: v.detach().clone() for k, v in loss_dict.items()},
+                          **{k: (v.detach().clone() if torch.is_tensor(v) else torch.tensor(float(v))) for k, v in stats.items()}})
+            if layer is not None:
+                assert np.array_equal(layer.last_unique["idxs"], np.unique(which))
+        torch.cuda.synchronize()
+        runs.append(dict(trace=trace, flat=fused.flat.clone(), m=fused.exp_avg.clone(), steps=list(fused._steps), tr=tr))
+    e, g = runs
+    gs = g["tr"]._gs
+    assert gs.eager_calls == 1 and gs.replays == n_iter - 1 and gs.captures >= (3 if name == "mixamo" else 1), (gs.eager_calls, gs.replays, gs.captures)
+    assert e["steps"] == g["steps"] == ([n_iter, 2] if name == "mixamo" else [n_iter])       # pose steps at i = 2, 4; stopped from 6 on
+    for i, (a, b) in enumerate(zip(e["trace"], g["trace"])):
+        assert sorted(a) == sorted(b)
+        for k in a:
+            assert torch.equal(a[k].cpu(), b[k].cpu()), (i + 1, k, a[k], b[k])
+    assert torch.equal(e["flat"], g["flat"]) and torch.equal(e["m"], g["m"])
+    print(f"{name}: {gs.captures} graphs for keys {sorted(map(str, gs.graphs))}")

@@ -4,8 +4,9 @@
 TAG=$1; SHA=$2
 cd $GRAFT_REPO_ROOT
 B=$GRAFT_REPO_ROOT/bench.py
+# (--graph off: the counters are attributed per kernel dispatch of the eager step -- the same kernels the captured graph replays)
 # ONLY="train3072 train384" restricts the run to those workloads (a kernel change that leaves the others untouched)
-run() { name=$1; shift; if [ -n "$ONLY" ] && ! echo " $ONLY " | grep -q " $name "; then return; fi; tools/pmc_passes.sh ${TAG}_$name -- python $B --cpu-rays 0 --extra off "$@" > /dev/null 2>&1; echo "# build $SHA; command: python bench.py --cpu-rays 0 --extra off $*" >> gpurun_out/${TAG}_${name}_summary.txt; }
+run() { name=$1; shift; if [ -n "$ONLY" ] && ! echo " $ONLY " | grep -q " $name "; then return; fi; tools/pmc_passes.sh ${TAG}_$name -- python $B --cpu-rays 0 --extra off --graph off "$@" > /dev/null 2>&1; echo "# build $SHA; command: python bench.py --cpu-rays 0 --extra off --graph off $*" >> gpurun_out/${TAG}_${name}_summary.txt; }
 run render64 --steps 3
 run api_render64 --workload api_render64 --steps 3
 run render64_bf16x3 --precision bf16x3 --steps 3
