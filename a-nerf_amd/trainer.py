@@ -104,13 +104,13 @@ class Trainer:
 
     def _train_batch_graphed(self, batch, i, global_step):
         args, f = self.args, self._fused
-        kp_idx = batch.get("kp_idx")
+        layer = None if self.popt_kwargs is None else self.popt_kwargs.get("popt_layer")
+        kp_idx = batch.get("kp_idx") if layer is not None else None      # only the pose layer reads it (on the host)
         if torch.is_tensor(kp_idx):
             kp_idx = kp_idx.detach().cpu().numpy()
         sb = self._static.load({k: v for k, v in batch.items() if k != "kp_idx"})
         popt_detach = not (args.opt_pose_stop is None or i < args.opt_pose_stop)
         no_pose = popt_detach or not args.opt_pose
-        layer = None if self.popt_kwargs is None else self.popt_kwargs.get("popt_layer")
         n_rays = int(batch["target_s"].shape[0])
         key = (n_rays, popt_detach, no_pose) + (layer.stage_batch(kp_idx) if layer is not None else ())
         only = 0 if (no_pose and len(f.param_groups) > 1) else None
@@ -272,12 +272,15 @@ class Trainer:
         args = self.args
         H, W, focal = self.hwf
         if self._gs is not None and self.device is not None and torch.device(self.device).type == "cuda":
-            if not self.render_kwargs_train.get("pytest", False):
+            multi = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+            why = ("render_kwargs_train['pytest'] uploads host random numbers every call" if self.render_kwargs_train.get("pytest", False) else
+                   "more than one rank: the gradient collectives have not been run under stream capture" if multi else None)
+            if why is None:
                 return self._train_batch_graphed(batch, i, global_step)
-            if not self.__dict__.get("_warned_pytest"):       # pytest = True: numpy-seeded random inputs are uploaded per call
-                self._warned_pytest = True
+            if self.__dict__.get("_warned_eager") != why:
+                self._warned_eager = why
                 import warnings
-                warnings.warn("Trainer.enable_graph: render_kwargs_train['pytest'] uploads host random numbers every call; running eagerly")
+                warnings.warn(f"Trainer.enable_graph: running eagerly ({why})")
         # kp_idx is consumed on the host (the pose layer groups rays by pose there): a loader's host tensor stays where it is
         batch = {k: (v.to(self.device) if torch.is_tensor(v) and self.device is not None and k != "kp_idx" else v)
                  for k, v in batch.items()}

@@ -1,0 +1,26 @@
+"""GPU: the drop-in surface end to end, as run_nerf.py drives the reference (run_nerf.py:504-640) -- a dataset in the reference's
+on-disk layout (written from a teacher's renders: there is no dataset in the image), the dataset reader's sampling and collate,
+create_raycaster from its data_attrs, Trainer.train_batch replayed from the captured hipGraph, a checkpoint in the reference's
+format, reload, render_path of a held-out camera (tools/train_synthetic.py).  The student must actually learn (loss down, PSNR up)
+and the reloaded checkpoint must render the same image."""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_dataset_to_trainer_to_checkpoint_to_render_path(tmp_path):
+    spec = importlib.util.spec_from_file_location("train_synthetic", os.path.join(ROOT, "tools", "train_synthetic.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    r = mod.main(["--iters", "150", "--hw", "64", "--n-kps", "3", "--n-cams", "3", "--n-rand", "512", "--n-sample-images", "4",
+                  "--graph", "on", "--out", str(tmp_path)])
+    assert r["graph"] and r["graphs"]["eager"] == 2 and r["graphs"]["replays"] == 148 and r["graphs"]["captures"] >= 1
+    assert r["last"][1] < 0.6 * r["first"][1], r                      # the loss fell
+    assert r["psnr_gain_db"] > 2.0, r                                  # ... and the PSNR against the teacher's pixels rose
+    assert r["held_out_psnr_db"] > 10.0, r                             # a camera the student never saw
+    assert r["reload_max_abs_diff"] == 0.0                             # checkpoint round trip: the same image, bit for bit
+    assert os.path.exists(r["checkpoint"]) and os.path.exists(r["dataset"])
