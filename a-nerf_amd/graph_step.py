@@ -105,14 +105,16 @@ class GraphedTrainStep:
         torch.autograd.graph.increment_version([p for g in opt.param_groups for p in g["params"]])
         g = torch.cuda.CUDAGraph()
         self.block.fills = 0
-        with ops.step_block(self.block):
-            with torch.cuda.graph(g, pool=self.pool):
-                out = self.step_fn(i)
-        fills = self.block.fills
+        try:
+            with ops.step_block(self.block):
+                with torch.cuda.graph(g, pool=self.pool):
+                    out = self.step_fn(i)
+        finally:
+            # the capture recorded the launches without running them (or failed half way): put the host-side counters back
+            fills = self.block.fills
+            rng.offset, opt._steps[:], opt._grad_scale[:] = snap[0], snap[1], snap[2]
         if self.pool is None:
             self.pool = g.pool()          # later graphs (other cadence phases) share it: they never run concurrently
-        # the capture recorded the launches without running them: put the host-side counters back
-        rng.offset, opt._steps[:], opt._grad_scale[:] = snap[0], snap[1], snap[2]
         self.captures += 1
         return g, out, fills
 

@@ -286,7 +286,7 @@ class FusedAdam:
             else:
                 runs.append([gi])
         pieces = [(seg[run[0]][0], seg[run[-1]][0] + seg[run[-1]][1]) for run in runs]
-        self._early = []
+        self._join_early()                            # (a previous call's leftovers, had step() not consumed them: joined, not dropped)
         if self._async:                               # ranges already (being) reduced under the backward: reduce around them
             pend, self._async = self._async, []
             if weight is not None and float(weight) != 1.0:
