@@ -1042,8 +1042,10 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
         return {"loss": loss}
 
     # --graph: the iteration as ONE hipGraph launch (a-nerf_amd/graph_step.py; per-step scalars in a device-resident block, ABI
-    # revision 6).  auto = single process with the fused tail; multi-rank runs keep the eager step (the RCCL collectives of the
-    # overlap path have never run under capture -- there is no second GPU to try them on)
+    # revision 6).  auto = single process with the fused tail; multi-rank runs keep the eager step unless --graph on: RCCL
+    # collectives inside the captured step have run with ONE rank only (forced collectives: tests/test_graph_step.py, and
+    # `ANERF_BENCH_FORCE_DIST=1 bench.py --graph on`: 3.01 -> 2.91 ms at the Mixamo shard, host 2.0 -> 0.05 ms) -- there is no
+    # second GPU to try them on
     use_graph = fused and (args.graph == "on" or (args.graph == "auto" and dist is None))
     gs = None
     if use_graph:
@@ -1121,8 +1123,8 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
     fb_ms = float(np.median(fb_all))
     # HIP-event time of the gradient all-reduce as the main stream sees it (with overlap: what is left of it after the coarse
     # half of the backward), plus the same collective on an idle GPU: the xGMI time of the 6.9 MB bucket itself
-    coll_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_c])) if (dist is not None and args.steps) else 0.0
-    coll_alone_ms = None
+    coll_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_c])) if (dist is not None and args.steps and gs is None) else 0.0   # (no event
+    coll_alone_ms = None                                                                                     # points inside a captured step)
     if dist is not None and fused:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         barrier()

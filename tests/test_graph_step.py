@@ -188,3 +188,61 @@ def test_dev_forms_equal_the_by_value_forms():
         assert all(torch.equal(x, y) for x, y in zip(a, b)) and torch.equal(na, nb)
     r = blk.read()
     assert r.adam_grad_scale[1] == 0.125 and r.adam_step_size[0] == 0.0 and r.tau_d == 2.0
+
+
+def _rccl_graph_worker(port, q):
+    """one rank, RCCL, collectives forced (ANERF_FORCE_COLLECTIVES): the data-parallel step -- both networks' all-reduces started
+    inside the backward on the side stream, the pose group's collective on its iteration, split Adam -- eager and captured"""
+    try:
+        import os, sys
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ANERF_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        warm = torch.zeros(8, device=dev)
+        dist.all_reduce(warm)                       # the communicator is built outside any capture
+        torch.cuda.synchronize()
+        graph_step = importlib.import_module("a-nerf_amd.graph_step")
+        runs = []
+        for mode in ("eager", "graph"):
+            torch.manual_seed(7)
+            caster, opt, popt, st = _setup(True, 128, dev)
+            opt.enable_overlap()
+            iteration = _make_iteration(caster, opt, popt, st, True)
+            gs = graph_step.GraphedTrainStep(iteration, caster, opt, eager_steps=2, enabled=mode == "graph")
+            losses = []
+            for k in range(1, 8):
+                _schedule(caster, opt, k)
+                losses.append(gs.step(k)["loss"].detach().clone())
+            torch.cuda.synchronize()
+            runs.append((losses, opt.flat.clone(), opt.exp_avg_sq.clone(), dict(opt.overlap_stats), gs.replays, gs.captures))
+        e, g = runs
+        same = all(torch.equal(a, b) for a, b in zip(e[0], g[0])) and torch.equal(e[1], g[1]) and torch.equal(e[2], g[2])
+        q.put({"same": bool(same), "eager_stats": e[3], "graph_stats": g[3], "replays": g[4], "captures": g[5]})
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put({"error": traceback.format_exc()})
+        raise
+
+
+@pytest.mark.gpu
+def test_rccl_collectives_inside_the_captured_step():
+    """The N > 1 form of the step under capture, as far as ONE GPU goes: a one-rank RCCL communicator with the collectives forced
+    (sums over one rank are the identity, the enqueue path -- side stream, async work handles, RCCL kernels inside the capture -- is
+    the real one).  Captured == eager, bit for bit; the eager run issues 2 early collectives per iteration."""
+    import multiprocessing as mp
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_graph_worker, args=(port, q))
+    p.start()
+    r = q.get(timeout=600)
+    p.join(timeout=120)
+    assert "error" not in r, r.get("error")
+    assert r["same"] and r["replays"] == 5 and r["captures"] == 2, r
+    assert r["eager_stats"]["early_collectives"] == 14 and r["eager_stats"]["main_collectives"] == 2, r      # pose group at k = 3, 6

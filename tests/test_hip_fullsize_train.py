@@ -137,3 +137,53 @@ def test_full_size_training_step_properties(n, code, precision):
         assert torch.equal(out2[k], out[k]), k
     rc = lib.anerf_train_forward(C.byref(cc), C.byref(io), p(ws), want - 16, stream)
     assert rc != 0 and len(lib.anerf_last_error()) > 0
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("n,code,want_skts", [(384, 16, True), (384, 0, True), (384, 0, False), (3072, 16, True)])
+def test_backward_in_pieces_equals_the_one_call_backward(n, code, want_skts, precision):
+    """AnerfBackwardIO.passes: the backward enqueued as fine pass / coarse parameter part / coarse pose tail (1, 4, 8 -- ABI
+    revision 6, what the data-parallel path uses to start BOTH networks' all-reduces inside the backward) or as its two halves
+    (1, 2: no pose gradients requested) produces the SAME bits as the one-call form in every parameter gradient, frame-code
+    gradient and dskts row; the hooks fire at the right points (the coarse network's parameter gradients are final at the second
+    hook: nothing the tail enqueues changes them)."""
+    cfg = ops.PathConfig(framecode_ch=code)
+    nets = _nets(cfg, precision)
+    inp = _inputs(n)
+    f = lambda k: inp[k].contiguous()
+    has_code = code > 0
+
+    def run(split):
+        out, state = ops.train_forward(cfg, nets["fwd_c"], nets["fwd_f"], f("rb"), f("skts"), f("cyls"), S, NI, t_rand=f("t_rand"),
+                                       u_imp=f("u_imp"), noise=f("noise"), noise_fine=f("noise_fine"), precision=precision,
+                                       cam_idx=f("cam") if has_code else None, codes_c=nets["codes_c"], codes_f=nets["codes_f"])
+        tgt = f("target")
+        g = {"rgb_map": 2.0 * (out["rgb_map"] - tgt), "rgb0": 2.0 * (out["rgb0"] - tgt), "acc_map": torch.full_like(out["acc_map"], 0.01)}
+        seen = {}
+        into = ([torch.zeros(sh, device="cuda") for sh in nets["shapes"]], [torch.zeros(sh, device="cuda") for sh in nets["shapes"]])
+
+        def after_fine():
+            torch.cuda.synchronize()
+            seen["fine"] = [t.clone() for t in into[1]]
+
+        def after_coarse_params():
+            torch.cuda.synchronize()
+            seen["coarse"] = [t.clone() for t in into[0]]
+        kw = dict(after_fine=after_fine, after_coarse_params=after_coarse_params) if split else {}
+        gc, gf, g_skts, gcc, gcf = ops.backward(state, g, nets["t_c"], nets["t_f"], ap.perm_tables(cfg, torch.device("cuda"), b3=precision == "bf16x3"),
+                                                nets["shapes"], nets["shapes"], nets["i_c"], nets["i_f"], want_skts=want_skts, want_codes_c=has_code,
+                                                want_codes_f=has_code, accumulate_into=into, **kw)
+        torch.cuda.synchronize()
+        return gc, gf, g_skts, gcc, gcf, seen
+    one = run(False)
+    two = run(True)
+    for a, b in zip(one[0] + one[1], two[0] + two[1]):
+        assert torch.equal(a, b)
+    if want_skts:
+        assert torch.equal(one[2], two[2]) and float(one[2].abs().max()) > 0
+    if has_code:
+        assert torch.equal(one[3], two[3]) and torch.equal(one[4], two[4]) and float(one[3].abs().max()) > 0
+    seen = two[5]
+    # at the first hook the fine network's gradients are final; at the second the coarse network's are (the tail does not touch them)
+    assert all(torch.equal(a, b) for a, b in zip(seen["fine"], two[1])) and all(torch.equal(a, b) for a, b in zip(seen["coarse"], two[0]))
+    assert float(two[0][0].abs().max()) > 0 and float(two[1][0].abs().max()) > 0
