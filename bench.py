@@ -640,8 +640,8 @@ def scaling_model(extras, device):
     #            for the slowest one (the max of 8 draws sits near the p90 of one rank's distribution)
     # What is hidden: the FINE network's collective runs under the coarse backward (>= 1 ms: hidden whatever the terms).  The COARSE
     # network's starts when its parameter gradients are enqueued (AnerfBackwardIO.passes = 4): in config 4 the pose-gradient tail
-    # (k_encode_bwd + k_pose_reduce of the coarse pass, the pose layer's backward; 115 us at 384 rays in
-    # profiles/r04_mix384_step_timeline.txt) runs on beside it and is not reduced on the 19 of 20 iterations that do not step the
+    # (k_encode_bwd + k_pose_reduce of the coarse pass, the pose layer's backward: 51 + 22 + 5 + 5 + 5 + 39 = 127 us at 384 rays in
+    # profiles/r05_mix384_step_timeline_graph.txt; 115 us is used, round 4's figure) runs on beside it and is not reduced on the 19 of 20 iterations that do not step the
     # pose group; in config 3 there is no tail, only the first network's share of k_adam (~5 us) runs under it.
     G, link, t_hop_ms = 8, 153e9, 3.0e-3
     net_bytes = bucket_bytes // 2
