@@ -165,6 +165,8 @@ def main(argv=None):
     res = {"iters": a.iters, "graph": a.graph == "on", "first": hist[0], "last": hist[-1], "psnr_gain_db": hist[-1][2] - hist[0][2],
            "held_out_psnr_db": psnr_held, "reload_max_abs_diff": float(np.abs(img_a - img_b).max()), "it_per_s": a.iters / dt,
            "host_ms_per_train_batch_median": float(np.median(host) * 1e3), "dataset": path, "checkpoint": ck,
+           "max_memory_allocated_mb": torch.cuda.max_memory_allocated() / 2 ** 20, "reserved_mb": torch.cuda.memory_reserved() / 2 ** 20,
+           "param_checksum": float(fused.flat.double().sum()),
            "graphs": None if tr._gs is None else {"captures": tr._gs.captures, "replays": tr._gs.replays, "eager": tr._gs.eager_calls}}
     print(json.dumps(res))
     return res
