@@ -103,8 +103,8 @@ def _schedule(caster, opt, k):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mixamo", [False, True])
-def test_captured_step_is_bit_identical_to_the_eager_step(mixamo):
+@pytest.mark.parametrize("mixamo, precision", [(False, "fp32"), (True, "fp32"), (True, "bf16x3")])
+def test_captured_step_is_bit_identical_to_the_eager_step(mixamo, precision):
     graph_step = importlib.import_module("a-nerf_amd.graph_step")
     dev = torch.device("cuda")
     n_iter, n_rays = 9, 192
@@ -112,6 +112,7 @@ def test_captured_step_is_bit_identical_to_the_eager_step(mixamo):
     for mode in ("eager", "graph"):
         torch.manual_seed(7)
         caster, opt, popt, st = _setup(mixamo, n_rays, dev)
+        caster.train_precision = precision          # bf16x3: the split-bf16 training kernels read tau from the step block too
         iteration = _make_iteration(caster, opt, popt, st, mixamo)
         gs = graph_step.GraphedTrainStep(iteration, caster, opt, eager_steps=2, enabled=mode == "graph")
         trace = []
