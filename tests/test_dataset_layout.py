@@ -182,3 +182,25 @@ def test_data_attrs_build_the_caster(tmp_path):
     caster = rk_test["ray_caster"]
     assert attrs["n_views"] == 3 and tuple(caster.joint_coords.shape[-3:]) == (24, 3, 3)
     np.testing.assert_array_equal(caster.joint_coords.reshape(24, 3, 3).numpy(), attrs["joint_coords"])
+
+
+def test_prefetching_generator_yields_the_sequential_batches(tmp_path):
+    """H5PoseData.batches: one background producer walks the image batches in order -- same generator consumption, same batches as
+    the plain loop (the role of the reference's DataLoader workers); a failure in the producer surfaces in the consumer"""
+    path, c = write_case("surreal_full", tmp_path, "npz")
+    ds = dataset.H5PoseData(path, device="cpu", kind="surreal")
+    torch.manual_seed(11)
+    qs = list(dataset.image_batches(len(ds), 4, 6))
+    np.random.seed(42)
+    want = [ds.sample_batch(q, 10) for q in qs]
+    for prefetch in (3, 0):                             # background producer / inline
+        np.random.seed(42)
+        got = list(ds.batches(qs, 10, prefetch=prefetch))
+        assert len(got) == len(want) == 6
+        for a, b in zip(want, got):
+            assert sorted(a) == sorted(b) and all(torch.equal(a[k], b[k]) for k in a)
+    with pytest.raises(IndexError):
+        list(ds.batches([[0, 1], [10 ** 6]], 10))
+    it = ds.batches(qs, 10, prefetch=1)                 # abandoning the generator early must not leave the producer stuck
+    next(it)
+    it.close()

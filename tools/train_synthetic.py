@@ -138,9 +138,10 @@ def main(argv=None):
     np.random.seed(0)
     hist, host = [], []
     t0 = time.perf_counter()
-    batches = dataset.image_batches(len(ds), a.n_sample_images, a.iters)
-    for i, q in enumerate(batches, 1):
-        batch = ds.sample_batch(q, n_per)                 # the reference's sampling (numpy's global generator) and collate
+    # the reference's sampling (numpy's global generator) and collate; inline -- the GPU step bounds this loop (prefetch > 0 would
+    # assemble batches ahead on a background thread: worth it only when sampling is the bottleneck)
+    batches = ds.batches(dataset.image_batches(len(ds), a.n_sample_images, a.iters), n_per, prefetch=0)
+    for i, batch in enumerate(batches, 1):
         h0 = time.perf_counter()
         loss_dict, stats = tr.train_batch(batch, i=i, global_step=i)
         host.append(time.perf_counter() - h0)
