@@ -273,8 +273,12 @@ class Trainer:
         H, W, focal = self.hwf
         if self._gs is not None and self.device is not None and torch.device(self.device).type == "cuda":
             multi = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+            layer = None if self.popt_kwargs is None else self.popt_kwargs.get("popt_layer")
+            unstaged = layer is not None and (layer.use_cache or layer.kp_map is not None or len(layer.rest_pose) != 1 or
+                                              not getattr(layer, "fused_batch", True))
             why = ("render_kwargs_train['pytest'] uploads host random numbers every call" if self.render_kwargs_train.get("pytest", False) else
-                   "more than one rank: the gradient collectives have not been run under stream capture" if multi else None)
+                   "more than one rank: the gradient collectives have not been run under stream capture" if multi else
+                   "this pose layer (cache / multi-view / per-pose rest poses) uploads its index tensors every call" if unstaged else None)
             if why is None:
                 return self._train_batch_graphed(batch, i, global_step)
             if self.__dict__.get("_warned_eager") != why:
