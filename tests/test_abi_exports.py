@@ -109,3 +109,28 @@ def test_layout_and_pack_table_host_side():
     L = lib_mod.AnerfLayout()
     assert lib_mod.load().anerf_layout(ctypes.byref(cc), 0, ctypes.byref(L)) == -1
     assert b"unsupported" in lib_mod.load().anerf_last_error()
+
+
+def test_revision6_entry_points_refuse_bad_arguments_before_any_launch():
+    """anerf_step_block_write / anerf_rand_fill_dev / anerf_adam_step_dev validate on the host (error code + message, nothing is
+    enqueued): NULL and misaligned blocks, group / n_groups / call_index out of range; an empty update is a no-op."""
+    lib_mod = importlib.import_module("a-nerf_amd._lib")
+    lib = lib_mod.load()
+    E_SHAPE, E_NULL = -2, -3
+    vals = lib_mod.AnerfStepValues()
+    fake = ctypes.c_void_p(0x7F0000001000)             # never dereferenced: every call below returns before its launch
+    assert lib.anerf_step_block_write(None, ctypes.byref(vals), None) == E_NULL
+    assert lib.anerf_step_block_write(fake, None, None) == E_NULL
+    assert lib.anerf_step_block_write(ctypes.c_void_p(0x7F0000001008), ctypes.byref(vals), None) == E_SHAPE
+    assert b"16-byte" in lib.anerf_last_error()
+    vals.n_groups = 5
+    assert lib.anerf_step_block_write(fake, ctypes.byref(vals), None) == E_SHAPE
+    job = (lib_mod.AnerfRandJob * 1)(lib_mod.AnerfRandJob(0x7F0000002000, 16, 0, 1.0))
+    assert lib.anerf_rand_fill_dev(job, 1, None, 0, None) == E_NULL
+    assert lib.anerf_rand_fill_dev(job, 1, fake, -1, None) == E_SHAPE
+    assert lib.anerf_rand_fill_dev(job, 0, fake, 0, None) == 0                      # no jobs: nothing to do
+    a = ctypes.c_void_p(0x7F0000003000)
+    assert lib.anerf_adam_step_dev(a, a, a, a, 64, 0.9, 0.999, 1e-8, fake, 4, 0, 1, None, None, None) == E_SHAPE
+    assert lib.anerf_adam_step_dev(a, a, a, a, 64, 0.9, 0.999, 1e-8, None, 0, 0, 1, None, None, None) == E_NULL
+    assert lib.anerf_adam_step_dev(a, a, a, a, 0, 0.9, 0.999, 1e-8, fake, 0, 0, 1, None, None, None) == 0
+    assert lib.anerf_adam_step_dev(ctypes.c_void_p(0x7F0000003004), a, a, a, 64, 0.9, 0.999, 1e-8, fake, 0, 0, 1, None, None, None) == E_SHAPE
