@@ -445,7 +445,7 @@ def main():
                             {"workload": tag, "value": e["value"], "ms_per_step": e["ms_per_step"], "frac": e["roofline"]["frac"]} |
                             ({"step_ms": e["step_ms"]["median"]} if e.get("step_ms") else {}) |
                             ({"host_ms": e["host_enqueue_ms"]["median"]} if e.get("host_enqueue_ms") else {}) |
-                            ({"graph": bool(e["graph"])} if "graph" in e else {}) |
+                            ({"graph": bool(e["graph"]) and "error" not in e["graph"]} if "graph" in e else {}) |
                             ({"sclk_mhz": [e["clocks"]["sclk_mhz_min"], e["clocks"]["sclk_mhz_max"]]} if (e.get("clocks") or {}).get("sclk_mhz_min") else {}))
             res["extra_workloads"] = ex
             res["extras_summary"] = summ
@@ -1085,10 +1085,18 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
     # step 6), which would dominate a short timed window of 3-20 ms steps
     for _ in range(8):
         step(eager=True)
+    graph_error = None
     if gs is not None:           # capture both cadence phases now (nothing runs): no capture inside the timed steps
-        gs.prepare(1)
-        if mixamo and args.opt_pose_step > 1:
-            gs.prepare(args.opt_pose_step)
+        try:
+            gs.prepare(1)
+            if mixamo and args.opt_pose_step > 1:
+                gs.prepare(args.opt_pose_step)
+        except Exception as e:   # a stack that cannot capture the step: say so in the record and time the eager step instead
+            graph_error = f"{type(e).__name__}: {e}"[:300]
+            sys.stderr.write(f"bench.py: hipGraph capture failed ({graph_error}); falling back to the eager step\n")
+            gs = None
+            torch.cuda.synchronize()
+            opt.zero_grad()
     for _ in range(args.warmup):
         step()
     import gc
@@ -1225,8 +1233,8 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
                "allocator_in_timed_region": {k: alloc1[k] - alloc0[k] for k in alloc0},
                "gc_collections_in_timed_region": [b - a for a, b in zip(gc0, gc1)],
                # True: every timed step was ONE hipGraphLaunch (+ the step-block write); captures / replays counted by the wrapper
-               "graph": False if gs is None else {"replays": gs.replays, "captures": gs.captures, "eager_calls": gs.eager_calls,
-                                                  "graphs": [list(k) for k in gs.graphs]}}
+               "graph": ({"error": graph_error} if graph_error else False) if gs is None else
+                        {"replays": gs.replays, "captures": gs.captures, "eager_calls": gs.eager_calls, "graphs": [list(k) for k in gs.graphs]}}
         res["config"]["graph"] = gs is not None
         if trace is not None:
             res["alloc_trace"] = [{"step": i, "new_segments": trace[i][0] - (trace[i - 1][0] if i else alloc0["num_device_alloc"]),
