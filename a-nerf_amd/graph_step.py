@@ -54,10 +54,15 @@ class StaticBatch:
 
 
 class GraphedTrainStep:
-    def __init__(self, step_fn, caster, optimizer, eager_steps=3, enabled=True):
+    def __init__(self, step_fn, caster, optimizer, eager_steps=3, enabled=True, capture_error_mode="global"):
         """step_fn(i) -> dict of tensors; caster: the RayCaster (its DeviceRng and embedders supply seed / offset / tau);
         optimizer: the FusedAdam of the step.  The first `eager_steps` calls run step_fn eagerly (lazy one-off initialisation
-        -- kernel attributes, allocator pools, index caches -- must not fall inside a capture)."""
+        -- kernel attributes, allocator pools, index caches -- must not fall inside a capture).
+        capture_error_mode: torch.cuda.graph's (hipStreamCaptureMode).  "global" (the default, the tested one) makes ANY thread's
+        allocation-class HIP call during the few milliseconds of a capture an error -- e.g. a DataLoader's pin-memory thread; pass
+        "thread_local" when such threads run beside the trainer (the autograd worker's launches into the capturing stream are
+        captured in either mode)."""
+        self.capture_error_mode = capture_error_mode
         self.step_fn, self.caster, self.opt = step_fn, getattr(caster, "module", caster), optimizer
         self.eager_left, self.enabled = int(eager_steps), bool(enabled)
         self.block = None
@@ -107,7 +112,7 @@ class GraphedTrainStep:
         self.block.fills = 0
         try:
             with ops.step_block(self.block):
-                with torch.cuda.graph(g, pool=self.pool):
+                with torch.cuda.graph(g, pool=self.pool, capture_error_mode=self.capture_error_mode):
                     out = self.step_fn(i)
         finally:
             # the capture recorded the launches without running them (or failed half way): put the host-side counters back
