@@ -122,10 +122,19 @@ def image_batches(n, N_images, n_iter, generator=None):
 class H5PoseData:
     """BaseH5Dataset's in-memory meta (dataset.py:125-183) + per-image pixel reads + batch assembly."""
 
+    PERFCAP_N_VAL = {"weipeng": 230, "nadia": 327}      # MonoPerfCapDataset.n_vals (load_perfcap.py:55)
+
     def __init__(self, path, device="cuda", kind="base", mask_img=False, N_cams=None, N_rand_kps=None, idx_map=None, N_nms=0.0,
-                 patch_size=1):
-        if kind not in ("base", "surreal", "mixamo"):
-            raise ValueError(f"H5PoseData: kind {kind!r} (base | surreal | mixamo)")
+                 patch_size=1, split="full", subject=None, n_val=None):
+        """kind: which of the reference's dataset classes' index arithmetic applies -- "base" (BaseH5Dataset), "surreal", "mixamo",
+        "h36m" (H36MDataset: split "train" / "val" by the sequence name inside `img_paths`, subjects ending in "c" keep the "-1"
+        takes; load_h36m.py:380-421), "perfcap" (MonoPerfCapDataset: the last n_val images are the validation set, camera
+        translations divided by 1.05; load_perfcap.py:65-89).  split: "full" (what load_data.py:117 passes unless --use_val),
+        "train", "val" (h36m / perfcap)."""
+        if kind not in ("base", "surreal", "mixamo", "h36m", "perfcap"):
+            raise ValueError(f"H5PoseData: kind {kind!r} (base | surreal | mixamo | h36m | perfcap)")
+        if split not in ("full", "train", "val"):
+            raise NotImplementedError(f"Split {split} is undefined!")
         if N_nms != 0 or patch_size != 1 or N_rand_kps is not None:
             raise NotImplementedError("N_nms > 0 (P_nms), patch_size > 1 and rand_train_kps are used by no shipped config")
         self.path, self.device, self.kind, self.mask_img = path, torch.device(device), kind, bool(mask_img)
@@ -169,6 +178,24 @@ class H5PoseData:
             self.bgs = np.full((1, self.HW[0] * self.HW[1], 3), 255, dtype=np.uint8)      # "set white bkgd manually"
             self.bg_idxs = np.zeros(self.n_images, dtype=np.int64)
             self.has_bg = True
+        elif kind == "h36m":                        # load_h36m.py:380-421
+            if "img_paths" not in keys:
+                raise KeyError(f"{path}: the H36M layout holds `img_paths` (the splits are read off the sequence names)")
+            seqs = [bytes(p).decode().split("/")[1] for p in rd("img_paths")]
+            if idx_map is None and subject is not None and str(subject).endswith("c"):
+                self._idx_map = np.array([i for i, q in enumerate(seqs) if q.endswith("-1")])
+            elif idx_map is None and split != "full":
+                is_val = np.array([any(q.startswith(v) for v in ("Greeting-", "Walking-", "Posing-")) for q in seqs])
+                self._idx_map = np.nonzero(is_val if split == "val" else ~is_val)[0]
+        elif kind == "perfcap":                     # load_perfcap.py:65-89
+            if idx_map is None and split != "full":
+                nv = n_val if n_val is not None else self.PERFCAP_N_VAL.get(subject)
+                if nv is None:
+                    raise ValueError("H5PoseData(kind='perfcap', split != 'full'): subject 'weipeng' / 'nadia', or n_val")
+                ids = np.arange(self.n_images)
+                self._idx_map = ids[-nv:] if split == "val" else ids[:-nv]
+            self.c2ws = self.c2ws.copy()
+            self.c2ws[..., :3, -1] /= 1.05          # "the estimation for MonoPerfCap is somehow off by a small scale"
         # per-image pixel reads: h5py slices one row from disk per access; numpy's NpzFile is lazy per KEY, not per row -- every
         # `f[key][idx]` would inflate the whole array again (0.2 s per row on a 39 MB `imgs`, three times per sampled image).
         # The .npz twin's image arrays (uint8) are therefore read ONCE here and indexed in memory as the reference indexes its

@@ -83,7 +83,24 @@ DATASET_CASES = {
     # Mixamo: a sorted subset of the file (selected.npy), white background whatever the file holds (load_mixamo.py:161-199)
     "mixamo": dict(n=10, n_poses=10, HW=(16, 20), focal=30.0, cls="MixamoDataset", kw=dict(subject="james"), batches=[[0, 3], [1, 2, 2]], seed=10,
                    selected=[7, 1, 4, 8], img_paths=True),
+    # H36M (load_h36m.py:369-428): train / val split by the sequence name inside img_paths, the "c" subjects keep the "-1" takes
+    "h36m_full": dict(n=10, n_poses=10, HW=(16, 20), focal=30.0, cls="H36MDataset", kw=dict(subject="S9", split="full"), batches=[[0, 9], [3, 4]],
+                      seed=11, img_paths="h36m"),
+    "h36m_train": dict(n=10, n_poses=10, HW=(16, 20), focal=30.0, cls="H36MDataset", kw=dict(subject="S9", split="train"), batches=[[0, 2, 4]],
+                       seed=12, img_paths="h36m"),
+    "h36m_val": dict(n=10, n_poses=10, HW=(16, 20), focal=30.0, cls="H36MDataset", kw=dict(subject="S9", split="val"), batches=[[1, 3]], seed=13,
+                     img_paths="h36m"),
+    "h36m_c": dict(n=10, n_poses=10, HW=(16, 20), focal=30.0, cls="H36MDataset", kw=dict(subject="S9c", split="full"), batches=[[0, 1, 2]], seed=14,
+                   img_paths="h36m"),
+    # MonoPerfCap (load_perfcap.py:54-89): the last n_val images are the validation set; camera translations divided by 1.05
+    "perfcap_full": dict(n=8, n_poses=8, HW=(16, 20), focal=30.0, cls="MonoPerfCapDataset", kw=dict(subject="weipeng", split="full"),
+                         batches=[[0, 7], [2, 5]], seed=15, n_val=3),
+    "perfcap_train": dict(n=8, n_poses=8, HW=(16, 20), focal=30.0, cls="MonoPerfCapDataset", kw=dict(subject="weipeng", split="train"),
+                          batches=[[0, 4]], seed=16, n_val=3),
+    "perfcap_val": dict(n=8, n_poses=8, HW=(16, 20), focal=30.0, cls="MonoPerfCapDataset", kw=dict(subject="weipeng", split="val"),
+                        batches=[[0, 2]], seed=17, n_val=3),
 }
+H36M_SEQS = ["Directions-1", "Greeting-1", "Walking-2", "Eating-2", "Posing-1", "Sitting-1", "Purchases-2", "Walking-1", "Photo-1", "Smoking-2"]
 DATASET_N_SAMPLES = 24
 
 
@@ -91,7 +108,9 @@ def dataset_dict(name):
     """the dict handed to write_to_h5py (images as [N,H,W,C]) for a DATASET_CASES entry; same arrays on every box"""
     c = DATASET_CASES[name]
     n, (H, W) = c["n"], c["HW"]
-    rng = np.random.default_rng(100 + sorted(DATASET_CASES).index(name.replace("_mask_img", "")))
+    base_names = ["base", "base_mask_img", "centers", "mixamo", "surreal_3cams", "surreal_full"]     # (the first fixtures' seeds stay what they were)
+    key = name.replace("_mask_img", "")
+    rng = np.random.default_rng(100 + (base_names.index(key) if key in base_names else 50 + sorted(DATASET_CASES).index(key)))
     poses = [synth.make_pose(50 + k) for k in range(c["n_poses"])]
     c2w = synth.default_c2w()
     c2ws = np.stack([c2w] * n).astype(np.float64)
@@ -113,6 +132,8 @@ def dataset_dict(name):
          "ext_scale": 0.001, "index": np.arange(n)}
     if c.get("centers"):
         d["centers"] = np.stack([np.full(n, W * 0.5) + rng.normal(0, 2, n), np.full(n, H * 0.5) + rng.normal(0, 2, n)], -1)
-    if c.get("img_paths"):
+    if c.get("img_paths") == "h36m":
+        d["img_paths"] = np.array([f"S9/{H36M_SEQS[k]}/frame{k:04d}.jpg" for k in range(n)])
+    elif c.get("img_paths"):
         d["img_paths"] = np.array([f"seq{k // 4}/Image{k % 4 + (2 if k == 6 else 0):04d}.png" for k in range(n)])
     return d

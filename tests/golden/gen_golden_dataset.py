@@ -7,7 +7,8 @@ that decides the fixture's content is the reference's code:
 
   * `core.process_spin.write_to_h5py` (process_spin.py:234-297) writes each tests/cases.py DATASET_CASES dict
     -> per-key manifest (dtype, shape, CRC-32 of the bytes): pins a-nerf_amd/dataset.py:write_npz_twin;
-  * `BaseH5Dataset` / `SurrealDataset` / `MixamoDataset` (dataset.py:20-420, load_surreal.py:302-380, load_mixamo.py:161-199)
+  * `BaseH5Dataset` / `SurrealDataset` / `MixamoDataset` / `H36MDataset` / `MonoPerfCapDataset` (dataset.py:20-420,
+    load_surreal.py:302-380, load_mixamo.py:161-199, load_h36m.py:369-428, load_perfcap.py:54-89)
     open that file; `ray_collate_fn([ds[q] for q in batch])` -- what DataLoader(batch_sampler=RayImageSampler, collate_fn=
     ray_collate_fn) does per iteration (load_data.py:71-82) -- with numpy's global generator seeded per batch
     -> every key of the collated batch: pins H5PoseData.sample_batch (values AND dtypes);
@@ -56,7 +57,10 @@ def main():
     from core.process_spin import write_to_h5py
     from core.load_surreal import SurrealDataset
     from core.load_mixamo import MixamoDataset
-    classes = {"BaseH5Dataset": ds_mod.BaseH5Dataset, "SurrealDataset": SurrealDataset, "MixamoDataset": MixamoDataset}
+    from core.load_h36m import H36MDataset
+    from core.load_perfcap import MonoPerfCapDataset
+    classes = {"BaseH5Dataset": ds_mod.BaseH5Dataset, "SurrealDataset": SurrealDataset, "MixamoDataset": MixamoDataset,
+               "H36MDataset": H36MDataset, "MonoPerfCapDataset": MonoPerfCapDataset}
 
     manifests = {}
     tmp = tempfile.mkdtemp()
@@ -68,6 +72,8 @@ def main():
         manifests[name] = manifest_of(path)
         if "selected" in c:
             np.save(path.replace("processed_h5py.h5", "selected.npy"), np.array(c["selected"]))
+        if "n_val" in c:      # the validation-set size is a per-subject table of the class (230 / 327 images): a class attribute, set
+            classes[c["cls"]].n_vals = dict(classes[c["cls"]].n_vals, **{c["kw"]["subject"]: c["n_val"]})      # to the fixture's size
         dset = classes[c["cls"]](path, N_samples=cases.DATASET_N_SAMPLES, **c["kw"])
         out = {"len": np.array(len(dset))}
         for b, q_idxs in enumerate(c["batches"]):

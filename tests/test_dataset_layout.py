@@ -24,7 +24,14 @@ import cases
 dataset = importlib.import_module("a-nerf_amd.dataset")
 synth = importlib.import_module("a-nerf_amd.synth")
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-KIND = {"BaseH5Dataset": "base", "SurrealDataset": "surreal", "MixamoDataset": "mixamo"}
+KIND = {"BaseH5Dataset": "base", "SurrealDataset": "surreal", "MixamoDataset": "mixamo", "H36MDataset": "h36m", "MonoPerfCapDataset": "perfcap"}
+
+
+def reader(path, c, **kw):
+    """H5PoseData with the arguments that correspond to the reference class's constructor arguments of a DATASET_CASES entry"""
+    k = c["kw"]
+    return dataset.H5PoseData(path, device="cpu", kind=KIND[c["cls"]], mask_img=k.get("mask_img", False), N_cams=k.get("N_cams"),
+                              split=k.get("split", "full"), subject=k.get("subject"), n_val=c.get("n_val"), **kw)
 
 
 def write_case(name, tmp_path, ext):
@@ -72,7 +79,7 @@ def h5py_shim():
 def test_collated_batch_matches_the_reference_dataset(name, ext, tmp_path, h5py_shim):
     g = dict(np.load(os.path.join(GOLDEN, f"dataset_{name}.npz")))
     path, c = write_case(name, tmp_path, ext)
-    ds = dataset.H5PoseData(path, device="cpu", kind=KIND[c["cls"]], mask_img=c["kw"].get("mask_img", False), N_cams=c["kw"].get("N_cams"))
+    ds = reader(path, c)
     if ext == "h5":
         assert isinstance(ds._f, h5py_shim.File)                       # the `.h5` branch of _open ran, rows are read per access
     assert len(ds) == int(g["len"])
@@ -105,7 +112,7 @@ def test_collated_batch_matches_the_reference_dataset(name, ext, tmp_path, h5py_
 def test_data_attrs_match_get_meta(name, tmp_path):
     g = dict(np.load(os.path.join(GOLDEN, f"dataset_{name}.npz")))
     path, c = write_case(name, tmp_path, "npz")
-    ds = dataset.H5PoseData(path, device="cpu", kind=KIND[c["cls"]], N_cams=c["kw"].get("N_cams"))
+    ds = reader(path, c)
     m = ds.data_attrs()
     assert sorted(m) == [str(k) for k in g["meta.keys"]]
     H, W, focals = m["hwf"]
