@@ -236,16 +236,16 @@ class H5PoseData:
             i_idxs = np.arange(self.n_images)
             _k = _kq = np.arange(len(self.kp3d))
             _c = _cq = np.arange(len(self.c2ws))
-        k_idxs, _ = self.get_kp_idx(_k, _kq)
-        c_idxs, _ = self.get_cam_idx(_c, _cq)
-        return k_idxs, c_idxs, i_idxs
+        k_idxs, kq_idxs = self.get_kp_idx(_k, _kq)
+        c_idxs, cq_idxs = self.get_cam_idx(_c, _cq)
+        return k_idxs, c_idxs, i_idxs, kq_idxs, cq_idxs
 
     def data_attrs(self, skel_type=None):
         """`get_meta()` (dataset.py:433-484, load_surreal.py:384-387): what create_raycaster / create_popt / the trainer read.
         skel_type: an object with `joint_trees` (parent index per joint); default: the 24-joint SMPL tree."""
         from . import synth
         parents = np.asarray(synth.SMPL_PARENTS if skel_type is None else skel_type.joint_trees)
-        k_idxs, c_idxs, _ = self._subset_idxs()
+        k_idxs, c_idxs, _, _, _ = self._subset_idxs()
         H, W = np.int32(self.HW[0]), np.int32(self.HW[1])                  # img_shape is stored as int32
         hwf = (np.repeat([H], len(c_idxs), 0), np.repeat([W], len(c_idxs), 0), self.focals[c_idxs])
         betas = self.betas
@@ -258,6 +258,31 @@ class H5PoseData:
                 "skel_type": skel_type, "joint_coords": per_joint_coords(self.rest_pose, parents), "rest_pose": self.rest_pose,
                 "gt_kp3d": None if self.gt_kp3d is None else self.gt_kp3d[k_idxs], "kp3d": self.kp3d[k_idxs], "skts": self.skts[k_idxs],
                 "bones": self.bones[k_idxs], "betas": betas, "kp_map": None, "kp_uidxs": None}
+
+    RENDER_SUBSET = {"surreal": (1, 15), "mixamo": (40, 15), "h36m": (80, 15), "perfcap": (10, 15)}   # (render_skip, N_render) of the classes
+
+    def render_data(self, render_skip=None, N_render=None):
+        """`get_render_data()` (dataset.py:486-541): every render_skip-th image of the served subset, at most N_render of them --
+        images / masks / backgrounds as float [*,H,W,C], their cameras and poses: what run_nerf.py hands to render_path for its
+        periodic test renders.  Defaults: the class attributes of the reference's dataset class for this `kind`."""
+        skip, n = self.RENDER_SUBSET.get(self.kind, (None, None))     # (BaseH5Dataset defines none: pass both)
+        skip, n = (skip if render_skip is None else render_skip), (n if N_render is None else N_render)
+        if skip is None or n is None:
+            raise ValueError("render_data: kind 'base' has no default render subset; pass render_skip and N_render")
+        k_idxs, c_idxs, i_idxs, kq_idxs, cq_idxs = self._subset_idxs()
+        sub = lambda a: np.asarray(a)[::skip][:n]
+        k_idxs, c_idxs, i_idxs, kq_idxs, cq_idxs = sub(k_idxs), sub(c_idxs), sub(i_idxs), sub(kq_idxs), sub(cq_idxs)
+        # PoseRefinedDataset (mixamo / h36m / perfcap) reports the QUERIED indices as kp_idxs / cam_idxs (dataset.py:570-584) --
+        # the rows of the pose layer and of the frame-code table -- the plain classes the file indices
+        refined = self.kind in ("mixamo", "h36m", "perfcap")
+        H, W = self.HW
+        img = lambda key, ch: np.stack([np.asarray(self._f[key][int(i)]) for i in i_idxs]).reshape(-1, H, W, ch)
+        Hs, Ws = np.repeat([np.int32(H)], len(c_idxs), 0), np.repeat([np.int32(W)], len(c_idxs), 0)
+        return {"imgs": img("imgs", 3).astype(np.float32) / 255., "fgs": img("masks", 1),
+                "bgs": self.bgs.reshape(-1, H, W, 3).astype(np.float32) / 255., "bg_idxs": self.bg_idxs[i_idxs], "bg_idxs_len": len(self.bgs),
+                "cam_idxs": cq_idxs.copy() if refined else c_idxs, "cam_idxs_len": len(self.c2ws), "c2ws": self.c2ws[c_idxs],
+                "hwf": (Hs, Ws, self.focals[c_idxs]), "center": None if self.centers is None else self.centers[c_idxs].copy(),
+                "kp_idxs": kq_idxs.copy() if refined else k_idxs, "kp_idxs_len": len(self.kp3d), "kp3d": self.kp3d[k_idxs], "skts": self.skts[k_idxs], "bones": self.bones[k_idxs]}
 
     # ---- per-image pieces, named as in BaseH5Dataset -------------------------------------------------------------
     def get_rays(self, c2w, focal, pixel_idxs, center=None):

@@ -13,6 +13,7 @@ that decides the fixture's content is the reference's code:
     ray_collate_fn) does per iteration (load_data.py:71-82) -- with numpy's global generator seeded per batch
     -> every key of the collated batch: pins H5PoseData.sample_batch (values AND dtypes);
   * `get_meta()` (dataset.py:433-484) -> the arrays create_raycaster / create_popt read: pins H5PoseData.data_attrs;
+    `get_render_data()` (dataset.py:486-541) -> what run_nerf's periodic test renders read: pins H5PoseData.render_data;
   * `RayImageSampler` (dataset.py:774-811) under torch.manual_seed -> the image batches of the first iterations: pins
     dataset.image_batches.
 
@@ -94,6 +95,15 @@ def main():
             out["meta.center"] = meta["center"]
         if meta["gt_kp3d"] is not None:
             out["meta.gt_kp3d"] = meta["gt_kp3d"]
+        # dataset.py:486-541: what run_nerf's test renders read (BaseH5Dataset itself defines no render subset: subclasses only)
+        rd = dset.get_render_data() if hasattr(dset, "render_skip") else {}
+        if rd:
+            out["render.keys"] = np.array(sorted(rd))
+        for k, v in rd.items():
+            if k == "hwf":
+                out["render.H"], out["render.W"], out["render.focals"] = np.asarray(v[0]), np.asarray(v[1]), np.asarray(v[2])
+            elif v is not None:
+                out[f"render.{k}"] = np.asarray(v)
         np.savez_compressed(os.path.join(HERE, f"dataset_{name}.npz"), **out)
         print(name, "len", len(dset), {k: (v.dtype, v.shape) for k, v in out.items() if k.startswith("b0.")})
     json.dump(manifests, open(os.path.join(HERE, "dataset_layout_manifest.json"), "w"), indent=1, sort_keys=True)

@@ -211,3 +211,24 @@ def test_prefetching_generator_yields_the_sequential_batches(tmp_path):
     it = ds.batches(qs, 10, prefetch=1)                 # abandoning the generator early must not leave the producer stuck
     next(it)
     it.close()
+
+
+@pytest.mark.parametrize("name", [n for n in sorted(cases.DATASET_CASES) if cases.DATASET_CASES[n]["cls"] != "BaseH5Dataset"])
+def test_render_data_matches_get_render_data(name, tmp_path):
+    """H5PoseData.render_data == the reference's get_render_data() (dataset.py:486-541): every key, dtype and value of the
+    render subset run_nerf.py hands to render_path for its periodic test renders (class defaults for render_skip / N_render)"""
+    g = dict(np.load(os.path.join(GOLDEN, f"dataset_{name}.npz")))
+    path, c = write_case(name, tmp_path, "npz")
+    rd = reader(path, c).render_data()
+    assert sorted(rd) == [str(k) for k in g["render.keys"]]
+    for k, v in rd.items():
+        items = dict(zip(("H", "W", "focals"), v)) if k == "hwf" else {k: v}
+        for kk, vv in items.items():
+            if vv is None:
+                assert f"render.{kk}" not in g
+                continue
+            want = g[f"render.{kk}"]
+            assert np.asarray(vv).shape == want.shape and np.asarray(vv).dtype == want.dtype, (kk, np.asarray(vv).dtype, want.dtype)
+            np.testing.assert_array_equal(np.asarray(vv), want, err_msg=kk)
+    with pytest.raises(ValueError, match="render subset"):
+        dataset.H5PoseData(path, device="cpu").render_data()
