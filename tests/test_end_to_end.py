@@ -22,5 +22,6 @@ def test_dataset_to_trainer_to_checkpoint_to_render_path(tmp_path):
     assert r["last"][1] < 0.6 * r["first"][1], r                      # the loss fell
     assert r["psnr_gain_db"] > 2.0, r                                  # ... and the PSNR against the teacher's pixels rose
     assert r["held_out_psnr_db"] > 10.0, r                             # a camera the student never saw
+    assert r["testset_frames"] == 9 and r["testset_psnr_db"] > 15.0, r      # the dataset's render subset through render_path (run_nerf's test render)
     assert r["reload_max_abs_diff"] == 0.0                             # checkpoint round trip: the same image, bit for bit
     assert os.path.exists(r["checkpoint"]) and os.path.exists(r["dataset"])

@@ -163,8 +163,17 @@ def main(argv=None):
     img_a, *_ = render_mod.render_path([held[0]] * a.n_kps, (a.hw, a.hw, focal), args.chunk, rk_test, **kw)
     img_b, *_ = render_mod.render_path([held[0]] * a.n_kps, (a.hw, a.hw, focal), args.chunk, rk2, **kw)
     psnr_held = float(-10 * np.log10(np.mean((np.clip(img_a, 0, 1) - np.clip(held[1], 0, 1)) ** 2)))
+    # ---- run_nerf.py's periodic test render (run_nerf.py:553-590, render_testset :148-180): the dataset's render subset --
+    # cameras, poses, ground-truth images, backgrounds by index -- through render_path, PSNR against the dataset's own images
+    rd = ds.render_data()
+    tt = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32, device=dev)
+    cyl_rd = torch.tensor(np.stack([synth.bounding_cylinder(k, ext_scale=args.ext_scale) for k in rd["kp3d"]]), dtype=torch.float32, device=dev)
+    rgbs_rd, *_ = render_mod.render_path(rd["c2ws"], rd["hwf"], args.chunk // 8, rk_test, bg_imgs=rd["bgs"], bg_indices=rd["bg_idxs"],
+                                          centers=rd["center"], kp=tt(rd["kp3d"]), skts=tt(rd["skts"]), cyls=cyl_rd, bones=tt(rd["bones"]),
+                                          ext_scale=args.ext_scale, white_bkgd=args.white_bkgd)
+    psnr_testset = float(-10 * np.log10(np.mean((np.clip(rgbs_rd, 0, 1) - rd["imgs"]) ** 2)))
     res = {"iters": a.iters, "graph": a.graph == "on", "first": hist[0], "last": hist[-1], "psnr_gain_db": hist[-1][2] - hist[0][2],
-           "held_out_psnr_db": psnr_held, "reload_max_abs_diff": float(np.abs(img_a - img_b).max()), "it_per_s": a.iters / dt,
+           "held_out_psnr_db": psnr_held, "testset_psnr_db": psnr_testset, "testset_frames": int(len(rd["imgs"])), "reload_max_abs_diff": float(np.abs(img_a - img_b).max()), "it_per_s": a.iters / dt,
            "host_ms_per_train_batch_median": float(np.median(host) * 1e3), "dataset": path, "checkpoint": ck,
            "max_memory_allocated_mb": torch.cuda.max_memory_allocated() / 2 ** 20, "reserved_mb": torch.cuda.memory_reserved() / 2 ** 20,
            "param_checksum": float(fused.flat.double().sum()),
