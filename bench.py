@@ -11,12 +11,14 @@ process per GPU, and the per-ray outputs are all-gathered over RCCL at the end o
 --gpus N > 1 from a plain shell starts N ranks of this script (one per GPU, RCCL, rendezvous on 127.0.0.1); under
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it joins the ranks it is given.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel
+Prints ONE strict-JSON line of <= 4 KB on rank 0 (contract keys only; the full record goes to bench_detail.json / --detail and
+to stderr) with `roofline` for the dominant kernel
 (k_mlp_fwd, MFMA-bound: algorithmic FLOPs / HIP-event time on the launch stream vs the 157.3 TFLOP/s fp32
 matrix peak; training workloads: the FLOPs the kernels execute, with a per-kernel list), `cpu_baseline` (the torch-CPU
 oracle = port of the reference path, timed on this host's cores over a bounded ray sample of the same frame), who ran
 (`ranks`, `backend`, `devices`, per-rank and collective times) and, for the default invocation, `extra_workloads`
-(BASELINE configs 3, 4 and 5 under the same clock).
+(BASELINE configs 3, 4 and 5 under the same clock; summarised per workload on the line) with the 8-GPU scaling model.
+Training workloads replay the iteration from ONE captured hipGraph in a single process (--graph; a-nerf_amd/graph_step.py).
 """
 import argparse
 import importlib
