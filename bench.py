@@ -110,6 +110,7 @@ class ClockSampler:
 
     def __init__(self, device_index=0, period_s=0.05):
         self.idx, self.period, self.samples, self._stop, self._th, self.err = device_index, period_s, [], None, None, None
+        self.mclk = []
 
     def _read(self, smi, h):
         clk = pw = None
@@ -118,6 +119,11 @@ class ClockSampler:
             clk = float(ci.get("clk", ci.get("cur_clk")))
         except Exception as e:
             self.err = self.err or f"clock: {type(e).__name__}: {e}"
+        try:        # memory clock: a lease with slow HBM shows in the store-heavy training forward first, not in sclk
+            mi = smi.amdsmi_get_clock_info(h, smi.AmdSmiClkType.MEM)
+            self.mclk.append(float(mi.get("clk", mi.get("cur_clk"))))
+        except Exception:
+            pass
         try:
             pi = smi.amdsmi_get_power_info(h)
             for k in ("current_socket_power", "average_socket_power", "socket_power"):
@@ -161,6 +167,7 @@ class ClockSampler:
         pw = [p for _, p in self.samples if p]
         f = lambda xs, fn: float(fn(xs)) if xs else None
         return {"samples": len(self.samples), "sclk_mhz_min": f(clk, min), "sclk_mhz_max": f(clk, max), "sclk_mhz_mean": f(clk, np.mean),
+                "mclk_mhz_min": f(self.mclk, min), "mclk_mhz_mean": f(self.mclk, np.mean),
                 "power_w_mean": f(pw, np.mean), "power_w_max": f(pw, max), "error": self.err}
 
 
@@ -171,6 +178,27 @@ def alloc_counters(device):
     """the caching allocator's hipMalloc / hipFree / retry counters: a timed region that grows the pool pays milliseconds per call"""
     st = torch.cuda.memory_stats(device)
     return {k: int(st.get(k, 0)) for k in _ALLOC_KEYS}
+
+
+def hbm_probe(device, mib=1024, reps=5):
+    """device-to-device copy bandwidth (read + write bytes / HIP-event time): one number that tells a lease with slow HBM -- the
+    store-heavy training forward drops first on such a box, with the shader clock unchanged -- from a kernel regression"""
+    try:
+        a = torch.empty(mib * 2 ** 20 // 4, dtype=torch.float32, device=device).normal_()
+        b = torch.empty_like(a)
+        b.copy_(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            b.copy_(a)
+        e1.record()
+        torch.cuda.synchronize()
+        gbps = 2 * a.numel() * 4 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a, b
+        torch.cuda.empty_cache()
+        return float(gbps)
+    except Exception:
+        return None
 
 
 def _flush_c_stdio():
@@ -233,7 +261,7 @@ def compact_line(res):
         line["alt_precision"] = {"precision": "bf16x3", "value": ap.get("value"), "ms_per_step": ap.get("ms_per_step"),
                                  "max_abs_rgb_vs_f32": ap.get("max_abs_rgb_vs_f32")}
     if isinstance(line.get("clocks"), dict):
-        line["clocks"] = {k: line["clocks"].get(k) for k in ("sclk_mhz_min", "sclk_mhz_max", "sclk_mhz_mean", "power_w_mean")}
+        line["clocks"] = {k: line["clocks"].get(k) for k in ("sclk_mhz_min", "sclk_mhz_max", "sclk_mhz_mean", "mclk_mhz_mean", "power_w_mean", "hbm_copy_GBps")}
     if isinstance(line.get("scaling_model_8gpu"), dict):         # the predictions only; terms and inputs are in the detail file
         sm = line["scaling_model_8gpu"]
         line["scaling_model_8gpu"] = {"note": "model, not a measurement: N = 1 timings + ring terms", "t_hop_us_assumed": sm.get("t_hop_us_assumed")} | {
@@ -819,7 +847,7 @@ def bench_render(args, rank, world, device, dist, synth, ops, pipeline):
             "allocator_in_timed_region": {k: alloc1[k] - alloc0[k] for k in alloc0},
             # shader clock / socket power DURING the timed steps (amdsmi, host thread); frac_at_observed_clock rescales the MFMA
             # peak (quoted at 2400 MHz, MI355X_MICROARCH.md) to the mean clock the kernel actually ran at
-            "clocks": clocks.summary(),
+            "clocks": dict(clocks.summary(), hbm_copy_GBps=hbm_probe(device)),
         }
         ck = res["clocks"]
         if ck.get("sclk_mhz_mean"):
@@ -1108,15 +1136,17 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
     alloc0 = alloc_counters(device)
     gc0 = [g["collections"] for g in gc.get_stats()]
     trace = [] if os.environ.get("ANERF_BENCH_ALLOC_TRACE") == "1" else None     # diagnostic: pool growth per step (costs host time)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(i)
-        if trace is not None:
-            st = torch.cuda.memory_stats(device)
-            trace.append((st["num_device_alloc"], st["reserved_bytes.all.current"], st["allocated_bytes.all.peak"]))
-    host_t[args.steps] = time.perf_counter()
-    barrier()
-    dt = dt_local = time.perf_counter() - t0
+    clocks = ClockSampler(device.index or 0, period_s=0.1)
+    with clocks:
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            loss = step(i)
+            if trace is not None:
+                st = torch.cuda.memory_stats(device)
+                trace.append((st["num_device_alloc"], st["reserved_bytes.all.current"], st["allocated_bytes.all.peak"]))
+        host_t[args.steps] = time.perf_counter()
+        barrier()
+        dt = dt_local = time.perf_counter() - t0
     alloc1 = alloc_counters(device)
     gc1 = [g["collections"] for g in gc.get_stats()]
     tt = torch.tensor([dt], device=device)
@@ -1233,7 +1263,7 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
                "step_ms": step_stats(step_all), "period_ms": step_stats(period_all), "host_enqueue_ms": step_stats(host_all),
                "slow_steps": outliers(step_all, host_all),
                "allocator_in_timed_region": {k: alloc1[k] - alloc0[k] for k in alloc0},
-               "gc_collections_in_timed_region": [b - a for a, b in zip(gc0, gc1)],
+               "gc_collections_in_timed_region": [b - a for a, b in zip(gc0, gc1)], "clocks": clocks.summary(),
                # True: every timed step was ONE hipGraphLaunch (+ the step-block write); captures / replays counted by the wrapper
                "graph": ({"error": graph_error} if graph_error else False) if gs is None else
                         {"replays": gs.replays, "captures": gs.captures, "eager_calls": gs.eager_calls, "graphs": [list(k) for k in gs.graphs]}}
