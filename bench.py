@@ -110,7 +110,7 @@ class ClockSampler:
 
     def __init__(self, device_index=0, period_s=0.05):
         self.idx, self.period, self.samples, self._stop, self._th, self.err = device_index, period_s, [], None, None, None
-        self.mclk = []
+        self.other = {}
 
     def _read(self, smi, h):
         clk = pw = None
@@ -119,11 +119,14 @@ class ClockSampler:
             clk = float(ci.get("clk", ci.get("cur_clk")))
         except Exception as e:
             self.err = self.err or f"clock: {type(e).__name__}: {e}"
-        try:        # memory clock: a lease with slow HBM shows in the store-heavy training forward first, not in sclk
-            mi = smi.amdsmi_get_clock_info(h, smi.AmdSmiClkType.MEM)
-            self.mclk.append(float(mi.get("clk", mi.get("cur_clk"))))
-        except Exception:
-            pass
+        # memory / data-fabric / SoC clocks: a lease that is slow with sclk unchanged shows in the tile kernels' L2 -> LDS weight
+        # stream and in the store-heavy training forward first
+        for name, typ in (("mclk", "MEM"), ("fclk", "DF"), ("socclk", "SOC")):
+            try:
+                mi = smi.amdsmi_get_clock_info(h, getattr(smi.AmdSmiClkType, typ))
+                self.other.setdefault(name, []).append(float(mi.get("clk", mi.get("cur_clk"))))
+            except Exception:
+                pass
         try:
             pi = smi.amdsmi_get_power_info(h)
             for k in ("current_socket_power", "average_socket_power", "socket_power"):
@@ -167,7 +170,8 @@ class ClockSampler:
         pw = [p for _, p in self.samples if p]
         f = lambda xs, fn: float(fn(xs)) if xs else None
         return {"samples": len(self.samples), "sclk_mhz_min": f(clk, min), "sclk_mhz_max": f(clk, max), "sclk_mhz_mean": f(clk, np.mean),
-                "mclk_mhz_min": f(self.mclk, min), "mclk_mhz_mean": f(self.mclk, np.mean),
+                "mclk_mhz_min": f(self.other.get("mclk", []), min), "mclk_mhz_mean": f(self.other.get("mclk", []), np.mean),
+                "fclk_mhz_mean": f(self.other.get("fclk", []), np.mean), "socclk_mhz_mean": f(self.other.get("socclk", []), np.mean),
                 "power_w_mean": f(pw, np.mean), "power_w_max": f(pw, max), "error": self.err}
 
 
