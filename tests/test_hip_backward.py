@@ -565,3 +565,49 @@ def test_ray_noise_std_training_step_vs_reference_golden(golden, monkeypatch, pr
         importlib.import_module("a-nerf_amd.pipeline").render_rays_forward(net_c=caster.network.packed(which),
                                                                           net_f=caster.network_fine.packed(which), extras=True,
                                                                           precision=precision, **kw)
+
+
+@pytest.mark.parametrize("n,S,Ni", [(1, 8, 8), (5, 17, 9), (3, 33, 8), (130, 8, 16), (2, 64, 128)])
+def test_ragged_training_sizes_vs_oracle_autograd(oracle, synth, n, S, Ni):
+    """Edge sizes on the TRAINING path (the forward-only edge cases are in test_hip_edge_cases.py): one ray, ray counts and sample
+    counts that leave tiles ragged (n * S and n * (S + Ni) not multiples of the 128-sample tile, S + Ni odd), more importance than
+    coarse samples -- outputs and every element of all 48 parameter gradients + dskts against the pinned oracle's autograd,
+    with jitter and density noise as explicit inputs (anerf_train_forward / anerf_backward through the one-node route)."""
+    ap = importlib.import_module("a-nerf_amd.autograd_path")
+    ro, rd, kp, skts, bones, cyls, _ = synth.scene_batch(n, [3, 4], ray_seed=40 + n, per_ray_pose=True)
+    Pc, Pf = synth.make_net_params(11), synth.make_net_params(12)
+    g = torch.Generator().manual_seed(n * 1000 + S)
+    rnd = dict(t_rand=torch.rand(n, S, generator=g), u_imp=torch.rand(n, Ni, generator=g), noise=torch.randn(n, S, generator=g),
+               noise_fine=torch.randn(n, S + Ni, generator=g))
+    cfg = ops.PathConfig()
+    pipeline = importlib.import_module("a-nerf_amd.pipeline")
+    rb = pipeline.make_ray_batch(dev(ro), dev(rd))
+    net_c = ops.pack_params(cfg, {k: dev(v) for k, v in Pc.items()})
+    net_f = ops.pack_params(cfg, {k: dev(v) for k, v in Pf.items()})
+    out, state = ops.train_forward(cfg, net_c, net_f, rb, dev(skts), dev(cyls), S, Ni, **{k: v.cuda() for k, v in rnd.items()})
+    gmaps = {"rgb_map": 2.0 * out["rgb_map"], "rgb0": 2.0 * out["rgb0"], "acc_map": torch.full_like(out["acc_map"], 0.3)}
+    shapes = [tuple(np.asarray(Pc[nm + sfx]).shape) for nm in ops.PARAM_ORDER for sfx in (".weight", ".bias")]
+    pk = lambda P, w: ops.pack_params(cfg, {k: dev(v) for k, v in P.items()}, which=w)[0]
+    gc, gf, g_skts, _, _ = ops.backward(state, gmaps, pk(Pc, 1), pk(Pf, 1), ap.perm_tables(cfg, rb.device), shapes, shapes,
+                                        pk(Pc, 2), pk(Pf, 2), want_skts=True)
+    torch.cuda.synchronize()
+    oc, of = oracle.params_from_numpy(Pc, True), oracle.params_from_numpy(Pf, True)
+    sk = t(skts).requires_grad_(True)
+    o = oracle.render_rays(oracle.OracleConfig(), oc, of, oracle.make_ray_batch(t(ro), t(rd)), sk, t(cyls), S, Ni, **rnd)
+    for k in ("rgb_map", "acc_map", "rgb0"):
+        np.testing.assert_allclose(out[k].cpu().numpy(), o[k].detach().numpy(), atol=1e-4, err_msg=k)
+    ((o["rgb_map"] ** 2).sum() + (o["rgb0"] ** 2).sum() + 0.3 * o["acc_map"].sum()).backward()
+    worst = 0.0
+    for got, P in ((gc, oc), (gf, of)):
+        for i, nm in enumerate(ops.PARAM_ORDER):
+            for j, sfx in enumerate((".weight", ".bias")):
+                ref = P[nm + sfx].grad
+                e = grad_err(got[2 * i + j], ref)
+                # a one-element tensor (alpha_linear.bias) summed over a handful of samples is a cancelling sum: the relative bar
+                # gets an absolute floor of a few fp32 ulps of the terms
+                floor = 3e-6 / (float(ref.abs().max()) + 1e-30)
+                worst = max(worst, e)
+                assert e <= GRAD_BAR + floor, (nm + sfx, e, float(ref.abs().max()))
+    e_sk = grad_err(g_skts, sk.grad)
+    assert e_sk <= 1e-3, e_sk
+    print(f"n={n} S={S} Ni={Ni}: worst parameter-gradient error {worst:.2e}, dskts {e_sk:.2e}")
