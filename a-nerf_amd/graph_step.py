@@ -110,11 +110,21 @@ class GraphedTrainStep:
         torch.autograd.graph.increment_version([p for g in opt.param_groups for p in g["params"]])
         g = torch.cuda.CUDAGraph()
         self.block.fills = 0
+        # Python's cycle collector must not run INSIDE the capture: it would free whatever cyclic garbage earlier iterations left
+        # behind (autograd contexts holding workspaces, pinned staging buffers), and releasing device / pinned memory records and
+        # queries events on streams -- not permitted while one of them is capturing (seen as a hard abort: a collection triggered by
+        # the step's own allocations, in the middle of the capture).  Collect now, keep the collector off until the capture ends.
+        import gc
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
         try:
             with ops.step_block(self.block):
                 with torch.cuda.graph(g, pool=self.pool, capture_error_mode=self.capture_error_mode):
                     out = self.step_fn(i)
         finally:
+            if gc_was_on:
+                gc.enable()
             # the capture recorded the launches without running them (or failed half way): put the host-side counters back
             fills = self.block.fills
             rng.offset, opt._steps[:], opt._grad_scale[:] = snap[0], snap[1], snap[2]

@@ -309,3 +309,60 @@ def test_graphed_trainer_is_bit_identical_to_the_eager_trainer(name):
             assert torch.equal(a[k].cpu(), b[k].cpu()), (i + 1, k, a[k], b[k])
     assert torch.equal(e["flat"], g["flat"]) and torch.equal(e["m"], g["m"])
     print(f"{name}: {gs.captures} graphs for keys {sorted(map(str, gs.graphs))}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph", [False, True])
+def test_resumed_run_continues_bit_identically(graph, tmp_path):
+    """Checkpoint / resume (SURVEY aux subsystems; trainer.py:485-517, raycasters.py:117-143, pose_opt.py:52-75): 4 iterations ->
+    save_nerf -> fresh modules -> load_nerf -> 4 more iterations end on EXACTLY the parameters, Adam moments, pose parameters and
+    random-stream position of 8 iterations straight -- networks, frame codes, embedder tau, both optimiser groups' step counts and
+    moments, the regulariser anchors and the device generator's offset all travel in the reference's `.tar` layout.  Eager and
+    captured-graph trainers."""
+    ops = importlib.import_module("a-nerf_amd.ops")
+    checkpoint = importlib.import_module("a-nerf_amd.checkpoint")
+    dev = torch.device("cuda")
+    n = 64
+
+    def make():
+        torch.manual_seed(3)
+        tr, caster, layer, fused, _ = _mixamo_trainer("fused", dev, opt_pose_step=2)
+        tr.render_kwargs_train["pytest"] = False
+        caster._rng = ops.DeviceRng(seed=99, stream_id=7)
+        if graph:
+            tr.enable_graph(eager_steps=1)
+        return tr, caster, layer, fused
+
+    def batch_of(i):
+        rng = np.random.default_rng(1000 + i)
+        poses = sorted(rng.choice(N_POSES, size=3, replace=False).tolist())
+        ro, rd, kp, skts, bones, cyls, which = synth.scene_batch(n, poses, ray_seed=100 + i, per_ray_pose=True)
+        which = np.asarray(poses)[np.asarray(which)]
+        t = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32)
+        return dict(rays=t(np.stack([ro, rd])), target_s=t(np.random.default_rng(200 + i).random((n, 3))), kp_idx=torch.tensor(which, dtype=torch.int64),
+                    kp3d=t(kp), bones=t(bones), skts=t(skts), cyls=t(cyls), cam_idxs=t(np.asarray(which, dtype=np.float32)), fgs=torch.ones(n, 1),
+                    bgs=torch.ones(n, 3))
+
+    # (a) eight iterations straight
+    tr, caster, layer, fused = make()
+    for i in range(1, 9):
+        tr.train_batch(batch_of(i), i=i, global_step=500 * i)
+    torch.cuda.synchronize()
+    want = dict(flat=fused.flat.clone(), m=fused.exp_avg.clone(), v=fused.exp_avg_sq.clone(), steps=list(fused._steps), offset=caster.rng().offset,
+                tau=caster.embed_fn.get_tau())
+    # (b) four, checkpoint, fresh modules, four more
+    tr, caster, layer, fused = make()
+    for i in range(1, 5):
+        tr.train_batch(batch_of(i), i=i, global_step=500 * i)
+    path = str(tmp_path / "002000.tar")
+    tr.save_nerf(path, 2000)
+    tr2, caster2, layer2, fused2 = make()
+    caster2._rng = ops.DeviceRng(seed=5, stream_id=11)                      # whatever the fresh process had: the checkpoint's stream takes over
+    r = checkpoint.load_nerf(path, tr2.render_kwargs_train["ray_caster"], fused2, layer2, None)
+    assert r["global_step"] == 2000 and fused2._steps == [4, 2] and caster2.rng().offset == 4
+    tr2.popt_kwargs["popt_anchors"] = r["poseopt_anchors"]
+    for i in range(5, 9):
+        tr2.train_batch(batch_of(i), i=i, global_step=500 * i)
+    torch.cuda.synchronize()
+    assert fused2._steps == want["steps"] and caster2.rng().offset == want["offset"] and caster2.embed_fn.get_tau() == want["tau"]
+    assert torch.equal(fused2.flat, want["flat"]) and torch.equal(fused2.exp_avg, want["m"]) and torch.equal(fused2.exp_avg_sq, want["v"])
