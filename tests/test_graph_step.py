@@ -115,13 +115,22 @@ def test_captured_step_is_bit_identical_to_the_eager_step(mixamo, precision):
         caster.train_precision = precision          # bf16x3: the split-bf16 training kernels read tau from the step block too
         iteration = _make_iteration(caster, opt, popt, st, mixamo)
         gs = graph_step.GraphedTrainStep(iteration, caster, opt, eager_steps=2, enabled=mode == "graph")
-        trace = []
+        trace, evals = [], []
+        render_mod = importlib.import_module("a-nerf_amd.render")
+        ekw = dict(chunk=4096, rays=st["rays"], use_viewdirs=True, ray_caster=caster, subject_idxs=None, N_samples=64, N_importance=16,
+                   perturb=0.0, raw_noise_std=0.0, preproc_kwargs={"density_scale": 1.0, "density_fn": torch.nn.functional.relu},
+                   cams=torch.tensor(st["pidx"], device=dev).to(torch.float32) if mixamo else None, **st["batch"])
         for k in range(1, n_iter + 1):
             _schedule(caster, opt, k)
             out = gs.step(k)
             trace.append((out["loss"].detach().clone(), out["stats"].detach().clone(), out["norms"].detach().clone(), out["rgb"].detach().clone()))
+            if k % 3 == 0:        # run_nerf's periodic test render BETWEEN training iterations: eager kernels re-gathering the weight
+                caster.eval()     # images the graph also writes, then training goes on
+                with torch.no_grad():
+                    evals.append(render_mod.render(512, 512, 600.0, **ekw)["rgb_map"].clone())
+                caster.train()
         torch.cuda.synchronize()
-        runs.append(dict(trace=trace, flat=opt.flat.clone(), m=opt.exp_avg.clone(), v=opt.exp_avg_sq.clone(), steps=list(opt._steps),
+        runs.append(dict(trace=trace, evals=evals, flat=opt.flat.clone(), m=opt.exp_avg.clone(), v=opt.exp_avg_sq.clone(), steps=list(opt._steps),
                          offset=caster.rng().offset, gs=gs, caster=caster, opt=opt, popt=popt, st=st))
     e, g = runs
     assert g["gs"].eager_calls == 2 and g["gs"].replays == n_iter - 2
@@ -132,6 +141,8 @@ def test_captured_step_is_bit_identical_to_the_eager_step(mixamo, precision):
         for x, y, what in zip(a, b, ("loss", "stats", "norms", "rgb_map")):
             assert torch.equal(x, y), (k + 1, what, float((x - y).abs().max()))
     assert torch.equal(e["flat"], g["flat"]) and torch.equal(e["m"], g["m"]) and torch.equal(e["v"], g["v"])
+    assert len(e["evals"]) == 3 and all(torch.equal(a, b) for a, b in zip(e["evals"], g["evals"]))      # the interleaved test renders
+    assert not torch.equal(g["evals"][0], g["evals"][2])                                                 # ... saw the parameters move
     assert len({float(t[0]) for t in g["trace"]}) == n_iter                 # the iterations differ (fresh draws, moving parameters)
     # the device block holds what the last iteration ran with
     blk, gs = g["gs"].block.read(), g["gs"]
