@@ -278,3 +278,34 @@ def test_c_abi_is_capturable_without_torch():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout, r.stderr)
     assert "bit-identical" in r.stdout and "6 replays" in r.stdout, r.stdout
+
+
+@pytest.mark.gpu
+def test_a_failing_capture_leaves_the_stepper_usable():
+    """an exception raised by the iteration WHILE it is being captured propagates, the host-side counters are put back, the cycle
+    collector is switched on again, and the next call captures and replays normally"""
+    import gc
+    graph_step = importlib.import_module("a-nerf_amd.graph_step")
+    dev = torch.device("cuda")
+    torch.manual_seed(7)
+    caster, opt, popt, st = _setup(False, 128, dev)
+    inner = _make_iteration(caster, opt, popt, st, False)
+    boom = {"on": False}
+
+    def iteration(k):
+        out = inner(k)
+        if boom["on"] and torch.cuda.is_current_stream_capturing():
+            raise ValueError("boom inside the capture")
+        return out
+    gs = graph_step.GraphedTrainStep(iteration, caster, opt, eager_steps=1)
+    gs.step(1)
+    steps0, off0 = list(opt._steps), caster.rng().offset
+    boom["on"] = True
+    with pytest.raises(ValueError, match="boom"):
+        gs.step(2)
+    assert gc.isenabled() and list(opt._steps) == steps0 and caster.rng().offset == off0 and gs.captures == 0 and not gs.graphs
+    boom["on"] = False
+    a = gs.step(2)["loss"].clone()
+    b = gs.step(3)["loss"].clone()
+    torch.cuda.synchronize()
+    assert gs.captures == 1 and gs.replays == 2 and opt._steps == [3] and torch.isfinite(a) and torch.isfinite(b) and not torch.equal(a, b)
