@@ -69,6 +69,10 @@ def parse():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x3"],
                     help="exact fp32 MFMA, or hi/lo-split bf16 MFMAs (3 per product, fp32 accumulate); train workloads: "
                          "bf16x3 applies to the forward kernel only, backward + weight-gradient GEMM stay fp32")
+    ap.add_argument("--live-traffic", default="auto", choices=["auto", "on", "off"],
+                    help="measure roofline.traffic in THIS run: two short rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE, WRITE_SIZE; "
+                         "separate passes) of the same workload in child processes after the timed steps.  auto = for the default "
+                         "invocation (render64, fp32, 1 GPU); otherwise the committed profiles/pmc_traffic.json entry is quoted")
     ap.add_argument("--detail", default=None, help="where the full record goes (default: bench_detail.json next to this script); "
                                                    "stdout carries only the <= 4 KB contract line")
     a = ap.parse_args()
@@ -223,7 +227,7 @@ _LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_st
               "ms_per_step_per_rank", "collective_ms_per_step", "collective_bytes", "collective_alone_ms", "shards", "shard_weights",
               "all_checks_ok", "graph", "alt_precision", "clocks", "extras_summary", "scaling_model_8gpu", "detail")
 _ROOF_KEYS = ("bound", "kernel", "achieved", "algorithmic", "peak", "unit", "frac", "frac_at_observed_clock", "avg_launch_ms", "flop_per_launch",
-              "traffic")
+              "traffic", "traffic_source")
 _CONFIG_KEYS = ("workload", "rays_per_step", "samples_per_ray", "n_importance", "parallelism", "opt_pose_step", "chunk", "tail", "graph")
 # dropped first (in this order) if a line would still exceed LINE_BUDGET
 _OPTIONAL = ("shard_weights", "shards", "devices", "collective_ms_per_step", "ms_per_step_per_rank", "clocks", "alt_precision",
@@ -463,6 +467,20 @@ def main():
     else:
         res = bench_render(args, rank, world, device, dist, synth, ops, pipeline)
     if rank == 0:
+        want_live = args.live_traffic == "on" or (args.live_traffic == "auto" and args.workload == "render64" and args.precision == "fp32"
+                                                 and args.extra != "off")
+        if want_live and world == 1 and dist is None and args.workload in ("render64", "hier", "hier128", "render64x64"):
+            kern = "k_mlp_fwd_b3" if args.precision == "bf16x3" else "k_mlp_fwd"
+            tr, why = live_traffic(["--workload", args.workload, "--precision", args.precision], kern)
+            if tr is not None:
+                quoted = res["roofline"].get("traffic")
+                res["roofline"]["traffic"] = tr["hbm_bytes"]
+                res["roofline"]["traffic_source"] = "live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE passes of this run (FETCH x2)"
+                res["roofline"]["traffic_live"] = dict(tr, committed_profile_value=quoted)
+            else:
+                res["roofline"]["traffic_source"] = f"profiles/pmc_traffic.json (live measurement failed: {why})"
+        elif res["roofline"].get("traffic") is not None:
+            res["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (committed rocprofv3 --pmc passes)"
         want_extra = args.extra == "on" or (args.extra == "auto" and args.workload == "render64" and args.precision == "fp32")
         if want_extra and world == 1:
             ex = extra_workloads(args, device, synth, ops, pipeline)
@@ -960,6 +978,48 @@ def attach_traffic(res, key, world):
         res["roofline"]["traffic"] = tr["hbm_bytes"]
         res["roofline"]["traffic_note"] = (f"bytes per launch/step, FETCH_SIZE(x2)+WRITE_SIZE, {tr['source']} (build {tr.get('git_sha', '?')}); "
                                            f"algorithmic {tr['algorithmic_bytes']:.3g} B" + ("; " + tr["note"] if tr.get("note") else ""))
+
+
+def live_traffic(argv_workload, kernel_sub, launches_per_step=1, timeout_s=120):
+    """HBM bytes per launch of the dominant kernel measured in THIS run: rocprofv3 --kernel-trace --pmc <counter> (one counter group
+    per pass, as MI355X_MICROARCH.md's HBM section prescribes) around a 2-step child run of the same workload; FETCH_SIZE and
+    WRITE_SIZE are in KiB, gfx950 counts a wide coalesced read stream at half its bytes (x2).  Returns (dict, None) or (None, why)."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="anerf_pmc_", dir="/tmp")
+    vals = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "-d", out, "--", sys.executable, os.path.abspath(__file__)] + argv_workload + \
+                  ["--steps", "2", "--warmup", "1", "--extra", "off", "--cpu-rays", "0", "--live-traffic", "off", "--graph", "off",
+                   "--detail", os.path.join(tmp, "d.json")]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {ctr} exited {r.returncode}: {r.stderr[-200:]}"
+            dbs = glob.glob(os.path.join(out, "**", "*_results.db"), recursive=True)
+            if not dbs:
+                return None, f"no rocprofv3 result database for {ctr}"
+            con = sqlite3.connect(dbs[0])
+            row = con.execute("select avg(value), count(*) from counters_collection where counter_name = ? and kernel_name like ?",
+                              (ctr, f"%{kernel_sub}%")).fetchone()
+            con.close()
+            if not row or row[0] is None:
+                return None, f"no {ctr} rows for kernel {kernel_sub}"
+            vals[ctr] = (float(row[0]), int(row[1]))
+    except Exception as e:
+        return None, f"{type(e).__name__}: {e}"[:300]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch, write = vals["FETCH_SIZE"][0] * 1024 * 2, vals["WRITE_SIZE"][0] * 1024
+    return {"hbm_bytes": launches_per_step * (fetch + write), "fetch_bytes_x2": fetch, "write_bytes": write,
+            "dispatches_averaged": vals["FETCH_SIZE"][1]}, None
 
 
 def bench_train(args, rank, world, device, dist, synth, mixamo=False):

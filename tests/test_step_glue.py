@@ -355,6 +355,9 @@ def test_driver_command_prints_one_bounded_strict_line():
     for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "flop_per_launch", "traffic"):
         assert k in j["roofline"], k
     assert j["roofline"]["bound"] == "mfma" and 0.5 < j["roofline"]["frac"] < 1.0 and j["roofline"]["peak"] == 157.3
+    # traffic: measured in this very run (two rocprofv3 --pmc passes in child processes) or, if that failed, the committed profile's
+    # value with the reason -- either way the record says which
+    assert j["roofline"]["traffic"] > 2.8e8 and ("live" in j["roofline"]["traffic_source"] or "pmc_traffic.json" in j["roofline"]["traffic_source"])
     assert j["value"] == pytest.approx(261121 / (j["ms_per_step"] * 1e-3), rel=1e-4)
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in j["cpu_baseline"], k
