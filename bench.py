@@ -992,6 +992,8 @@ def live_traffic(argv_workload, kernel_sub, launches_per_step=1, timeout_s=120):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process is itself running under a profiler (no nested rocprofv3 passes)"
     tmp = tempfile.mkdtemp(prefix="anerf_pmc_", dir="/tmp")
     vals = {}
     try:
