@@ -260,21 +260,40 @@ def test_rccl_collectives_inside_the_captured_step():
     assert r["eager_stats"]["early_collectives"] == 14 and r["eager_stats"]["main_collectives"] == 2, r      # pose group at k = 3, 6
 
 
+def _demo(name):
+    """path of a built tests/csrc demo (normally built by __graft_entry__.build() and shipped with the tree; built here otherwise)"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "csrc", name)
+    if not os.path.exists(exe):
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        if not os.path.exists(hipcc):
+            pytest.skip(f"tests/csrc/{name} is not built and there is no hipcc on this box")
+        subprocess.check_call([hipcc, "-O2", "-std=c++17", "--offload-arch=gfx950", "-I", os.path.join(root, "include"), exe + ".hip", "-L",
+                               os.path.join(root, "a-nerf_amd"), "-lanerf_hip", "-Wl,-rpath,$ORIGIN/../../a-nerf_amd", "-o", exe])
+    return exe
+
+
+@pytest.mark.gpu
+def test_whole_training_iteration_through_the_c_abi_alone():
+    """tests/csrc/train_step_demo.hip: plain C++, no Python, no torch -- random inputs, weight-image gather, anerf_train_forward,
+    anerf_loss, anerf_backward, Adam for two 8x256 networks on 192 rays x (64+16) samples; six iterations eagerly (scalars as
+    arguments) and six replays of ONE hipGraph captured with the HIP runtime API (scalars in the step block, no node update) end on
+    bit-identical parameters and losses, and the loss goes down."""
+    import subprocess
+    r = subprocess.run([_demo("train_step_demo")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert "bit-identical" in r.stdout and "no node update" in r.stdout and "replayed 6 times" in r.stdout, r.stdout
+
+
 @pytest.mark.gpu
 def test_c_abi_is_capturable_without_torch():
     """tests/csrc/graph_demo.hip (built by __graft_entry__.build()): hipStreamBeginCapture / hipGraphInstantiate / hipGraphLaunch from
     plain C++ around anerf_rand_fill_dev + anerf_adam_step_dev, anerf_step_block_write between replays -- six replays of ONE graph,
     no node update, every byte of parameters, moments and norms equal to the eager by-value calls."""
-    import os
     import subprocess
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "tests", "csrc", "graph_demo")
-    if not os.path.exists(exe):          # normally built by __graft_entry__.build() and shipped with the tree; build it here otherwise
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        if not os.path.exists(hipcc):
-            pytest.skip("tests/csrc/graph_demo is not built and there is no hipcc on this box")
-        subprocess.check_call([hipcc, "-O2", "-std=c++17", "--offload-arch=gfx950", "-I", os.path.join(root, "include"), exe + ".hip", "-L",
-                               os.path.join(root, "a-nerf_amd"), "-lanerf_hip", "-Wl,-rpath,$ORIGIN/../../a-nerf_amd", "-o", exe])
+    exe = _demo("graph_demo")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.stdout, r.stderr)
     assert "bit-identical" in r.stdout and "6 replays" in r.stdout, r.stdout
