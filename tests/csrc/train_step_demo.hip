@@ -20,9 +20,13 @@
 
 template <typename T> static T* dalloc(size_t n) { T* p; CK(hipMalloc(&p, n * sizeof(T))); CK(hipMemset(p, 0, n * sizeof(T))); return p; }
 
-int main() {
+int main(int argc, char** argv) {
+  // train_step_demo [n_rays [timed_iterations]]: with a second argument the eager and the captured iteration are also TIMED
+  // (HIP events over `timed_iterations` back-to-back iterations each): what a non-Python host pays per step
   const AnerfConfig cfg = {24, 7, 4, 0, 8, 256, 4, 0, 1.0f, 0.0f, 0};   // configs/surreal/surreal.txt
-  const int N = 192, S = 64, NI = 16, ITERS = 6;
+  const int N = argc > 1 ? atoi(argv[1]) : 192, S = 64, NI = 16, ITERS = 6;
+  const int TIMED = argc > 2 ? atoi(argv[2]) : 0;
+  if (N < 16 || N > 65536) { fprintf(stderr, "n_rays in 16..65536\n"); return 2; }
   const uint64_t SEED = 0xA5EEDull;
   hipStream_t st;
   CK(hipStreamCreate(&st));
@@ -86,7 +90,7 @@ int main() {
   std::vector<float> ro(3 * N), rd(3 * N), tgt(3 * N), skt(24 * 16, 0.f), cut(24, 0.5f);
   for (int r = 0; r < N; ++r) {
     ro[3 * r] = 0.f; ro[3 * r + 1] = 0.f; ro[3 * r + 2] = 3.f;
-    rd[3 * r] = -0.25f + 0.5f * (float)(r % 16) / 15.f; rd[3 * r + 1] = -0.3f + 0.6f * (float)(r / 16) / 11.f; rd[3 * r + 2] = -1.f;
+    rd[3 * r] = -0.25f + 0.5f * (float)(r % 16) / 15.f; rd[3 * r + 1] = -0.3f + 0.6f * (float)((r / 16) % 12) / 11.f; rd[3 * r + 2] = -1.f;
     tgt[3 * r] = 0.9f; tgt[3 * r + 1] = 0.2f + 0.5f * (float)(r % 7) / 6.f; tgt[3 * r + 2] = 0.1f;
   }
   for (int j = 0; j < 24; ++j) {                                         // world -> bone: identity rotation, joints on a helix
@@ -146,7 +150,7 @@ int main() {
     AnerfForwardIO f = io;
     if (dev) f.step = block; else f.tau_v = f.tau_d = tau_of(it);
     AK(anerf_train_forward(&cfg, &f, ws, ws_bytes, st));
-    AK(anerf_loss(rgb, acc, rgb0, acc0, d_tgt, d_bg, 0, N, 0, 0.1f, 1.0f, loss4 + (dev ? 0 : 4 * it), g_rgb, g_acc, g_rgb0, g_acc0, lpart, st));
+    AK(anerf_loss(rgb, acc, rgb0, acc0, d_tgt, d_bg, 0, N, 0, 0.1f, 1.0f, loss4 + (dev || it > ITERS ? 0 : 4 * it), g_rgb, g_acc, g_rgb0, g_acc0, lpart, st));
     AK(anerf_backward(&cfg, &f, &bw, ws, ws_bytes, scratch, sc_bytes, st));
     if (dev) AK(anerf_adam_step_dev(P, G, M, V, NP, 0.9f, 0.999f, 1e-8f, block, 0, 1, 48, apart, norms, st));
     else AK(anerf_adam_step(P, G, M, V, NP, lr_of(it), 0.9f, 0.999f, 1e-8f, it, 1.0f, 1, 48, apart, norms, st));
@@ -189,6 +193,32 @@ int main() {
   for (int it = 1; it <= ITERS; ++it)
     if (memcmp(&la[4 * it], &lb[4 * it], 16) != 0) { printf("MISMATCH: loss of iteration %d: %.9g vs %.9g\n", it, la[4 * it], lb[4 * it]); return 1; }
   if (!(la[4] > 0.f) || !isfinite(la[4 * ITERS]) || !(la[4 * ITERS] < la[4])) { printf("loss did not go down: %.6f -> %.6f\n", la[4], la[4 * ITERS]); return 1; }
+  if (TIMED > 0) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    float ms_eager = 0.f, ms_graph = 0.f;
+    for (int w = 0; w < 3; ++w) iteration(ITERS + 1 + w, false);
+    CK(hipEventRecord(e0, st));
+    for (int k = 0; k < TIMED; ++k) iteration(ITERS + 4 + k, false);
+    CK(hipEventRecord(e1, st));
+    CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms_eager, e0, e1));
+    AnerfStepValues v;
+    memset(&v, 0, sizeof(v));
+    v.rng_seed = SEED; v.tau_v = v.tau_d = 20.f; v.n_groups = 1; v.lr[0] = 1e-4f; v.beta1[0] = 0.9f; v.beta2[0] = 0.999f; v.grad_scale[0] = 1.f;
+    CK(hipEventRecord(e0, st));
+    for (int k = 0; k < TIMED; ++k) {
+      v.rng_offset = 100 + k; v.adam_step[0] = ITERS + 1 + k;
+      AK(anerf_step_block_write(block, &v, st));
+      CK(hipGraphLaunch(exec, st));
+    }
+    CK(hipEventRecord(e1, st));
+    CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms_graph, e0, e1));
+    printf("train_step_demo timing: %d rays, %d iterations each: eager %.4f ms / iteration, captured graph %.4f ms / iteration (C++ host, HIP events)\n",
+           N, TIMED, ms_eager / TIMED, ms_graph / TIMED);
+  }
   printf("train_step_demo: %d iterations (%d rays, %d+%d samples) through the C ABI alone; ONE captured graph of %zu nodes replayed %d times, "
          "no node update; parameters and losses bit-identical to the eager run; loss %.6f -> %.6f\n", ITERS, N, S, NI, n_nodes, ITERS, la[4], la[4 * ITERS]);
   return 0;
