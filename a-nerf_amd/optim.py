@@ -66,6 +66,30 @@ class FusedAdam:
         else:
             self.add_param_group({"params": params})
 
+    @classmethod
+    def from_torch(cls, optimizer, pose_optimizer=None, pose_step_every=1):
+        """One FusedAdam over the parameters of the torch Adam(s) run_nerf.py builds (create_raycaster's `optimizer`,
+        run_nerf.py:518; create_popt's `pose_optimizer`, :523), taking over their hyper-parameters and -- when they were restored
+        from a checkpoint -- their state.  The pose optimiser's groups come after the network's and get
+        `step_every = pose_step_every` (args.opt_pose_step).  The parameters must be on the GPU already; the torch optimisers are
+        not used afterwards: hand the Trainer `fused.group_optimizer(0)` / `fused.group_optimizer(1)` in their place."""
+        groups, state, base = [], {}, 0
+        for opt, every in ((optimizer, 1), (pose_optimizer, int(pose_step_every))):
+            if opt is None:
+                continue
+            if not isinstance(opt, torch.optim.Adam) or any(g.get("amsgrad") or g.get("weight_decay") or g.get("maximize") for g in opt.param_groups):
+                raise TypeError("FusedAdam.from_torch: plain torch.optim.Adam only (no amsgrad / weight decay / maximize)")
+            sd = opt.state_dict()
+            for g in opt.param_groups:
+                groups.append({"params": list(g["params"]), "lr": g["lr"], "betas": tuple(g["betas"]), "eps": g["eps"], "step_every": every})
+            state.update({base + int(k): v for k, v in sd["state"].items()})
+            base += sum(len(g["params"]) for g in opt.param_groups)
+        fused = cls(groups)
+        if state:
+            saved = fused.state_dict()
+            fused.load_state_dict({"state": state, "param_groups": saved["param_groups"]})
+        return fused
+
     def add_param_group(self, group):
         """torch.optim.Optimizer.add_param_group; extra key `step_every` (default 1).  Call before the first step."""
         if self.flat is not None:

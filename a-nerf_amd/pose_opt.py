@@ -357,6 +357,45 @@ class PoseOptLayer(nn.Module):
         return self.cache_kps[idxs], self.cache_bones[idxs], self.cache_skts[idxs], self.cache_l2ws[idxs], self.cache_rots[idxs]
 
 
+def create_popt(args, data_attrs, ckpt=None, device=None):
+    """core/pose_opt.py:14-83, same arguments and the same `(pose_optimizer, popt_kwargs)` pair run_nerf.py:523 unpacks: the pose
+    layer over the dataset's poses (`data_attrs` = dataset.get_meta() / H5PoseData.data_attrs()), a torch Adam over its parameters
+    (lr = opt_pose_lrate), the regularisation anchors {kps, bones, rots, beta}; a checkpoint (or --init_poseopt) restores layer,
+    optimiser and anchors unless --no_poseopt_reload, --use_ckpt_anchor re-derives the anchors from the restored layer.
+    (To share the flat data-parallel bucket instead: build one FusedAdam with the layer's parameters as its second group --
+    `step_every = opt_pose_step` -- hand `fused.group_optimizer(1)` to the Trainer as its pose_optimizer, load the pose group's
+    state with `checkpoint.load_nerf`.)"""
+    skel_type = data_attrs["skel_type"]
+    rest_pose = torch.as_tensor(np.asarray(data_attrs["rest_pose"])).reshape(-1, len(skel_type.joint_names), 3)
+    beta = torch.tensor(data_attrs["betas"])
+    init_kps, init_bones = torch.tensor(data_attrs["kp3d"]), torch.tensor(data_attrs["bones"])
+    popt_layer = PoseOptLayer(init_kps.clone().to(device), init_bones.clone().to(device), rest_pose.to(device), beta=beta, skel_type=skel_type,
+                              kp_map=data_attrs.get("kp_map", None), kp_uidxs=data_attrs.get("kp_uidxs", None),
+                              rest_pose_idxs=data_attrs.get("rest_pose_idxs", None), use_cache=args.opt_pose_cache, use_rot6d=args.opt_rot6d)
+    popt_layer = popt_layer.to(device)
+    pose_optimizer = torch.optim.Adam(params=list(popt_layer.parameters()), lr=args.opt_pose_lrate, betas=(0.9, 0.999))
+    anchor_kps, anchor_bones, anchor_beta = init_kps, init_bones, beta
+    if (ckpt is not None or args.init_poseopt is not None) and not args.no_poseopt_reload:
+        pose_ckpt = torch.load(args.init_poseopt, weights_only=False) if args.init_poseopt is not None else ckpt
+        popt_layer.load_state_dict(pose_ckpt["poseopt_layer_state_dict"])
+        pose_optimizer.load_state_dict(pose_ckpt["pose_optimizer_state_dict"])
+        if "poseopt_anchors" in pose_ckpt:
+            anchor_kps, anchor_bones, anchor_beta = (pose_ckpt["poseopt_anchors"][k] for k in ("kps", "bones", "beta"))
+        if args.use_ckpt_anchor:      # the checkpoint's poses become the optimisation constraint
+            with torch.no_grad():
+                anchor_kps, anchor_bones, _, _, _ = popt_layer(np.arange(anchor_bones.shape[0]))
+            anchor_kps, anchor_bones = anchor_kps.cpu().clone(), popt_layer.to_bones3d(anchor_bones).cpu().clone()
+            anchor_beta = popt_layer.get_beta()
+        print("load smpl state dict")
+    # anchor rotations recomputed from the bones, so that the two are consistent
+    anchor_rots = axisang_to_rot(anchor_bones.reshape(-1, 3)).reshape(*anchor_kps.shape[:2], 3, 3)
+    popt_anchors = {"kps": anchor_kps, "bones": anchor_bones, "rots": anchor_rots, "beta": anchor_beta}
+    if popt_layer.use_cache:
+        popt_layer.update_cache()
+    pose_optimizer.zero_grad()           # gradients that came with the checkpoint
+    return pose_optimizer, {"popt_anchors": popt_anchors, "popt_layer": popt_layer, "skel_type": skel_type}
+
+
 def load_poseopt_from_state_dict(state_dict):
     """pose_opt.py:211-240: rebuild the layer from a checkpoint's `poseopt_layer_state_dict`."""
     sd = state_dict["poseopt_layer_state_dict"]

@@ -28,7 +28,7 @@ TARGETS = [
     ("core.cutoff_embedder", "CutoffEmbedder.update_alpha"),
     ("core.trainer", "render"), ("core.trainer", "batchify_rays"), ("core.trainer", "decay_optimizer_lrate"),
     ("core.trainer", "Trainer.__init__"), ("core.trainer", "Trainer.train_batch"),
-    ("core.pose_opt", "PoseOptLayer.__init__"), ("core.pose_opt", "PoseOptLayer.forward"),
+    ("core.pose_opt", "PoseOptLayer.__init__"), ("core.pose_opt", "PoseOptLayer.forward"), ("core.pose_opt", "create_popt"),
 ]
 
 

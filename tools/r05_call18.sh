@@ -1,13 +1,8 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT
-O=gpurun_out/r05_c18; mkdir -p $O
-timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$? bytes=$(wc -c < $O/bench_default.json)"
-cp bench_detail.json $O/bench_detail.json
-python - <<'PY'
-import json
-l=json.loads(open("gpurun_out/r05_c18/bench_default.json").read())
-print(l["value"], l["roofline"]["frac"], l["clocks"])
-print([(e["workload"], e["step_ms"], e.get("sclk_mhz")) for e in l["extras_summary"]])
-d=json.load(open("gpurun_out/r05_c18/bench_detail.json"))
-print([e.get("clocks") for e in d["extra_workloads"]][1])
-PY
+# round 5, call 18: create_popt on the device + the pose-refinement end-to-end run
+O=gpurun_out/r05_call18; mkdir -p $O
+timeout 600 python -m pytest tests/test_create_popt.py tests/test_end_to_end.py -x -q -m gpu 2>&1 | tail -5
+for cfg in "--from-teacher --pose-noise 0.05 --iters 400" "--from-teacher --pose-noise 0.05 --iters 400 --pose-lrate 0.002 --pose-step 1" "--pose-noise 0.05 --iters 600" "--from-teacher --pose-noise 0.05 --iters 400 --graph off"; do
+  echo "== $cfg"
+  timeout 600 python tools/train_synthetic.py $cfg 2>&1 | grep -v Saved | tail -4 | cut -c1-1500 | tee -a $O/pose_refine.txt
+done
