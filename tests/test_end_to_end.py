@@ -34,7 +34,7 @@ def test_pose_refinement_recovers_perturbed_poses(tmp_path):
     layer / its Adam / the anchors from the dataset's attributes (run_nerf.py:523), FusedAdam.from_torch puts both optimisers in one
     bucket, the Trainer refines poses and networks together from captured graphs -- the photometric loss must pull the poses
     back: mean per-joint error (scene units / ext_scale, the reference's MPJPE convention) more than halved in 400 iterations
-    after the subject was learnt on the true poses (measured: 86 -> 14 mm; profiles/r05_pose_refine.txt)."""
+    after the subject was learnt on the true poses (measured: 85 -> 12.6 mm; 800 iterations: profiles/r05_pose_refine.txt)."""
     spec = importlib.util.spec_from_file_location("train_synthetic", os.path.join(ROOT, "tools", "train_synthetic.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)

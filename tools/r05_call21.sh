@@ -1,4 +1,4 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT
-O=gpurun_out/r05_c21; mkdir -p $O
-for i in 1 2; do timeout 1500 python -m pytest tests -m gpu -x -q > $O/gpu_tests_$i.txt 2>&1; echo "pytest $i rc=$?"; tail -2 $O/gpu_tests_$i.txt; done
+# round 5, call 21: the new GPU tests (create_popt on the device, pose refinement end to end)
+O=gpurun_out/r05_call21; mkdir -p $O
+timeout 900 python -m pytest tests/test_create_popt.py tests/test_end_to_end.py -q -m gpu 2>&1 | tail -15 | tee $O/tests.txt

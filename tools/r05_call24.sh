@@ -1,9 +1,10 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r05_c24 /tmp/prof; export TMPDIR=/tmp
-for n in 384 3072; do
-  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof/cpp_$n -- $GRAFT_REPO_ROOT/tests/csrc/train_step_demo $n 50 > /tmp/prof/cpp_$n.log 2>&1); echo "rc=$?"
-  python tools/rocprof_summary.py gpurun_out/r05_c24/train_step_demo_cpp_${n}.txt /tmp/prof/cpp_$n > /dev/null
-  echo "# command: rocprofv3 --kernel-trace --stats -- tests/csrc/train_step_demo $n 50   (plain C++ host: 6 + 53 eager iterations, 6 + 50 graph replays)" >> gpurun_out/r05_c24/train_step_demo_cpp_${n}.txt
-  head -14 gpurun_out/r05_c24/train_step_demo_cpp_${n}.txt | cut -c1-130
+# round 5, call 24: the pose-refinement record (analytic subject, mixamo.txt's arrangement incl. frame codes)
+O=gpurun_out/r05_call24; mkdir -p $O
+for cfg in "--subject spheres --pose-noise 0.05 --pretrain 1500 --iters 800 --pose-step 1" \
+           "--subject spheres --pose-noise 0.05 --pretrain 1500 --iters 800 --pose-step 1 --graph off" \
+           "--subject spheres --pose-noise 0.05 --pretrain 1500 --iters 800 --pose-step 1 --net-lrate 0 --pose-coef 0" \
+           "--subject spheres --pose-noise 0.05 --iters 2500 --pose-step 4"; do
+  echo "== $cfg" | tee -a $O/pose_refine.txt
+  timeout 600 python tools/train_synthetic.py $cfg 2>&1 | grep "iter .*00 \|iter     1 \|^{" | tee -a $O/pose_refine.txt | grep "^{" | cut -c1-200
 done

@@ -199,8 +199,9 @@ def main(argv=None):
     attrs = ds.data_attrs(skel_type=Skel)
     refine = a.pose_noise > 0
     over = dict(N_rand=a.n_rand, N_sample_images=a.n_sample_images)
-    if refine:              # mixamo.txt, whose 500k-iteration schedule is compressed to this run's length; frame codes off (the teacher
-        over.update(opt_pose_step=a.pose_step, opt_framecode=False, loss_fn="MSE", lrate_decay=500, decay_unit=1000)     # has none)
+    if refine:              # mixamo.txt, whose 500k-iteration schedule is compressed to this run's length; its per-image frame codes stay
+        # on for the analytic subject (off against the NeRF teacher, which has none and shares the student's architecture)
+        over.update(opt_pose_step=a.pose_step, opt_framecode=a.subject == "spheres", loss_fn="MSE", lrate_decay=500, decay_unit=1000)
         if a.pose_lrate is not None:
             over["opt_pose_lrate"] = a.pose_lrate
         if a.pose_coef is not None:
@@ -211,8 +212,10 @@ def main(argv=None):
     torch.manual_seed(0)
     rk_train, rk_test, start, grad_vars, torch_opt, _ = raycaster.create_raycaster(args, attrs, device=dev)
     caster = rk_test["ray_caster"]
+    fc = args.framecode_size if args.opt_framecode else 0
     for net, src, seed in ((caster.network, teacher.network, 11), (caster.network_fine, teacher.network_fine, 12)):
-        net.load_state_dict(src.state_dict() if a.from_teacher else {k: torch.tensor(v) for k, v in synth.make_net_params(seed).items()})
+        net.load_state_dict(src.state_dict() if a.from_teacher else {k: torch.tensor(v) for k, v in synth.make_net_params(
+            seed, args.multires, args.multires_views, fc, attrs["n_views"] if fc else 0).items()})
     attrs_t = dict(attrs, hwf=(a.hw, a.hw, focal))
     true_kp = torch.tensor(np.stack([q["kp"] for q in poses]), dtype=torch.float32, device=dev)
     n_per = a.n_rand // a.n_sample_images
@@ -248,7 +251,7 @@ def main(argv=None):
     pre = None
     if refine and a.pretrain > 0:      # the subject is learnt on the true poses first; the perturbed estimates take over afterwards
         ds0 = dataset.H5PoseData(path.replace(".npz", "_truepose.npz"), device=dev, kind="surreal")
-        args0 = ref_args("surreal", N_rand=a.n_rand, N_sample_images=a.n_sample_images)
+        args0 = argparse.Namespace(**dict(vars(args), opt_pose=False, opt_pose_coef=0.0, lrate=ref_args("mixamo").lrate))     # same caster, no pose layer
         fused0 = optim.FusedAdam.from_torch(torch_opt).attach(caster)
         tr0 = trainer_mod.Trainer(args0, attrs_t, fused0.group_optimizer(0), None, rk_train, rk_test, popt_kwargs=None, device=dev)
         h0, _, dt0 = run(tr0, ds0, a.pretrain, tag="pretrain ")
@@ -287,6 +290,8 @@ def main(argv=None):
         with torch.no_grad():       # the held-out view is rendered with the REFINED poses
             rkp, rbones, rskts, _, _ = layer(np.arange(a.n_kps))
         kw.update(kp=rkp, skts=rskts, bones=layer.to_bones3d(rbones), cyls=t(np.stack([synth.bounding_cylinder(k) for k in rkp.cpu().numpy()])))
+    if args.opt_framecode:      # a camera no frame code was learnt for: index -1 = the mean code (embedding.py:21-22)
+        kw["cams"] = torch.full((a.n_kps,), -1, dtype=torch.int64, device=dev)
     img_a, *_ = render_mod.render_path([held[0]] * a.n_kps, (a.hw, a.hw, focal), args.chunk, rk_test, **kw)
     img_b, *_ = render_mod.render_path([held[0]] * a.n_kps, (a.hw, a.hw, focal), args.chunk, rk2, **kw)
     psnr_held = float(-10 * np.log10(np.mean((np.clip(img_a, 0, 1) - np.clip(held[1], 0, 1)) ** 2)))
@@ -295,8 +300,17 @@ def main(argv=None):
     rd = ds.render_data()
     tt = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32, device=dev)
     cyl_rd = torch.tensor(np.stack([synth.bounding_cylinder(k, ext_scale=args.ext_scale) for k in rd["kp3d"]]), dtype=torch.float32, device=dev)
+    kp_rd, skts_rd, bones_rd = tt(rd["kp3d"]), tt(rd["skts"]), tt(rd["bones"])
+    if refine and rd.get("kp_idxs") is not None:          # run_nerf.py:555-559: a refining run renders its test set with the layer's poses
+        with torch.no_grad():
+            kp_rd, b, skts_rd, _, _ = layer(np.asarray(rd["kp_idxs"]))
+        bones_rd = layer.to_bones3d(b)
+        cyl_rd = torch.tensor(np.stack([synth.bounding_cylinder(k, ext_scale=args.ext_scale) for k in kp_rd.cpu().numpy()]), dtype=torch.float32, device=dev)
     rgbs_rd, *_ = render_mod.render_path(rd["c2ws"], rd["hwf"], args.chunk // 8, rk_test, bg_imgs=rd["bgs"], bg_indices=rd["bg_idxs"],
-                                          centers=rd["center"], kp=tt(rd["kp3d"]), skts=tt(rd["skts"]), cyls=cyl_rd, bones=tt(rd["bones"]),
+                                          centers=rd["center"], kp=kp_rd, skts=skts_rd, cyls=cyl_rd, bones=bones_rd,
+                                          # run_nerf.py:571; the SURREAL arrangement reports camera-DATA indices (one per image), its
+                                          # per-view code is the camera's number (load_surreal.py:330: image index // N_kps)
+                                          cams=torch.tensor(np.asarray(rd["cam_idxs"]) // a.n_kps, device=dev) if args.opt_framecode else None,
                                           ext_scale=args.ext_scale, white_bkgd=args.white_bkgd)
     psnr_testset = float(-10 * np.log10(np.mean((np.clip(rgbs_rd, 0, 1) - rd["imgs"]) ** 2)))
     res = {"iters": a.iters, "graph": a.graph == "on", "first": hist[0], "last": hist[-1], "psnr_gain_db": hist[-1][2] - hist[0][2],
