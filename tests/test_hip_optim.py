@@ -227,6 +227,63 @@ def test_fused_adam_groups_cadence_and_checkpoint_round_trip(tmp_path):
 
 
 @pytest.mark.gpu
+def test_from_torch_takes_over_hyper_parameters_and_restored_state():
+    """run_nerf.py hands the trainer two torch Adams (create_raycaster's, create_popt's), possibly restored from a checkpoint:
+    FusedAdam.from_torch builds the one-bucket optimiser from them -- groups, learning rates, cadence, moments, step counts --
+    and continues exactly where they would (torch's own steps as the reference)."""
+    c = build("train_pytest")
+    g = torch.Generator(device="cuda").manual_seed(3)
+
+    def fresh():
+        caster = make_caster(c)
+        extra = [torch.nn.Parameter(torch.linspace(-1, 1, 24 * 6, device="cuda").reshape(24, 6).clone()),
+                 torch.nn.Parameter(torch.linspace(0, 2, 9, device="cuda").clone())]
+        return caster, [p for p in caster.parameters() if p.requires_grad], extra
+
+    (_, net_a, pose_a), (_, net_b, pose_b) = fresh(), fresh()
+    grads = [[torch.randn(p.shape, device="cuda", generator=g) * 1e-2 for p in net_a + pose_a] for _ in range(6)]
+
+    def torch_pair(net, pose):
+        return torch.optim.Adam(net, lr=5e-4, betas=(0.9, 0.999)), torch.optim.Adam(pose, lr=2e-3, betas=(0.9, 0.999))
+
+    def torch_iteration(t_net, t_pose, params, i):
+        for p, gr in zip(params, grads[i - 1]):
+            p.grad = gr.clone() if p.grad is None else p.grad + gr
+        t_net.step()
+        t_net.zero_grad()
+        if i % 2 == 0:
+            t_pose.step()
+            t_pose.zero_grad()
+
+    ta_net, ta_pose = torch_pair(net_a, pose_a)
+    tb_net, tb_pose = torch_pair(net_b, pose_b)
+    for i in (1, 2, 3):                                   # three iterations on torch's optimisers: net at step 3, pose at step 1,
+        torch_iteration(ta_net, ta_pose, net_a + pose_a, i)          # one pose gradient accumulated and pending
+        torch_iteration(tb_net, tb_pose, net_b + pose_b, i)
+    pending = [p.grad.clone() for p in pose_b]
+    fused = optim.FusedAdam.from_torch(tb_net, tb_pose, pose_step_every=2)
+    assert [gr["lr"] for gr in fused.param_groups] == [5e-4, 2e-3] and [gr["step_every"] for gr in fused.param_groups] == [1, 2]
+    assert fused._steps == [3, 1] and all(p.data_ptr() >= fused.flat.data_ptr() for p in net_b + pose_b)
+    sd = fused.group_optimizer(1).state_dict()
+    for j, p in enumerate(pose_b):
+        assert torch.equal(sd["state"][j]["exp_avg"], tb_pose.state[p]["exp_avg"]) and float(sd["state"][j]["step"]) == 1.0
+    for p, gr in zip(pose_b, pending):                    # materialize() keeps gradients that were pending
+        assert torch.equal(p.grad, gr)
+    for i in (4, 5, 6):
+        torch_iteration(ta_net, ta_pose, net_a + pose_a, i)
+        for p, gr in zip(net_b + pose_b, grads[i - 1]):
+            p.grad.add_(gr)
+        fused.step(zero_grad=True, i=i)
+    assert fused._steps == [6, 3]
+    for a, b in zip(net_a + pose_a, net_b + pose_b):
+        np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().cpu().numpy(), rtol=2e-6, atol=2e-7)
+    with pytest.raises(TypeError):
+        optim.FusedAdam.from_torch(torch.optim.SGD(net_a, lr=0.1))
+    with pytest.raises(TypeError):
+        optim.FusedAdam.from_torch(torch.optim.Adam(net_a, lr=0.1, amsgrad=True))
+
+
+@pytest.mark.gpu
 def test_backward_with_the_cached_unit_seed_equals_plain_backward():
     """optim.backward(loss) seeds the graph with a cached 1.0 and the fused losses skip their `gradient * 1` launches: the
     gradients w.r.t. the rendered maps (and through the pose regulariser) are bit-identical to loss.backward()'s, also when the
