@@ -11,7 +11,7 @@ from it through `BaseH5Dataset` + `ray_collate_fn` (`core/dataset.py:20-420, 813
 `H5PoseData` reads that layout -- from a real `.h5` when `h5py` is importable (it is not in the build image; the import is
 optional and loud), or from an `.npz` twin holding the same keys with the same shapes and dtypes (`write_npz_twin`) -- and
 `sample_batch()` assembles exactly the batch dict `ray_collate_fn` hands to `Trainer.train_batch` (`rays [2,N,3], target_s,
-kp_idx, kp3d, bones, skts, cyls, cam_idxs, fgs, bgs`, all per-ray replicated), as device tensors.  `kind` selects the
+kp_idx, kp3d, bones, skts, cyls, cam_idxs, fgs, bgs`, all per-ray replicated), as device tensors (`kp_idx` on the host, where the pose layer reads it).  `kind` selects the
 index arithmetic of the reference's dataset classes: "base" (BaseH5Dataset), "surreal" (SurrealDataset: images and cameras
 arranged (N_cams, N_kps), poses shared by the cameras; load_surreal.py:302-380), "mixamo" (MixamoDataset: the sorted subset
 named by `*selected.npy`, white background; load_mixamo.py:161-199).
@@ -138,6 +138,7 @@ class H5PoseData:
         if N_nms != 0 or patch_size != 1 or N_rand_kps is not None:
             raise NotImplementedError("N_nms > 0 (P_nms), patch_size > 1 and rand_train_kps are used by no shipped config")
         self.path, self.device, self.kind, self.mask_img = path, torch.device(device), kind, bool(mask_img)
+        self.staged_uploads, self.staging_slots, self._staging = True, 3, {}          # see _upload_staged (device "cuda" only)
         f = _open(path)
         keys = set(f.keys())
         missing = [k for k in REQUIRED if k not in keys]
@@ -342,17 +343,68 @@ class H5PoseData:
             cols["cam_idxs"].append(np.full(n_per_image, cam_idx, np.int64))
             cols["kp3d"].append(rep(self.kp3d)), cols["bones"].append(rep(self.bones)), cols["skts"].append(rep(self.skts))
             cols["cyls"].append(rep(self.cyls))
-        # plain pageable uploads: 0.21 ms for the 11 tensors of a 1024-ray batch on the MI355X box; `pin_memory()` + non-blocking
-        # copies measured 2.2 ms there (pinning a fresh buffer per tensor costs more than the copy; tools/r05_probe_upload.py)
-        batch = {k: torch.as_tensor(np.concatenate(v, 0)).to(self.device) for k, v in cols.items()}
+        # kp_idx stays on the host: its one consumer, the pose layer, groups the rays by pose there (trainer.py:299 `kp_idx.cpu().numpy()`
+        # in the reference) -- a device copy would be read back every iteration, a blocking transfer behind the previous step
+        kp_idx_host = torch.as_tensor(np.concatenate(cols.pop("kp_idx"), 0)) if self.device.type == "cuda" else None
+        if self.staged_uploads and (self.device.type == "cuda" or self.staged_uploads == "always"):
+            batch = self._upload_staged(cols)
+        else:
+            # plain pageable uploads: 0.21 ms for the 11 tensors of a 1024-ray batch on the MI355X box; `pin_memory()` + non-blocking
+            # copies measured 2.2 ms there (pinning a fresh buffer per tensor costs more than the copy; tools/r05_probe_upload.py)
+            batch = {k: torch.as_tensor(np.concatenate(v, 0)).to(self.device) for k, v in cols.items()}
+        if kp_idx_host is not None:
+            batch["kp_idx"] = kp_idx_host
         batch["rays"] = torch.stack([batch["rays_o"], batch["rays_d"]], 0)
         return batch
+
+    def _upload_staged(self, cols):
+        """The batch through ONE pinned host arena and ONE asynchronous copy.  A pageable upload blocks the host until the stream
+        reaches it, i.e. until the previous training step has finished -- sampling and the GPU step then alternate instead of
+        overlapping.  Here the columns are concatenated straight into a pinned arena (allocated once per batch layout), one
+        non-blocking copy moves it into a device arena of the same layout, the batch's tensors are typed views of that.  Arenas
+        form a ring of `self.staging_slots` (default 3): a batch's tensors stay valid until that many later batches have been
+        sampled -- consume (or clone) them before; an event per slot keeps a slot's pinned memory from being rewritten under a
+        copy still in flight."""
+        parts = {k: (v, sum(a.shape[0] for a in v), v[0].shape[1:], np.result_type(*[a.dtype for a in v])) for k, v in cols.items()}
+        cuda = self.device.type == "cuda"            # (staged_uploads = "always" runs the same packing on the host: the CPU test's handle)
+        key = tuple((k, n, tail, str(dt)) for k, (_, n, tail, dt) in parts.items())
+        ring = self._staging.get(key)
+        if ring is None:
+            off, layout = 0, {}
+            for k, (_, n, tail, dt) in parts.items():
+                nbytes = int(n * int(np.prod(tail, dtype=np.int64)) * dt.itemsize)
+                layout[k] = (off, nbytes, (n,) + tuple(tail), dt)
+                off += (nbytes + 255) // 256 * 256
+            slots = []
+            for _ in range(max(2, int(self.staging_slots))):
+                host = torch.empty(max(off, 1), dtype=torch.uint8, pin_memory=cuda)
+                dev = torch.empty(max(off, 1), dtype=torch.uint8, device=self.device)
+                hv = {k: host.numpy()[o:o + nb].view(dt).reshape(shape) for k, (o, nb, shape, dt) in layout.items()}
+                dv = {k: dev[o:o + nb].view(getattr(torch, np.dtype(dt).name)).reshape(shape) for k, (o, nb, shape, dt) in layout.items()}
+                slots.append({"host": host, "dev": dev, "hv": hv, "dv": dv, "event": None})
+            ring = self._staging[key] = {"slots": slots, "next": 0}
+        slot = ring["slots"][ring["next"]]
+        ring["next"] = (ring["next"] + 1) % len(ring["slots"])
+        if slot["event"] is not None:
+            slot["event"].synchronize()
+        for k, (v, _, _, _) in parts.items():
+            np.concatenate(v, 0, out=slot["hv"][k])
+        slot["dev"].copy_(slot["host"], non_blocking=True)
+        if cuda:
+            if slot["event"] is None:
+                slot["event"] = torch.cuda.Event()
+            slot["event"].record(torch.cuda.current_stream(self.device))
+        return dict(slot["dv"])
 
     def batches(self, q_batches, n_per_image, rng=None, prefetch=2, mask_img=None):
         """`sample_batch` for every entry of `q_batches` (e.g. `image_batches(...)`), assembled `prefetch` batches ahead by ONE
         background thread -- the role of the reference's `DataLoader(..., num_workers=...)` (load_data.py:71-82).  One producer
         walks the batches in order, so the generator is consumed exactly as by the sequential loop: a seeded run yields the same
-        batches.  (While it runs, nothing else in the process should draw from the same generator -- numpy's global one by default.)"""
+        batches.  (While it runs, nothing else in the process should draw from the same generator -- numpy's global one by default.)
+        On the GPU the batches' tensors are views of a small ring of upload arenas (`_upload_staged`): use each batch before asking
+        for the one `staging_slots` later, or clone what must live longer (`staged_uploads = False`: independent tensors)."""
+        if self.staging_slots < int(prefetch or 0) + 3:      # queued + in production + in the consumer's hands must not share an arena
+            self.staging_slots, self._staging = int(prefetch) + 3, {}
         if not prefetch:                        # inline: the right choice while the GPU step, not the sampling, bounds the loop -- a
             for qb in q_batches:                # Python producer thread costs the training thread the GIL (E2E run, 1024 rays: 162 -> 148 it/s)
                 yield self.sample_batch(qb, n_per_image, rng, mask_img)

@@ -213,6 +213,39 @@ def test_prefetching_generator_yields_the_sequential_batches(tmp_path):
     it.close()
 
 
+def test_staged_upload_packs_the_same_batch(tmp_path):
+    """_upload_staged (the GPU reader's one-arena, one-copy upload) run on the host: same keys, shapes, dtypes and values as the
+    plain path; a batch's tensors live in a ring slot -- intact while fewer than `staging_slots` later batches were sampled,
+    reused by the batch that many later; a second batch layout gets its own ring"""
+    path, c = write_case("mixamo", tmp_path, "npz")
+    plain, staged = reader(path, c), reader(path, c)
+    staged.staged_uploads = "always"
+    qs, n = c["batches"], cases.DATASET_N_SAMPLES
+    got = []
+    for b in range(4):
+        np.random.seed(5 + b)
+        want = plain.sample_batch(qs[0], n)
+        np.random.seed(5 + b)
+        have = staged.sample_batch(qs[0], n)
+        assert sorted(want) == sorted(have)
+        for k in want:
+            assert have[k].dtype == want[k].dtype and have[k].shape == want[k].shape and torch.equal(have[k], want[k]), k
+        base = min(v.data_ptr() for k, v in have.items() if k != "rays")
+        assert all((v.data_ptr() - base) % 256 == 0 for k, v in have.items() if k != "rays")      # 256-byte aligned arena offsets
+        got.append((have, {k: v.clone() for k, v in want.items()}))
+    assert len(staged._staging) == 1 and len(next(iter(staged._staging.values()))["slots"]) == 3
+    for b in (1, 2, 3):                                                   # the three latest batches are intact ...
+        assert all(torch.equal(got[b][0][k], got[b][1][k]) for k in got[b][1] if k != "rays")
+    assert got[0][0]["rays_o"].data_ptr() == got[3][0]["rays_o"].data_ptr()        # ... the first one's slot went to the fourth
+    np.random.seed(1)
+    other = staged.sample_batch(qs[1], n)                                  # another batch size: another ring
+    assert len(staged._staging) == 2 and other["target_s"].shape[0] == n * len(qs[1])
+    np.random.seed(9)
+    n_before = staged.staging_slots
+    list(staged.batches([qs[0]] * 2, n, prefetch=2))                      # a prefetching generator widens the rings first
+    assert staged.staging_slots == 5 > n_before
+
+
 @pytest.mark.parametrize("name", [n for n in sorted(cases.DATASET_CASES) if cases.DATASET_CASES[n]["cls"] != "BaseH5Dataset"])
 def test_render_data_matches_get_render_data(name, tmp_path):
     """H5PoseData.render_data == the reference's get_render_data() (dataset.py:486-541): every key, dtype and value of the

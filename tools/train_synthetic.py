@@ -176,6 +176,7 @@ def main(argv=None):
     ap.add_argument("--n-sample-images", type=int, default=8)
     ap.add_argument("--graph", default="on", choices=["on", "off"])
     ap.add_argument("--out", default=None)
+    ap.add_argument("--staged-uploads", default="on", choices=["on", "off"], help="the reader's one-arena asynchronous upload (off: pageable copies)")
     ap.add_argument("--pose-noise", type=float, default=0.0, help="rad: the dataset's poses are the true ones perturbed by this much; "
                     "> 0 trains mixamo.txt's way (pose layer from create_popt, rot6d, frame codes, L1, pose regulariser)")
     ap.add_argument("--pose-step", type=int, default=4, help="opt_pose_step of the pose-refinement run (mixamo.txt: 20, over 500k iterations)")
@@ -196,6 +197,7 @@ def main(argv=None):
 
     # ---- the student, as run_nerf.py builds it: dataset -> data_attrs -> create_raycaster -> optimiser -> Trainer
     ds = dataset.H5PoseData(path, device=dev, kind="surreal")
+    ds.staged_uploads = a.staged_uploads == "on"
     attrs = ds.data_attrs(skel_type=Skel)
     refine = a.pose_noise > 0
     over = dict(N_rand=a.n_rand, N_sample_images=a.n_sample_images)
@@ -251,6 +253,7 @@ def main(argv=None):
     pre = None
     if refine and a.pretrain > 0:      # the subject is learnt on the true poses first; the perturbed estimates take over afterwards
         ds0 = dataset.H5PoseData(path.replace(".npz", "_truepose.npz"), device=dev, kind="surreal")
+        ds0.staged_uploads = ds.staged_uploads
         args0 = argparse.Namespace(**dict(vars(args), opt_pose=False, opt_pose_coef=0.0, lrate=ref_args("mixamo").lrate))     # same caster, no pose layer
         fused0 = optim.FusedAdam.from_torch(torch_opt).attach(caster)
         tr0 = trainer_mod.Trainer(args0, attrs_t, fused0.group_optimizer(0), None, rk_train, rk_test, popt_kwargs=None, device=dev)
@@ -317,7 +320,7 @@ def main(argv=None):
            "held_out_psnr_db": psnr_held, "testset_psnr_db": psnr_testset, "testset_frames": int(len(rd["imgs"])), "reload_max_abs_diff": float(np.abs(img_a - img_b).max()), "it_per_s": a.iters / dt,
            "host_ms_per_train_batch_median": float(np.median(host) * 1e3), "dataset": path, "checkpoint": ck,
            "max_memory_allocated_mb": torch.cuda.max_memory_allocated() / 2 ** 20, "reserved_mb": torch.cuda.memory_reserved() / 2 ** 20,
-           "param_checksum": float(fused.flat.double().sum()), "pose_refinement": pose_res, "pretrain": pre, "subject": a.subject,
+           "param_checksum": float(fused.flat.double().sum()), "pose_refinement": pose_res, "pretrain": pre, "subject": a.subject, "staged_uploads": ds.staged_uploads,
            "graphs": None if tr._gs is None else {"captures": tr._gs.captures, "replays": tr._gs.replays, "eager": tr._gs.eager_calls}}
     print(json.dumps(res))
     return res
