@@ -246,6 +246,39 @@ def test_staged_upload_packs_the_same_batch(tmp_path):
     assert staged.staging_slots == 5 > n_before
 
 
+@pytest.mark.gpu
+def test_device_reader_uploads_the_reference_batch(tmp_path):
+    """the reader on the GPU: the staged upload (pinned arena, one asynchronous copy) delivers the reference's collated batch -- the
+    fixture's values and dtypes -- as device tensors, `kp_idx` on the host; pageable uploads (`staged_uploads = False`) the same"""
+    g = dict(np.load(os.path.join(GOLDEN, "dataset_mixamo.npz")))
+    path, c = write_case("mixamo", tmp_path, "npz")
+    n = cases.DATASET_N_SAMPLES
+    for staged in (True, False):
+        k = c["kw"]
+        ds = dataset.H5PoseData(path, device="cuda", kind="mixamo", subject=k.get("subject"))
+        ds.staged_uploads = staged
+        kept = []
+        for rep in range(2):                                  # twice: the second pass reuses arenas that are still in the ring
+            for b, q_idxs in enumerate(c["batches"]):
+                np.random.seed(c["seed"] + b)
+                got = ds.sample_batch(q_idxs, n)
+                kept.append((b, got))
+                assert got["kp_idx"].device.type == "cpu" and got["kp_idx"].dtype == torch.int64
+                for key, v in got.items():
+                    want = g[f"b{b}.{key}"]
+                    if key != "kp_idx":
+                        assert v.device.type == "cuda", key
+                    if key in ("rays_d", "rays") and want.dtype == np.float64:
+                        np.testing.assert_allclose(v.cpu().numpy(), want, rtol=3e-7, atol=3e-7)
+                    else:
+                        assert v.cpu().numpy().dtype == want.dtype, key
+                        np.testing.assert_array_equal(v.cpu().numpy(), want, err_msg=key)
+        assert (len(ds._staging) == 2) == staged              # two batch sizes, two rings
+        torch.cuda.synchronize()
+        for b, got in kept[-2:]:                              # the latest batches are still what they were
+            np.testing.assert_array_equal(got["target_s"].cpu().numpy(), g[f"b{b}.target_s"])
+
+
 @pytest.mark.parametrize("name", [n for n in sorted(cases.DATASET_CASES) if cases.DATASET_CASES[n]["cls"] != "BaseH5Dataset"])
 def test_render_data_matches_get_render_data(name, tmp_path):
     """H5PoseData.render_data == the reference's get_render_data() (dataset.py:486-541): every key, dtype and value of the
