@@ -9,6 +9,12 @@ core/process_spin.py:234-297 (SURREAL arrangement: images (N_cams, N_kps), poses
 from other seeds and is trained on pixels sampled by H5PoseData (the reference's sampling, collate and index arithmetic).
 
   python tools/train_synthetic.py [--iters 300] [--hw 96] [--graph on|off] [--out DIR]
+  python tools/train_synthetic.py --subject spheres --pose-noise 0.05 [--pretrain 1500] --iters 800 --pose-step 1
+
+The second form is A-NeRF's own use, pose refinement (mixamo.txt's arrangement: rot6d pose layer from create_popt, its Adam folded
+into the one-bucket optimiser by FusedAdam.from_torch, per-camera frame codes, pose regulariser): the images show the TRUE poses
+of an analytic ball-and-stick body (`render_spheres`: shape and colours follow the pose, unlike the NeRF teacher's smooth volume),
+the dataset's kp3d / bones / skts are perturbed estimates; the summary reports the mean per-joint error before / after.
 
 Prints one line per 50 iterations and a final JSON summary (PSNR against the teacher's pixels at start / end, held-out view
 PSNR, it/s, host time per iteration).  Used by tests/test_end_to_end.py with a short run.
