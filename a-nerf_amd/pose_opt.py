@@ -362,9 +362,11 @@ def create_popt(args, data_attrs, ckpt=None, device=None):
     layer over the dataset's poses (`data_attrs` = dataset.get_meta() / H5PoseData.data_attrs()), a torch Adam over its parameters
     (lr = opt_pose_lrate), the regularisation anchors {kps, bones, rots, beta}; a checkpoint (or --init_poseopt) restores layer,
     optimiser and anchors unless --no_poseopt_reload, --use_ckpt_anchor re-derives the anchors from the restored layer.
-    (To share the flat data-parallel bucket instead: build one FusedAdam with the layer's parameters as its second group --
-    `step_every = opt_pose_step` -- hand `fused.group_optimizer(1)` to the Trainer as its pose_optimizer, load the pose group's
-    state with `checkpoint.load_nerf`.)"""
+    The reference's `--use_ckpt_anchor` branch unpacks four of forward's five return values (pose_opt.py:65 against :311-316) and
+    raises; here it does what its comment describes (anchors = the restored layer's poses, bones back in axis-angle).
+    To put the layer into the flat data-parallel bucket: `optim.FusedAdam.from_torch(optimizer, pose_optimizer,
+    pose_step_every=args.opt_pose_step)` takes both torch Adams over (hyper-parameters and restored state) and
+    `fused.group_optimizer(1)` is the Trainer's pose_optimizer."""
     skel_type = data_attrs["skel_type"]
     rest_pose = torch.as_tensor(np.asarray(data_attrs["rest_pose"])).reshape(-1, len(skel_type.joint_names), 3)
     beta = torch.tensor(data_attrs["betas"])
