@@ -350,7 +350,7 @@ class H5PoseData:
             batch = self._upload_staged(cols)
         else:
             # plain pageable uploads: 0.21 ms for the 11 tensors of a 1024-ray batch on the MI355X box; `pin_memory()` + non-blocking
-            # copies measured 2.2 ms there (pinning a fresh buffer per tensor costs more than the copy; tools/r05_probe_upload.py)
+            # copies measured 2.2 ms there (pinning a fresh buffer per tensor costs more than the copy; tools/leases/r05_probe_upload.py)
             batch = {k: torch.as_tensor(np.concatenate(v, 0)).to(self.device) for k, v in cols.items()}
         if kp_idx_host is not None:
             batch["kp_idx"] = kp_idx_host
