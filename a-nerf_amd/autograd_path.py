@@ -119,7 +119,7 @@ class _MlpRawFn(torch.autograd.Function):
             if need_skts:
                 if skts.shape[0] != n:
                     raise NotImplementedError("skts.requires_grad needs per-ray skts [N,24,4,4]")
-                g_skts = torch.zeros_like(skts)
+                g_skts = torch.empty_like(skts)          # every element is written (row 3 as zeros) by k_pose_reduce
                 dyw = torch.empty(P, 72, dtype=torch.float32, device=dev)
                 dqw = torch.empty(P, 72, dtype=torch.float32, device=dev)
                 _lib.check(lib.anerf_encode_backward(

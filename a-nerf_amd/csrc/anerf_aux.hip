@@ -39,27 +39,31 @@ __global__ void k_pack(AnerfNetParams P, const int32_t* __restrict__ table, long
 // 64-bit integers: the sums in 2^-32 fixed point, so that the cross-wave accumulation (integer atomics) is exact and
 // order-independent -- the fallback value, and with it every z of a missed ray, is bit-reproducible.
 constexpr double STATS_FIX = 4294967296.0;   // 2^32
+// near / far of one ray: the ray/circle intersection in the ground plane (ray_utils.py:292-326); NaN when the ray misses the circle
+__device__ __forceinline__ void ray_bounds_of(const float* __restrict__ r, const float* __restrict__ c, float& nn, float& ff) {
+  const float ox = r[0], oz = r[2], dx = r[3], dz = r[5], near = r[6], far = r[7];
+  const float pnx = fmaf(dx, near, ox), pnz = fmaf(dz, near, oz);
+  const float pfx = fmaf(dx, far, ox), pfz = fmaf(dz, far, oz);
+  const float ncx = c[0] - pnx, ncz = c[1] - pnz;
+  const float nfx = pfx - pnx, nfz = pfz - pnz;
+  const float nf_len = sqrtf(nfx * nfx + nfz * nfz);
+  const float scale = sqrtf(dx * dx + dz * dz);
+  const float cross = ncx * nfz - ncz * nfx;
+  const float dist = fabsf(cross) / nf_len;
+  const float Q = sqrtf(c[2] * c[2] - dist * dist);   // NaN when the ray misses the circle
+  const float K = (ncx * nfx + ncz * nfz) / nf_len;
+  const float inside = (Q < K) ? 1.f : 0.f;
+  nn = near + inside * (K - Q) / scale;
+  ff = near + (K + Q) / scale;
+}
+
 __global__ void k_ray_bounds(const float* __restrict__ rays, int ray_stride, const float* __restrict__ cyls, int cyl_stride, int n,
                              float* __restrict__ near_far, unsigned long long* __restrict__ stats) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   float sn = 0.f, sf = 0.f, cn = 0.f, cf = 0.f;
   if (i < n) {
-    const float* r = rays + (long long)i * ray_stride;
-    const float ox = r[0], oz = r[2], dx = r[3], dz = r[5], near = r[6], far = r[7];
-    const float pnx = fmaf(dx, near, ox), pnz = fmaf(dz, near, oz);
-    const float pfx = fmaf(dx, far, ox), pfz = fmaf(dz, far, oz);
-    const float* c = cyls + (long long)i * cyl_stride;   // 5, or 0: one cylinder shared by every ray of the call
-    const float ncx = c[0] - pnx, ncz = c[1] - pnz;
-    const float nfx = pfx - pnx, nfz = pfz - pnz;
-    const float nf_len = sqrtf(nfx * nfx + nfz * nfz);
-    const float scale = sqrtf(dx * dx + dz * dz);
-    const float cross = ncx * nfz - ncz * nfx;
-    const float dist = fabsf(cross) / nf_len;
-    const float Q = sqrtf(c[2] * c[2] - dist * dist);   // NaN when the ray misses the circle
-    const float K = (ncx * nfx + ncz * nfz) / nf_len;
-    const float inside = (Q < K) ? 1.f : 0.f;
-    const float nn = near + inside * (K - Q) / scale;
-    const float ff = near + (K + Q) / scale;
+    float nn, ff;
+    ray_bounds_of(rays + (long long)i * ray_stride, cyls + (long long)i * cyl_stride, nn, ff);   // cyl_stride 5, or 0: one shared cylinder
     near_far[2 * i + 0] = nn;
     near_far[2 * i + 1] = ff;
     if (nn == nn) { sn = nn; cn = 1.f; }
@@ -100,6 +104,77 @@ __global__ void k_coarse_z(const float* __restrict__ near_far, const unsigned lo
     near_far_fixed[2 * ray] = nn;
     near_far_fixed[2 * ray + 1] = ff;
   }
+  auto zat = [&](int k) -> float {
+    const float t = (float)k / (float)(S - 1);
+    return lindisp ? 1.f / (1.f / nn * (1.f - t) + 1.f / ff * t) : nn * (1.f - t) + ff * t;
+  };
+  float z = zat(s);
+  if (t_rand) {
+    const float lo = s == 0 ? z : 0.5f * (z + zat(s - 1));
+    const float hi = s == S - 1 ? z : 0.5f * (zat(s + 1) + z);
+    z = lo + (hi - lo) * t_rand[idx];
+  }
+  z_out[idx] = z;
+}
+
+// A2 + A3 in ONE launch for the caster-call sizes of training and chunked rendering (n <= BOUNDS_Z_MAX_RAYS; round 6: the stats
+// zero fill + k_ray_bounds + k_coarse_z were three dispatches on the ~4.7 us launch floor).  One thread per sample computes ITS
+// ray's bounds (the same inlined arithmetic) -- no near/far array, no grid-wide dependency -- unless one of the block's rays misses
+// the cylinder: only then does the block need the call-wide NaN-mean statistics, and it recomputes them itself, in exactly
+// k_ray_bounds' form (64-ray groups aligned to multiples of 64, the same shuffle tree per group, the same 2^-32 fixed-point
+// conversion per group; integer sums are order-independent), so the fallback values are bit-identical to the two-kernel route.
+constexpr int BOUNDS_Z_MAX_RAYS = 16384;
+__global__ __launch_bounds__(256) void k_bounds_z(const float* __restrict__ rays, int ray_stride, const float* __restrict__ cyls,
+                                                  int cyl_stride, int n, int S, const float* __restrict__ t_rand, int lindisp,
+                                                  float* __restrict__ z_out) {
+  __shared__ long long sh_s[4][2];
+  __shared__ unsigned long long sh_c[4][2];
+  const long long idx = blockIdx.x * 256LL + threadIdx.x;
+  const bool valid = idx < (long long)n * S;
+  const int ray = valid ? (int)(idx / S) : 0, s = valid ? (int)(idx - (long long)ray * S) : 0;
+  float nn = 0.f, ff = 0.f;
+  if (valid) ray_bounds_of(rays + (long long)ray * ray_stride, cyls + (long long)ray * cyl_stride, nn, ff);
+  const int bad = valid && (!(nn == nn) || !(ff == ff));
+  if (__syncthreads_or(bad)) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    long long a0 = 0, a1 = 0;
+    unsigned long long a2 = 0, a3 = 0;
+    for (int g = wave; g < (n + 63) / 64; g += 4) {
+      const int i = g * 64 + lane;
+      float sn = 0.f, sf = 0.f, cn = 0.f, cf = 0.f;
+      if (i < n) {
+        float bn, bf;
+        ray_bounds_of(rays + (long long)i * ray_stride, cyls + (long long)i * cyl_stride, bn, bf);
+        if (bn == bn) { sn = bn; cn = 1.f; }
+        if (bf == bf) { sf = bf; cf = 1.f; }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        sn += __shfl_xor(sn, o);
+        sf += __shfl_xor(sf, o);
+        cn += __shfl_xor(cn, o);
+        cf += __shfl_xor(cf, o);
+      }
+      if ((cn + cf) > 0.f) {
+        a0 += __double2ll_rn((double)sn * STATS_FIX);
+        a1 += __double2ll_rn((double)sf * STATS_FIX);
+        a2 += (unsigned long long)cn;
+        a3 += (unsigned long long)cf;
+      }
+    }
+    if (lane == 0) {
+      sh_s[wave][0] = a0; sh_s[wave][1] = a1; sh_c[wave][0] = a2; sh_c[wave][1] = a3;
+    }
+    __syncthreads();
+    if (bad) {   // torch.where(isnan(Q)) rows: both replaced (ray_utils.py:331-342)
+      const long long t0 = sh_s[0][0] + sh_s[1][0] + sh_s[2][0] + sh_s[3][0], t1 = sh_s[0][1] + sh_s[1][1] + sh_s[2][1] + sh_s[3][1];
+      const unsigned long long c0 = sh_c[0][0] + sh_c[1][0] + sh_c[2][0] + sh_c[3][0], c1 = sh_c[0][1] + sh_c[1][1] + sh_c[2][1] + sh_c[3][1];
+      const float* r = rays + (long long)ray * ray_stride;
+      nn = c0 > 0 ? (float)((double)t0 / STATS_FIX / (double)c0) : r[6];
+      ff = c1 > 0 ? (float)((double)t1 / STATS_FIX / (double)c1) : r[7];
+    }
+  }
+  if (!valid) return;
   auto zat = [&](int k) -> float {
     const float t = (float)k / (float)(S - 1);
     return lindisp ? 1.f / (1.f / nn * (1.f - t) + 1.f / ff * t) : nn * (1.f - t) + ff * t;
@@ -449,6 +524,15 @@ int launch_ray_bounds(const float* rays, int ray_stride, const float* cyls, int 
   hipLaunchKernelGGL(k_ray_bounds, dim3((n + 255) / 256), dim3(256), 0, st, rays, ray_stride, cyls, cyl_stride, n, near_far,
                      reinterpret_cast<unsigned long long*>(stats));
   return check_launch("k_ray_bounds");
+}
+
+int bounds_z_max_rays() { return BOUNDS_Z_MAX_RAYS; }
+int launch_bounds_z(const float* rays, int ray_stride, const float* cyls, int cyl_stride, int n, int S, const float* t_rand, int lindisp,
+                    float* z, hipStream_t st) {
+  const long long tot = (long long)n * S;
+  hipLaunchKernelGGL(k_bounds_z, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, rays, ray_stride, cyls, cyl_stride, n, S, t_rand,
+                     lindisp, z);
+  return check_launch("k_bounds_z");
 }
 
 int launch_coarse_z(const float* near_far, const float* stats, const float* rays, int ray_stride, int n, int S,

@@ -27,6 +27,8 @@ int check_launch(const char* what) {
 struct MlpArgs;
 int launch_pack(const AnerfNetParams*, const int32_t*, long long, float*, hipStream_t);
 int launch_ray_bounds(const float*, int, const float*, int, int, float*, float*, hipStream_t);
+int bounds_z_max_rays();
+int launch_bounds_z(const float*, int, const float*, int, int, int, const float*, int, float*, hipStream_t);
 int launch_coarse_z(const float*, const float*, const float*, int, int, int, const float*, int, float*, float*,
                     hipStream_t);
 int launch_composite(const AnerfConfig*, const float*, const float*, const float*, int, const float*, int, int, float*,
@@ -975,9 +977,18 @@ int forward_impl(const AnerfConfig* cfg, const AnerfForwardIO* io, char* ws, con
         io->tau_v, io->tau_d, io->cutoff_v, io->cutoff_d, n, ns, raw, stream);
   };
   // ABI revision 4: io->cyl_shared = one cylinder [5] for every ray of the call (a frame's rays under render_path)
-  int rc = ray_bounds_checked(io->rays, io->ray_stride, io->cyls, io->cyl_shared ? 0 : 5, n, F(w.near_far), F(w.stats), stream);
-  if (rc) return rc;
-  rc = anerf_coarse_z(F(w.near_far), F(w.stats), io->rays, io->ray_stride, n, S, io->t_rand, io->lindisp, F(w.z), nullptr, stream);
+  int rc;
+  if (n <= bounds_z_max_rays()) {
+    // A2 + A3 as ONE launch (k_bounds_z: bit-identical to the staged pair, tests/test_hip_edge_cases.py); same argument checks
+    if (!io->rays || !io->cyls) return set_error(ANERF_E_NULL, "ray_bounds: NULL pointer");
+    if (io->ray_stride < 8) return set_error(ANERF_E_SHAPE, "ray_bounds: ray_stride >= 8 required");
+    if (S < 2 || S > MAX_SAMPLES) return set_error(ANERF_E_SHAPE, "coarse_z: 2 <= N_samples <= 512");
+    rc = launch_bounds_z(io->rays, io->ray_stride, io->cyls, io->cyl_shared ? 0 : 5, n, S, io->t_rand, io->lindisp, F(w.z), (hipStream_t)stream);
+  } else {
+    rc = ray_bounds_checked(io->rays, io->ray_stride, io->cyls, io->cyl_shared ? 0 : 5, n, F(w.near_far), F(w.stats), stream);
+    if (rc) return rc;
+    rc = anerf_coarse_z(F(w.near_far), F(w.stats), io->rays, io->ray_stride, n, S, io->t_rand, io->lindisp, F(w.z), nullptr, stream);
+  }
   if (rc) return rc;
   prof_rec(io->profile, ANERF_PROF_FWD(0), stream);
   rc = mlp(io->packed_c, io->aux_c, io->codes_c, F(w.z), S, F(w.raw), sv_c, io->pts_noise);
@@ -1133,8 +1144,7 @@ int anerf_backward(const AnerfConfig* cfg, const AnerfForwardIO* io, const Anerf
   const bool do_fine = hier && (b->passes == 0 || (b->passes <= 3 && (b->passes & 1)));
   const bool do_coarse = !hier || b->passes == 0 || (b->passes & 2) || coarse_part;
   const bool coarse_only = hier && !do_fine;              // second half of a split backward: g_skts already holds the fine pass
-  if (b->g_skts && !coarse_only && hipMemsetAsync(b->g_skts, 0, (size_t)n * 24 * 16 * 4, st) != hipSuccess)
-    return set_error(ANERF_E_LAUNCH, "backward: hipMemsetAsync");
+  // (no zero fill of g_skts: the first pose-gradient pass WRITES all four rows of every 4 x 4 block, row 3 as zeros -- k_pose_reduce)
   bool skts_written = coarse_only;
   // one network pass: composite backward -> dz chain -> weight gradients (-> input gradients -> pose / code gradients)
   auto pass = [&](int which_pass, const AnerfSaved& sv, const float* raw, const float* zz, int ns, const float* noise, const float* g_rgb,

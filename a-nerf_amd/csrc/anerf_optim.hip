@@ -94,6 +94,91 @@ __global__ __launch_bounds__(RB) void k_loss(const float* __restrict__ rgb, cons
   }
 }
 
+// Small batches (n <= LOSS_ONE_MAX rays, i.e. the 8-GPU shard of a 3072-ray step; round 6): k_loss + k_loss_final as ONE block that
+// walks the same "virtual blocks" in turn -- thread t of virtual block b takes ray 256 b + t, the block sums use the same tree, the
+// partials are then summed as k_loss_final sums them -- so the four outputs carry the SAME bits as the two-launch route.
+constexpr int LOSS_ONE_MAX = 1024;
+__global__ __launch_bounds__(RB) void k_loss_one(const float* __restrict__ rgb, const float* __restrict__ acc,
+                                                 const float* __restrict__ rgb0, const float* __restrict__ acc0,
+                                                 const float* __restrict__ target, const float* __restrict__ bgs, int bg_stride,
+                                                 int n, int nblk, int kind, float beta, float coarse_w, float* __restrict__ g_rgb,
+                                                 float* __restrict__ g_acc, float* __restrict__ g_rgb0,
+                                                 float* __restrict__ g_acc0, float* __restrict__ out) {
+  __shared__ float sh[4];
+  __shared__ float part[LOSS_ONE_MAX / RB][3];
+  const float inv = 1.0f / (3.0f * (float)n);
+  auto term = [&](float d) {
+    const float a = fabsf(d);
+    return kind == 0 ? d * d : (kind == 1 || a >= beta) ? a - (kind == 2 ? 0.5f * beta : 0.f) : 0.5f * d * d / beta;
+  };
+  auto dterm = [&](float d) {
+    const float a = fabsf(d);
+    return kind == 0 ? 2.0f * d * inv
+                     : (kind == 1 || a >= beta) ? (d > 0.f ? inv : (d < 0.f ? -inv : 0.f)) : d / beta * inv;
+  };
+  for (int vb = 0; vb < nblk; ++vb) {
+    float lf = 0.f, lc = 0.f, se = 0.f;
+    const int r = vb * RB + threadIdx.x;
+    if (r < n) {
+      float bg[3] = {0.f, 0.f, 0.f};
+      if (bgs) {
+        bg[0] = bgs[(long long)r * bg_stride + 0];
+        bg[1] = bgs[(long long)r * bg_stride + 1];
+        bg[2] = bgs[(long long)r * bg_stride + 2];
+      }
+      const float tt[3] = {target[3 * r], target[3 * r + 1], target[3 * r + 2]};
+      {
+        const float om = bgs ? 1.0f - acc[r] : 0.f;
+        float ga = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float d = rgb[3 * r + c] + om * bg[c] - tt[c];
+          se += d * d;
+          lf += term(d);
+          const float g = dterm(d);
+          if (g_rgb) g_rgb[3 * r + c] = g;
+          ga -= g * bg[c];
+        }
+        if (g_acc) g_acc[r] = ga;
+      }
+      if (rgb0) {
+        const float om = bgs ? 1.0f - acc0[r] : 0.f;
+        float ga = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float d = rgb0[3 * r + c] + om * bg[c] - tt[c];
+          lc += term(d);
+          const float g = coarse_w * dterm(d);
+          if (g_rgb0) g_rgb0[3 * r + c] = g;
+          ga -= g * bg[c];
+        }
+        if (g_acc0) g_acc0[r] = ga;
+      }
+    }
+    lf = block_sum(lf, sh);
+    lc = block_sum(lc, sh);
+    se = block_sum(se, sh);
+    if (threadIdx.x == 0) {
+      part[vb][0] = lf; part[vb][1] = lc; part[vb][2] = se;
+    }
+  }
+  __syncthreads();
+  // k_loss_final's sums: thread i takes partials i, i + 256, ... (here nblk <= 4 < 256: thread i < nblk holds exactly one)
+  float a = 0.f, b = 0.f, c = 0.f;
+  if ((int)threadIdx.x < nblk) {
+    a += part[threadIdx.x][0]; b += part[threadIdx.x][1]; c += part[threadIdx.x][2];
+  }
+  a = block_sum(a, sh);
+  b = block_sum(b, sh);
+  c = block_sum(c, sh);
+  if (threadIdx.x == 0) {
+    out[1] = a * inv;
+    out[2] = b * inv;
+    out[0] = a * inv + coarse_w * (b * inv);
+    out[3] = c * inv;
+  }
+}
+
 // out[0] = total loss, out[1] = fine loss, out[2] = coarse loss (unweighted), out[3] = fine MSE (PSNR = -10 log10)
 __global__ __launch_bounds__(RB) void k_loss_final(const float* __restrict__ partial, int nblk, int n, float coarse_w,
                                                    float* __restrict__ out) {
@@ -203,6 +288,11 @@ int anerf_loss(const float* rgb, const float* acc, const float* rgb0, const floa
     return set_error(ANERF_E_NULL, "loss: NULL pointer");
   const int nblk = anerf_loss_blocks(n_rays);
   hipStream_t st = (hipStream_t)stream;
+  if (n_rays <= LOSS_ONE_MAX) {   // one launch, the same bits (k_loss_one)
+    hipLaunchKernelGGL(k_loss_one, dim3(1), dim3(RB), 0, st, rgb, acc, rgb0, acc0, target, bgs, (int)bg_stride, (int)n_rays, nblk,
+                       (int)loss_type, huber_beta, rgb0 ? coarse_weight : 0.f, g_rgb, g_acc, g_rgb0, g_acc0, out4);
+    return check_launch("k_loss_one");
+  }
   hipLaunchKernelGGL(k_loss, dim3(nblk), dim3(RB), 0, st, rgb, acc, rgb0, acc0, target, bgs, (int)bg_stride, (int)n_rays,
                      (int)loss_type, huber_beta, coarse_weight, g_rgb, g_acc, g_rgb0, g_acc0, partials);
   int rc = check_launch("k_loss");

@@ -149,37 +149,57 @@ __global__ __launch_bounds__(256) void k_encode_bwd(const float* __restrict__ dx
   }
 }
 
-// one thread per (ray, joint, row r<3); 128 threads per ray, 72 active
-__global__ __launch_bounds__(128) void k_pose_reduce(const float* __restrict__ dY, const float* __restrict__ dQ,
+// One block of 320 threads per ray: thread (g, l) = (sample group g < 4, column l < 72 = (joint, row r < 3)) sums the ray's samples
+// s = g, g + 4, ... in order; the four group sums are combined in the fixed order (g0 + g1) + (g2 + g3) through LDS (round 6: a
+// 4-way split of what was ONE 64..80-step dependent chain per thread -- the kernel is latency-bound, 27 -> ~8 us at 384 rays).
+// Not accumulating (first network pass of a step): threads 288..311 also write row 3 of their joint's 4 x 4 block (= 0: the
+// homogeneous row has no gradient), so the caller needs no zero fill of dskts.
+__global__ __launch_bounds__(320) void k_pose_reduce(const float* __restrict__ dY, const float* __restrict__ dQ,
                                                      const float* __restrict__ rays, int ray_stride,
                                                      const float* __restrict__ z, int n, int S, int accumulate,
                                                      float* __restrict__ dskts, const float* __restrict__ pnoise) {
-  const int ray = blockIdx.x, l = threadIdx.x;
-  if (ray >= n || l >= 72) return;
-  const float* rp = rays + (long long)ray * ray_stride;
-  const float o0 = rp[0], o1 = rp[1], o2 = rp[2], d0 = rp[3], d1 = rp[4], d2 = rp[5];
-  float R0 = 0.f, R1 = 0.f, R2 = 0.f, T = 0.f, Q = 0.f;
-  for (int s = 0; s < S; ++s) {
-    const long long p = (long long)ray * S + s;
-    const float zz = z[p];
-    const float dy = dY[p * 72 + l], dq = dQ[p * 72 + l];
-    float x0 = fmaf(d0, zz, o0), x1 = fmaf(d1, zz, o1), x2 = fmaf(d2, zz, o2);
-    if (pnoise) {
-      x0 += pnoise[3 * p]; x1 += pnoise[3 * p + 1]; x2 += pnoise[3 * p + 2];
+  __shared__ float sh[4][72][5];
+  const int ray = blockIdx.x, t = threadIdx.x;
+  if (ray >= n) return;
+  const int g = t / 72, l = t - 72 * g;
+  if (g < 4) {
+    const float* rp = rays + (long long)ray * ray_stride;
+    const float o0 = rp[0], o1 = rp[1], o2 = rp[2], d0 = rp[3], d1 = rp[4], d2 = rp[5];
+    float R0 = 0.f, R1 = 0.f, R2 = 0.f, T = 0.f, Q = 0.f;
+    for (int s = g; s < S; s += 4) {
+      const long long p = (long long)ray * S + s;
+      const float zz = z[p];
+      const float dy = dY[p * 72 + l], dq = dQ[p * 72 + l];
+      float x0 = fmaf(d0, zz, o0), x1 = fmaf(d1, zz, o1), x2 = fmaf(d2, zz, o2);
+      if (pnoise) {
+        x0 += pnoise[3 * p]; x1 += pnoise[3 * p + 1]; x2 += pnoise[3 * p + 2];
+      }
+      R0 = fmaf(dy, x0, R0);
+      R1 = fmaf(dy, x1, R1);
+      R2 = fmaf(dy, x2, R2);
+      T += dy;
+      Q += dq;
     }
-    R0 = fmaf(dy, x0, R0);
-    R1 = fmaf(dy, x1, R1);
-    R2 = fmaf(dy, x2, R2);
-    T += dy;
-    Q += dq;
+    sh[g][l][0] = R0; sh[g][l][1] = R1; sh[g][l][2] = R2; sh[g][l][3] = T; sh[g][l][4] = Q;
   }
-  const int j = l / 3, r = l - 3 * j;
-  float* o = dskts + ((long long)ray * 24 + j) * 16 + r * 4;
-  const float g0 = fmaf(Q, d0, R0), g1 = fmaf(Q, d1, R1), g2 = fmaf(Q, d2, R2);
-  if (accumulate) {   // second network pass of a step (anerf_backward): same sum autograd forms from two overwriting calls
-    o[0] += g0; o[1] += g1; o[2] += g2; o[3] += T;
-  } else {
-    o[0] = g0; o[1] = g1; o[2] = g2; o[3] = T;
+  __syncthreads();
+  if (t < 72) {
+    const float* rp = rays + (long long)ray * ray_stride;
+    const float d0 = rp[3], d1 = rp[4], d2 = rp[5];
+    float v[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) v[k] = (sh[0][t][k] + sh[1][t][k]) + (sh[2][t][k] + sh[3][t][k]);
+    const int j = t / 3, r = t - 3 * j;
+    float* o = dskts + ((long long)ray * 24 + j) * 16 + r * 4;
+    const float g0 = fmaf(v[4], d0, v[0]), g1 = fmaf(v[4], d1, v[1]), g2 = fmaf(v[4], d2, v[2]);
+    if (accumulate) {   // second network pass of a step (anerf_backward): same sum autograd forms from two overwriting calls
+      o[0] += g0; o[1] += g1; o[2] += g2; o[3] += v[3];
+    } else {
+      o[0] = g0; o[1] = g1; o[2] = g2; o[3] = v[3];
+    }
+  } else if (!accumulate && t >= 288 && t < 312) {
+    float* o = dskts + ((long long)ray * 24 + (t - 288)) * 16 + 12;
+    o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f;
   }
 }
 
@@ -243,7 +263,7 @@ int launch_encode_bwd(int ld, const float* dx, const float* du, int uw, const fl
                        tau_v, tau_d, cut_v, cut_d, P, S, dY, dQ, pnoise, gate_bones, tau_dev);
   int rc = check_launch("k_encode_bwd");
   if (rc) return rc;
-  hipLaunchKernelGGL(k_pose_reduce, dim3(n), dim3(128), 0, st, (const float*)dY, (const float*)dQ, rays, ray_stride, z, n, S,
+  hipLaunchKernelGGL(k_pose_reduce, dim3(n), dim3(320), 0, st, (const float*)dY, (const float*)dQ, rays, ray_stride, z, n, S,
                      accumulate ? 1 : 0, dskts, pnoise);
   return check_launch("k_pose_reduce");
 }

@@ -21,12 +21,44 @@ Contract of `step_fn(i)` (the caller's iteration; i = the reference's iteration 
   * the optimiser is a `FusedAdam` stepped with `i=i`; groups with `step_every > 1` (the pose cadence, trainer.py:476-478)
     get one graph per set of due groups;
   * it returns a dict of tensors (loss, statistics): they live in the graph's pool and hold the last replay's values.
-Not capturable here: `--freq_schedule` (its band factors are re-uploaded per iteration), a batch whose pose layout (number of
-distinct poses) changes -- `step()` falls back to the eager call for those, loudly once.
+Not capturable here: `--freq_schedule` (its band factors are re-uploaded per iteration) -- `step()` falls back to the eager call
+for it, loudly once.
+
+Robustness (round 6):
+  * every NEW (due groups, key) variant runs eagerly once before it is captured (a variant first seen mid-run -- the
+    opt_pose_stop transition, a batch with another number of distinct poses -- may do lazy one-off work on its code path: a
+    pageable upload, a first-use kernel attribute);
+  * a capture that fails (anything not permitted under stream capture) is undone -- current stream, allocator routing, host
+    counters, the optimiser's in-flight collective handles -- the variant is marked eager-only with ONE warning and the
+    iteration runs eagerly: a long run does not die at a transition;
+  * more than one rank: the captured step holds the gradient collectives (RCCL all-reduces on the side stream, captured like
+    any other launch; tests/test_graph_step.py::test_rccl_collectives_inside_the_captured_step).  Ranks may mix replayed and eager
+    iterations freely -- both enqueue the same collectives in the same order -- but a timed run wants one mode: `agree(dist)`
+    (one 1-element all-reduce, OUTSIDE any capture, at a point every rank reaches) turns the graphs off on EVERY rank if any
+    rank's prepared capture failed.
 """
 import torch
 
 from . import ops
+
+
+def collectives_capturable(group=None):
+    """(ok, why not).  With more than one rank the captured step holds the gradient collectives: that works with RCCL (backend
+    "nccl": the all-reduce is a kernel launch on the optimiser's side stream) and not with gloo, which moves the bucket through the
+    host and synchronises the stream -- under capture that is not an error one can undo but a crash inside the transport (seen as
+    SIGSEGV with two gloo ranks on one GPU), so it is not attempted."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) <= 1 and not ops_force_collectives():
+        return True, None
+    backend = str(dist.get_backend(group))
+    if backend != "nccl":
+        return False, f"process-group backend {backend!r}: only RCCL (\"nccl\") collectives can be captured with the step"
+    return True, None
+
+
+def ops_force_collectives():
+    import os
+    return os.environ.get("ANERF_FORCE_COLLECTIVES") == "1"
 
 
 class StaticBatch:
@@ -52,24 +84,36 @@ class StaticBatch:
             out[k] = b
         return out
 
+    @staticmethod
+    def identity(sb):
+        """what a captured graph has frozen of a loaded batch: (key, address) of every tensor entry + which entries are None.
+        Part of the graph key in Trainer._train_batch_graphed: an entry that changes shape / dtype or flips between tensor and
+        None at the same n_rays gets ANOTHER graph instead of a replay that reads the old buffer."""
+        return tuple(sorted((k, v.data_ptr() if torch.is_tensor(v) else None) for k, v in sb.items()
+                            if torch.is_tensor(v) or v is None))
+
 
 class GraphedTrainStep:
-    def __init__(self, step_fn, caster, optimizer, eager_steps=3, enabled=True, capture_error_mode="global"):
+    def __init__(self, step_fn, caster, optimizer, eager_steps=3, enabled=True, capture_error_mode="global", warm_each_key=True):
         """step_fn(i) -> dict of tensors; caster: the RayCaster (its DeviceRng and embedders supply seed / offset / tau);
         optimizer: the FusedAdam of the step.  The first `eager_steps` calls run step_fn eagerly (lazy one-off initialisation
         -- kernel attributes, allocator pools, index caches -- must not fall inside a capture).
         capture_error_mode: torch.cuda.graph's (hipStreamCaptureMode).  "global" (the default, the tested one) makes ANY thread's
         allocation-class HIP call during the few milliseconds of a capture an error -- e.g. a DataLoader's pin-memory thread; pass
         "thread_local" when such threads run beside the trainer (the autograd worker's launches into the capturing stream are
-        captured in either mode)."""
+        captured in either mode).
+        warm_each_key: every new (due groups, key) variant runs eagerly once before it is captured (see the module text)."""
         self.capture_error_mode = capture_error_mode
+        self.warm_each_key = bool(warm_each_key)       # False: capture a new variant at first sight (the caller vouches for warm caches)
         self.step_fn, self.caster, self.opt = step_fn, getattr(caster, "module", caster), optimizer
         self.eager_left, self.enabled = int(eager_steps), bool(enabled)
         self.block = None
         self.graphs = {}            # (due-groups tuple, caller's key) -> (CUDAGraph, outputs, fills per step)
         self.pool = None
-        self.replays = self.captures = self.eager_calls = 0
+        self.replays = self.captures = self.eager_calls = self.failed_captures = 0
         self.why_eager = None
+        self.warmed = set()         # graph keys whose code path has run eagerly (prepare() vouches for its own)
+        self.eager_only = {}        # graph key -> why its capture failed (runs eagerly from then on)
 
     # ---- host-side bookkeeping the eager path does inside FusedAdam / DeviceRng -------------------------------------
     def _capturable(self):
@@ -78,7 +122,8 @@ class GraphedTrainStep:
             return "--freq_schedule re-uploads its band factors every iteration"
         if len(self.opt.param_groups) > 4:
             return "more than 4 optimiser groups"
-        return None
+        ok, why = collectives_capturable()
+        return None if ok else why
 
     def _fill_block(self, i, due):
         """the values iteration i runs with, exactly as the eager calls would pass them as kernel arguments"""
@@ -110,6 +155,8 @@ class GraphedTrainStep:
         torch.autograd.graph.increment_version([p for g in opt.param_groups for p in g["params"]])
         g = torch.cuda.CUDAGraph()
         self.block.fills = 0
+        if self.pool is None:
+            self.pool = torch.cuda.graph_pool_handle()      # ONE pool for every graph of this stepper (they never run concurrently);
         # Python's cycle collector must not run INSIDE the capture: it would free whatever cyclic garbage earlier iterations left
         # behind (autograd contexts holding workspaces, pinned staging buffers), and releasing device / pinned memory records and
         # queries events on streams -- not permitted while one of them is capturing (seen as a hard abort: a collection triggered by
@@ -118,20 +165,69 @@ class GraphedTrainStep:
         gc.collect()
         gc_was_on = gc.isenabled()
         gc.disable()
+        dev = self.block.buf.device
+        ctx = torch.cuda.graph(g, pool=self.pool, capture_error_mode=self.capture_error_mode)
+        entered = False
         try:
             with ops.step_block(self.block):
-                with torch.cuda.graph(g, pool=self.pool, capture_error_mode=self.capture_error_mode):
-                    out = self.step_fn(i)
+                ctx.__enter__()
+                entered = True
+                out = self.step_fn(i)
+                ctx.__exit__(None, None, None)
+                entered = False
+        except BaseException:
+            # torch.cuda.graph.__exit__ is not exception-safe: a capture that was invalidated half way (a synchronising call, a
+            # pageable copy, an unjoined side stream) raises out of capture_end() BEFORE the current stream is put back and before
+            # the allocator stops routing this stream's allocations into the graph pool.  Undo all of it.
+            if entered:
+                try:
+                    g.capture_end()
+                except Exception:
+                    pass
+                try:
+                    ctx.stream_ctx.__exit__(None, None, None)
+                except Exception:
+                    pass
+            try:
+                torch._C._cuda_endAllocateToPool(dev.index if dev.index is not None else torch.cuda.current_device(), self.pool)
+            except Exception:
+                pass
+            if hasattr(opt, "abort_step"):
+                opt.abort_step()          # collective handles created under the dead capture
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+            self.failed_captures += 1
+            raise
         finally:
             if gc_was_on:
                 gc.enable()
             # the capture recorded the launches without running them (or failed half way): put the host-side counters back
             fills = self.block.fills
             rng.offset, opt._steps[:], opt._grad_scale[:] = snap[0], snap[1], snap[2]
-        if self.pool is None:
-            self.pool = g.pool()          # later graphs (other cadence phases) share it: they never run concurrently
         self.captures += 1
         return g, out, fills
+
+    def _mark_eager_only(self, gk, err):
+        why = f"{type(err).__name__}: {err}"[:300]
+        self.eager_only[gk] = why
+        import warnings
+        warnings.warn(f"GraphedTrainStep: capture of variant {gk!r} failed ({why}); this variant runs eagerly from now on")
+
+    def agree(self, dist, group=None):
+        """More than one rank, at a point EVERY rank reaches (after prepare(), before a timed stretch): one 1-element all-reduce
+        (MIN) of "all my captures so far succeeded", outside any capture.  If any rank had a failure, every rank switches its
+        graphs off -- the whole job then runs the eager step.  Returns True when the graphs stay on."""
+        ok = 1.0 if (self.enabled and not self.eager_only and self._capturable() is None) else 0.0
+        flag = torch.tensor([ok], dtype=torch.float32, device=self.block.buf.device if self.block is not None else "cuda")
+        if dist is not None and dist.is_available() and dist.is_initialized():
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if float(flag.item()) < 1.0:
+            if self.enabled:
+                self.why_eager = "a rank's capture failed (agreed over all ranks)" if ok else (self.why_eager or "this rank's capture failed")
+            self.enabled = False
+        return self.enabled
 
     def prepare(self, i, key=None, due=None):
         """capture the graph iteration i would replay, now (nothing runs, no counter moves): keeps the capture -- milliseconds of
@@ -143,8 +239,15 @@ class GraphedTrainStep:
             self.block = ops.StepBlock(next(iter(self.opt.params)).device)
         due = tuple(self.opt._due(i)) if due is None else tuple(due)
         gk = due if key is None else (due, key)
+        if gk in self.eager_only:
+            return False
         if gk not in self.graphs:
-            self.graphs[gk] = self._capture(i, due)
+            self.warmed.add(gk)
+            try:
+                self.graphs[gk] = self._capture(i, due)
+            except Exception as e:
+                self._mark_eager_only(gk, e)
+                return False
         return True
 
     def step(self, i, key=None, due=None):
@@ -155,6 +258,8 @@ class GraphedTrainStep:
         if why is None and self.eager_left > 0:
             self.eager_left -= 1
             why = "warm-up"
+            d0 = tuple(self.opt._due(i)) if due is None else tuple(due)
+            self.warmed.add(d0 if key is None else (d0, key))          # this variant's code path has now run eagerly
         if why is None:
             why = self._capturable()
             if why is not None and self.why_eager != why:
@@ -170,7 +275,20 @@ class GraphedTrainStep:
         gk = due if key is None else (due, key)
         hit = self.graphs.get(gk)
         if hit is None:
-            hit = self.graphs[gk] = self._capture(i, due)
+            if gk in self.eager_only:
+                self.eager_calls += 1
+                return self.step_fn(i)
+            if self.warm_each_key and gk not in self.warmed:
+                # first sight of this variant: its code path runs eagerly once (lazy one-off work must not fall inside a capture)
+                self.warmed.add(gk)
+                self.eager_calls += 1
+                return self.step_fn(i)
+            try:
+                hit = self.graphs[gk] = self._capture(i, due)
+            except Exception as e:
+                self._mark_eager_only(gk, e)
+                self.eager_calls += 1
+                return self.step_fn(i)
         g, out, fills = hit
         self._fill_block(i, due)
         self.block.write()

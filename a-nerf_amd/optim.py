@@ -258,6 +258,12 @@ class FusedAdam:
                 torch.cuda.current_stream(self.flat_grad.device).wait_stream(self._side)
         self._join_early()
 
+    def abort_step(self):
+        """Forget every in-flight collective handle WITHOUT waiting on it: for handles created under a stream capture that was
+        then abandoned (graph_step.GraphedTrainStep: nothing was launched, there is nothing to join, and `work.wait()` on such a
+        handle would touch events of a dead capture)."""
+        self._async, self._early = [], []
+
     def _join_early(self):
         """join the collectives all_reduce_grads() left in flight for step()'s split Adam (see there)"""
         early, self._early = self._early, []

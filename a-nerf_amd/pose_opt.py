@@ -295,11 +295,29 @@ class PoseOptLayer(nn.Module):
         if sl is None:
             sl = slots[(key, str(dev))] = (torch.empty(len(uniq), dtype=torch.int64, device=dev), torch.empty(len(arr), dtype=torch.int32, device=dev),
                                            torch.empty(len(uniq), dtype=torch.float32, device=dev))
-        # (a fresh pinned tensor per upload: torch's host allocator hands its block out again only after this copy has run)
-        up = lambda dst, a: dst.copy_(torch.from_numpy(np.ascontiguousarray(a)).pin_memory(), non_blocking=True)
-        up(sl[0], uniq.astype(np.int64))
-        up(sl[1], inv.astype(np.int32))
-        up(sl[2], (counts / float(len(arr))).astype(np.float32))
+        # staging: a small PERSISTENT pinned ring per (U, N) -- three slots, an event per slot -- instead of three fresh pin_memory()
+        # tensors per iteration (pinning costs ~0.2 ms per tensor, tools/leases/r05_probe_upload.py; and a pinned ALLOCATION from
+        # another thread aborts a capture in "global" capture-error mode).  A slot is rewritten only after the copies that read it
+        # have run (event.synchronize(): three iterations back, normally long done).
+        rings = self.__dict__.setdefault("_static_ring", {})
+        ring = rings.get((key, str(dev)))
+        if ring is None:
+            mk = lambda: (torch.empty(len(uniq), dtype=torch.int64).pin_memory(), torch.empty(len(arr), dtype=torch.int32).pin_memory(),
+                          torch.empty(len(uniq), dtype=torch.float32).pin_memory(), torch.cuda.Event())
+            ring = rings[(key, str(dev))] = {"slots": [mk() for _ in range(3)], "next": 0, "used": [False, False, False]}
+        k = ring["next"]
+        ring["next"] = (k + 1) % 3
+        h_idx, h_inv, h_w, ev = ring["slots"][k]
+        if ring["used"][k]:
+            ev.synchronize()
+        h_idx.numpy()[:] = uniq
+        h_inv.numpy()[:] = inv
+        h_w.numpy()[:] = counts / float(len(arr))
+        sl[0].copy_(h_idx, non_blocking=True)
+        sl[1].copy_(h_inv, non_blocking=True)
+        sl[2].copy_(h_w, non_blocking=True)
+        ev.record(torch.cuda.current_stream(dev))
+        ring["used"][k] = True
         self.__dict__["_staged"] = (arr.tobytes(), sl, uniq, counts)
         return key
 

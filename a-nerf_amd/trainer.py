@@ -72,13 +72,19 @@ class Trainer:
         return None
 
     # ---- the iteration as one hipGraph launch (opt-in) ------------------------------------------------------------------
-    def enable_graph(self, on=True, eager_steps=2, capture_error_mode="global"):
+    def enable_graph(self, on=True, eager_steps=2, capture_error_mode="global", warm_each_key=True):
         """Replay the device side of train_batch -- pose layer, render, losses, backward, optimiser -- from a captured hipGraph
         (graph_step.GraphedTrainStep): one launch per iteration instead of ~45, same kernels and bit-identical results.  Needs the
         fused tail (a FusedAdam).  The loader's batch is copied into persistent device tensors before each replay; the pose
         layer's grouping of the rays is staged the same way; learning rate, tau, Adam's step count and the random offset travel
         through the device-resident step block.  Each (batch size, number of distinct poses, pose-optimisation phase) gets its
-        own graph on first use; `--freq_schedule` runs stay eager (with a warning)."""
+        own graph on its SECOND use (the first runs eagerly: warm caches); a variant whose capture fails runs eagerly from then on,
+        with one warning; `--freq_schedule` runs stay eager (with a warning).  With more than one rank the gradient collectives
+        are captured with the step.
+        ALIASING: in graph mode the tensors train_batch returns (loss_dict, stats: 0-dim device tensors) are views into the graph's
+        private pool and the NEXT replay overwrites them in place -- read them (`.item()`, `float()`) or `.clone()` them before the
+        next train_batch call if they are to be kept, e.g. to average over a logging interval.  The eager path returns fresh
+        tensors every call.  (Cloning them here would put seven more launches behind every replay.)"""
         if not on:
             self._gs = self._static = None
             return self
@@ -88,7 +94,8 @@ class Trainer:
         caster = self.render_kwargs_train["ray_caster"]
         self._static = graph_step.StaticBatch(self.device if self.device is not None else next(caster.parameters()).device)
         self._gs = graph_step.GraphedTrainStep(self._graph_body, caster, self._fused, eager_steps=eager_steps,
-                                               capture_error_mode=capture_error_mode)      # "thread_local": beside pin-memory threads
+                                               capture_error_mode=capture_error_mode,      # "thread_local": beside pin-memory threads
+                                               warm_each_key=warm_each_key)
         return self
 
     def _graph_body(self, i):
@@ -113,7 +120,9 @@ class Trainer:
         popt_detach = not (args.opt_pose_stop is None or i < args.opt_pose_stop)
         no_pose = popt_detach or not args.opt_pose
         n_rays = int(batch["target_s"].shape[0])
-        key = (n_rays, popt_detach, no_pose) + (layer.stage_batch(kp_idx) if layer is not None else ())
+        # the key holds everything a captured graph has frozen: sizes, phase flags, the pose layout, and the ADDRESSES of the
+        # static inputs (an entry that changes shape / dtype or flips tensor <-> None gets another graph, not a stale buffer)
+        key = (n_rays, popt_detach, no_pose) + (layer.stage_batch(kp_idx) if layer is not None else ()) + (self._static.identity(sb),)
         only = 0 if (no_pose and len(f.param_groups) > 1) else None
         self._cur = (sb, kp_idx, popt_detach, no_pose)
         out = self._gs.step(i, key=key, due=f._due(i, only))
@@ -270,15 +279,19 @@ class Trainer:
 
     # ---- one iteration (trainer.py:228-277) --------------------------------------------------------------------------
     def train_batch(self, batch, i=0, global_step=0):
+        """one iteration (trainer.py:228-277) -> (loss_dict, stats).  After enable_graph() the returned tensors alias the graph's
+        pool and hold the LATEST replay's values: see enable_graph."""
         args = self.args
         H, W, focal = self.hwf
         if self._gs is not None and self.device is not None and torch.device(self.device).type == "cuda":
-            multi = torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
             layer = None if self.popt_kwargs is None else self.popt_kwargs.get("popt_layer")
             unstaged = layer is not None and (layer.use_cache or layer.kp_map is not None or len(layer.rest_pose) != 1 or
                                               not getattr(layer, "fused_batch", True))
+            # more than one rank: the gradient collectives are captured with the step (RCCL all-reduces on the optimiser's side
+            # stream; tests/test_graph_step.py::test_rccl_collectives_inside_the_captured_step).  A transport that cannot be
+            # captured (gloo moves the bucket through the host) is not attempted: GraphedTrainStep runs eagerly and says why.  Ranks
+            # may mix replayed and eager iterations -- both enqueue the same collectives in the same order.
             why = ("render_kwargs_train['pytest'] uploads host random numbers every call" if self.render_kwargs_train.get("pytest", False) else
-                   "more than one rank: the gradient collectives have not been run under stream capture" if multi else
                    "this pose layer (cache / multi-view / per-pose rest poses) uploads its index tensors every call" if unstaged else None)
             if why is None:
                 return self._train_batch_graphed(batch, i, global_step)

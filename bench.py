@@ -60,8 +60,9 @@ def parse():
                     help="append `extra_workloads` (5 steps each of train N_rand=3072, train 384 rays, 64+128 bf16x3 render, each "
                          "with its own roofline) to the record; auto = only for the default invocation (render64, fp32, 1 GPU)")
     ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                    help="train workloads: replay the iteration as ONE captured hipGraph (a-nerf_amd/graph_step.py).  auto = on in a single "
-                         "process with the fused tail, off for multi-rank runs")
+                    help="train workloads: replay the iteration as ONE captured hipGraph (a-nerf_amd/graph_step.py).  auto = on with the fused tail for "
+                         "any number of ranks (the gradient collectives are captured with the step; all ranks fall back to the eager step "
+                         "together if any rank's capture fails)")
     ap.add_argument("--dry-run", action="store_true",
                     help="multi-rank plumbing without a GPU: rendezvous (gloo), the real shard arithmetic of the workload, the "
                          "collectives with their real shapes (frame all-gather / gradient-bucket all-reduce), record assembly and "
@@ -275,7 +276,11 @@ def compact_line(res):
         line["scaling_model_8gpu"] = {"note": "model, not a measurement: N = 1 timings + ring terms", "t_hop_us_assumed": sm.get("t_hop_us_assumed")} | {
             k: {"speedup_no_latency_no_skew": v["without_latency_and_skew"]["speedup_8gpu"], "speedup_with_latency": v["with_latency"]["speedup_8gpu"],
                 "speedup_with_latency_and_skew": v["with_latency_and_skew"]["speedup_8gpu"], "exposed_collective_ms": v["exposed_collective_ms"],
-                "skew_ms": v["skew_ms_p95_minus_median"]}
+                "skew_ms": v["skew_ms_p95_minus_median"]} |
+               # the two forms the N > 1 command can run, each rank's step measured with the collectives live (one-rank RCCL):
+               # [predicted speedup with latency + skew, shard step ms, host enqueue ms]
+               {row: [(v.get(row) or {}).get("speedup_8gpu"), (v.get(row) or {}).get("shard_step_ms"), (v.get(row) or {}).get("host_enqueue_ms")]
+                for row in ("graphed", "eager_overlap") if isinstance(v.get(row), dict) and "speedup_8gpu" in v[row]}
             for k, v in sm.items() if isinstance(v, dict) and "with_latency" in v}
     if "cpu_baseline" in line and isinstance(line["cpu_baseline"], dict):
         line["cpu_baseline"] = dict(line["cpu_baseline"], sample=str(line["cpu_baseline"].get("sample", ""))[:200])
@@ -485,7 +490,7 @@ def main():
         if want_extra and world == 1:
             ex = extra_workloads(args, device, synth, ops, pipeline)
             if dist is None:
-                res["scaling_model_8gpu"] = scaling_model(ex, device)
+                res["scaling_model_8gpu"] = scaling_model(ex, device, args, synth)
             summ = []
             for e in ex:
                 key = e.pop("_key", None)
@@ -646,7 +651,7 @@ def extra_workloads(args, device, synth, ops, pipeline):
     return out
 
 
-def scaling_model(extras, device):
+def scaling_model(extras, device, args=None, synth=None):
     """What the N = 1 run can say about the 8-GPU strong-scaling target before a SCALE run exists: the 384-ray shard step
     measured here (= each rank's compute at N = 8), the gradient bucket's all-reduce on a ONE-rank RCCL communicator (the fixed
     launch + kernel cost of the collective; no xGMI traffic) and a ring model for the wire time (2 (G-1)/G x bytes over one
@@ -677,8 +682,9 @@ def scaling_model(extras, device):
         e1.record()
         torch.cuda.synchronize()
         coll1 = e0.elapsed_time(e1) / 20
-        if created:
+        if created and args is None:
             dist.destroy_process_group()
+            created = False
         _flush_c_stdio()
     except Exception as e:
         out["collective_world1_error"] = f"{type(e).__name__}: {e}"
@@ -703,6 +709,41 @@ def scaling_model(extras, device):
     coll_net_ms = launch_ms + lat_ms + wire_ms
     out.update({"collective_bytes": bucket_bytes, "collective_world1_ms": coll1, "xgmi_link_GBps_assumed": link / 1e9, "t_hop_us_assumed": t_hop_ms * 1e3,
                 "per_network_collective_ms": {"launch": launch_ms, "latency_2(G-1)_hops": lat_ms, "ring_wire": wire_ms, "total": coll_net_ms}})
+    # ---- each rank's step at N = 8, measured with the collectives LIVE on the one-rank communicator above, in BOTH forms the N > 1
+    # command can take: the captured step (`--graph auto`'s default for any world since round 6) and the eager
+    # overlap step every rank falls back to if a capture fails.  The shard runs of `extra_workloads` (no process group: no
+    # collective kernels, no side stream) stay in the record as `shard_step_ms_no_collectives`.
+    live = {}
+    if args is not None and coll1 is not None:
+        import copy
+        import torch.distributed as dist
+        prev = os.environ.get("ANERF_FORCE_COLLECTIVES")
+        os.environ["ANERF_FORCE_COLLECTIVES"] = "1"
+        try:
+            for wl, every in (("train", 1), ("train_mixamo", 20)):
+                for mode in ("on", "off"):
+                    a = copy.copy(args)
+                    a.workload, a.n_rand, a.opt_pose_step, a.graph = wl, 384, every, mode
+                    a.steps, a.warmup, a.cpu_rays, a.extra, a.precision = max(20, args.steps), 3, 0, "off", "fp32"
+                    try:
+                        r = bench_train(a, 0, 1, device, dist, synth, mixamo=wl == "train_mixamo", per_kernel=False)
+                        per = r.get("period_ms") or r["step_ms"]
+                        live[(wl, mode)] = {"step_ms": r["step_ms"]["median"], "skew_ms": max(0.0, per["p95"] - per["median"]),
+                                            "host_ms": r["host_enqueue_ms"]["median"], "graph": bool(r["config"].get("graph")),
+                                            "overlap": r.get("overlap")}
+                    except Exception as e:
+                        live[(wl, mode)] = {"error": f"{type(e).__name__}: {e}"[:200]}
+                    torch.cuda.empty_cache()
+        except Exception as e:
+            out["live_collective_runs_error"] = f"{type(e).__name__}: {e}"[:200]
+        finally:
+            if created:
+                dist.destroy_process_group()
+            _flush_c_stdio()
+            if prev is None:
+                os.environ.pop("ANERF_FORCE_COLLECTIVES", None)
+            else:
+                os.environ["ANERF_FORCE_COLLECTIVES"] = prev
     for name, full, shard, n, window_ms, pose_every in (("config3", ("train", 3072, 1), ("train", 384, 1), 3072, 0.005, 0),
                                                         ("config4_opt_pose_step20", ("train_mixamo", 3072, 20), ("train_mixamo", 384, 20), 3072, 0.115, 20)):
         if full in by and shard in by:
@@ -713,12 +754,30 @@ def scaling_model(extras, device):
             exp_old = launch_ms + wire_ms                                         # round-4 model: no latency, no skew, coarse half exposed
             exp_lat_seq = coll_net_ms                                             # + latency, the coarse collective behind the backward (round 4's schedule)
             exp_lat = max(0.0, coll_net_ms - window_ms) + small                   # + latency, this round's schedule
-            mk = lambda e: {"step_ms_8gpu": t8 + e, "speedup_8gpu": t1 / (t8 + e), "rays_per_s_8gpu": n / ((t8 + e) * 1e-3)}
-            out[name] = {"step_ms_1gpu": t1, "shard_step_ms": t8, "speedup_before_allreduce": t1 / t8,
+            mk = lambda e, t=None: {"step_ms_8gpu": (t or t8) + e, "speedup_8gpu": t1 / ((t or t8) + e), "rays_per_s_8gpu": n / (((t or t8) + e) * 1e-3)}
+            out[name] = {"step_ms_1gpu": t1, "shard_step_ms_no_collectives": t8, "speedup_before_allreduce": t1 / t8,
                          "hidden_window_ms": window_ms, "skew_ms_p95_minus_median": skew, "exposed_collective_ms": exp_lat,
                          "without_latency_and_skew": mk(exp_old), "with_latency_coarse_collective_after_backward": mk(exp_lat_seq),
                          "with_latency": mk(exp_lat), "with_latency_and_skew": mk(exp_lat + skew),
                          "predicted_speedup_8gpu": t1 / (t8 + exp_lat + skew)}
+            # the two forms of the N = 8 step, collectives live: t8 = that run's median step (its launch cost is then inside t8: the
+            # exposed term below keeps it, i.e. counts it twice -- the conservative side), skew = that run's own p95 - median
+            wl = shard[0]
+            for mode, row in (("on", "graphed"), ("off", "eager_overlap")):
+                lv = live.get((wl, mode))
+                if not lv or "error" in lv:
+                    out[name][row] = lv or {"error": "not measured (no RCCL communicator in this process)"}
+                    continue
+                t8m = lv["step_ms"]
+                # an eager rank cannot run faster than its host enqueues: the period is max(GPU step, host time)
+                t8e = max(t8m, lv["host_ms"])
+                out[name][row] = dict(mk(exp_lat + lv["skew_ms"], t8e), shard_step_ms=t8m, host_enqueue_ms=lv["host_ms"], skew_ms=lv["skew_ms"],
+                                      ran_as_graph=lv["graph"], speedup_before_collective_terms=t1 / t8e)
+            g_row, e_row = out[name].get("graphed") or {}, out[name].get("eager_overlap") or {}
+            if "speedup_8gpu" in g_row:
+                out[name]["predicted_speedup_8gpu"] = g_row["speedup_8gpu"]          # the default N > 1 form
+            if "speedup_8gpu" in e_row:
+                out[name]["predicted_speedup_8gpu_eager_fallback"] = e_row["speedup_8gpu"]
     return out
 
 
@@ -1024,7 +1083,7 @@ def live_traffic(argv_workload, kernel_sub, launches_per_step=1, timeout_s=120):
             "dispatches_averaged": vals["FETCH_SIZE"][1]}, None
 
 
-def bench_train(args, rank, world, device, dist, synth, mixamo=False):
+def bench_train(args, rank, world, device, dist, synth, mixamo=False, per_kernel=True):
     """BASELINE config 3: SURREAL training step, N_rand = 3072 rays (global), 64 + 16 samples, fwd + bwd + Adam,
     through the reference-shaped API (RayCaster mirror + render() + loss).  Strong scaling: each rank takes
     N_rand / world rays; gradients are averaged with one RCCL all-reduce of a flat bucket per step.
@@ -1138,11 +1197,15 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
         return {"loss": loss}
 
     # --graph: the iteration as ONE hipGraph launch (a-nerf_amd/graph_step.py; per-step scalars in a device-resident block, ABI
-    # revision 6).  auto = single process with the fused tail; multi-rank runs keep the eager step unless --graph on: RCCL
-    # collectives inside the captured step have run with ONE rank only (forced collectives: tests/test_graph_step.py, and
-    # `ANERF_BENCH_FORCE_DIST=1 bench.py --graph on`: 3.01 -> 2.91 ms at the Mixamo shard, host 2.0 -> 0.05 ms) -- there is no
-    # second GPU to try them on
-    use_graph = fused and (args.graph == "on" or (args.graph == "auto" and dist is None))
+    # revision 6).  auto = on with the fused tail, for ANY number of ranks (round 6): with more than one rank the gradient
+    # collectives -- both networks' all-reduces on the optimiser's side stream, the pose group's on its iteration -- are captured
+    # with the step (bit-identical to the eager step on a one-rank RCCL communicator: tests/test_graph_step.py; 3.01 -> 2.91 ms at
+    # the Mixamo shard, host 2.0 -> 0.05 ms).  After the captures every rank reports success through ONE 1-element all-reduce
+    # OUTSIDE any capture (GraphedTrainStep.agree); if any rank's capture failed, ALL ranks time the eager step and the record
+    # says so (`graph`: {"error": ...}, config.graph = false).
+    # (gloo -- the control-flow tests with ranks sharing one GPU -- cannot be captured and is not attempted: GraphedTrainStep
+    # reports why, the ranks agree, the record says graph = false)
+    use_graph = fused and args.graph != "off"
     gs = None
     if use_graph:
         graph_step = importlib.import_module("a-nerf_amd.graph_step")
@@ -1188,8 +1251,13 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
             if mixamo and args.opt_pose_step > 1:
                 gs.prepare(args.opt_pose_step)
         except Exception as e:   # a stack that cannot capture the step: say so in the record and time the eager step instead
-            graph_error = f"{type(e).__name__}: {e}"[:300]
-            sys.stderr.write(f"bench.py: hipGraph capture failed ({graph_error}); falling back to the eager step\n")
+            gs.eager_only[("prepare",)] = f"{type(e).__name__}: {e}"[:300]
+        if os.environ.get("ANERF_BENCH_FAIL_CAPTURE_RANK") == str(rank):       # test hook: this rank's capture "failed"
+            gs.eager_only[("test hook",)] = "ANERF_BENCH_FAIL_CAPTURE_RANK"
+        mine_ok = not gs.eager_only and gs._capturable() is None
+        if not gs.agree(dist):                      # one tiny all-reduce outside the capture: every rank runs the same mode
+            graph_error = ("; ".join(gs.eager_only.values()) or gs._capturable()) if not mine_ok else "another rank's capture failed (agreed over all ranks)"
+            sys.stderr.write(f"bench.py: rank {rank}: hipGraph capture not usable ({graph_error}); all ranks fall back to the eager step\n")
             gs = None
             torch.cuda.synchronize()
             opt.zero_grad()
@@ -1268,7 +1336,7 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False):
     uw = 648 + (16 if mixamo else 0)
     F_FWD, F_BWD, F_GEMM, F_IN = F_MLP, 2 * 557696, F_MLP, 2 * (2 * 256 * 432 + 128 * uw)
     kernels = None
-    if args.steps > 0:
+    if args.steps > 0 and per_kernel:
         prof = ops.Profile()
         acc = {}
         n_prof = 8

@@ -206,7 +206,8 @@ int anerf_weight_grads(const AnerfConfig* cfg, const AnerfSaved* saved, const fl
 int anerf_input_grads(const AnerfConfig* cfg, const float* packed_i, const float* dz, const float* dzv,
                       int64_t p_pad, int64_t n_points, float* dx, float* du, void* stream);
 
-/* Backward of the fused encoding: dx/du -> dskts [N,24,4,4] (rows 0..2 written; caller zero-fills the tensor once).
+/* Backward of the fused encoding: dx/du -> dskts [N,24,4,4] (every element written: rows 0..2 the gradient, row 3 zeros; no zero
+ * fill needed -- round 6; an earlier revision left row 3 to the caller).
  * skts must be per ray (stride 384).  dy_ws, dq_ws: scratch [N*S][72] each. */
 int anerf_encode_backward(const AnerfConfig* cfg, const float* dx, const float* du, const float* rays,
                           int32_t ray_stride, const float* z_vals, const float* skts, int64_t skt_ray_stride,

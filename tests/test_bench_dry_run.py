@@ -106,6 +106,15 @@ def test_dry_run_bucket_is_the_real_flat_bucket(workload, floats):
     assert r.returncode == 0, r.stderr[-2000:]
     j = strict_line(r.stdout)
     assert j["collective_bytes"] == 4 * floats and j["backend"].startswith("nccl")
+    # a process group is up: --graph auto still replays the step from the captured graph, collectives inside (round 6)
+    assert j["config"]["graph"] is True, j["config"]
+    if workload == "train":
+        # ... unless a rank reports a failed capture: then every rank times the eager step, and the record says so
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--n-rand", "64", "--steps", "2", "--warmup", "1",
+                            "--cpu-rays", "0", "--extra", "off"], env=dict(e, ANERF_BENCH_FAIL_CAPTURE_RANK="0"), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        j = strict_line(r.stdout)
+        assert j["config"]["graph"] is False and "error" in j["graph"], (j["config"], j.get("graph"))
 
 
 def test_line_budget_holds_for_a_full_default_record():

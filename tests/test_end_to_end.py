@@ -44,4 +44,5 @@ def test_pose_refinement_recovers_perturbed_poses(tmp_path):
     assert r["pretrain"]["last"][2] > r["pretrain"]["first"][2] + 6.0, r          # the subject was learnt (PSNR up by > 6 dB)
     assert 60.0 < p["mpjpe_mm_start"] < 120.0 and p["mpjpe_mm_end"] < 0.5 * p["mpjpe_mm_start"], p
     assert p["pose_steps"] == 400 and p["reloaded_pose_adam_steps"] == 400 and p["reloaded_layer_identical"], p
-    assert r["graphs"]["replays"] == 398 and r["reload_max_abs_diff"] == 0.0, r
+    # (each new variant -- another number of distinct poses in the batch -- runs eagerly once before its capture)
+    assert 390 <= r["graphs"]["replays"] <= 398 and r["graphs"]["replays"] + r["graphs"]["eager"] == 400 and r["reload_max_abs_diff"] == 0.0, r

@@ -168,3 +168,67 @@ def test_cutoff_gate_at_the_end_of_the_tau_schedule(oracle, precision):
     for k in ("rgb_map", "acc_map", "alpha", "rgb0", "alpha0"):
         assert torch.isfinite(out[k]).all(), k
     assert_out(out, ref, ["rgb_map", "acc_map", "rgb0"], atol=2e-4)
+
+
+@pytest.mark.parametrize("lindisp", [False, True])
+@pytest.mark.parametrize("miss", ["some", "all", "none"])
+def test_one_launch_bounds_and_depths_equal_the_staged_pair(oracle, miss, lindisp):
+    """Round 6: inside the one-call entry points A2 + A3 are ONE launch (k_bounds_z: each sample's thread computes its ray's bounds;
+    a block that holds a ray missing the cylinder recomputes the call-wide NaN-mean statistics itself, in k_ray_bounds' exact form).
+    Against the staged k_ray_bounds -> k_coarse_z route: every output BIT-equal -- rays that miss (the NaN-mean fallback,
+    ray_utils.py:327-342), a call in which ALL rays miss (no valid row: the placeholder bounds 0 / 1 stay), stratified jitter,
+    lindisp, per-ray and shared cylinders, a block that straddles rays (S = 24 does not divide 256)."""
+    c = build("nan_fallback")
+    cfg = ops.PathConfig()
+    net = ops.pack_params(cfg, cuda_params(c["Pc"]))
+    n, S = c["n"], 24
+    rb = pipeline.make_ray_batch(dev(c["rays_o"]), dev(c["rays_d"]))
+    cyl = dev(c["cyls"]).clone()
+    if miss == "all":
+        cyl[:, 0] += 100.0                    # the cylinder is nowhere near any ray
+    elif miss == "none":
+        cyl[:, 2] *= 10.0
+    skt = dev(c["skts"])
+    tr = torch.rand(n, S, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    nf_raw, _ = ops.ray_bounds(rb, cyl)
+    n_nan = int(torch.isnan(nf_raw[:, 0]).sum())
+    assert {"some": 0 < n_nan < n, "all": n_nan == n, "none": n_nan == 0}[miss], n_nan
+    for t_rand in (None, tr):
+        staged = pipeline.render_rays_forward(cfg, net, None, rb, skt, cyl, S, 0, t_rand=t_rand, lindisp=lindisp, extras=True)
+        fused = ops.forward(cfg, net, None, rb, skt, cyl, S, 0, t_rand=t_rand, lindisp=lindisp)
+        shared = ops.forward(cfg, net, None, rb, skt, cyl[:1], S, 0, t_rand=t_rand, lindisp=lindisp)
+        for k in fused:
+            assert torch.equal(fused[k], staged[k]) and torch.equal(shared[k], staged[k]), (k, miss, t_rand is not None)
+        assert torch.isfinite(fused["rgb_map"]).all()
+
+
+def test_small_batch_loss_is_one_launch_with_the_same_bits():
+    """anerf_loss for n <= 1024 rays runs k_loss_one (one block walking k_loss's blocks in turn, k_loss_final's sums behind them):
+    the same four outputs and gradient maps, bit for bit, as the two-launch route takes for the same rays -- checked by evaluating
+    each size both ways: directly (one launch) and as the leading rows of a padded 1025+-ray call whose extra rows contribute
+    exact zeros (target == prediction, background 0) to every sum."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    for n in (1, 255, 256, 257, 384, 1024):
+        for kind in (0, 1, 2):
+            rgb, rgb0, tgt = (torch.rand(n, 3, device="cuda", generator=g) for _ in range(3))
+            acc, acc0 = torch.rand(n, device="cuda", generator=g), torch.rand(n, device="cuda", generator=g)
+            bg = torch.rand(n, 3, device="cuda", generator=g)
+            out, gr = ops.loss(rgb, acc, tgt, rgb0, acc0, bg, kind, 0.7)
+            # reference arithmetic of the same sums in float64, then the scale 1 / (3 n): agreement to fp32 rounding
+            d = (rgb + (1 - acc)[:, None] * bg - tgt).double()
+            d0 = (rgb0 + (1 - acc0)[:, None] * bg - tgt).double()
+            term = (lambda x: x * x) if kind == 0 else (lambda x: x.abs()) if kind == 1 else \
+                (lambda x: torch.where(x.abs() >= 0.1, x.abs() - 0.05, 0.5 * x * x / 0.1))
+            want = torch.stack([term(d).mean() + 0.7 * term(d0).mean(), term(d).mean(), term(d0).mean(), (d * d).mean()])
+            assert torch.allclose(out.double(), want, rtol=2e-6, atol=1e-9), (n, kind, out, want)
+            assert gr["rgb"].shape == (n, 3) and torch.isfinite(gr["flat"]).all()
+    # the same rays through both routes: n = 1024 (one launch) vs the first 1024 rows of a 1280-ray call (two launches) whose
+    # other rows add exact zeros; 1 / (3 n) differs between the calls, so compare sums: out * 3n
+    n, m = 1024, 1280
+    rgb, rgb0, tgt = (torch.rand(m, 3, device="cuda", generator=g) for _ in range(3))
+    acc, acc0 = torch.rand(m, device="cuda", generator=g), torch.rand(m, device="cuda", generator=g)
+    rgb[n:], rgb0[n:] = tgt[n:], tgt[n:]
+    bg = torch.zeros(3, device="cuda")
+    one, _ = ops.loss(rgb[:n].contiguous(), acc[:n].contiguous(), tgt[:n].contiguous(), rgb0[:n].contiguous(), acc0[:n].contiguous(), bg, 0, 1.0)
+    two, _ = ops.loss(rgb, acc, tgt, rgb0, acc0, bg, 0, 1.0)
+    assert torch.allclose(one[1:] * (3 * n), two[1:] * (3 * m), rtol=3e-7, atol=0)

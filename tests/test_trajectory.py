@@ -281,7 +281,9 @@ def test_graphed_trainer_is_bit_identical_to_the_eager_trainer(name):
         tr.render_kwargs_train["pytest"] = False
         caster._rng = ops.DeviceRng(seed=99, stream_id=7)
         if graph:       # (the Mixamo case also takes the capture mode meant for runs with pin-memory threads beside the trainer)
-            tr.enable_graph(eager_steps=1, capture_error_mode="thread_local" if name == "mixamo" else "global")
+            # warm_each_key=False: every new variant is captured at first sight -- this test is about many graphs in few iterations
+            # (the default, one eager pass per new variant, is counted in tests/test_graph_step.py)
+            tr.enable_graph(eager_steps=1, capture_error_mode="thread_local" if name == "mixamo" else "global", warm_each_key=False)
         trace = []
         rng = np.random.default_rng(5)
         for i in range(1, n_iter + 1):
@@ -330,7 +332,7 @@ def test_resumed_run_continues_bit_identically(graph, tmp_path):
         tr.render_kwargs_train["pytest"] = False
         caster._rng = ops.DeviceRng(seed=99, stream_id=7)
         if graph:
-            tr.enable_graph(eager_steps=1)
+            tr.enable_graph(eager_steps=1, warm_each_key=False)
         return tr, caster, layer, fused
 
     def batch_of(i):

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void k_probe(const char* __restrict__ wstream0
   const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   int slot = 0;
   long long goff = 0;
-  if (DMA && DMA != 5) {
+  if (DMA && DMA != 5 && DMA < 9) {
     const long long g0 = (long long)((blockIdx.x % 8) * stage_skew) * STAGE_BYTES;
     issue(g0, 0); issue(g0 + STAGE_BYTES, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -260,6 +260,103 @@ __global__ __launch_bounds__(256) void k_probe(const char* __restrict__ wstream0
     if (threadIdx.x == 0) { clocks[2 * blockIdx.x] = t1 - t0; clocks[2 * blockIdx.x + 1] = r1 - r0; }
     return;
   }
+  if (DMA == 9 || DMA == 10) {
+    // PARTIAL LDS BYPASS (round 6): 8 of the stage's 32 fragments -- the last group, k-step 1 / blocks 4..7 -- do not
+    // go through LDS at all: every wave fetches them itself with 8 x global_load_dwordx4 (L2 -> A-operand VGPRs, 32 staging
+    // registers), issued right behind the stage barrier IN FRONT of the LDS-DMA pieces, so that `s_waitcnt vmcnt(6)` before the
+    // group's MFMAs waits for exactly these loads (vector-memory operations return in issue order).  The LDS-DMA ring carries the
+    // other 24 fragments (6 pieces per wave instead of 8); LDS work per stage: 24 x 4 KiB of reads + 24 KiB of DMA writes instead
+    // of 32 x 4 + 32.  DMA == 10: the same with the direct loads' group FIRST in the NEXT stage (a whole stage of latency cover,
+    // 64 staging registers: does the L2 latency matter?).
+    f32x4 stg[8];
+    auto issue6 = [&](long long go, int sl) __attribute__((always_inline)) {
+      const char* g = wstream + go + wave * 6 * FRAG;
+      const unsigned lds0 = (unsigned)reinterpret_cast<size_t>((lds_ptr_t)(smem + sl * STAGE_BYTES + wave * 6 * FRAG));
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %1, %2\n\t"
+                   "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+                   "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+                   "global_load_lds_dwordx4 %1, %2 offset:3072"
+                   :: "s"(lds0), "v"(lane16), "s"(g) : "memory", "m0");
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %1, %2\n\t"
+                   "global_load_lds_dwordx4 %1, %2 offset:1024"
+                   :: "s"(lds0 + 4 * FRAG), "v"(lane16), "s"(g + 4 * FRAG) : "memory", "m0");
+    };
+    auto direct = [&](long long go) __attribute__((always_inline)) {
+      const char* g = wstream + go + 24 * FRAG;           // the same 8 KiB for all four waves (they hit in L1 / L2)
+      asm volatile("global_load_dwordx4 %0, %4, %5\n\t"
+                   "global_load_dwordx4 %1, %4, %5 offset:1024\n\t"
+                   "global_load_dwordx4 %2, %4, %5 offset:2048\n\t"
+                   "global_load_dwordx4 %3, %4, %5 offset:3072"
+                   : "=v"(stg[0]), "=v"(stg[1]), "=v"(stg[2]), "=v"(stg[3]) : "v"(lane16), "s"(g) : "memory");
+      asm volatile("global_load_dwordx4 %0, %4, %5\n\t"
+                   "global_load_dwordx4 %1, %4, %5 offset:1024\n\t"
+                   "global_load_dwordx4 %2, %4, %5 offset:2048\n\t"
+                   "global_load_dwordx4 %3, %4, %5 offset:3072"
+                   : "=v"(stg[4]), "=v"(stg[5]), "=v"(stg[6]), "=v"(stg[7]) : "v"(lane16), "s"(g + 4 * FRAG) : "memory");
+    };
+    auto mms = [&](int j, int b) __attribute__((always_inline)) {
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, stg[2 * j]), al = __builtin_bit_cast(bf16x8, stg[2 * j + 1]);
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[b], 0, 0, 0);
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[b], 0, 0, 0);
+      acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[b], 0, 0, 0);
+    };
+    const long long wrap = stream_bytes - STAGE_BYTES;
+    issue6(0, 0); issue6(STAGE_BYTES, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    direct(0);
+    issue6(2LL * STAGE_BYTES, 2);
+    long long go = 3LL * STAGE_BYTES, dgo = STAGE_BYTES;     // go: the stage the freed slot is refilled with; dgo: the NEXT stage's direct part
+    int sl = 0;
+    rd(fa, smem + lane16, 0, 0, 4);
+    for (int st = 0; st < stages; ++st) {
+      const char* cur = smem + sl * STAGE_BYTES + lane16;
+      const int nsl = sl == SLOTS - 1 ? 0 : sl + 1;
+      const char* nxt = smem + nsl * STAGE_BYTES + lane16;
+      // group 0: k-step 0, blocks 0..3 (fa[0..7]); request group 1
+      mm(fa, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      rd(fa, cur, 0, 4, 4);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(fa, 1); mm(fa, 2); mm(fa, 3);
+      // group 1: k-step 0, blocks 4..7; request group 2
+      mm(fa, 4);
+      __builtin_amdgcn_sched_barrier(0);
+      rd(fb, cur, 1, 0, 4);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(fa, 5); mm(fa, 6); mm(fa, 7);
+      // group 2: k-step 1, blocks 0..3; NO request: group 3 comes from the staging registers
+      mm(fb, 0); mm(fb, 1); mm(fb, 2); mm(fb, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      // group 3: k-step 1, blocks 4..7 straight from L2; request the NEXT stage's group 0
+      asm volatile("s_waitcnt vmcnt(6)" : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[3]), "+v"(stg[4]), "+v"(stg[5]), "+v"(stg[6]), "+v"(stg[7]) :: "memory");
+      mms(0, 4);
+      __builtin_amdgcn_sched_barrier(0);
+      rd(fa, nxt, 0, 0, 4);
+      __builtin_amdgcn_sched_barrier(0);
+      mms(1, 5); mms(2, 6); mms(3, 7);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      direct(dgo);
+      issue6(go, sl);
+      go += STAGE_BYTES;
+      if (go > wrap) go = 0;
+      dgo += STAGE_BYTES;
+      if (dgo > wrap) dgo = 0;
+      sl = nsl;
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[b][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0) { clocks[2 * blockIdx.x] = t1 - t0; clocks[2 * blockIdx.x + 1] = r1 - r0; }
+    return;
+  }
   if (READS == 2) rd(fa, smem + lane16, 0, 0, 8);
   if (READS == 3) rd(fa, smem + lane16, 0, 0, 4);
   for (int st = 0; st < stages; ++st) {
@@ -394,5 +491,9 @@ int main() {
   run<4, 0>("hidden DMA, vmcnt(0) but NO barrier, no reads", w, stream_bytes, out, clocks, blocks, stages);
   run<5, 0>("barrier only (no DMA), no reads", w, stream_bytes, out, clocks, blocks, stages);
   run<0, 0>("MFMA only again", w, stream_bytes, out, clocks, blocks, stages);
+  // round 6: partial LDS bypass -- 8 of 32 fragments per stage straight from L2 into A-operand VGPRs, 24 through the LDS-DMA ring
+  run<2, 3>("[r6] today's structure again: hidden DMA + raw barrier, reads one group ahead", w, stream_bytes, out, clocks, blocks, stages);
+  run<9, 3>("[r6] PARTIAL BYPASS: 24 fragments via LDS-DMA ring + 8 via global_load_dwordx4 per wave", w, stream_bytes, out, clocks, blocks, stages);
+  run<9, 3, 1>("[r6] NO MFMA: partial bypass memory work only (24 reads x 4 waves + 24 KiB DMA + 4 x 8 KiB direct)", w, stream_bytes, out, clocks, blocks, stages);
   return 0;
 }
