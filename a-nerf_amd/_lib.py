@@ -35,7 +35,7 @@ class AnerfSaved(C.Structure):
                 ("p_pad", C.c_int64)]
 
 
-ABI_VERSION = 6        # revision of include/anerf.h these structures were written for (checked against anerf_version())
+ABI_VERSION = 7        # revision of include/anerf.h these structures were written for (checked against anerf_version())
 PROF_SLOTS = 16
 
 
@@ -186,6 +186,8 @@ SIGNATURES = {
     "anerf_cyl_bbox": (C.c_int, [C.c_void_p] * 5 + [C.c_int32, C.c_void_p, C.c_void_p]),
     "anerf_kp_loss": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
                                 C.c_void_p]),
+    "anerf_kp_loss_add": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     "anerf_adam_blocks": (C.c_int, [C.c_int64]),
     "anerf_adam_step": (C.c_int, [C.c_void_p] * 4 + [C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32,
                                   C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),

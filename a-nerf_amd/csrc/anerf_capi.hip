@@ -209,7 +209,7 @@ using namespace anerf;
 extern "C" {
 
 const char* anerf_last_error(void) { return g_err; }
-int anerf_version(void) { return 6; }
+int anerf_version(void) { return 7; }
 
 int anerf_layout(const AnerfConfig* cfg, int which, AnerfLayout* out) {
   if (!out) return set_error(ANERF_E_NULL, "out is NULL");

@@ -557,7 +557,8 @@ using namespace anerf;
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_kp_loss(const float* __restrict__ vals, int rot6d, const float* __restrict__ anchors,
                                                  const float* __restrict__ w, int U, float tol, float coef,
-                                                 float* __restrict__ loss, float* __restrict__ g_vals) {
+                                                 float* __restrict__ loss, float* __restrict__ g_vals,
+                                                 const float* __restrict__ base, float* __restrict__ total) {
   __shared__ float sh[4];
   float acc = 0.f;
   const int dim = rot6d ? 6 : 3, stride = rot6d ? 9 : 3;
@@ -585,7 +586,11 @@ __global__ __launch_bounds__(256) void k_kp_loss(const float* __restrict__ vals,
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) *loss = sh[0] + sh[1] + sh[2] + sh[3];     // fixed order: bit-reproducible
+  if (threadIdx.x == 0) {
+    const float kp = sh[0] + sh[1] + sh[2] + sh[3];     // fixed order: bit-reproducible
+    *loss = kp;
+    if (total) *total = *base + kp;                      // anerf_kp_loss_add: the trainer's `total_loss + kp_loss` (one fp32 add, as torch's)
+  }
 }
 
 extern "C" {
@@ -596,7 +601,17 @@ int anerf_kp_loss(const float* values, int32_t rot6d, const float* anchors, cons
   if (!loss) return set_error(ANERF_E_NULL, "kp_loss: loss is NULL");
   if (n_poses > 0 && (!values || !anchors || !pose_weights)) return set_error(ANERF_E_NULL, "kp_loss: NULL pointer");
   hipLaunchKernelGGL(k_kp_loss, dim3(1), dim3(256), 0, (hipStream_t)stream, values, (int)(rot6d != 0), anchors, pose_weights,
-                     (int)n_poses, tol, coef, loss, g_values);
+                     (int)n_poses, tol, coef, loss, g_values, (const float*)nullptr, (float*)nullptr);
+  return check_launch("k_kp_loss");
+}
+
+int anerf_kp_loss_add(const float* values, int32_t rot6d, const float* anchors, const float* pose_weights, int32_t n_poses, float tol,
+                      float coef, const float* base, float* loss, float* total, float* g_values, void* stream) {
+  if (n_poses < 0) return set_error(ANERF_E_SHAPE, "kp_loss_add: n_poses >= 0");
+  if (!loss || !base || !total) return set_error(ANERF_E_NULL, "kp_loss_add: loss / base / total is NULL");
+  if (n_poses > 0 && (!values || !anchors || !pose_weights)) return set_error(ANERF_E_NULL, "kp_loss_add: NULL pointer");
+  hipLaunchKernelGGL(k_kp_loss, dim3(1), dim3(256), 0, (hipStream_t)stream, values, (int)(rot6d != 0), anchors, pose_weights,
+                     (int)n_poses, tol, coef, loss, g_values, base, total);
   return check_launch("k_kp_loss");
 }
 

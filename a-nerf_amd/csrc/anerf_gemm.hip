@@ -568,6 +568,13 @@ __device__ __forceinline__ void reduce_dw_one(const GemmBatch& G, const float* _
     // per thread was no faster: the kernel lives on threads in flight, not on bytes per thread)
     float s = 0.f;
     int c = 0;
+    for (; c + 9 <= pr.chunks; c += 9) {      // (round 6: nine in flight -- 18 chunks = two batches; the additions keep their order)
+      float v[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) v[k] = src[(long long)(c + k) * mn];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) s += v[k];
+    }
     for (; c + 6 <= pr.chunks; c += 6) {
       const float v0 = src[(long long)c * mn], v1 = src[(long long)(c + 1) * mn], v2 = src[(long long)(c + 2) * mn],
                   v3 = src[(long long)(c + 3) * mn], v4 = src[(long long)(c + 4) * mn], v5 = src[(long long)(c + 5) * mn];

@@ -26,6 +26,24 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
   return sh[0] + sh[1] + sh[2] + sh[3];   // fixed order
 }
 
+// three block sums at once: the same shuffle tree and the same sh[0] + sh[1] + sh[2] + sh[3] order per value as three block_sum
+// calls (bit-identical results), one pair of barriers instead of three
+__device__ __forceinline__ void block_sum3(float& a, float& b, float& c, float (*sh3)[4]) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o);
+    b += __shfl_xor(b, o);
+    c += __shfl_xor(c, o);
+  }
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { sh3[0][w] = a; sh3[1][w] = b; sh3[2][w] = c; }
+  __syncthreads();
+  a = sh3[0][0] + sh3[0][1] + sh3[0][2] + sh3[0][3];
+  b = sh3[1][0] + sh3[1][1] + sh3[1][2] + sh3[1][3];
+  c = sh3[2][0] + sh3[2][1] + sh3[2][2] + sh3[2][3];
+}
+
 // One thread per ray.  partial[b][0..3] = sum of per-channel terms of (fine loss, coarse loss, fine squared error, 0)
 __global__ __launch_bounds__(RB) void k_loss(const float* __restrict__ rgb, const float* __restrict__ acc,
                                              const float* __restrict__ rgb0, const float* __restrict__ acc0,
@@ -104,8 +122,9 @@ __global__ __launch_bounds__(RB) void k_loss_one(const float* __restrict__ rgb, 
                                                  int n, int nblk, int kind, float beta, float coarse_w, float* __restrict__ g_rgb,
                                                  float* __restrict__ g_acc, float* __restrict__ g_rgb0,
                                                  float* __restrict__ g_acc0, float* __restrict__ out) {
-  __shared__ float sh[4];
+  __shared__ float sh3[3][4];
   __shared__ float part[LOSS_ONE_MAX / RB][3];
+  constexpr int NV = LOSS_ONE_MAX / RB;
   const float inv = 1.0f / (3.0f * (float)n);
   auto term = [&](float d) {
     const float a = fabsf(d);
@@ -116,10 +135,13 @@ __global__ __launch_bounds__(RB) void k_loss_one(const float* __restrict__ rgb, 
     return kind == 0 ? 2.0f * d * inv
                      : (kind == 1 || a >= beta) ? (d > 0.f ? inv : (d < 0.f ? -inv : 0.f)) : d / beta * inv;
   };
-  for (int vb = 0; vb < nblk; ++vb) {
-    float lf = 0.f, lc = 0.f, se = 0.f;
+  // every virtual block's per-thread terms first (independent rays: their loads overlap), the block sums afterwards, in block order
+  float lf[NV], lc[NV], se[NV];
+#pragma unroll
+  for (int vb = 0; vb < NV; ++vb) {
+    lf[vb] = lc[vb] = se[vb] = 0.f;
     const int r = vb * RB + threadIdx.x;
-    if (r < n) {
+    if (vb < nblk && r < n) {
       float bg[3] = {0.f, 0.f, 0.f};
       if (bgs) {
         bg[0] = bgs[(long long)r * bg_stride + 0];
@@ -133,8 +155,8 @@ __global__ __launch_bounds__(RB) void k_loss_one(const float* __restrict__ rgb, 
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const float d = rgb[3 * r + c] + om * bg[c] - tt[c];
-          se += d * d;
-          lf += term(d);
+          se[vb] += d * d;
+          lf[vb] += term(d);
           const float g = dterm(d);
           if (g_rgb) g_rgb[3 * r + c] = g;
           ga -= g * bg[c];
@@ -147,7 +169,7 @@ __global__ __launch_bounds__(RB) void k_loss_one(const float* __restrict__ rgb, 
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const float d = rgb0[3 * r + c] + om * bg[c] - tt[c];
-          lc += term(d);
+          lc[vb] += term(d);
           const float g = coarse_w * dterm(d);
           if (g_rgb0) g_rgb0[3 * r + c] = g;
           ga -= g * bg[c];
@@ -155,11 +177,14 @@ __global__ __launch_bounds__(RB) void k_loss_one(const float* __restrict__ rgb, 
         if (g_acc0) g_acc0[r] = ga;
       }
     }
-    lf = block_sum(lf, sh);
-    lc = block_sum(lc, sh);
-    se = block_sum(se, sh);
-    if (threadIdx.x == 0) {
-      part[vb][0] = lf; part[vb][1] = lc; part[vb][2] = se;
+  }
+#pragma unroll
+  for (int vb = 0; vb < NV; ++vb) {
+    if (vb < nblk) {          // (nblk is uniform over the block: every thread takes the same barriers)
+      block_sum3(lf[vb], lc[vb], se[vb], sh3);
+      if (threadIdx.x == 0) {
+        part[vb][0] = lf[vb]; part[vb][1] = lc[vb]; part[vb][2] = se[vb];
+      }
     }
   }
   __syncthreads();
@@ -168,9 +193,7 @@ __global__ __launch_bounds__(RB) void k_loss_one(const float* __restrict__ rgb, 
   if ((int)threadIdx.x < nblk) {
     a += part[threadIdx.x][0]; b += part[threadIdx.x][1]; c += part[threadIdx.x][2];
   }
-  a = block_sum(a, sh);
-  b = block_sum(b, sh);
-  c = block_sum(c, sh);
+  block_sum3(a, b, c, sh3);
   if (threadIdx.x == 0) {
     out[1] = a * inv;
     out[2] = b * inv;

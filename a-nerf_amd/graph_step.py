@@ -56,6 +56,18 @@ def collectives_capturable(group=None):
     return True, None
 
 
+def _clear_sticky_hip_error():
+    """hipGetLastError() until it reports success: a failed stream capture leaves the runtime's per-thread sticky error set, and the
+    library's launch checks (hipGetLastError after every launch) would blame the next kernel for it."""
+    try:
+        hip = ops.Profile._hip_runtime()
+        for _ in range(8):
+            if hip.hipGetLastError() == 0:
+                break
+    except Exception:
+        pass
+
+
 def ops_force_collectives():
     import os
     return os.environ.get("ANERF_FORCE_COLLECTIVES") == "1"
@@ -176,28 +188,44 @@ class GraphedTrainStep:
                 ctx.__exit__(None, None, None)
                 entered = False
         except BaseException:
-            # torch.cuda.graph.__exit__ is not exception-safe: a capture that was invalidated half way (a synchronising call, a
-            # pageable copy, an unjoined side stream) raises out of capture_end() BEFORE the current stream is put back and before
-            # the allocator stops routing this stream's allocations into the graph pool.  Undo all of it.
+            # torch.cuda.graph.__exit__ is not exception-safe.  Two cases:
+            #  (a) the iteration raised a Python exception, the HIP capture itself is intact: capture_end() below succeeds and tidies up;
+            #  (b) the capture was INVALIDATED (a synchronising call, a host read, a pageable copy, an unjoined side stream):
+            #      hipStreamEndCapture fails inside capture_end() BEFORE torch (1) stops routing this stream's allocations into the graph
+            #      pool, (2) takes the default generator's state out of its "capturing" stage -- every later capture_begin() would then
+            #      throw "Cannot register the state during capturing stage" and the half-built CUDAGraph's destructor would terminate
+            #      the process ("The graph should be registered to the state") -- and (3) with the runtime's sticky error still set: the
+            #      next launch of the eager fallback would report "operation failed due to a previous error during capture".
+            ended = False
             if entered:
                 try:
                     g.capture_end()
+                    ended = True
                 except Exception:
                     pass
                 try:
                     ctx.stream_ctx.__exit__(None, None, None)
                 except Exception:
                     pass
-            try:
-                torch._C._cuda_endAllocateToPool(dev.index if dev.index is not None else torch.cuda.current_device(), self.pool)
-            except Exception:
-                pass
+            if not ended:
+                idx = dev.index if dev.index is not None else torch.cuda.current_device()
+                try:
+                    torch._C._cuda_endAllocateToPool(idx, self.pool)                       # (1)
+                except Exception:
+                    pass
+                try:
+                    gen = torch.cuda.default_generators[idx]
+                    gen.graphsafe_set_state(gen.clone_state())                              # (2) a fresh state object (same seed / offset)
+                except Exception:
+                    pass
+            _clear_sticky_hip_error()                                                       # (3)
             if hasattr(opt, "abort_step"):
                 opt.abort_step()          # collective handles created under the dead capture
             try:
                 torch.cuda.synchronize()
             except Exception:
                 pass
+            _clear_sticky_hip_error()
             self.failed_captures += 1
             raise
         finally:

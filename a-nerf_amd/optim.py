@@ -546,11 +546,14 @@ class _LossFn(torch.autograd.Function):
         out, g = ops.loss(rgb, acc, target, rgb0, acc0, bgs, loss_type, coarse_weight, want_grads=need, beta=beta)
         ctx.g = g
         ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)      # (else autograd zero-fills a gradient for the statistics output every step: one launch)
         return out[0], out
 
     @staticmethod
     def backward(ctx, go, _):
         g = ctx.g
+        if go is None or g is None:
+            return (None,) * 9
         flat = g["flat"]
         scaled = flat if is_unit_seed(go) else flat * go    # ONE launch for the four maps (they are views of one buffer); none when
                                                             # the graph was seeded by optim.backward()

@@ -101,35 +101,52 @@ def expand_poses(x_u, inverse_idxs):
 
 
 class _KpLossFn(torch.autograd.Function):
+    """(values, ..., base) -> kp_loss, or (kp_loss, base + kp_loss) when a base loss is given: the regulariser AND the trainer's
+    `total = rgb losses + kp_loss` in the one launch (anerf_kp_loss_add, ABI revision 7)."""
+
     @staticmethod
-    def forward(ctx, values, anchors, weights, rot6d, tol, coef):
+    def forward(ctx, values, anchors, weights, rot6d, tol, coef, base):
         import ctypes as C
         from . import _lib
         values, anchors, weights = ops._f32c(values, "values"), ops._f32c(anchors, "anchors"), ops._f32c(weights, "weights")
         u = values.shape[0]
-        loss = torch.empty(1, dtype=torch.float32, device=values.device)
+        out = torch.empty(2, dtype=torch.float32, device=values.device)          # [kp_loss, base + kp_loss]
         g = torch.empty_like(values) if ctx.needs_input_grad[0] else None
-        _lib.check(_lib.load().anerf_kp_loss(ops._p(values), int(bool(rot6d)), ops._p(anchors), ops._p(weights), u, float(tol), float(coef),
-                                             ops._p(loss), ops._p(g), ops._stream()), "anerf_kp_loss")
-        ctx.g = g
-        return loss[0]
+        ctx.g, ctx.with_base = g, base is not None
+        ctx.set_materialize_grads(False)
+        if base is None:
+            _lib.check(_lib.load().anerf_kp_loss(ops._p(values), int(bool(rot6d)), ops._p(anchors), ops._p(weights), u, float(tol), float(coef),
+                                                 ops._p(out), ops._p(g), ops._stream()), "anerf_kp_loss")
+            return out[0]
+        if base.numel() != 1 or base.dtype != torch.float32 or base.device != values.device:
+            raise ValueError("kp_loss(add_to=...): a float32 scalar on the values' device")
+        _lib.check(_lib.load().anerf_kp_loss_add(ops._p(values), int(bool(rot6d)), ops._p(anchors), ops._p(weights), u, float(tol), float(coef),
+                                                 C.c_void_p(base.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(out.data_ptr() + 4),
+                                                 ops._p(g), ops._stream()), "anerf_kp_loss_add")
+        return out[0], out[1]
 
     @staticmethod
-    def backward(ctx, go):
-        if ctx.g is None:
-            return None, None, None, None, None, None
+    def backward(ctx, g_kp, g_total=None):
         from .optim import is_unit_seed
-        return (ctx.g if is_unit_seed(go) else ctx.g * go), None, None, None, None, None
+        # upstream of `values`: through kp_loss itself and / or through the total; the unit seed of optim.backward() passes unscaled
+        ups = [u for u in (g_kp, g_total) if u is not None]
+        gv = None
+        if ctx.g is not None and ups:
+            up = ups[0] if len(ups) == 1 else ups[0] + ups[1]
+            gv = ctx.g if is_unit_seed(up) else ctx.g * up
+        return gv, None, None, None, None, None, (g_total if ctx.with_base else None)
 
 
-def kp_loss(values, anchors, pose_weights, rot6d, tol, coef):
+def kp_loss(values, anchors, pose_weights, rot6d, tol, coef, add_to=None):
     """Trainer._compute_kp_loss (core/trainer.py:382-403) over the U distinct poses of a batch in one launch each way.
     values: rots [U,24,3,3] (rot6d = True; the reference compares rots[..., :3, :2]) or axis-angle bones [U,24,3];
-    anchors [U,24,6] / [U,24,3] (popt_anchors of those poses); pose_weights [U] = rays of pose u / N."""
+    anchors [U,24,6] / [U,24,3] (popt_anchors of those poses); pose_weights [U] = rays of pose u / N.
+    add_to: a scalar loss tensor (the trainer's total so far) -> returns (kp_loss, add_to + kp_loss), the sum formed by the same
+    launch (no separate add kernel); differentiable w.r.t. both."""
     want = (24, 3, 3) if rot6d else (24, 3)
     if tuple(values.shape[1:]) != want or tuple(anchors.shape[1:]) != ((24, 6) if rot6d else (24, 3)) or anchors.shape[0] != values.shape[0]:
         raise ValueError(f"kp_loss: values {tuple(values.shape)} / anchors {tuple(anchors.shape)} do not match rot6d={rot6d}")
-    return _KpLossFn.apply(values, anchors, pose_weights, rot6d, tol, coef)
+    return _KpLossFn.apply(values, anchors, pose_weights, rot6d, tol, coef, add_to)
 
 
 def calculate_kinematic(bones, pelvis, rest_pose):

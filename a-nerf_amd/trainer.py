@@ -187,14 +187,15 @@ class Trainer:
                 comp = preds["rgb0"] + ((1. - preds["acc0"])[..., None] * bgs if args.use_background else 0.)
                 stats["psnr0"] = mse2psnr(img2mse(comp, batch["target_s"]))
         if not popt_detach:
-            kp_l, kp_stats = self._compute_kp_loss(batch, kp_opts)
+            # (on the device the regulariser's launch also forms `total + kp_loss`: no separate add kernel)
+            kp_l, kp_stats = self._compute_kp_loss(batch, kp_opts, add_to=total if total.is_cuda else None)
+            total = kp_l.pop("_total", None) if "_total" in kp_l else total + kp_l["kp_loss"]
             loss_dict.update(kp_l)
             stats.update(kp_stats)
-            total = total + kp_l["kp_loss"]
         loss_dict["total_loss"] = total
         return loss_dict, stats
 
-    def _compute_kp_loss(self, batch, kp_opts):
+    def _compute_kp_loss(self, batch, kp_opts, add_to=None):
         """trainer.py:382-403 over the batch's DISTINCT poses (pose_opt.kp_loss: one launch each way); equals the reference's
         mean over the per-ray replicated batch.  `use_temp_loss` is used by no shipped config."""
         args = self.args
@@ -212,11 +213,11 @@ class Trainer:
                 full = self._anchors_dev = ((id(anchors), str(dev), bool(args.opt_rot6d)), a.contiguous(), anchors["kps"].to(dev).contiguous())
             anc, w, anc_kps = full[1].index_select(0, lu["idx_dev"]), lu["w_dev"], full[2].index_select(0, lu["idx_dev"])
             values = lu["rots"] if args.opt_rot6d else lu["bones"]
-            loss = pose_opt.kp_loss(values, anc, w, bool(args.opt_rot6d), args.opt_pose_tol, args.opt_pose_coef)
+            loss = pose_opt.kp_loss(values, anc, w, bool(args.opt_rot6d), args.opt_pose_tol, args.opt_pose_coef, add_to=add_to)
             with torch.no_grad():
                 pj = (anc_kps - lu["kp"].detach()).pow(2.).sum(-1).pow(0.5)
                 mpjpc = (pj.mean(-1) * w).sum() / args.ext_scale
-            return {"kp_loss": loss}, {"MPJPC": mpjpc}
+            return ({"kp_loss": loss} if add_to is None else {"kp_loss": loss[0], "_total": loss[1]}), {"MPJPC": mpjpc}
         key = (lu["idxs"].tobytes(), lu["counts"].tobytes(), bool(args.opt_rot6d))
         hit = self._anchor_cache.get(key)
         if hit is None:
@@ -231,11 +232,11 @@ class Trainer:
             hit = self._anchor_cache[key] = (anc, w, anchors["kps"].to(dev)[sel].contiguous())
         anc, w, anc_kps = hit
         values = lu["rots"] if args.opt_rot6d else lu["bones"]
-        loss = pose_opt.kp_loss(values, anc, w, bool(args.opt_rot6d), args.opt_pose_tol, args.opt_pose_coef)
+        loss = pose_opt.kp_loss(values, anc, w, bool(args.opt_rot6d), args.opt_pose_tol, args.opt_pose_coef, add_to=add_to)
         with torch.no_grad():            # mean per-joint position change, in mm (trainer.py:400-401)
             pj = (anc_kps - lu["kp"].detach()).pow(2.).sum(-1).pow(0.5)
             mpjpc = (pj.mean(-1) * w).sum() / args.ext_scale
-        return {"kp_loss": loss}, {"MPJPC": mpjpc}
+        return ({"kp_loss": loss} if add_to is None else {"kp_loss": loss[0], "_total": loss[1]}), {"MPJPC": mpjpc}
 
     # ---- step 3b: backward + optimiser steps (trainer.py:441-483) ------------------------------------------------------
     def optimize(self, loss, i, popt_detach=False):

@@ -1176,7 +1176,8 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False, per_kernel
         loss, _ = (optim.fused_nerf_loss if fused else render_mod.nerf_loss)(out, target, bgs=1.0,
                                                                               loss_fn="L1" if mixamo else "MSE")
         if mixamo:   # _compute_kp_loss (trainer.py:382-403; opt_pose_tol 0.01, opt_pose_coef 2.0, mixamo.txt:45,54), one launch
-            loss = loss + pose_opt.kp_loss(popt.last_unique["rots"], anchor_u, w_u, True, 0.01, 2.0)
+            loss = pose_opt.kp_loss(popt.last_unique["rots"], anchor_u, w_u, True, 0.01, 2.0, add_to=loss)[1] if fused else \
+                loss + pose_opt.kp_loss(popt.last_unique["rots"], anchor_u, w_u, True, 0.01, 2.0)
         (optim.backward if fused else torch.autograd.backward)(loss)      # fused tail: cached unit seed, no `grad * 1` launches
         if mark:
             mark("bwd_done")

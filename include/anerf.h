@@ -491,6 +491,12 @@ int64_t anerf_pose_batch_scratch_size(int32_t n_unique, int32_t n_rays);
 int anerf_kp_loss(const float* values, int32_t rot6d, const float* anchors, const float* pose_weights, int32_t n_poses, float tol,
                   float coef, float* loss, float* g_values, void* stream);
 
+/* ABI revision 7: the same launch also forms the trainer's sum `total_loss = rgb losses + kp_loss` (core/trainer.py:236-246):
+ * total [1] = base [1] + loss (one fp32 add -- what the separate torch add kernel computed; that kernel was one of the launch-floor
+ * dispatches of the 384-ray step).  base: DEVICE scalar (e.g. out4[0] of anerf_loss); base, loss, total must not be NULL. */
+int anerf_kp_loss_add(const float* values, int32_t rot6d, const float* anchors, const float* pose_weights, int32_t n_poses, float tol,
+                      float coef, const float* base, float* loss, float* total, float* g_values, void* stream);
+
 /* ---- ABI revision 3: per-step host glue as single launches (the 384-rays-per-rank step) --------
  * Everything a training iteration does around the caster call used to be a string of small torch launches (4 weight-image
  * gathers, 2 x torch.rand + 2 x torch.randn + scaling, ones_like / norm / div / cat for the ray batch): ~0.3 ms of a

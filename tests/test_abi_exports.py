@@ -18,7 +18,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in anerf.h but not exported"
     assert declared == set(lib_mod.SIGNATURES), (declared ^ set(lib_mod.SIGNATURES))
-    assert lib.anerf_version() == lib_mod.ABI_VERSION == 6
+    assert lib.anerf_version() == lib_mod.ABI_VERSION == 7
 
 
 def test_step_block_structs_match_the_compiled_header(tmp_path):

@@ -321,6 +321,19 @@ def test_fused_kp_loss_equals_the_reference_expression(rot6d):
     np.testing.assert_allclose(layer.bones.grad.cpu().numpy(), 3.0 * g_ref.cpu().numpy(), rtol=2e-5,
                                atol=2e-6 * float(g_ref.abs().max()) * 3.0)
     assert float(layer.bones.grad[1].abs().max()) == 0.0          # pose 1 is not in the batch
+    # ABI revision 7: `add_to` -- the same launch forms the trainer's `total + kp_loss`: the SAME bits as torch's add, the same
+    # gradients into the pose parameters and an untouched unit gradient into the base loss
+    base = torch.rand((), device="cuda").requires_grad_(True)
+    layer.zero_grad()
+    layer(kp_idx)
+    lu = layer.last_unique
+    vals = lu["rots"] if rot6d else lu["bones"]
+    kp2, total = po.kp_loss(vals, anchors_u, w, rot6d, tol, coef, add_to=base * 1.0)
+    assert torch.equal(kp2, got) and torch.equal(total, base.detach() + got.detach())
+    (3.0 * total).backward()
+    np.testing.assert_allclose(layer.bones.grad.cpu().numpy(), 3.0 * g_ref.cpu().numpy(), rtol=2e-5,
+                               atol=2e-6 * float(g_ref.abs().max()) * 3.0)
+    assert float(base.grad) == 3.0
 
 
 def _pose_layer(n_poses, rot6d, seed=5):

@@ -197,9 +197,11 @@ def test_one_launch_bounds_and_depths_equal_the_staged_pair(oracle, miss, lindis
         staged = pipeline.render_rays_forward(cfg, net, None, rb, skt, cyl, S, 0, t_rand=t_rand, lindisp=lindisp, extras=True)
         fused = ops.forward(cfg, net, None, rb, skt, cyl, S, 0, t_rand=t_rand, lindisp=lindisp)
         shared = ops.forward(cfg, net, None, rb, skt, cyl[:1], S, 0, t_rand=t_rand, lindisp=lindisp)
-        for k in fused:
-            assert torch.equal(fused[k], staged[k]) and torch.equal(shared[k], staged[k]), (k, miss, t_rand is not None)
-        assert torch.isfinite(fused["rgb_map"]).all()
+        bits = lambda x: x.contiguous().view(torch.int32)        # (lindisp with the placeholder near = 0 divides by zero, in the
+        for k in fused:                                          # reference too: NaN depths must be the SAME NaNs)
+            assert torch.equal(bits(fused[k]), bits(staged[k])) and torch.equal(bits(shared[k]), bits(staged[k])), (k, miss, t_rand is not None)
+        if not lindisp:
+            assert torch.isfinite(fused["rgb_map"]).all()
 
 
 def test_small_batch_loss_is_one_launch_with_the_same_bits():

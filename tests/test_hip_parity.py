@@ -72,7 +72,7 @@ def close(a, b, atol, rtol=0.0, msg=""):
 
 def test_library_loads_on_gpu():
     lib = importlib.import_module("a-nerf_amd._lib").load()
-    assert lib.anerf_version() == importlib.import_module("a-nerf_amd._lib").ABI_VERSION == 6
+    assert lib.anerf_version() == importlib.import_module("a-nerf_amd._lib").ABI_VERSION == 7
     assert torch.cuda.is_available()
 
 

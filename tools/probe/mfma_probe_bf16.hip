@@ -283,26 +283,89 @@ __global__ __launch_bounds__(256) void k_probe(const char* __restrict__ wstream0
                    "global_load_lds_dwordx4 %1, %2 offset:1024"
                    :: "s"(lds0 + 4 * FRAG), "v"(lane16), "s"(g + 4 * FRAG) : "memory", "m0");
     };
-    auto direct = [&](long long go) __attribute__((always_inline)) {
+    f32x4 stg2[8];                                         // DMA == 10: the second staging set
+    auto direct_to = [&](f32x4 (&d)[8], long long go) __attribute__((always_inline)) {
       const char* g = wstream + go + 24 * FRAG;           // the same 8 KiB for all four waves (they hit in L1 / L2)
       asm volatile("global_load_dwordx4 %0, %4, %5\n\t"
                    "global_load_dwordx4 %1, %4, %5 offset:1024\n\t"
                    "global_load_dwordx4 %2, %4, %5 offset:2048\n\t"
                    "global_load_dwordx4 %3, %4, %5 offset:3072"
-                   : "=v"(stg[0]), "=v"(stg[1]), "=v"(stg[2]), "=v"(stg[3]) : "v"(lane16), "s"(g) : "memory");
+                   : "=v"(d[0]), "=v"(d[1]), "=v"(d[2]), "=v"(d[3]) : "v"(lane16), "s"(g) : "memory");
       asm volatile("global_load_dwordx4 %0, %4, %5\n\t"
                    "global_load_dwordx4 %1, %4, %5 offset:1024\n\t"
                    "global_load_dwordx4 %2, %4, %5 offset:2048\n\t"
                    "global_load_dwordx4 %3, %4, %5 offset:3072"
-                   : "=v"(stg[4]), "=v"(stg[5]), "=v"(stg[6]), "=v"(stg[7]) : "v"(lane16), "s"(g + 4 * FRAG) : "memory");
+                   : "=v"(d[4]), "=v"(d[5]), "=v"(d[6]), "=v"(d[7]) : "v"(lane16), "s"(g + 4 * FRAG) : "memory");
     };
-    auto mms = [&](int j, int b) __attribute__((always_inline)) {
-      const bf16x8 ah = __builtin_bit_cast(bf16x8, stg[2 * j]), al = __builtin_bit_cast(bf16x8, stg[2 * j + 1]);
+    auto direct = [&](long long go) __attribute__((always_inline)) { direct_to(stg, go); };
+    auto mms_of = [&](const f32x4 (&d)[8], int j, int b) __attribute__((always_inline)) {
+      if (NOMM) { acc[b][0] += d[2 * j][0]; acc[b][1] += d[2 * j + 1][0]; return; }
+      const bf16x8 ah = __builtin_bit_cast(bf16x8, d[2 * j]), al = __builtin_bit_cast(bf16x8, d[2 * j + 1]);
       acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[b], 0, 0, 0);
       acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[b], 0, 0, 0);
       acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[b], 0, 0, 0);
     };
+    auto mms = [&](int j, int b) __attribute__((always_inline)) { mms_of(stg, j, b); };
     const long long wrap = stream_bytes - STAGE_BYTES;
+    if (DMA == 10) {
+      // one WHOLE stage of lead for the direct loads: two staging sets alternate (64 VGPRs -- 9 more than k_mlp_fwd_b3 has free);
+      // the set a stage's last group consumes was requested at the top of the PREVIOUS stage and is complete at that stage's
+      // closing vmcnt(0): no counted wait in front of the group at all
+      issue6(0, 0); issue6(STAGE_BYTES, 1);
+      direct_to(stg, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      direct_to(stg2, STAGE_BYTES);
+      issue6(2LL * STAGE_BYTES, 2);
+      long long go = 3LL * STAGE_BYTES, dgo = 2LL * STAGE_BYTES;
+      int sl = 0;
+      rd(fa, smem + lane16, 0, 0, 4);
+      auto body = [&](f32x4 (&use)[8]) __attribute__((always_inline)) {
+        const char* cur = smem + sl * STAGE_BYTES + lane16;
+        const int nsl = sl == SLOTS - 1 ? 0 : sl + 1;
+        const char* nxt = smem + nsl * STAGE_BYTES + lane16;
+        mm(fa, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(fa, cur, 0, 4, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(fa, 1); mm(fa, 2); mm(fa, 3);
+        mm(fa, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(fb, cur, 1, 0, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(fa, 5); mm(fa, 6); mm(fa, 7);
+        mm(fb, 0); mm(fb, 1); mm(fb, 2); mm(fb, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" : "+v"(use[0]), "+v"(use[1]), "+v"(use[2]), "+v"(use[3]), "+v"(use[4]), "+v"(use[5]), "+v"(use[6]), "+v"(use[7]));
+        mms_of(use, 0, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(fa, nxt, 0, 0, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        mms_of(use, 1, 5); mms_of(use, 2, 6); mms_of(use, 3, 7);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        direct_to(use, dgo);                       // this set again in two stages
+        issue6(go, sl);
+        go += STAGE_BYTES;
+        if (go > wrap) go = 0;
+        dgo += STAGE_BYTES;
+        if (dgo > wrap) dgo = 0;
+        sl = nsl;
+      };
+      for (int st = 0; st < stages; st += 2) {
+        body(stg);
+        body(stg2);
+      }
+      const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+      float s = 0.f;
+#pragma unroll
+      for (int b = 0; b < 8; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[b][r];
+      out[blockIdx.x * 256 + threadIdx.x] = s;
+      if (threadIdx.x == 0) { clocks[2 * blockIdx.x] = t1 - t0; clocks[2 * blockIdx.x + 1] = r1 - r0; }
+      return;
+    }
     issue6(0, 0); issue6(STAGE_BYTES, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -495,5 +558,7 @@ int main() {
   run<2, 3>("[r6] today's structure again: hidden DMA + raw barrier, reads one group ahead", w, stream_bytes, out, clocks, blocks, stages);
   run<9, 3>("[r6] PARTIAL BYPASS: 24 fragments via LDS-DMA ring + 8 via global_load_dwordx4 per wave", w, stream_bytes, out, clocks, blocks, stages);
   run<9, 3, 1>("[r6] NO MFMA: partial bypass memory work only (24 reads x 4 waves + 24 KiB DMA + 4 x 8 KiB direct)", w, stream_bytes, out, clocks, blocks, stages);
+  run<10, 3>("[r6] PARTIAL BYPASS, direct loads a WHOLE stage ahead (two staging sets, 64 VGPRs)", w, stream_bytes, out, clocks, blocks, stages);
+  run<10, 3, 1>("[r6] NO MFMA: the same memory work, direct loads a whole stage ahead", w, stream_bytes, out, clocks, blocks, stages);
   return 0;
 }
