@@ -1,6 +1,7 @@
 // anerf_capi.hip -- the extern "C" boundary of libanerf_hip.so (declared in include/anerf.h).
 // Host-side only: argument checking, weight-image layout / pack tables, kernel dispatch.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 #include <vector>
@@ -66,6 +67,12 @@ int launch_encode_bwd(int ld, const float* dx, const float* du, int uw, const fl
                       const float* skts, long long skt_stride, float tau_v, float tau_d, const float* cut_v,
                       const float* cut_d, int n, int S, float* dY, float* dQ, float* dskts, bool accumulate, hipStream_t st,
                       const float* pnoise = nullptr, int gate_bones = 0, const float* tau_dev = nullptr);
+int launch_pose_reduce(const float* dY, const float* dQ, const float* rays, int ray_stride, const float* z, int n, int S, float* dskts,
+                       bool accumulate, hipStream_t st, const float* pnoise);
+int mlp_bwd_in_enc_entry(int ld, int code, const float* packed_i, const float* dz, const float* dzv, float* du, long long P, long long Ppad,
+                         int nstages, const float* rays, int ray_stride, const float* z, const float* skts, long long skt_stride,
+                         float tau_v, float tau_d, const float* cut_v, const float* cut_d, int S, float* dY, float* dQ, const float* pnoise,
+                         int gate_bones, const float* tau_dev, hipStream_t st);
 int launch_gather_rows3(const float* a, const float* b, const long long* idx, int n, int S, int Ni, float* out, hipStream_t st);
 int launch_code_reduce(const float* du, int uw, const float* cam, int n, int S, int n_codes, float* rowsum, float* dcodes,
                        hipStream_t st);
@@ -1154,7 +1161,19 @@ int anerf_backward(const AnerfConfig* cfg, const AnerfForwardIO* io, const Anerf
     const BwdWs w = bwd_ws(cfg, P, want_in);
     auto B = [&](int64_t off) { return reinterpret_cast<float*>(sb + off); };
     const int64_t pp = sv.p_pad;
+    // round 6: the fp32 one-call backward applies the encoding's backward INSIDE k_mlp_bwd_in (k_mlp_bwd_in_enc: dX' / dU' never
+    // stored, dY / dQ written by the tile kernel); the pose tail is then k_pose_reduce alone.  ANERF_NO_FUSED_ENCODE_BWD=1 keeps the
+    // separate k_mlp_bwd_in -> k_encode_bwd pair (A/B measurements; the split-bf16 path and the staged entry points always use it)
+    static const bool no_fuse = getenv("ANERF_NO_FUSED_ENCODE_BWD") != nullptr && getenv("ANERF_NO_FUSED_ENCODE_BWD")[0] == '1';
+    const bool fuse_enc = b->g_skts && !b3 && !no_fuse &&
+                          (cfg->multires_views == 4 || (cfg->multires_views == 0 && cfg->framecode_ch == 0)) &&
+                          (cfg->framecode_ch == 0 || cfg->framecode_ch == 16) && cfg->multires == 7;
     auto pose_tail = [&]() {
+      if (fuse_enc) {
+        int r3 = launch_pose_reduce(B(w.dy), B(w.dq), io->rays, io->ray_stride, zz, (int)n, ns, b->g_skts, skts_written, st, pn);
+        if (!r3) skts_written = true;
+        return r3;
+      }
       int r2 = launch_encode_bwd(cfg->multires_views, B(w.dx), B(w.du), uw, io->rays, io->ray_stride, zz, io->skts, io->skt_ray_stride,
                                  io->tau_v, io->tau_d, io->cutoff_v, io->cutoff_d, (int)n, ns, B(w.dy), B(w.dq), b->g_skts, skts_written, st, pn,
                                  cfg->cutoff_bones, io->step ? &io->step->tau_v : nullptr);
@@ -1192,7 +1211,17 @@ int anerf_backward(const AnerfConfig* cfg, const AnerfForwardIO* io, const Anerf
     prof_rec(b->profile, ANERF_PROF_GEMM(which_pass) + 1, stream);
     if (r || !want_in) return r;
     prof_rec(b->profile, ANERF_PROF_BWD_IN(which_pass), stream);
-    r = (b3 ? anerf_input_grads_b3 : anerf_input_grads)(cfg, packed_i, B(w.dz), B(w.dzv), pp, P, B(w.dx), B(w.du), stream);
+    if (fuse_enc) {
+      AnerfLayout Li;
+      r = anerf_layout(cfg, 2, &Li);
+      if (r) return r;
+      if (!packed_i) return set_error(ANERF_E_NULL, "backward: input-gradient weight image");
+      r = mlp_bwd_in_enc_entry(cfg->multires_views, cfg->framecode_ch, packed_i, B(w.dz), B(w.dzv), B(w.du), P, pp, Li.n_stages, io->rays,
+                               io->ray_stride, zz, io->skts, io->skt_ray_stride, io->tau_v, io->tau_d, io->cutoff_v, io->cutoff_d, ns,
+                               B(w.dy), B(w.dq), pn, cfg->cutoff_bones, io->step ? &io->step->tau_v : nullptr, st);
+    } else {
+      r = (b3 ? anerf_input_grads_b3 : anerf_input_grads)(cfg, packed_i, B(w.dz), B(w.dzv), pp, P, B(w.dx), B(w.du), stream);
+    }
     if (r) return r;
     prof_rec(b->profile, ANERF_PROF_BWD_IN(which_pass) + 1, stream);
     // frame-code gradients first: they are PARAMETER gradients (all-reduced), the pose gradients behind them are not

@@ -412,6 +412,378 @@ int mlp_bwd_in_entry(const float* packed_i, const float* dz, const float* dzv, f
   return check_launch("k_mlp_bwd_in");
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 6: k_mlp_bwd_in with the backward of the fused ENCODING as its column-group epilogue.
+// The lane (sample m, half h) that receives a 256-column group of dX' / dU' is the lane whose forward twin generated those
+// columns -- it owns joints j = 8 G + 4 h + t -- so it can apply the hand-derived backward of transform / norms / gates /
+// sin-cos (k_encode_bwd's arithmetic) to the group while the values are still in registers, and keep only
+//     dv[12] (distance) + dr[36] (unit bone direction) + de[36] (unit ray direction in bone space)      = 84 partial sums
+// per lane across the five groups.  dX' / dU' (4.4 KB per sample written by this kernel and read again by k_encode_bwd: 1.2 GB
+// per launch at 3072 rays) are never stored; what leaves the kernel is dY / dQ [P][72] (576 B per sample) for k_pose_reduce and
+// the two quads of frame-code columns of dU' that k_code_rowsum reads.
+// Register budget (k_mlp_bwd_in compiles to 228 VGPR + 128 AGPR, 0 scratch): the 84 sums live across the MFMA segments, where the
+// allocator parks them in the 128 unused AGPRs (v_accvgpr_write / _read at the epilogue boundaries); an epilogue itself runs
+// with the accumulators dead and needs, per joint quad G, ~50 transient registers (4 joints' bone-space state + the sin/cos
+// chain) next to the 128 values of the group.  sin/cos: one exact evaluation per chain anchor (distance: bands 0 and 4, as the
+// forward kernel; unit-vector components: band 0 without range reduction) and double-angle steps in between.
+struct EncArgs {
+  const float* rays; const float* z; const float* skts; const float* cut_v; const float* cut_d; const float* pnoise; const float* tau_dev;
+  float* dY; float* dQ;
+  long long skt_stride;
+  int ray_stride, S, gate_bones;
+  float tau_v, tau_d;
+};
+
+// (no __restrict__ on the pointers of the epilogue functions: for a noalias read-only pointer the compiler may -- and did -- hoist all
+// 36 bone-matrix loads of all five epilogues over the `asm volatile("" ::: "memory")` fences to the top of the kernel and spill them)
+struct JointQuad { float v[4], rh[12], e[12], qn[4]; };
+__device__ __forceinline__ void joint_quad(const float* sk, int G, int h, float x0, float x1, float x2, float d0, float d1,
+                                           float d2, JointQuad& q) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int j = 8 * G + 4 * h + t;
+    const f32x4 r0 = *reinterpret_cast<const f32x4*>(sk + j * 16), r1 = *reinterpret_cast<const f32x4*>(sk + j * 16 + 4),
+                r2 = *reinterpret_cast<const f32x4*>(sk + j * 16 + 8);
+    const float y0 = r0.x * x0 + r0.y * x1 + r0.z * x2 + r0.w;
+    const float y1 = r1.x * x0 + r1.y * x1 + r1.z * x2 + r1.w;
+    const float y2 = r2.x * x0 + r2.y * x1 + r2.z * x2 + r2.w;
+    const float n = sqrtf(y0 * y0 + y1 * y1 + y2 * y2);
+    const float inv = 1.f / fmaxf(n, 1e-12f);
+    q.v[t] = n;
+    q.rh[3 * t] = y0 * inv; q.rh[3 * t + 1] = y1 * inv; q.rh[3 * t + 2] = y2 * inv;
+    const float q0 = r0.x * d0 + r0.y * d1 + r0.z * d2, q1 = r1.x * d0 + r1.y * d1 + r1.z * d2,
+                q2 = r2.x * d0 + r2.y * d1 + r2.z * d2;
+    const float qq = sqrtf(q0 * q0 + q1 * q1 + q2 * q2);
+    const float qi = 1.f / fmaxf(qq, 1e-12f);
+    q.qn[t] = qq;
+    q.e[3 * t] = q0 * qi; q.e[3 * t + 1] = q1 * qi; q.e[3 * t + 2] = q2 * qi;
+  }
+}
+
+// dX' k-groups KG0 .. KG0 + NK - 1 (stream order: k-group kg = 3 band + G for the 15 distance bands [raw, sin f, cos f: f = 0..6],
+// 45 + 3 G + g for the bone directions); outv[4 (kg - KG0) + t] = the lane's value for joint (G, t).
+// A group that holds the bone-direction k-groups turns them into their share of dY at once -- (dr - (dr . r) r) / v, with the
+// cutoff_bones gate's terms -- and parks it in the sample's dY row (the closing group adds dv r to it): 36 fewer live registers.
+// value of local k-group X (0..31), slot T of the finished group: accumulator block X >> 2, register 4 (X & 3) + T (take<>'s order)
+#define OV(X, T) acc[(X) >> 2][4 * ((X) & 3) + (T)]
+template <int KG0, int NK>
+__device__ __forceinline__ void enc_x_group(const f32x16 (&acc)[8], float (&dv)[12], const float* sk, int h, float x0,
+                                            float x1, float x2, float tau_v, const float* cut_v, int gate_bones,
+                                            float* dY_row, int& anchor) {
+  auto has = [](int kg) { return kg >= KG0 && kg < KG0 + NK; };
+#pragma unroll
+  for (int G = 0; G < 3; ++G) {
+    // one joint quad at a time: without the fences the scheduler hoists all 36 bone-matrix loads and the three quads' transcendental
+    // chains to the top of the epilogue (latency hiding it does not need here) and the kernel spills
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    // `anchor` is an opaque zero that every region's loads are addressed through and that the previous region's results are tied
+    // to (asm below): fences alone order memory operations only -- the optimiser had gathered all three regions' loads in front of
+    // all three regions' arithmetic (and the scheduler then moved them up into the MFMA segment, where they spilled)
+    asm volatile("" : "+v"(anchor) : "v"(OV(G < NK ? G : 0, 0)));
+    JointQuad q;
+    joint_quad(sk + anchor, G, h, x0, x1, x2, 0.f, 0.f, 0.f, q);
+    float wv[4], wvp[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      wv[t] = cutoff_gate(tau_v, q.v[t], (cut_v + anchor)[8 * G + 4 * h + t]);
+      wvp[t] = -tau_v * wv[t] * (1.f - wv[t]);
+    }
+    if (has(G)) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) dv[4 * G + t] += OV(G - KG0, t) * (wv[t] + q.v[t] * wvp[t]);
+    }
+    // which bands of this joint quad lie in the group: chain anchors at f = 0 and f = 4
+    int fmin = 99, fmax = -1;
+#pragma unroll
+    for (int f = 0; f < 7; ++f)
+      if (has(3 + 6 * f + G) || has(6 + 6 * f + G)) { fmin = f < fmin ? f : fmin; fmax = f; }
+    float s[4], c[4];
+#pragma unroll
+    for (int f = 0; f < 7; ++f) {
+      if (f > fmax || fmax < 0) continue;
+      const int anchor = fmin >= 4 ? 4 : 0;
+      if (f < anchor) continue;
+      const float F = (float)(1 << f);
+      if (f == 0 || f == 4) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) sincos_f32(q.v[t] * F, s[t], c[t]);
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float s2 = 2.f * s[t] * c[t], c2 = fmaf(-2.f * s[t], s[t], 1.f);
+          s[t] = s2; c[t] = c2;
+        }
+      }
+      const int ks = 3 + 6 * f + G, kc = 6 + 6 * f + G;
+      if (has(ks)) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dv[4 * G + t] += OV(ks - KG0, t) * (F * c[t] * wv[t] + s[t] * wvp[t]);
+      }
+      if (has(kc)) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) dv[4 * G + t] += OV(kc - KG0, t) * (-F * s[t] * wv[t] + c[t] * wvp[t]);
+      }
+    }
+    if (has(45 + 3 * G)) {      // (the three bone-direction k-groups of a joint quad lie in the same group)
+      float oy[12];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        // flat index 4 g + t' of the quad's 12 direction values = 3 (joint in quad) + component
+        float d_r[3];
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+          const int i = 3 * t + cc;
+          d_r[cc] = OV(45 + 3 * G + i / 4 - KG0, (i & 3));
+        }
+        float dot = d_r[0] * q.rh[3 * t] + d_r[1] * q.rh[3 * t + 1] + d_r[2] * q.rh[3 * t + 2];
+        if (gate_bones) {   // cutoff_bones: the network saw r * w(v) -- d r = w * d(r w); the gate's slope adds (d(r w) . r) w' to d v
+          dv[4 * G + t] += dot * wvp[t];
+          dot *= wv[t];
+          d_r[0] *= wv[t]; d_r[1] *= wv[t]; d_r[2] *= wv[t];
+        }
+        const float iv = 1.f / fmaxf(q.v[t], 1e-12f);
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) oy[3 * t + cc] = (d_r[cc] - dot * q.rh[3 * t + cc]) * iv;
+      }
+#pragma unroll
+      for (int w4 = 0; w4 < 3; ++w4)
+        *reinterpret_cast<f32x4*>(dY_row + 3 * (8 * G + 4 * h) + 4 * w4) = f32x4{oy[4 * w4], oy[4 * w4 + 1], oy[4 * w4 + 2], oy[4 * w4 + 3]};
+    }
+    asm volatile("" : "+v"(anchor) : "v"(dv[4 * G]), "v"(dv[4 * G + 1]), "v"(dv[4 * G + 2]), "v"(dv[4 * G + 3]));
+  }
+}
+
+// dU' k-groups KU0 .. KU0 + NK - 1 (stream order: 9 band + 3 G + g for the 1 + 2 LD direction bands, then CODE / 8 frame-code k-groups).
+// The raw sums d e of a joint quad travel between the groups in the sample's dQ row (FIRST writes, the others add); LAST finishes
+// the quad: dQ = (de - (de . e) e) / |q|, dY = its parked direction share + dv r.
+template <int KU0, int NK, int LD, int CODE, bool FIRST, bool LAST>
+__device__ __forceinline__ void enc_u_group(const f32x16 (&acc)[8], float (&dv)[12], const float* sk, int h, float x0,
+                                            float x1, float x2, float d0, float d1, float d2, float tau_d,
+                                            const float* cut_d, float* du_row_h, float* dY_row,
+                                            float* dQ_row, int& anchor) {
+  auto has = [](int ku) { return ku >= KU0 && ku < KU0 + NK; };
+#pragma unroll
+  for (int G = 0; G < 3; ++G) {
+    __builtin_amdgcn_sched_barrier(0);     // (one joint quad at a time, see enc_x_group)
+    asm volatile("" ::: "memory");
+    asm volatile("" : "+v"(anchor) : "v"(OV(0, 0)));
+    float de[12];
+    if (FIRST) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) de[i] = 0.f;
+    } else {
+#pragma unroll
+      for (int w4 = 0; w4 < 3; ++w4) {
+        const f32x4 pv = *reinterpret_cast<const f32x4*>(dQ_row + anchor + 3 * (8 * G + 4 * h) + 4 * w4);
+        de[4 * w4] = pv.x; de[4 * w4 + 1] = pv.y; de[4 * w4 + 2] = pv.z; de[4 * w4 + 3] = pv.w;
+      }
+    }
+    f32x4 py[3];
+    if (LAST) {
+#pragma unroll
+      for (int w4 = 0; w4 < 3; ++w4) py[w4] = *reinterpret_cast<const f32x4*>(dY_row + anchor + 3 * (8 * G + 4 * h) + 4 * w4);
+    }
+    JointQuad q;
+    joint_quad(sk + anchor, G, h, x0, x1, x2, d0, d1, d2, q);
+    float wd[4], wdp[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      wd[t] = cutoff_gate(tau_d, q.v[t], (cut_d + anchor)[8 * G + 4 * h + t]);
+      wdp[t] = -tau_d * wd[t] * (1.f - wd[t]);
+    }
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      const int k0 = 3 * G + g;
+      if (has(k0)) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int i = 4 * g + t, a = i / 3;
+          const float gt = OV(k0 - KU0, t);
+          de[i] += gt * wd[a];
+          dv[4 * G + a] += gt * q.e[i] * wdp[a];
+        }
+      }
+      int fmax = -1;
+#pragma unroll
+      for (int f = 0; f < LD; ++f)
+        if (has(9 * (1 + 2 * f) + k0) || has(9 * (2 + 2 * f) + k0)) fmax = f;
+      float s[4], c[4];
+#pragma unroll
+      for (int f = 0; f < LD; ++f) {
+        if (f > fmax) continue;
+        const float F = (float)(1 << f);
+        if (f == 0) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) sincos_unit_f32(q.e[4 * g + t], s[t], c[t]);
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float s2 = 2.f * s[t] * c[t], c2 = fmaf(-2.f * s[t], s[t], 1.f);
+            s[t] = s2; c[t] = c2;
+          }
+        }
+        const int ks = 9 * (1 + 2 * f) + k0, kc = 9 * (2 + 2 * f) + k0;
+        if (has(ks)) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int i = 4 * g + t, a = i / 3;
+            const float gs = OV(ks - KU0, t);
+            de[i] += gs * c[t] * F * wd[a];
+            dv[4 * G + a] += gs * s[t] * wdp[a];
+          }
+        }
+        if (has(kc)) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int i = 4 * g + t, a = i / 3;
+            const float gc = OV(kc - KU0, t);
+            de[i] -= gc * s[t] * F * wd[a];
+            dv[4 * G + a] += gc * c[t] * wdp[a];
+          }
+        }
+      }
+    }
+    if (!LAST) {
+#pragma unroll
+      for (int w4 = 0; w4 < 3; ++w4)
+        *reinterpret_cast<f32x4*>(dQ_row + 3 * (8 * G + 4 * h) + 4 * w4) = f32x4{de[4 * w4], de[4 * w4 + 1], de[4 * w4 + 2], de[4 * w4 + 3]};
+    } else {   // through the norms: q -> e, and the distance part of y -> (v, r)   (k_encode_bwd's closing block)
+      float oy[12], oq[12];
+      const float pyf[12] = {py[0].x, py[0].y, py[0].z, py[0].w, py[1].x, py[1].y, py[1].z, py[1].w, py[2].x, py[2].y, py[2].z, py[2].w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float dote = de[3 * t] * q.e[3 * t] + de[3 * t + 1] * q.e[3 * t + 1] + de[3 * t + 2] * q.e[3 * t + 2];
+        const float iq = 1.f / fmaxf(q.qn[t], 1e-12f);
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+          oy[3 * t + cc] = fmaf(dv[4 * G + t], q.rh[3 * t + cc], pyf[3 * t + cc]);
+          oq[3 * t + cc] = (de[3 * t + cc] - dote * q.e[3 * t + cc]) * iq;
+        }
+      }
+#pragma unroll
+      for (int w4 = 0; w4 < 3; ++w4) {
+        *reinterpret_cast<f32x4*>(dY_row + 3 * (8 * G + 4 * h) + 4 * w4) = f32x4{oy[4 * w4], oy[4 * w4 + 1], oy[4 * w4 + 2], oy[4 * w4 + 3]};
+        *reinterpret_cast<f32x4*>(dQ_row + 3 * (8 * G + 4 * h) + 4 * w4) = f32x4{oq[4 * w4], oq[4 * w4 + 1], oq[4 * w4 + 2], oq[4 * w4 + 3]};
+      }
+    }
+    asm volatile("" : "+v"(anchor) : "v"(dv[4 * G]), "v"(dv[4 * G + 1]), "v"(dv[4 * G + 2]), "v"(dv[4 * G + 3]), "v"(de[0]), "v"(de[11]));
+  }
+  // frame-code columns (the last CODE / 8 k-groups of dU'): k_code_rowsum reads them from du
+#pragma unroll
+  for (int j = 0; j < CODE / 8; ++j) {
+    const int ku = 9 * (1 + 2 * LD) + j;
+    if (has(ku)) *reinterpret_cast<f32x4*>(du_row_h + 8 * ku) = f32x4{OV(ku - KU0, 0), OV(ku - KU0, 1), OV(ku - KU0, 2), OV(ku - KU0, 3)};
+  }
+}
+
+template <int LD, int CODE>
+__global__ __launch_bounds__(256) void k_mlp_bwd_in_enc(const BwdInArgs A, const EncArgs E) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 31, h = lane >> 5;
+  Pipe3B pipe;
+  pipe.init(A.packed_i, smem, wave, lane, A.nstages);
+  const long long p = (long long)blockIdx.x * TILE + wave * 32 + m;
+  const long long pc = p < A.P ? p : A.P - 1;      // tail lanes recompute the last valid row and rewrite it with identical values
+  const float* z0 = A.dz + pc * 256 + 4 * h;
+  const float* z5 = A.dz + (5 * A.Ppad + pc) * 256 + 4 * h;
+  const float* zv = A.dzv + pc * 128 + 4 * h;
+  constexpr int UW = 72 * (1 + 2 * LD) + CODE, NKU = UW / 8;
+  float* du = A.du + pc * UW + 4 * h;
+  // the sample's geometry (k_encode_bwd's prologue)
+  const long long ray = div_samples(pc, E.S);
+  const float* rp = E.rays + ray * E.ray_stride;
+  const float zz = E.z[pc];
+  const float d0 = rp[3], d1 = rp[4], d2 = rp[5];
+  float x0 = fmaf(d0, zz, rp[0]), x1 = fmaf(d1, zz, rp[1]), x2 = fmaf(d2, zz, rp[2]);
+  if (E.pnoise) {
+    x0 += E.pnoise[3 * pc]; x1 += E.pnoise[3 * pc + 1]; x2 += E.pnoise[3 * pc + 2];
+  }
+  const float* sk = E.skts + ray * E.skt_stride;
+  const float tau_v = E.tau_dev ? E.tau_dev[0] : E.tau_v, tau_d = E.tau_dev ? E.tau_dev[1] : E.tau_d;
+  int anchor = 0;    // see enc_x_group
+  float dv[12];      // the one set of partial sums that stays in registers; the direction sums travel in the dY / dQ rows
+#pragma unroll
+  for (int i = 0; i < 12; ++i) dv[i] = 0.f;
+  float* dYr = E.dY + pc * 72;
+  float* dQr = E.dQ + pc * 72;
+  f32x4 cur[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) cur[i] = *reinterpret_cast<const f32x4*>(z0 + 8 * i);
+  pipe.begin();
+  pipe.prime();
+  f32x16 acc[8];
+  const float outv[128] = {};     // (bwd_in_segment's store operand: unused with SPK = 0)
+  bool pending = false;
+  float* none = nullptr;
+  // ---- dX' columns 0..255 (k-groups 0..31)
+  zero_acc<8>(acc);
+  bwd_in_segment<32, 0>(pipe, acc, cur, z0, z5, outv, none, 0, 0, pending);
+  bwd_in_segment<32, 0>(pipe, acc, cur, z5, z0, outv, none, 0, 0, pending);
+  __builtin_amdgcn_sched_barrier(0);     // the epilogue reads the accumulators in place (a 128-register copy would spill)
+  enc_x_group<0, 32>(acc, dv, sk, h, x0, x1, x2, tau_v, E.cut_v, E.gate_bones, dYr, anchor);
+  // ---- dX' columns 256..431 (k-groups 32..53)
+  zero_acc<8>(acc);
+  bwd_in_segment<32, 0, 6>(pipe, acc, cur, z0, z5, outv, none, 0, 0, pending);
+  bwd_in_segment<32, 0, 6>(pipe, acc, cur, z5, zv, outv, none, 0, 0, pending);
+  __builtin_amdgcn_sched_barrier(0);     // the epilogue reads the accumulators in place (a 128-register copy would spill)
+  enc_x_group<32, 22>(acc, dv, sk, h, x0, x1, x2, tau_v, E.cut_v, E.gate_bones, dYr, anchor);
+  // ---- dU' = Wvu'^T dzv, 256 columns (32 k-groups) at a time
+  if constexpr (NKU <= 32) {          // multires_views = 0: one narrow group (72 columns: 3 blocks)
+    zero_acc<8>(acc);
+    bwd_in_segment<16, 0, 3>(pipe, acc, cur, zv, nullptr, outv, none, 0, 0, pending);
+    __builtin_amdgcn_sched_barrier(0);     // the epilogue reads the accumulators in place (a 128-register copy would spill)
+    enc_u_group<0, NKU, LD, CODE, true, true>(acc, dv, sk, h, x0, x1, x2, d0, d1, d2, tau_d, E.cut_d, du, dYr, dQr, anchor);
+  } else {
+    zero_acc<8>(acc);
+    bwd_in_segment<16, 0, 8>(pipe, acc, cur, zv, zv, outv, none, 0, 0, pending);
+    __builtin_amdgcn_sched_barrier(0);     // the epilogue reads the accumulators in place (a 128-register copy would spill)
+    enc_u_group<0, 32, LD, CODE, true, false>(acc, dv, sk, h, x0, x1, x2, d0, d1, d2, tau_d, E.cut_d, du, dYr, dQr, anchor);
+    zero_acc<8>(acc);
+    bwd_in_segment<16, 0, 8>(pipe, acc, cur, zv, zv, outv, none, 0, 0, pending);
+    __builtin_amdgcn_sched_barrier(0);     // the epilogue reads the accumulators in place (a 128-register copy would spill)
+    enc_u_group<32, 32, LD, CODE, false, false>(acc, dv, sk, h, x0, x1, x2, d0, d1, d2, tau_d, E.cut_d, du, dYr, dQr, anchor);
+    zero_acc<8>(acc);
+    bwd_in_segment<16, 0, 5>(pipe, acc, cur, zv, nullptr, outv, none, 0, 0, pending);     // 136 / 152 columns: 5 blocks
+    __builtin_amdgcn_sched_barrier(0);     // the epilogue reads the accumulators in place (a 128-register copy would spill)
+    enc_u_group<64, NKU - 64, LD, CODE, false, true>(acc, dv, sk, h, x0, x1, x2, d0, d1, d2, tau_d, E.cut_d, du, dYr, dQr, anchor);
+  }
+}
+
+#undef OV
+
+int mlp_bwd_in_enc_entry(int ld, int code, const float* packed_i, const float* dz, const float* dzv, float* du, long long P, long long Ppad,
+                         int nstages, const float* rays, int ray_stride, const float* z, const float* skts, long long skt_stride,
+                         float tau_v, float tau_d, const float* cut_v, const float* cut_d, int S, float* dY, float* dQ, const float* pnoise,
+                         int gate_bones, const float* tau_dev, hipStream_t st) {
+  BwdInArgs b;
+  b.packed_i = packed_i; b.dz = dz; b.dzv = dzv; b.dx = nullptr; b.du = du; b.P = P; b.Ppad = Ppad; b.nstages = nstages;
+  b.uw = 72 * (1 + 2 * ld) + code;
+  EncArgs e;
+  e.rays = rays; e.z = z; e.skts = skts; e.cut_v = cut_v; e.cut_d = cut_d; e.pnoise = pnoise; e.tau_dev = tau_dev; e.dY = dY; e.dQ = dQ;
+  e.skt_stride = skt_stride; e.ray_stride = ray_stride; e.S = S; e.gate_bones = gate_bones; e.tau_v = tau_v; e.tau_d = tau_d;
+  const long long nblk = (P + TILE - 1) / TILE;
+  if (nblk <= 0) return ANERF_OK;
+  const size_t lds = RING_SLOTS * STAGE_BYTES;
+  static unsigned long long lds_set[3] = {};   // per-device bits, see ensure_dynamic_lds
+  if (ld == 4 && code == 16) {
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_mlp_bwd_in_enc<4, 16>), (int)lds, &lds_set[0]);
+    hipLaunchKernelGGL((k_mlp_bwd_in_enc<4, 16>), dim3((unsigned)nblk), dim3(256), lds, st, b, e);
+  } else if (ld == 4 && code == 0) {
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_mlp_bwd_in_enc<4, 0>), (int)lds, &lds_set[1]);
+    hipLaunchKernelGGL((k_mlp_bwd_in_enc<4, 0>), dim3((unsigned)nblk), dim3(256), lds, st, b, e);
+  } else if (ld == 0 && code == 0) {
+    ensure_dynamic_lds(reinterpret_cast<const void*>(k_mlp_bwd_in_enc<0, 0>), (int)lds, &lds_set[2]);
+    hipLaunchKernelGGL((k_mlp_bwd_in_enc<0, 0>), dim3((unsigned)nblk), dim3(256), lds, st, b, e);
+  } else {
+    return set_error(ANERF_E_CONFIG, "mlp_bwd_in_enc: multires_views must be 0 or 4, framecode_ch 0 or 16");
+  }
+  return check_launch("k_mlp_bwd_in_enc");
+}
+
 int mlp_bwd_entry(const float* packed_t, const float* aux, const float* draw, const AnerfSaved* sv, float* dz, float* df,
                   float* dzv, long long P, int nstages, hipStream_t st) {
   BwdArgs b;

@@ -268,6 +268,12 @@ int launch_encode_bwd(int ld, const float* dx, const float* du, int uw, const fl
   return check_launch("k_pose_reduce");
 }
 
+int launch_pose_reduce(const float* dY, const float* dQ, const float* rays, int ray_stride, const float* z, int n, int S, float* dskts,
+                       bool accumulate, hipStream_t st, const float* pnoise) {
+  hipLaunchKernelGGL(k_pose_reduce, dim3(n), dim3(320), 0, st, dY, dQ, rays, ray_stride, z, n, S, accumulate ? 1 : 0, dskts, pnoise);
+  return check_launch("k_pose_reduce");
+}
+
 int launch_code_reduce(const float* du, int uw, const float* cam, int n, int S, int n_codes, float* rowsum, float* dcodes,
                        hipStream_t st) {
   hipLaunchKernelGGL(k_code_rowsum, dim3((n + 3) / 4), dim3(256), 0, st, du, uw, n, S, rowsum);

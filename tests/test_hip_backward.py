@@ -228,7 +228,7 @@ def test_eval_mode_with_gradients_uses_the_mean_code(golden):
                                           ("mixamo_train", 1, 8, 1), ("train_pytest", 3, 300, 212)])
 def test_one_call_training_step_equals_the_staged_nodes(name, n, S, Ni, precision):
     """anerf_train_forward / anerf_backward (one autograd node, one C call each way) vs the staged per-kernel autograd nodes:
-    same kernels in the same order, so outputs, all parameter gradients and dskts are bit-identical; ragged sizes exercise
+    same kernels in the same order, so outputs and all parameter gradients are bit-identical (dskts: see below); ragged sizes exercise
     the zeroed pad rows of the saved planes (P not a multiple of 128) and N_importance = 0 the single-pass form."""
     c = build(name)
     n = c["n"] if n is None else n
@@ -266,7 +266,15 @@ def test_one_call_training_step_equals_the_staged_nodes(name, n, S, Ni, precisio
         assert set(o1) == set(o2) and set(g1) == set(g2)
         for k in o1:
             assert torch.equal(o1[k], o2[k]), (route, k)
-        assert torch.equal(s1, s2) and float(s1.abs().max()) > 0
+        # dskts: the fp32 one-call backward applies the encoding's backward inside k_mlp_bwd_in (k_mlp_bwd_in_enc, round 6: band 0 / 4
+        # anchors + double-angle steps, sums per column group); the staged nodes and the split-bf16 path keep k_encode_bwd (one
+        # sincos per band, one pass over the row).  The same derivative in another order of operations: equal to rounding, not bits.
+        if precision == "fp32":
+            scale = float(s2.abs().max())
+            assert float((s1 - s2).abs().max()) <= 2e-5 * scale and scale > 0, (route, float((s1 - s2).abs().max()), scale)
+            assert torch.equal(s1, res["one_call"][1])            # ... and bit-identical among the one-call routes
+        else:
+            assert torch.equal(s1, s2) and float(s1.abs().max()) > 0
         for k in g1:          # incl. the frame-code tables: k_code_reduce is a fixed-order reduction (no atomics)
             assert torch.equal(g1[k], g2[k]), (route, k)
         assert all(float(v.abs().max()) > 0 for k, v in g1.items())
