@@ -72,7 +72,7 @@ int launch_pose_reduce(const float* dY, const float* dQ, const float* rays, int 
 int mlp_bwd_in_enc_entry(int ld, int code, const float* packed_i, const float* dz, const float* dzv, float* du, long long P, long long Ppad,
                          int nstages, const float* rays, int ray_stride, const float* z, const float* skts, long long skt_stride,
                          float tau_v, float tau_d, const float* cut_v, const float* cut_d, int S, float* dY, float* dQ, const float* pnoise,
-                         int gate_bones, const float* tau_dev, hipStream_t st);
+                         int gate_bones, const float* tau_dev, int n_rays, hipStream_t st);
 int launch_gather_rows3(const float* a, const float* b, const long long* idx, int n, int S, int Ni, float* out, hipStream_t st);
 int launch_code_reduce(const float* du, int uw, const float* cam, int n, int S, int n_codes, float* rowsum, float* dcodes,
                        hipStream_t st);
@@ -1218,7 +1218,7 @@ int anerf_backward(const AnerfConfig* cfg, const AnerfForwardIO* io, const Anerf
       if (!packed_i) return set_error(ANERF_E_NULL, "backward: input-gradient weight image");
       r = mlp_bwd_in_enc_entry(cfg->multires_views, cfg->framecode_ch, packed_i, B(w.dz), B(w.dzv), B(w.du), P, pp, Li.n_stages, io->rays,
                                io->ray_stride, zz, io->skts, io->skt_ray_stride, io->tau_v, io->tau_d, io->cutoff_v, io->cutoff_d, ns,
-                               B(w.dy), B(w.dq), pn, cfg->cutoff_bones, io->step ? &io->step->tau_v : nullptr, st);
+                               B(w.dy), B(w.dq), pn, cfg->cutoff_bones, io->step ? &io->step->tau_v : nullptr, (int)n, st);
     } else {
       r = (b3 ? anerf_input_grads_b3 : anerf_input_grads)(cfg, packed_i, B(w.dz), B(w.dzv), pp, P, B(w.dx), B(w.du), stream);
     }

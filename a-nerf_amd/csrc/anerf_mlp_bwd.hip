@@ -430,20 +430,25 @@ struct EncArgs {
   const float* rays; const float* z; const float* skts; const float* cut_v; const float* cut_d; const float* pnoise; const float* tau_dev;
   float* dY; float* dQ;
   long long skt_stride;
-  int ray_stride, S, gate_bones;
+  int ray_stride, S, gate_bones, n_rays;
   float tau_v, tau_d;
 };
+// LDS behind the weight ring: rows 0..2 of the bone matrices of the <= 18 rays a 128-sample tile touches (as the forward kernel
+// stages them) + the 2 x 24 cutoffs -- each of the five epilogues re-derives its joints' bone-space state from them, and at one wave
+// per SIMD a dependent global load in front of every joint quad (15 per tile) was most of the epilogues' time
+constexpr int ENC_BONES_OFF = RING_SLOTS * STAGE_BYTES;
+constexpr int ENC_CUT_OFF = ENC_BONES_OFF + MAX_TILE_RAYS * 72 * 16;
+constexpr int ENC_LDS_BYTES = ENC_CUT_OFF + 256;
 
 // (no __restrict__ on the pointers of the epilogue functions: for a noalias read-only pointer the compiler may -- and did -- hoist all
 // 36 bone-matrix loads of all five epilogues over the `asm volatile("" ::: "memory")` fences to the top of the kernel and spill them)
 struct JointQuad { float v[4], rh[12], e[12], qn[4]; };
-__device__ __forceinline__ void joint_quad(const float* sk, int G, int h, float x0, float x1, float x2, float d0, float d1,
+__device__ __forceinline__ void joint_quad(const f32x4* sk, int G, int h, float x0, float x1, float x2, float d0, float d1,
                                            float d2, JointQuad& q) {
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int j = 8 * G + 4 * h + t;
-    const f32x4 r0 = *reinterpret_cast<const f32x4*>(sk + j * 16), r1 = *reinterpret_cast<const f32x4*>(sk + j * 16 + 4),
-                r2 = *reinterpret_cast<const f32x4*>(sk + j * 16 + 8);
+    const f32x4 r0 = sk[3 * j], r1 = sk[3 * j + 1], r2 = sk[3 * j + 2];      // (LDS: this ray's [24][3] float4 rows)
     const float y0 = r0.x * x0 + r0.y * x1 + r0.z * x2 + r0.w;
     const float y1 = r1.x * x0 + r1.y * x1 + r1.z * x2 + r1.w;
     const float y2 = r2.x * x0 + r2.y * x1 + r2.z * x2 + r2.w;
@@ -467,7 +472,7 @@ __device__ __forceinline__ void joint_quad(const float* sk, int G, int h, float 
 // value of local k-group X (0..31), slot T of the finished group: accumulator block X >> 2, register 4 (X & 3) + T (take<>'s order)
 #define OV(X, T) acc[(X) >> 2][4 * ((X) & 3) + (T)]
 template <int KG0, int NK>
-__device__ __forceinline__ void enc_x_group(const f32x16 (&acc)[8], float (&dv)[12], const float* sk, int h, float x0,
+__device__ __forceinline__ void enc_x_group(const f32x16 (&acc)[8], float (&dv)[12], const f32x4* sk, int h, float x0,
                                             float x1, float x2, float tau_v, const float* cut_v, int gate_bones,
                                             float* dY_row, int& anchor) {
   auto has = [](int kg) { return kg >= KG0 && kg < KG0 + NK; };
@@ -558,7 +563,7 @@ __device__ __forceinline__ void enc_x_group(const f32x16 (&acc)[8], float (&dv)[
 // The raw sums d e of a joint quad travel between the groups in the sample's dQ row (FIRST writes, the others add); LAST finishes
 // the quad: dQ = (de - (de . e) e) / |q|, dY = its parked direction share + dv r.
 template <int KU0, int NK, int LD, int CODE, bool FIRST, bool LAST>
-__device__ __forceinline__ void enc_u_group(const f32x16 (&acc)[8], float (&dv)[12], const float* sk, int h, float x0,
+__device__ __forceinline__ void enc_u_group(const f32x16 (&acc)[8], float (&dv)[12], const f32x4* sk, int h, float x0,
                                             float x1, float x2, float d0, float d1, float d2, float tau_d,
                                             const float* cut_d, float* du_row_h, float* dY_row,
                                             float* dQ_row, int& anchor) {
@@ -702,7 +707,25 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_in_enc(const BwdInArgs A, const
   if (E.pnoise) {
     x0 += E.pnoise[3 * pc]; x1 += E.pnoise[3 * pc + 1]; x2 += E.pnoise[3 * pc + 2];
   }
-  const float* sk = E.skts + ray * E.skt_stride;
+  // stage the bone matrices of this tile's rays + the cutoffs (visible behind pipe.begin()'s barrier)
+  const long long tile_p0 = (long long)blockIdx.x * TILE;
+  const long long ray0 = div_samples(tile_p0, E.S);
+  long long ray1 = div_samples(tile_p0 + TILE - 1, E.S);
+  if (ray1 > E.n_rays - 1) ray1 = E.n_rays - 1;
+  {
+    f32x4* bw = reinterpret_cast<f32x4*>(smem + ENC_BONES_OFF);
+    const int n_stage = (int)(ray1 - ray0 + 1) * 72;
+    for (int i = tid; i < n_stage; i += 256) {
+      const int ri = i / 72, rem = i - ri * 72, j = rem / 3, row = rem - 3 * j;
+      bw[i] = *reinterpret_cast<const f32x4*>(E.skts + (ray0 + ri) * E.skt_stride + j * 16 + row * 4);
+    }
+    float* cw = reinterpret_cast<float*>(smem + ENC_CUT_OFF);
+    if (tid < 24) cw[tid] = E.cut_v[tid];
+    else if (tid < 48) cw[tid] = E.cut_d[tid - 24];
+  }
+  const f32x4* sk = reinterpret_cast<const f32x4*>(smem + ENC_BONES_OFF) + (int)(ray - ray0) * 72;
+  const float* cutv_l = reinterpret_cast<const float*>(smem + ENC_CUT_OFF);
+  const float* cutd_l = cutv_l + 24;
   const float tau_v = E.tau_dev ? E.tau_dev[0] : E.tau_v, tau_d = E.tau_dev ? E.tau_dev[1] : E.tau_d;
   int anchor = 0;    // see enc_x_group
   float dv[12];      // the one set of partial sums that stays in registers; the direction sums travel in the dY / dQ rows
@@ -724,32 +747,32 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_in_enc(const BwdInArgs A, const
   bwd_in_segment<32, 0>(pipe, acc, cur, z0, z5, outv, none, 0, 0, pending);
   bwd_in_segment<32, 0>(pipe, acc, cur, z5, z0, outv, none, 0, 0, pending);
   __builtin_amdgcn_sched_barrier(0);     // the epilogue reads the accumulators in place (a 128-register copy would spill)
-  enc_x_group<0, 32>(acc, dv, sk, h, x0, x1, x2, tau_v, E.cut_v, E.gate_bones, dYr, anchor);
+  enc_x_group<0, 32>(acc, dv, sk, h, x0, x1, x2, tau_v, cutv_l, E.gate_bones, dYr, anchor);
   // ---- dX' columns 256..431 (k-groups 32..53)
   zero_acc<8>(acc);
   bwd_in_segment<32, 0, 6>(pipe, acc, cur, z0, z5, outv, none, 0, 0, pending);
   bwd_in_segment<32, 0, 6>(pipe, acc, cur, z5, zv, outv, none, 0, 0, pending);
   __builtin_amdgcn_sched_barrier(0);     // the epilogue reads the accumulators in place (a 128-register copy would spill)
-  enc_x_group<32, 22>(acc, dv, sk, h, x0, x1, x2, tau_v, E.cut_v, E.gate_bones, dYr, anchor);
+  enc_x_group<32, 22>(acc, dv, sk, h, x0, x1, x2, tau_v, cutv_l, E.gate_bones, dYr, anchor);
   // ---- dU' = Wvu'^T dzv, 256 columns (32 k-groups) at a time
   if constexpr (NKU <= 32) {          // multires_views = 0: one narrow group (72 columns: 3 blocks)
     zero_acc<8>(acc);
     bwd_in_segment<16, 0, 3>(pipe, acc, cur, zv, nullptr, outv, none, 0, 0, pending);
     __builtin_amdgcn_sched_barrier(0);     // the epilogue reads the accumulators in place (a 128-register copy would spill)
-    enc_u_group<0, NKU, LD, CODE, true, true>(acc, dv, sk, h, x0, x1, x2, d0, d1, d2, tau_d, E.cut_d, du, dYr, dQr, anchor);
+    enc_u_group<0, NKU, LD, CODE, true, true>(acc, dv, sk, h, x0, x1, x2, d0, d1, d2, tau_d, cutd_l, du, dYr, dQr, anchor);
   } else {
     zero_acc<8>(acc);
     bwd_in_segment<16, 0, 8>(pipe, acc, cur, zv, zv, outv, none, 0, 0, pending);
     __builtin_amdgcn_sched_barrier(0);     // the epilogue reads the accumulators in place (a 128-register copy would spill)
-    enc_u_group<0, 32, LD, CODE, true, false>(acc, dv, sk, h, x0, x1, x2, d0, d1, d2, tau_d, E.cut_d, du, dYr, dQr, anchor);
+    enc_u_group<0, 32, LD, CODE, true, false>(acc, dv, sk, h, x0, x1, x2, d0, d1, d2, tau_d, cutd_l, du, dYr, dQr, anchor);
     zero_acc<8>(acc);
     bwd_in_segment<16, 0, 8>(pipe, acc, cur, zv, zv, outv, none, 0, 0, pending);
     __builtin_amdgcn_sched_barrier(0);     // the epilogue reads the accumulators in place (a 128-register copy would spill)
-    enc_u_group<32, 32, LD, CODE, false, false>(acc, dv, sk, h, x0, x1, x2, d0, d1, d2, tau_d, E.cut_d, du, dYr, dQr, anchor);
+    enc_u_group<32, 32, LD, CODE, false, false>(acc, dv, sk, h, x0, x1, x2, d0, d1, d2, tau_d, cutd_l, du, dYr, dQr, anchor);
     zero_acc<8>(acc);
     bwd_in_segment<16, 0, 5>(pipe, acc, cur, zv, nullptr, outv, none, 0, 0, pending);     // 136 / 152 columns: 5 blocks
     __builtin_amdgcn_sched_barrier(0);     // the epilogue reads the accumulators in place (a 128-register copy would spill)
-    enc_u_group<64, NKU - 64, LD, CODE, false, true>(acc, dv, sk, h, x0, x1, x2, d0, d1, d2, tau_d, E.cut_d, du, dYr, dQr, anchor);
+    enc_u_group<64, NKU - 64, LD, CODE, false, true>(acc, dv, sk, h, x0, x1, x2, d0, d1, d2, tau_d, cutd_l, du, dYr, dQr, anchor);
   }
 }
 
@@ -758,16 +781,17 @@ __global__ __launch_bounds__(256) void k_mlp_bwd_in_enc(const BwdInArgs A, const
 int mlp_bwd_in_enc_entry(int ld, int code, const float* packed_i, const float* dz, const float* dzv, float* du, long long P, long long Ppad,
                          int nstages, const float* rays, int ray_stride, const float* z, const float* skts, long long skt_stride,
                          float tau_v, float tau_d, const float* cut_v, const float* cut_d, int S, float* dY, float* dQ, const float* pnoise,
-                         int gate_bones, const float* tau_dev, hipStream_t st) {
+                         int gate_bones, const float* tau_dev, int n_rays, hipStream_t st) {
   BwdInArgs b;
   b.packed_i = packed_i; b.dz = dz; b.dzv = dzv; b.dx = nullptr; b.du = du; b.P = P; b.Ppad = Ppad; b.nstages = nstages;
   b.uw = 72 * (1 + 2 * ld) + code;
   EncArgs e;
   e.rays = rays; e.z = z; e.skts = skts; e.cut_v = cut_v; e.cut_d = cut_d; e.pnoise = pnoise; e.tau_dev = tau_dev; e.dY = dY; e.dQ = dQ;
   e.skt_stride = skt_stride; e.ray_stride = ray_stride; e.S = S; e.gate_bones = gate_bones; e.tau_v = tau_v; e.tau_d = tau_d;
+  e.n_rays = n_rays;
   const long long nblk = (P + TILE - 1) / TILE;
   if (nblk <= 0) return ANERF_OK;
-  const size_t lds = RING_SLOTS * STAGE_BYTES;
+  const size_t lds = ENC_LDS_BYTES;
   static unsigned long long lds_set[3] = {};   // per-device bits, see ensure_dynamic_lds
   if (ld == 4 && code == 16) {
     ensure_dynamic_lds(reinterpret_cast<const void*>(k_mlp_bwd_in_enc<4, 16>), (int)lds, &lds_set[0]);

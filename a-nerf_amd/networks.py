@@ -161,10 +161,24 @@ class NeRF(nn.Module):
         flat = self._packed[which][1]
         return flat[:sf], flat[sf:]
 
-    def _stale(self, which):
-        """(version key, flat buffer to (re)fill, parameters, schedule) when image `which` is out of date, else None"""
+    def params_struct(self, ver, sched):
+        """(AnerfNetParams, keep-alive list) of the path parameters, cached while their addresses (and the schedule) stay what
+        they are -- building it walks 24 tensors through ctypes, six times per training step otherwise"""
         P = self.named_path_params()
-        ver, sched = self._image_version(P, True)
+        ptrs = tuple(v[0] for v in ver[:len(P)])
+        key = (ptrs, None if sched is None else sched.serial)
+        hit = self.__dict__.get("_pstruct")
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                st, keep = ops.net_params_struct({k: v.detach() for k, v in P.items()}, sched=sched)
+            hit = self.__dict__["_pstruct"] = (key, st, keep)
+        return hit[1], hit[2]
+
+    def _stale(self, which, ver_sched=None):
+        """(version key, flat buffer to (re)fill, parameters, schedule) when image `which` is out of date, else None.
+        ver_sched: this network's _image_version(..., True), computed once by the caller for all its images"""
+        P = self.named_path_params()
+        ver, sched = ver_sched if ver_sched is not None else self._image_version(P, True)
         hit = self._packed.get(which)
         if hit is not None and hit[0] == ver:
             return None
@@ -332,16 +346,18 @@ def prepack(pairs):
     """Refresh every stale weight image among `pairs` = [(NeRF, which), ...] with ONE launch (anerf_pack_params_multi); the
     following `net.packed(which)` calls are cache hits.  A training step needs four images (W and W^T of both networks) right
     after each optimiser step: one launch instead of four."""
-    jobs, done, seen = [], [], set()
+    jobs, done, seen, vers = [], [], set(), {}
     for net, which in pairs:
         if net is None or (id(net), which) in seen:
             continue
         seen.add((id(net), which))
-        st = net._stale(which)
+        if id(net) not in vers:      # one walk over the network's 24 (address, version) pairs for all of its images
+            vers[id(net)] = net._image_version(net.named_path_params(), True)
+        st = net._stale(which, vers[id(net)])
         if st is None:
             continue
         ver, flat, P, sched = st
-        jobs.append((net.path_cfg, {k: v.detach() for k, v in P.items()}, which, flat, sched))
+        jobs.append((net.path_cfg, net.params_struct(ver, sched), which, flat, sched))     # (the cached AnerfNetParams)
         done.append((net, which, ver, flat))
     if jobs:
         with torch.no_grad():

@@ -169,8 +169,9 @@ def pack_params_multi(jobs):
         table = pack_table(cfg, dev, which)
         sched = rest[0] if rest else None
         _check_sched(cfg, sched)
-        st, k = net_params_struct(params, sched=sched)
-        keep += k + [table]
+        # params: the state-dict-named tensors, or a prebuilt (AnerfNetParams, keep-alive list) pair (NeRF.params_struct's cache)
+        st, k = params if isinstance(params, tuple) else net_params_struct(params, sched=sched)
+        keep += list(k) + [table]
         if which >= 3:     # bf16x3 image: hi/lo-split stream part (one table entry per bf16 element) + fp32 aux part
             arr.append(_lib.AnerfPackJob(st, table.data_ptr(), 2 * sf, out.data_ptr(), 1))
             arr.append(_lib.AnerfPackJob(st, table.data_ptr() + 4 * 2 * sf, af, out.data_ptr() + 4 * sf, 0))

@@ -697,10 +697,11 @@ def scaling_model(extras, device, args=None, synth=None):
     #   skew     p95 - median of the step period at the shard size, measured in this run: with 8 ranks in lockstep each step waits
     #            for the slowest one (the max of 8 draws sits near the p90 of one rank's distribution)
     # What is hidden: the FINE network's collective runs under the coarse backward (>= 1 ms: hidden whatever the terms).  The COARSE
-    # network's starts when its parameter gradients are enqueued (AnerfBackwardIO.passes = 4): in config 4 the pose-gradient tail
-    # (k_encode_bwd + k_pose_reduce of the coarse pass, the pose layer's backward: 51 + 22 + 5 + 5 + 5 + 39 = 127 us at 384 rays in
-    # profiles/r05_mix384_step_timeline_graph.txt; 115 us is used, round 4's figure) runs on beside it and is not reduced on the 19 of 20 iterations that do not step the
-    # pose group; in config 3 there is no tail, only the first network's share of k_adam (~5 us) runs under it.
+    # network's starts when its parameter gradients are enqueued (AnerfBackwardIO.passes = 4): in config 4 the pose-gradient tail runs
+    # on beside it and is not reduced on the 19 of 20 iterations that do not step the pose group.  Round 6: with the encoding's backward
+    # inside k_mlp_bwd_in_enc that tail is k_pose_reduce + the pose layer's backward = 8.5 + 4.9 + 40.1 = 53 us at 384 rays
+    # (profiles/r06_train_mixamo384_step_timeline_graph_c.txt; it was 115-127 us with k_encode_bwd in it: the step got 60 us shorter
+    # and the window 62 us narrower); in config 3 there is no tail, only the first network's share of k_adam (~5 us) runs under it.
     G, link, t_hop_ms = 8, 153e9, 3.0e-3
     net_bytes = bucket_bytes // 2
     wire_ms = 2 * (G - 1) / G * net_bytes / link * 1e3
@@ -724,7 +725,8 @@ def scaling_model(extras, device, args=None, synth=None):
                 for mode in ("on", "off"):
                     a = copy.copy(args)
                     a.workload, a.n_rand, a.opt_pose_step, a.graph = wl, 384, every, mode
-                    a.steps, a.warmup, a.cpu_rays, a.extra, a.precision = max(20, args.steps), 3, 0, "off", "fp32"
+                    # (60 steps: the skew term is p95 - median of the step period, and with 20 periods the p95 IS the maximum)
+                    a.steps, a.warmup, a.cpu_rays, a.extra, a.precision = max(60, args.steps), 3, 0, "off", "fp32"
                     try:
                         r = bench_train(a, 0, 1, device, dist, synth, mixamo=wl == "train_mixamo", per_kernel=False)
                         per = r.get("period_ms") or r["step_ms"]
@@ -745,7 +747,7 @@ def scaling_model(extras, device, args=None, synth=None):
             else:
                 os.environ["ANERF_FORCE_COLLECTIVES"] = prev
     for name, full, shard, n, window_ms, pose_every in (("config3", ("train", 3072, 1), ("train", 384, 1), 3072, 0.005, 0),
-                                                        ("config4_opt_pose_step20", ("train_mixamo", 3072, 20), ("train_mixamo", 384, 20), 3072, 0.115, 20)):
+                                                        ("config4_opt_pose_step20", ("train_mixamo", 3072, 20), ("train_mixamo", 384, 20), 3072, 0.053, 20)):
         if full in by and shard in by:
             t1, t8 = by[full]["step_ms"]["median"], by[shard]["step_ms"]["median"]
             per = by[shard].get("period_ms") or by[shard]["step_ms"]
