@@ -551,9 +551,13 @@ __device__ __forceinline__ void enc_x_group(const f32x16 (&acc)[8], float (&dv)[
 #pragma unroll
         for (int cc = 0; cc < 3; ++cc) oy[3 * t + cc] = (d_r[cc] - dot * q.rh[3 * t + cc]) * iv;
       }
+#ifndef ANERF_EXP_ENC_NOSTORE   // ablation build only (tools/ablate.sh): what do the parked partial sums cost?  results are wrong
 #pragma unroll
       for (int w4 = 0; w4 < 3; ++w4)
         *reinterpret_cast<f32x4*>(dY_row + 3 * (8 * G + 4 * h) + 4 * w4) = f32x4{oy[4 * w4], oy[4 * w4 + 1], oy[4 * w4 + 2], oy[4 * w4 + 3]};
+#else
+      asm volatile("" :: "v"(oy[0]), "v"(oy[5]), "v"(oy[11]));
+#endif
     }
     asm volatile("" : "+v"(anchor) : "v"(dv[4 * G]), "v"(dv[4 * G + 1]), "v"(dv[4 * G + 2]), "v"(dv[4 * G + 3]));
   }
@@ -650,9 +654,13 @@ __device__ __forceinline__ void enc_u_group(const f32x16 (&acc)[8], float (&dv)[
       }
     }
     if (!LAST) {
+#ifndef ANERF_EXP_ENC_NOSTORE
 #pragma unroll
       for (int w4 = 0; w4 < 3; ++w4)
         *reinterpret_cast<f32x4*>(dQ_row + 3 * (8 * G + 4 * h) + 4 * w4) = f32x4{de[4 * w4], de[4 * w4 + 1], de[4 * w4 + 2], de[4 * w4 + 3]};
+#else
+      asm volatile("" :: "v"(de[0]), "v"(de[5]), "v"(de[11]));
+#endif
     } else {   // through the norms: q -> e, and the distance part of y -> (v, r)   (k_encode_bwd's closing block)
       float oy[12], oq[12];
       const float pyf[12] = {py[0].x, py[0].y, py[0].z, py[0].w, py[1].x, py[1].y, py[1].z, py[1].w, py[2].x, py[2].y, py[2].z, py[2].w};

@@ -1353,7 +1353,7 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False, per_kernel
                         t = prof.ms(kind, ps)
                         if t is not None:
                             acc.setdefault((kind, ps), []).append(t)
-        names = {"fwd": "k_mlp_fwd<train>", "bwd": "k_mlp_bwd", "gemm": "k_gemm_tn + k_reduce_dw", "bwd_in": "k_mlp_bwd_in"}
+        names = {"fwd": "k_mlp_fwd<train>", "bwd": "k_mlp_bwd", "gemm": "k_gemm_tn + k_reduce_dw", "bwd_in": "k_mlp_bwd_in_enc (input gradients + the encoding's backward as its epilogue)"}
         flops = {"fwd": F_FWD, "bwd": F_BWD, "gemm": F_GEMM, "bwd_in": F_IN}
         b3k = args.precision == "bf16x3"
         kernels = []
@@ -1383,7 +1383,7 @@ def bench_train(args, rank, world, device, dist, synth, mixamo=False, per_kernel
                # `frac` prices the FLOPs the kernels EXECUTE (forward 1.724 + backward-data 1.115 + weight-gradient GEMM 1.724
                # [+ input gradients] MFLOP per sample) against the HIP-event time of forward + backward; `survey_3x` keeps SURVEY
                # 8(d)'s "training = 3 x forward" convention next to it (it over-counts the backward-data kernel)
-               "roofline": {"bound": "mfma", "kernel": "k_mlp_fwd<train> + k_mlp_bwd + k_gemm_tn" + (" + k_mlp_bwd_in" if mixamo else "") +
+               "roofline": {"bound": "mfma", "kernel": "k_mlp_fwd<train> + k_mlp_bwd + k_gemm_tn" + (" + k_mlp_bwd_in_enc" if mixamo else "") +
                                                        (" (both nets), HIP-event time of the whole captured step (hipGraph: loss + optimiser included)"
                                                         if gs is not None else " (both nets), HIP-event time of fwd+bwd"),
                             # bf16x3: every algorithmic FLOP is issued as 3 bf16 MFMA FLOPs, priced against the bf16 peak

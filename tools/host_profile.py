@@ -12,6 +12,12 @@ sys.path.insert(0, ROOT)
 sys.argv = ["bench.py"] + sys.argv[1:]
 import bench  # noqa: E402
 
+if os.environ.get("ANERF_PROFILE_SINGLE_THREAD") == "1":
+    # run the autograd engine on the calling thread: the backward's Python (the custom Functions' backward bodies, the
+    # data-parallel hooks) then shows up in this profile instead of hiding inside `run_backward`
+    import torch
+    torch.autograd.set_multithreading_enabled(False)
+
 pr = cProfile.Profile()
 pr.enable()
 try:
