@@ -442,7 +442,12 @@ constexpr int ENC_LDS_BYTES = ENC_CUT_OFF + 256;
 
 // (no __restrict__ on the pointers of the epilogue functions: for a noalias read-only pointer the compiler may -- and did -- hoist all
 // 36 bone-matrix loads of all five epilogues over the `asm volatile("" ::: "memory")` fences to the top of the kernel and spill them)
-struct JointQuad { float v[4], rh[12], e[12], qn[4]; };
+struct JointQuad { float v[4], iv[4], rh[12], e[12], iq[4]; };      // distance, 1 / distance, unit direction, unit ray direction, 1 / |R d|
+// 1 / sqrt(x) from v_rsq_f32 (1 ulp) + one Newton step: 5 VALU against ~20 for sqrtf + an IEEE division -- joint_quad runs 15 times per tile
+__device__ __forceinline__ float rsqrt_nr(float x) {
+  const float r = __builtin_amdgcn_rsqf(x);
+  return r * fmaf(-0.5f * x * r, r, 1.5f);
+}
 __device__ __forceinline__ void joint_quad(const f32x4* sk, int G, int h, float x0, float x1, float x2, float d0, float d1,
                                            float d2, JointQuad& q) {
 #pragma unroll
@@ -452,23 +457,19 @@ __device__ __forceinline__ void joint_quad(const f32x4* sk, int G, int h, float 
     const float y0 = r0.x * x0 + r0.y * x1 + r0.z * x2 + r0.w;
     const float y1 = r1.x * x0 + r1.y * x1 + r1.z * x2 + r1.w;
     const float y2 = r2.x * x0 + r2.y * x1 + r2.z * x2 + r2.w;
-    const float n = sqrtf(y0 * y0 + y1 * y1 + y2 * y2);
-    const float inv = 1.f / fmaxf(n, 1e-12f);
-    q.v[t] = n;
+    const float n2 = fmaxf(y0 * y0 + y1 * y1 + y2 * y2, 1e-24f);      // (|y| clamped at 1e-12 as F.normalize / the forward do)
+    const float inv = rsqrt_nr(n2);
+    q.v[t] = n2 * inv;
+    q.iv[t] = inv;
     q.rh[3 * t] = y0 * inv; q.rh[3 * t + 1] = y1 * inv; q.rh[3 * t + 2] = y2 * inv;
     const float q0 = r0.x * d0 + r0.y * d1 + r0.z * d2, q1 = r1.x * d0 + r1.y * d1 + r1.z * d2,
                 q2 = r2.x * d0 + r2.y * d1 + r2.z * d2;
-    const float qq = sqrtf(q0 * q0 + q1 * q1 + q2 * q2);
-    const float qi = 1.f / fmaxf(qq, 1e-12f);
-    q.qn[t] = qq;
+    const float qi = rsqrt_nr(fmaxf(q0 * q0 + q1 * q1 + q2 * q2, 1e-24f));
+    q.iq[t] = qi;
     q.e[3 * t] = q0 * qi; q.e[3 * t + 1] = q1 * qi; q.e[3 * t + 2] = q2 * qi;
   }
 }
 
-// dX' k-groups KG0 .. KG0 + NK - 1 (stream order: k-group kg = 3 band + G for the 15 distance bands [raw, sin f, cos f: f = 0..6],
-// 45 + 3 G + g for the bone directions); outv[4 (kg - KG0) + t] = the lane's value for joint (G, t).
-// A group that holds the bone-direction k-groups turns them into their share of dY at once -- (dr - (dr . r) r) / v, with the
-// cutoff_bones gate's terms -- and parks it in the sample's dY row (the closing group adds dv r to it): 36 fewer live registers.
 // value of local k-group X (0..31), slot T of the finished group: accumulator block X >> 2, register 4 (X & 3) + T (take<>'s order)
 #define OV(X, T) acc[(X) >> 2][4 * ((X) & 3) + (T)]
 template <int KG0, int NK>
@@ -547,7 +548,7 @@ __device__ __forceinline__ void enc_x_group(const f32x16 (&acc)[8], float (&dv)[
           dot *= wv[t];
           d_r[0] *= wv[t]; d_r[1] *= wv[t]; d_r[2] *= wv[t];
         }
-        const float iv = 1.f / fmaxf(q.v[t], 1e-12f);
+        const float iv = q.iv[t];
 #pragma unroll
         for (int cc = 0; cc < 3; ++cc) oy[3 * t + cc] = (d_r[cc] - dot * q.rh[3 * t + cc]) * iv;
       }
@@ -667,7 +668,7 @@ __device__ __forceinline__ void enc_u_group(const f32x16 (&acc)[8], float (&dv)[
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const float dote = de[3 * t] * q.e[3 * t] + de[3 * t + 1] * q.e[3 * t + 1] + de[3 * t + 2] * q.e[3 * t + 2];
-        const float iq = 1.f / fmaxf(q.qn[t], 1e-12f);
+        const float iq = q.iq[t];
 #pragma unroll
         for (int cc = 0; cc < 3; ++cc) {
           oy[3 * t + cc] = fmaf(dv[4 * G + t], q.rh[3 * t + cc], pyf[3 * t + cc]);
