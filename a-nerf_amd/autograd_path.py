@@ -214,7 +214,7 @@ class _RenderRaysFn(torch.autograd.Function):
                 codes_into = (cp[0].grad if cp[0] is not None else None, cp[1].grad if cp[1] is not None else None)
         # data-parallel overlap (opt-in on the attached optimiser): the fine network's path gradients are complete when the
         # first half of the backward is enqueued; their all-reduce starts there and runs under the coarse pass
-        hook = hook_c = None
+        hook = hook_c = hook_w = None
         if direct and getattr(sink, "overlap", False):
             sink.check_one_backward()        # raises on a second backward of the same step (nothing is enqueued yet)
         if direct and hier and getattr(sink, "overlap", False):
@@ -227,11 +227,17 @@ class _RenderRaysFn(torch.autograd.Function):
             # ... and the coarse network's, once ITS parameter gradients are enqueued: under the pose-gradient tail of the coarse
             # pass and the pose layer's backward when there is one (Mixamo-type configurations), else at the end of the pass
             hook_c = lambda: sink.begin_async_all_reduce(coarse_params)
+            # round 6: with input gradients in the step (pose refinement / frame codes) the coarse network's WEIGHTS -- 99.9 % of its
+            # bytes -- are final behind the GEMM, a whole input-gradient kernel (180 us at the 384-ray shard) before the frame codes:
+            # their all-reduce starts there (AnerfBackwardIO.passes = 16), and hook_c is left with the frame-code table alone
+            if want_in:
+                hook_w = lambda: sink.begin_async_all_reduce(meta["params"][:24])
+                hook_c = (lambda: sink.begin_async_all_reduce([cp[0]])) if (codes_into is not None and want_cc) else None
         grads_c, grads_f, g_skts, g_cc, g_cf = ops.backward(
             state, dict(zip(ctx.keys, gs)), meta["packed_t_c"], meta["packed_t_f"], perm_tables(meta["kw"]["cfg"], dev, b3=b3),
             ctx.shapes[:24], ctx.shapes[24:], pi[0], pi[1], want_skts, want_cc, want_cf,
             accumulate_into=(into[:24], into[24:]) if direct else None, after_fine=hook, codes_into=codes_into,
-            sched=meta.get("sched"), after_coarse_params=hook_c)
+            sched=meta.get("sched"), after_coarse_params=hook_c, after_coarse_weights=hook_w)
         ctx.state = None
         if direct:
             if codes_into is not None:

@@ -1142,12 +1142,19 @@ int anerf_backward(const AnerfConfig* cfg, const AnerfForwardIO* io, const Anerf
   hipStream_t st = (hipStream_t)stream;
   auto F = [&](int64_t off) { return reinterpret_cast<float*>(ws + off); };
   const int uw = u_width(cfg);
-  if (b->passes < 0 || (b->passes > 3 && b->passes != 4 && b->passes != 8)) return set_error(ANERF_E_CONFIG, "backward: passes must be 0..3, 4 or 8");
+  if (b->passes < 0 || (b->passes > 3 && b->passes != 4 && b->passes != 8 && b->passes != 16 && b->passes != 32))
+    return set_error(ANERF_E_CONFIG, "backward: passes must be 0..3, 4, 8, 16 or 32");
   // ABI revision 6: passes = 4 / 8 split the COARSE pass once more -- 4 = everything that ends in PARAMETER gradients (weights, biases,
   // frame codes: complete when this call is enqueued, so their all-reduce can start), 8 = its pose-gradient tail (k_encode_bwd +
   // k_pose_reduce into g_skts), which reads dx / du of the preceding passes = 4 call from the SAME scratch
-  const int coarse_part = b->passes == 4 ? 1 : (b->passes == 8 ? 2 : 0);
-  if (coarse_part && (!hier || !b->g_skts)) return set_error(ANERF_E_CONFIG, "backward: passes = 4 / 8 need n_importance > 0 and g_skts");
+  // Round 6 (still ABI revision 7: new VALUES of an existing field): passes = 16 / 32 split the passes = 4 part once more -- 16 = the
+  // coarse pass up to its WEIGHT gradients (composite backward, k_mlp_bwd, GEMM + reduction: 99.9 % of the coarse network's bucket
+  // bytes are final here, and the 3.46 MB all-reduce can start under the 180 us input-gradient kernel), 32 = the input-gradient
+  // part (k_mlp_bwd_in[_enc] + frame-code gradients), which reads dz / dzv of the passes = 16 call from the SAME scratch
+  const int coarse_part = b->passes == 4 ? 1 : (b->passes == 8 ? 2 : (b->passes == 16 ? 3 : (b->passes == 32 ? 4 : 0)));
+  if ((coarse_part == 1 || coarse_part == 2) && (!hier || !b->g_skts))
+    return set_error(ANERF_E_CONFIG, "backward: passes = 4 / 8 need n_importance > 0 and g_skts");
+  if (coarse_part >= 3 && (!hier || !want_in)) return set_error(ANERF_E_CONFIG, "backward: passes = 16 / 32 need n_importance > 0 and input gradients (g_skts or frame codes)");
   const bool do_fine = hier && (b->passes == 0 || (b->passes <= 3 && (b->passes & 1)));
   const bool do_coarse = !hier || b->passes == 0 || (b->passes & 2) || coarse_part;
   const bool coarse_only = hier && !do_fine;              // second half of a split backward: g_skts already holds the fine pass
@@ -1181,7 +1188,9 @@ int anerf_backward(const AnerfConfig* cfg, const AnerfForwardIO* io, const Anerf
       return r2;
     };
     if (part == 2) return pose_tail();       // passes = 8: dx / du are where the passes = 4 call left them
-    int r = zero_pad_rows(B(w.draw), 1, pp, P, 4, st);
+    int r = ANERF_OK;
+    if (part != 4) {                         // (passes = 32: dz / dzv are where the passes = 16 call left them)
+    r = zero_pad_rows(B(w.draw), 1, pp, P, 4, st);
     if (!r) r = zero_pad_rows(B(w.dz), 8, pp, P, 256, st);
     if (!r) r = zero_pad_rows(B(w.df), 1, pp, P, 256, st);
     if (!r) r = zero_pad_rows(B(w.dzv), 1, pp, P, 128, st);
@@ -1209,7 +1218,8 @@ int anerf_backward(const AnerfConfig* cfg, const AnerfForwardIO* io, const Anerf
                             T.gemm_ws_floats, b3, b->accumulate != 0, stream);
     }
     prof_rec(b->profile, ANERF_PROF_GEMM(which_pass) + 1, stream);
-    if (r || !want_in) return r;
+    }   // part != 4
+    if (r || !want_in || part == 3) return r;      // (passes = 16 ends behind the weight gradients)
     prof_rec(b->profile, ANERF_PROF_BWD_IN(which_pass), stream);
     if (fuse_enc) {
       AnerfLayout Li;
@@ -1232,7 +1242,7 @@ int anerf_backward(const AnerfConfig* cfg, const AnerfForwardIO* io, const Anerf
       r = anerf_code_grads(cfg, B(w.du), io->cam_idx, (int)n, ns, g_codes, io->n_codes, B(w.rowsum), stream);
       if (r) return r;
     }
-    if (b->g_skts && part != 1) r = pose_tail();
+    if (b->g_skts && part != 1 && part != 4) r = pose_tail();
     return r;
   };
   if (do_fine) {   // the fine pass first, as autograd runs it

@@ -805,7 +805,7 @@ def train_forward(cfg, net_c, net_f, rays, skts, cyls, n_samples, n_importance=0
 
 def backward(state, g, packed_t_c, packed_t_f, perm, shapes_c, shapes_f, packed_i_c=None, packed_i_f=None, want_skts=False,
              want_codes_c=False, want_codes_f=False, accumulate_into=None, after_fine=None, codes_into=None, sched=None,
-             after_coarse_params=None):
+             after_coarse_params=None, after_coarse_weights=None):
     """anerf_backward.  g: dict of gradients of the rendered maps (keys as the output dict; rgb_map and, when hierarchical,
     rgb0 are required -- missing ones are taken as zero).  shapes_*: parameter shapes in AnerfNetGrads order (w0, b0, ...).
     accumulate_into: optional (list_c, list_f) of existing gradient tensors the parameter gradients are ADDED to in place
@@ -818,6 +818,9 @@ def backward(state, g, packed_t_c, packed_t_f, perm, shapes_c, shapes_f, packed_
     calls (passes = 4, then 8) and the callable runs in between: the coarse network's all-reduce then runs under the
     pose-gradient tail (k_encode_bwd, k_pose_reduce and the pose layer's own backward), none of which is all-reduced on an
     iteration that does not step the pose group.
+    after_coarse_weights: optional callable (with after_fine, input gradients requested); runs when the COARSE network's weight /
+    bias gradients are on the stream (passes = 16), in front of its input-gradient kernel: the data-parallel path starts the
+    3.46 MB all-reduce there and has only the frame-code table left for after_coarse_params (behind passes = 32).
     sched: the InputSchedule the weight images were packed with (its factors multiply the same gradient columns), or None.
     Returns (grads_c, grads_f, g_skts, g_codes_c, g_codes_f)."""
     cfg, io = state["cfg"], state["io"]
@@ -881,13 +884,22 @@ def backward(state, g, packed_t_c, packed_t_f, perm, shapes_c, shapes_f, packed_
     want_in = int(want_skts or want_codes_c or want_codes_f)
     scratch, sbytes = _workspace(lib.anerf_backward_scratch_size, "anerf_backward_scratch_size", dev, C.byref(cc), n, S, Ni, want_in)
     split = after_fine is not None and hier
-    plan = (0,) if not split else ((1, 4, 8) if (after_coarse_params is not None and want_skts) else (1, 2))
+    if not split:
+        plan = (0,)
+    elif after_coarse_weights is not None and want_in:
+        plan = (1, 16, 32) + ((8,) if want_skts else ())
+    elif after_coarse_params is not None and want_skts:
+        plan = (1, 4, 8)
+    else:
+        plan = (1, 2)
     for passes in plan:
         b.passes = passes
         _lib.check(lib.anerf_backward(C.byref(cc), C.byref(io), C.byref(b), _p(state["ws"]), state["ws_bytes"], _p(scratch), sbytes,
                                       _stream()), "anerf_backward")
         if passes == 1:
             after_fine()
-        elif passes in (2, 4) and after_coarse_params is not None:
+        elif passes == 16:
+            after_coarse_weights()
+        elif passes in (2, 4, 32) and after_coarse_params is not None:
             after_coarse_params()
     return grads_c, grads_f, g_skts, g_codes_c, g_codes_f

@@ -701,7 +701,8 @@ def scaling_model(extras, device, args=None, synth=None):
     # on beside it and is not reduced on the 19 of 20 iterations that do not step the pose group.  Round 6: with the encoding's backward
     # inside k_mlp_bwd_in_enc that tail is k_pose_reduce + the pose layer's backward = 8.5 + 4.9 + 40.1 = 53 us at 384 rays
     # (profiles/r06_train_mixamo384_step_timeline_graph_c.txt; it was 115-127 us with k_encode_bwd in it: the step got 60 us shorter
-    # and the window 62 us narrower); in config 3 there is no tail, only the first network's share of k_adam (~5 us) runs under it.
+    # and the window 62 us narrower) -- which is why the coarse WEIGHTS' collective now starts a kernel earlier, behind the GEMM (see the
+    # loop below); in config 3 there is no tail, only the first network's share of k_adam (~5 us) runs under it.
     G, link, t_hop_ms = 8, 153e9, 3.0e-3
     net_bytes = bucket_bytes // 2
     wire_ms = 2 * (G - 1) / G * net_bytes / link * 1e3
@@ -746,8 +747,13 @@ def scaling_model(extras, device, args=None, synth=None):
                 os.environ.pop("ANERF_FORCE_COLLECTIVES", None)
             else:
                 os.environ["ANERF_FORCE_COLLECTIVES"] = prev
-    for name, full, shard, n, window_ms, pose_every in (("config3", ("train", 3072, 1), ("train", 384, 1), 3072, 0.005, 0),
-                                                        ("config4_opt_pose_step20", ("train_mixamo", 3072, 20), ("train_mixamo", 384, 20), 3072, 0.053, 20)):
+    # Round 6, second step: in config 4 the coarse network's WEIGHT all-reduce (3.46 MB, the full `coll_net_ms`) starts behind the GEMM
+    # (AnerfBackwardIO.passes = 16) and has the input-gradient kernel + the frame-code kernels + the pose tail over it: 183 + 14 + 53 =
+    # 250 us (profiles/r06_train_mixamo384_step_timeline_graph_d.txt); what starts behind the input gradients (passes = 32) is the
+    # frame-code table alone -- a latency-only collective (launch + 2 (G-1) hops) under the 53 us pose tail.
+    for name, full, shard, n, window_ms, pose_every, codes_window_ms in (
+            ("config3", ("train", 3072, 1), ("train", 384, 1), 3072, 0.005, 0, None),
+            ("config4_opt_pose_step20", ("train_mixamo", 3072, 20), ("train_mixamo", 384, 20), 3072, 0.250, 20, 0.053)):
         if full in by and shard in by:
             t1, t8 = by[full]["step_ms"]["median"], by[shard]["step_ms"]["median"]
             per = by[shard].get("period_ms") or by[shard]["step_ms"]
@@ -756,6 +762,8 @@ def scaling_model(extras, device, args=None, synth=None):
             exp_old = launch_ms + wire_ms                                         # round-4 model: no latency, no skew, coarse half exposed
             exp_lat_seq = coll_net_ms                                             # + latency, the coarse collective behind the backward (round 4's schedule)
             exp_lat = max(0.0, coll_net_ms - window_ms) + small                   # + latency, this round's schedule
+            if codes_window_ms is not None:
+                exp_lat += max(0.0, launch_ms + lat_ms - codes_window_ms)         # the frame-code table's own small collective
             mk = lambda e, t=None: {"step_ms_8gpu": (t or t8) + e, "speedup_8gpu": t1 / ((t or t8) + e), "rays_per_s_8gpu": n / (((t or t8) + e) * 1e-3)}
             out[name] = {"step_ms_1gpu": t1, "shard_step_ms_no_collectives": t8, "speedup_before_allreduce": t1 / t8,
                          "hidden_window_ms": window_ms, "skew_ms_p95_minus_median": skew, "exposed_collective_ms": exp_lat,

@@ -450,7 +450,14 @@ typedef struct AnerfBackwardIO {
                          * in PARAMETER gradients (weights, biases, frame codes), 8 = its pose-gradient tail into g_skts, reading the
                          * input gradients the passes = 4 call left in the SAME scratch.  On iterations where the pose group is not
                          * stepped the tail produces nothing that is all-reduced, so the coarse network's collective (started after
-                         * the passes = 4 call) runs under it instead of after the backward. */
+                         * the passes = 4 call) runs under it instead of after the backward.
+                         * ABI revision 7 -- the passes = 4 part in two calls (n_importance > 0 and input gradients requested): 16 = the
+                         * coarse pass up to its WEIGHT gradients (composite backward, k_mlp_bwd, GEMM + reduction), 32 = its
+                         * input-gradient part (k_mlp_bwd_in[_enc] + frame-code gradients), reading dz / dzv of the passes = 16 call
+                         * from the SAME scratch; then 8 as before.  The coarse network's 3.46 MB of weight gradients can be
+                         * all-reduced from behind the passes = 16 call, under the input-gradient kernel; only its frame-code
+                         * table (n_codes x 16 floats) is left for the tail's window.
+                         * (g_skts is written in full by the first pose-gradient pass: "zero-filled" above is history.) */
   const AnerfProfile* profile;   /* ABI revision 3 (HOST pointer, may be NULL): see AnerfProfile */
 } AnerfBackwardIO;
 int64_t anerf_train_workspace_size(const AnerfConfig* cfg, int32_t n_rays, int32_t n_samples, int32_t n_importance);

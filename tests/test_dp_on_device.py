@@ -127,7 +127,9 @@ def _worker(rank, world, port, mixamo, n_rays, q):
             # both networks' collectives start inside the backward (fine: after its pass; coarse: after the parameter part of its
             # pass, i.e. under the pose-gradient tail in the Mixamo configuration); what is left for all_reduce_grads() is the pose
             # group on the iterations it is due (3 of 1..4 -> one main collective); the first-reduced network's Adam runs early
-            want = {"early_collectives": 2 * len(iters), "main_collectives": 1 if mixamo else 0, "split_adam_steps": len(iters) - (1 if mixamo else 0)}    # (not on the iteration whose pose group is still to reduce)
+            # (Mixamo: three early collectives per iteration since round 6 -- fine network + codes, coarse weights behind the GEMM,
+            # coarse frame codes behind the input-gradient kernel)
+            want = {"early_collectives": (3 if mixamo else 2) * len(iters), "main_collectives": 1 if mixamo else 0, "split_adam_steps": len(iters) - (1 if mixamo else 0)}    # (not on the iteration whose pose group is still to reduce)
             overlap_same = overlap_same and st_o == want
             if st_o != want:
                 print("overlap stats", st_o, "expected", want, flush=True)

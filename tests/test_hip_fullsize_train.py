@@ -173,7 +173,12 @@ def test_backward_in_pieces_equals_the_one_call_backward(n, code, want_skts, pre
         def after_coarse_params():
             torch.cuda.synchronize()
             seen["coarse"] = [t.clone() for t in into[0]]
+        def after_coarse_weights():
+            torch.cuda.synchronize()
+            seen["coarse_w"] = [t.clone() for t in into[0]]
         kw = dict(after_fine=after_fine, after_coarse_params=after_coarse_params) if split else {}
+        if split == "weights":          # (1, 16, 32[, 8]): the coarse pass stops behind its weight gradients first
+            kw["after_coarse_weights"] = after_coarse_weights
         gc, gf, g_skts, gcc, gcf = ops.backward(state, g, nets["t_c"], nets["t_f"], ap.perm_tables(cfg, torch.device("cuda"), b3=precision == "bf16x3"),
                                                 nets["shapes"], nets["shapes"], nets["i_c"], nets["i_f"], want_skts=want_skts, want_codes_c=has_code,
                                                 want_codes_f=has_code, accumulate_into=into, **kw)
@@ -181,6 +186,16 @@ def test_backward_in_pieces_equals_the_one_call_backward(n, code, want_skts, pre
         return gc, gf, g_skts, gcc, gcf, seen
     one = run(False)
     two = run(True)
+    if has_code or want_skts:
+        # ABI revision 7: passes = 16 / 32 -- the coarse network's weight and bias gradients are FINAL at the extra hook (the
+        # input-gradient kernel behind it only adds frame-code and pose gradients), everything else as the three-piece form
+        four = run("weights")
+        for a, b in zip(one[0] + one[1], four[0] + four[1]):
+            assert torch.equal(a, b)
+        assert torch.equal(one[2], four[2]) if want_skts else True
+        if has_code:
+            assert torch.equal(one[3], four[3]) and torch.equal(one[4], four[4])
+        assert all(torch.equal(a, b) for a, b in zip(four[5]["coarse_w"], four[0])) and all(torch.equal(a, b) for a, b in zip(four[5]["fine"], four[1]))
     for a, b in zip(one[0] + one[1], two[0] + two[1]):
         assert torch.equal(a, b)
     if want_skts:
