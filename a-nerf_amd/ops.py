@@ -36,7 +36,9 @@ class PathConfig:
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """the current HIP stream of the current device as the C ABI takes it.  torch.cuda.current_stream() builds a Stream object through
+    three Python layers (~9 us; 23 calls per training step = 0.2 ms of the eager path's host time): ask the C binding directly"""
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def _p(t):

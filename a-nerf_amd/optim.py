@@ -283,11 +283,20 @@ class FusedAdam:
             return
         fg = self.flat_grad
         base = fg.data_ptr()
-        lo = min(p.grad.data_ptr() for p in params) - base
-        hi = max(p.grad.data_ptr() + p.grad.numel() * 4 for p in params) - base
-        if lo < 0 or hi > fg.numel() * 4 or (hi - lo) != 4 * sum(p.numel() for p in params):
+        # the bucket range of this parameter list: computed once per list (48 data_ptr / numel calls per hook otherwise) and checked
+        # against the gradients' current addresses through the first and last tensor
+        rk = (id(params[0]), id(params[-1]), len(params), base, params[0].grad.data_ptr(), params[-1].grad.data_ptr())
+        rng = self.__dict__.setdefault("_range_cache", {}).get(rk)
+        if rng is None:
+            lo = min(p.grad.data_ptr() for p in params) - base
+            hi = max(p.grad.data_ptr() + p.grad.numel() * 4 for p in params) - base
+            ok = not (lo < 0 or hi > fg.numel() * 4 or (hi - lo) != 4 * sum(p.numel() for p in params))
+            if len(self._range_cache) > 64:
+                self._range_cache.clear()
+            rng = self._range_cache[rk] = (lo // 4, hi // 4, ok)
+        lo, hi, ok = rng
+        if not ok:
             return                                   # not one contiguous run of the bucket: leave it to the main collective
-        lo, hi = lo // 4, hi // 4
         if any(not (hi <= alo or lo >= ahi) for _, alo, ahi in self._async):
             return                                   # overlaps a range already in flight (same hook twice): the main collective's job
         if self._side is None:
