@@ -134,7 +134,11 @@ class GraphedTrainStep:
             return "--freq_schedule re-uploads its band factors every iteration"
         if len(self.opt.param_groups) > 4:
             return "more than 4 optimiser groups"
-        ok, why = collectives_capturable()
+        import torch.distributed as dist
+        up = dist.is_available() and dist.is_initialized()         # (the answer can only change when a process group comes up)
+        if self.__dict__.get("_cc", (None,))[0] != up:
+            self._cc = (up, collectives_capturable())
+        ok, why = self._cc[1]
         return None if ok else why
 
     def _fill_block(self, i, due):
