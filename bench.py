@@ -542,12 +542,35 @@ def dry_run(args, rank, world):
             o += (n + 3) // 4 * 4
         bucket = torch.zeros(o)
         units, name = N, f"training step plumbing, N_rand={N}" + (" (config 4 bucket: + frame codes + pose group)" if mixamo else " (config 3 bucket)")
+        # the step's MODE, agreed as bench_train agrees it (GraphedTrainStep.agree): every rank reports "my captures succeeded" through
+        # ONE 1-element all-reduce (MIN) outside the step; if any rank failed, all ranks run the eager step.  (ANERF_BENCH_FAIL_CAPTURE_RANK:
+        # the test hook bench_train has -- that rank reports a failed capture.)
+        cap_ok = os.environ.get("ANERF_BENCH_FAIL_CAPTURE_RANK") != str(rank)
+        flag = torch.tensor([1.0 if cap_ok else 0.0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        graph_mode = bool(float(flag.item()) >= 1.0)
+        n_early = [0]
+        # the collectives of ONE step in the order the overlap path issues them (autograd_path._RenderRaysFn.backward): the fine
+        # network's range from behind the fine pass; the coarse network's -- in configurations with input gradients its 24 weight /
+        # bias tensors from behind the GEMM, then its frame-code table from behind the input-gradient kernel (AnerfBackwardIO.passes =
+        # 16 / 32) --; what is left of the due groups (the pose group on its iteration) in all_reduce_grads()
+        codes = 8 * 16 if mixamo else 0
+        early = [(n_net, 2 * n_net)] + ([(0, n_net - codes), (n_net - codes, n_net)] if mixamo else [(0, n_net)])
 
         def step(i):
             bucket.fill_(float(rank + 1) * (hi - lo) / max(N, 1))                    # this rank's mean-loss gradient x its ray share
             due = [0] + ([1] if mixamo and (i + 1) % args.opt_pose_step == 0 else [])
             lo_e, hi_e = offs[due[0]][0], offs[due[-1]][0] + offs[due[-1]][1]
-            dist.all_reduce(bucket[lo_e:hi_e])                                       # ONE collective over what is due
+            even = N % world == 0                                                    # (ragged shards: weighted, one collective, no overlap)
+            done = []
+            if even:
+                for a, b in early:
+                    dist.all_reduce(bucket[a:b])
+                    done.append((a, b))
+                n_early[0] += len(early)
+            covered = max((b for _, b in done), default=lo_e) if done else lo_e
+            if covered < hi_e:
+                dist.all_reduce(bucket[covered:hi_e])                                # ONE collective over the rest of what is due
             return lo_e, hi_e
         expect = sum(float(r + 1) * (min(N, (r + 1) * ((N + world - 1) // world)) - min(N, r * ((N + world - 1) // world))) / max(N, 1)
                      for r in range(world))
@@ -581,7 +604,8 @@ def dry_run(args, rank, world):
         # (a ring all-reduce sums each chunk in its own rank order: elements may differ in the last bit for ragged shares)
         ok = float((bucket[span[0]:span[1]] - expect).abs().max()) < 1e-5 * max(1.0, expect)
         checks = {"all_reduce_sum_ok": ok, "expected": expect, "got": float(bucket[span[0]]), "bucket_floats": int(bucket.numel()),
-                  "reduced_floats_last_step": int(span[1] - span[0])}
+                  "reduced_floats_last_step": int(span[1] - span[0]), "graph_mode_agreed": graph_mode, "my_capture_succeeded": cap_ok,
+                  "early_collectives": int(n_early[0])}
     else:
         frame = gather_buf[:N]                       # the assembled frame: row r belongs to rank r // per
         owner = torch.arange(N) // per
@@ -599,7 +623,8 @@ def dry_run(args, rank, world):
                "ms_per_step": float(tt.item()) / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic", "dry_run": True,
                "config": {"workload": "DRY RUN (no kernels, CPU, gloo): " + name, "rays_per_step": units,
-                          "parallelism": f"ray-sharded x{world}" + (", 1 all-reduce/step" if train else ", 1 all-gather/step")},
+                          "parallelism": f"ray-sharded x{world}" + (", 1 all-reduce/step" if train else ", 1 all-gather/step")} |
+                         ({"graph": all(r["checks"]["graph_mode_agreed"] for r in allr)} if train else {}),
                "ranks": dist.get_world_size(), "backend": dist.get_backend() + " (dry run: rendezvous, sharding, collectives, record; no kernels)",
                "shards": [r["shard"] for r in allr], "shard_weights": [r["weight"] for r in allr],
                "ms_per_step_per_rank": [r["ms_per_step"] for r in allr], "checks_per_rank": [r["checks"] for r in allr],

@@ -85,6 +85,20 @@ def test_world8_training_bucket_is_sharded_reduced_and_recorded(flags, shard0, f
         assert w == pytest.approx((b - a) * 8 / n)
     for c in j["checks_per_rank"]:
         assert c["all_reduce_sum_ok"] and c["bucket_floats"] == floats and c["reduced_floats_last_step"] == reduced
+    # round 6: the step's mode is agreed over all ranks (one 1-element all-reduce, MIN), and an even split issues the overlap path's
+    # early collectives -- fine network, coarse network (config 4: its weights, then its frame-code table) -- before the rest
+    assert j["config"]["graph"] is True and all(c["graph_mode_agreed"] and c["my_capture_succeeded"] for c in j["checks_per_rank"])
+    per_step = 0 if n % 8 else (3 if "train_mixamo" in flags else 2)
+    assert all(c["early_collectives"] == per_step * (j["steps"] + j["warmup"]) for c in j["checks_per_rank"])
+
+
+def test_world8_one_failed_capture_sends_every_rank_to_the_eager_step():
+    """bench_train's agreement (GraphedTrainStep.agree) at world 8: rank 5 reports a failed capture (test hook) -- EVERY rank then
+    runs the eager step, the record says so, and the collectives still add up"""
+    j = record(run("--gpus", "8", "--workload", "train_mixamo", "--opt-pose-step", "3", env={"ANERF_BENCH_FAIL_CAPTURE_RANK": "5"}))
+    assert j["ranks"] == 8 and j["all_checks_ok"] and j["config"]["graph"] is False
+    assert [c["my_capture_succeeded"] for c in j["checks_per_rank"]] == [r != 5 for r in range(8)]
+    assert not any(c["graph_mode_agreed"] for c in j["checks_per_rank"])
 
 
 def test_world2_and_a_dying_rank():
