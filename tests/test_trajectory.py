@@ -368,3 +368,78 @@ def test_resumed_run_continues_bit_identically(graph, tmp_path):
     torch.cuda.synchronize()
     assert fused2._steps == want["steps"] and caster2.rng().offset == want["offset"] and caster2.embed_fn.get_tau() == want["tau"]
     assert torch.equal(fused2.flat, want["flat"]) and torch.equal(fused2.exp_avg, want["m"]) and torch.equal(fused2.exp_avg_sq, want["v"])
+
+
+def _trainer_rccl_worker(port, q):
+    """one rank, RCCL, collectives forced: the Trainer's data-parallel iteration (overlap on: three early collectives per step in
+    this Mixamo arrangement, the pose group's own on its cadence, split Adam) eager and through Trainer.enable_graph()"""
+    try:
+        import os
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ANERF_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        warm = torch.zeros(8, device=dev)
+        dist.all_reduce(warm)
+        torch.cuda.synchronize()
+        ops = importlib.import_module("a-nerf_amd.ops")
+        n_iter, n = 8, 64
+        runs = []
+        for graph in (False, True):
+            torch.manual_seed(3)
+            tr, caster, layer, fused, _ = _mixamo_trainer("fused", dev, opt_pose_step=2, opt_pose_stop=7)
+            fused.enable_overlap()
+            tr.render_kwargs_train["pytest"] = False
+            caster._rng = ops.DeviceRng(seed=99, stream_id=7)
+            if graph:
+                tr.enable_graph(eager_steps=1, warm_each_key=False)
+            trace = []
+            rng = np.random.default_rng(5)
+            for i in range(1, n_iter + 1):
+                poses = sorted(rng.choice(N_POSES, size=3, replace=False).tolist())
+                ro, rd, kp, skts, bones, cyls, which = synth.scene_batch(n, poses, ray_seed=100 + i, per_ray_pose=True)
+                t = lambda x: torch.tensor(np.asarray(x), dtype=torch.float32)
+                which = np.asarray(poses)[np.asarray(which)]
+                batch = dict(rays=t(np.stack([ro, rd])), target_s=t(np.random.default_rng(200 + i).random((n, 3))),
+                             kp_idx=torch.tensor(which, dtype=torch.int64), kp3d=t(kp), bones=t(bones), skts=t(skts), cyls=t(cyls),
+                             cam_idxs=t(np.asarray(which, dtype=np.float32)), fgs=torch.ones(n, 1), bgs=torch.ones(n, 3))
+                loss_dict, stats = tr.train_batch(batch, i=i, global_step=500 * i)
+                trace.append(loss_dict["total_loss"].detach().clone())
+            torch.cuda.synchronize()
+            gs = tr._gs
+            runs.append(dict(trace=trace, flat=fused.flat.clone(), m=fused.exp_avg.clone(), stats=dict(fused.overlap_stats),
+                             replays=0 if gs is None else gs.replays, captures=0 if gs is None else gs.captures,
+                             eager_only=[] if gs is None else list(gs.eager_only.values())))
+        e, g = runs
+        same = all(torch.equal(a, b) for a, b in zip(e["trace"], g["trace"])) and torch.equal(e["flat"], g["flat"]) and torch.equal(e["m"], g["m"])
+        q.put({"same": bool(same), "eager_stats": e["stats"], "replays": g["replays"], "captures": g["captures"], "eager_only": g["eager_only"]})
+        dist.destroy_process_group()
+    except Exception:
+        import traceback
+        q.put({"error": traceback.format_exc()})
+        raise
+
+
+@pytest.mark.gpu
+def test_graphed_trainer_with_rccl_collectives_inside_the_capture():
+    """Round 6: Trainer.enable_graph() no longer steps aside when a process group is up -- the data-parallel iteration is captured
+    with its collectives.  As far as ONE GPU goes: a one-rank RCCL communicator with the collectives forced (sums over one rank are
+    the identity; side stream, async work handles and RCCL kernels under capture are the real thing).  Eight train_batch calls on
+    fresh batches crossing the pose cadence and opt_pose_stop: losses, parameters and Adam moments bit-identical to the eager
+    data-parallel trainer; three early collectives per iteration while the pose layer is refined (fine network, coarse weights,
+    coarse frame codes), two after it stopped."""
+    import multiprocessing as mp
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_trainer_rccl_worker, args=(port, q))
+    p.start()
+    r = q.get(timeout=600)
+    p.join(timeout=120)
+    assert "error" not in r, r.get("error")
+    assert r["same"] and not r["eager_only"] and r["replays"] >= 5 and r["captures"] >= 2, r
+    assert r["eager_stats"]["early_collectives"] >= 2 * 8, r
