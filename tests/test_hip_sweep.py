@@ -53,6 +53,9 @@ _K = int(os.environ.get("ANERF_SWEEP_DRAWS", "1"))
 SWEEP = [(s, "fp32") for s in range(12 * _K)] + [(s, "bf16x3") for s in range(1000, 1000 + 6 * _K)]
 
 
+ILL_ATOL = 5e-3       # element bound on an excused ray (observed 1.4e-3): a fraction of a bin width of nearly empty space
+
+
 def ill_conditioned_rays(weights, u, step=1e-3):
     """Rays with an importance sample whose inverse-CDF step is tiny.  sample_pdf (ray_utils.py:183-199; oracle.importance_z) places
     a sample at t = (u - cdf_lo) / (cdf_hi - cdf_lo) inside its bin: numerator and denominator are differences of O(1) float32
@@ -61,14 +64,18 @@ def ill_conditioned_rays(weights, u, step=1e-3):
     neighbour move by 1e-4 .. 1e-3 (profiles/r06_sweep_alpha_outliers.txt: the cdf steps under the offending samples are 1.09e-5,
     1.13e-5, 1.14e-5 and 4.7e-4; right below 1e-5 the reference's `denom < 1e-5 -> 1` switch adds a discontinuity).  Two float32
     evaluations of the REFERENCE disagree on such rays in the same way (tools/diag/fullsize_grad_noise.py).  A sample lands in such a
-    bin with probability ~1e-5 per bin, so a draw has none or one or two of these rays: they are excused from the element-wise
-    output comparison (held to a bin-width bound instead), and a draw that has one is held to widened gradient bars."""
+    bin with probability ~1e-5 per bin, and in one of the density's thin tails (pdf 1e-4 .. 1e-3) somewhat more often: a training
+    draw has none, one or two of these rays, a densely sampled render draw up to a third.  They are excused from the 1e-4 element
+    comparison and held to ILL_ATOL instead; a training draw that has one is held to widened gradient bars."""
     pw = weights[:, 1:-1].double() + 1e-5
     pdf = pw / pw.sum(-1, keepdim=True)
     cdf = torch.cat([torch.zeros_like(pdf[:, :1]), torch.cumsum(pdf, -1)], -1)
-    k = torch.searchsorted(cdf, u.double().contiguous(), right=True)
+    u = u.double().contiguous()
+    k = torch.searchsorted(cdf, u, right=True)
     den = torch.gather(cdf, 1, k.clamp(max=cdf.shape[-1] - 1)) - torch.gather(cdf, 1, (k - 1).clamp(min=0))
-    return (den < step).any(-1)
+    # the unperturbed samples' end points are exact: u = 0 sits ON cdf[0] = 0 (t = 0 / den), u = 1 beyond the last entry (hi = lo)
+    exact = (u == 0) | (k >= cdf.shape[-1])
+    return ((den < step) & ~exact).any(-1)
 
 
 def run_case(oracle, seed, precision, d=None):
@@ -132,13 +139,13 @@ def test_seeded_configuration_vs_oracle_autograd(oracle, seed, precision):
     tag = {k: v for k, v in d.items() if k not in ("rng", "cut_v", "cut_d")}
     ill = R["ill"]
     n_ill = int(ill.sum())
-    assert n_ill <= max(2, d["n"] // 10), (n_ill, tag)
+    assert n_ill <= 2 + d["n"] // 2, (n_ill, tag)
     for k in ("rgb_map", "acc_map", "alpha") + (("rgb0", "alpha0") if Ni else ()):
         keep = ~ill if k in ("rgb_map", "acc_map", "alpha") else torch.ones_like(ill)      # the coarse pass has no importance samples
         np.testing.assert_allclose(out[k].detach().cpu()[keep].numpy(), o[k].detach()[keep].numpy(), atol=2e-4 if b3 else 1e-4, rtol=0,
                                    err_msg=f"{k} {tag}")
         if n_ill:       # a shifted sample changes its ray by a fraction of a bin width of (nearly) empty space, not by an arbitrary amount
-            np.testing.assert_allclose(out[k].detach().cpu()[~keep].numpy(), o[k].detach()[~keep].numpy(), atol=2e-2, rtol=0, err_msg=f"{k} {tag}")
+            np.testing.assert_allclose(out[k].detach().cpu()[~keep].numpy(), o[k].detach()[~keep].numpy(), atol=ILL_ATOL, rtol=0, err_msg=f"{k} {tag}")
     assert abs(float(loss.detach()) - float(lo.detach())) < (2e-5 if b3 else 5e-6) * (1 + 200 * n_ill), tag
     # gradient bars.  fp32: the fused-variant test's (test_hip_backward.py) -- on few rays one ReLU flipping between the two float32
     # evaluations is visible in a bias entry, so parameters are held Frobenius-relative with a loose element bar.  bf16x3: products
@@ -177,3 +184,92 @@ def test_seeded_configuration_vs_oracle_autograd(oracle, seed, precision):
             e_code = max(e_code, rel_max(gcf, of["framecodes.codes.weight"].grad))
         assert e_code <= code_bar, (e_code, tag)
     print(f"seed {seed} [{precision}] {tag}: ill-conditioned rays {n_ill}, dskts {e_sk:.2e} (median ray {e_sk_med:.2e}), parameters {worst:.2e} ({where}) / Frobenius {wfro:.2e} (median tensor {med:.2e}), frame codes {e_code:.2e}")
+
+
+# ---- the render (inference) path: anerf_forward, the headline kernel's entry point -------------------------------------------------
+def draw_render(seed):
+    r = np.random.RandomState(9000 + seed)
+    n = int(r.choice([1, 31, 32, 33, 127, 128, 129]) if r.rand() < 0.3 else r.randint(1, 301))
+    S = int(r.randint(8, 97))
+    Ni = 0 if r.rand() < 0.2 else int(r.randint(1, 129))
+    mv = int(r.choice([0, 4]))
+    code = int(r.choice([0, 16])) if mv == 4 else 0
+    single = bool(r.rand() < 0.25) and Ni > 0
+    return dict(n=n, S=S, Ni=Ni, mv=mv, code=code, single_net=single, mean_code=bool(code and r.rand() < 0.4),
+                gate_bones=bool(r.rand() < 0.3), lindisp=bool(r.rand() < 0.3), perturb=bool(r.rand() < 0.5), per_ray=bool(r.rand() < 0.5),
+                n_poses=int(r.randint(1, 4)), softplus=bool(r.rand() < 0.3), density_scale=float(r.choice([1.0, 0.5, 2.0])),
+                tau_v=float(r.choice([20.0, 2000.0])), tau_d=float(r.choice([20.0, 2000.0])), rng=r)
+
+
+RENDER_SWEEP = [(s, "fp32") for s in range(10 * _K)] + [(s, "bf16x3") for s in range(1000, 1000 + 6 * _K)]
+
+
+@pytest.mark.parametrize("seed,precision", RENDER_SWEEP)
+def test_seeded_render_configuration_vs_oracle(oracle, seed, precision):
+    """anerf_forward (eval: no gradients, optional jitter / density noise, deterministic importance samples when not perturbed,
+    mean frame code, single-network merge, softplus density) on a drawn shape against oracle.render_rays; the one-call entry
+    point must also equal the staged per-kernel calls bit for bit (two-network draws)."""
+    d = draw_render(seed)
+    n, S, Ni, mv, code, r = d["n"], d["S"], d["Ni"], d["mv"], d["code"], d["rng"]
+    b3 = precision == "bf16x3"
+    ck = dict(multires_views=mv, framecode_ch=code, density_scale=d["density_scale"], softplus_shift=1.0 if d["softplus"] else None)
+    cfg, ocfg = ops.PathConfig(cutoff_bones=d["gate_bones"], **ck), oracle.OracleConfig(**ck)
+    n_codes = 5
+    mk = dict(multires_views=mv, **(dict(framecode_ch=code, n_codes=n_codes) if code else {}))
+    Pc_np = synth.make_net_params(500 + seed, **mk)
+    Pf_np = Pc_np if d["single_net"] else synth.make_net_params(600 + seed, **mk)
+    ro, rd, kp, skts, bones, cyls, pidx = synth.scene_batch(n, list(range(30, 30 + d["n_poses"])), ray_seed=80 + seed,
+                                                            per_ray_pose=d["per_ray"])
+    rnd = {}
+    if d["perturb"]:
+        rnd = {"t_rand": r.rand(n, S).astype(np.float32), "noise": r.randn(n, S).astype(np.float32)}
+        if Ni:
+            rnd.update(u_imp=r.rand(n, Ni).astype(np.float32), noise_fine=r.randn(n, S + Ni).astype(np.float32))
+    cam = r.randint(0, n_codes, n).astype(np.float32)
+    Pc, Pf = {k: dev(v) for k, v in Pc_np.items()}, {k: dev(v) for k, v in Pf_np.items()}
+    which = 3 if b3 else 0
+    net_c = ops.pack_params(cfg, Pc, which)
+    net_f = net_c if d["single_net"] else ops.pack_params(cfg, Pf, which)
+    codes_c, codes_f, cam_d = Pc.get("framecodes.codes.weight"), Pf.get("framecodes.codes.weight"), dev(cam) if code else None
+    if d["mean_code"]:          # eval with cam_idx < 0 -> the table's mean row (embedding.py:21-22): host-side policy of the mirror
+        codes_c, codes_f, cam_d = codes_c.mean(0, keepdim=True), codes_f.mean(0, keepdim=True), torch.zeros(n, device="cuda")
+    kw = dict(tau_v=d["tau_v"], tau_d=d["tau_d"], cam_idx=cam_d, codes_c=codes_c, codes_f=codes_f, lindisp=d["lindisp"],
+              single_net=d["single_net"], precision=precision, **{k: dev(v) for k, v in rnd.items()})
+    rb = pipeline.make_ray_batch(dev(ro), dev(rd))
+    out = pipeline.render_rays_forward(cfg, net_c, net_f, rb, dev(skts), dev(cyls), S, Ni, **kw)
+    with torch.no_grad():
+        P1 = oracle.params_from_numpy(Pc_np)
+        o = oracle.render_rays(ocfg, P1, P1 if d["single_net"] else oracle.params_from_numpy(Pf_np), oracle.make_ray_batch(t(ro), t(rd)),
+                               t(skts), t(cyls), S, Ni, tau_v=d["tau_v"], tau_d=d["tau_d"],
+                               cam_idx=(-torch.ones(n) if d["mean_code"] else t(cam)) if code else None,
+                               gate_r=d["gate_bones"], lindisp=d["lindisp"], single_net=d["single_net"], eval_mean_code=d["mean_code"],
+                               return_extras=True, **{k: t(v) for k, v in rnd.items()})
+    tag = {k: v for k, v in d.items() if k != "rng"}
+    ill = torch.zeros(n, dtype=torch.bool)
+    if Ni:
+        u = t(rnd["u_imp"]) if d["perturb"] else torch.linspace(0.0, 1.0, Ni)[None].expand(n, -1)
+        w = o["_extras"]["weights"]
+        if d["single_net"]:      # the single-network pdf (max-pooled weights + 0.01, oracle.importance_z) has no tiny steps
+            w = None
+        ill = ill_conditioned_rays(w, u) if w is not None else ill
+    n_ill = int(ill.sum())
+    assert n_ill <= 2 + n // 2, (n_ill, tag)         # (dense sampling of a thin density tail flags up to a third of the rays)
+    atol = 2e-4 if b3 else 1e-4
+    worst, worst_ill = {}, 0.0
+    for k in ("rgb_map", "acc_map", "alpha", "disp_map") + (("rgb0", "acc0", "alpha0", "disp0") if Ni else ()):
+        keep = ~ill if k in ("rgb_map", "acc_map", "alpha", "disp_map") else torch.ones_like(ill)
+        a, b = out[k].detach().cpu(), o[k]
+        if k.startswith("disp"):        # 1 / depth: relative (nan_to_num'd background rays are compared as they are)
+            np.testing.assert_allclose(a[keep].numpy(), b[keep].numpy(), rtol=2e-3 if b3 else 5e-4, atol=atol, err_msg=f"{k} {tag}")
+        else:
+            np.testing.assert_allclose(a[keep].numpy(), b[keep].numpy(), atol=atol, rtol=0, err_msg=f"{k} {tag}")
+            worst[k] = float((a[keep] - b[keep]).abs().max()) if int(keep.sum()) else 0.0
+            if n_ill and int((~keep).sum()):
+                worst_ill = max(worst_ill, float((a[~keep] - b[~keep]).abs().max()))
+                np.testing.assert_allclose(a[~keep].numpy(), b[~keep].numpy(), atol=ILL_ATOL, rtol=0, err_msg=f"{k} (ill-conditioned rays) {tag}")
+    # one call == staged calls, bit for bit (the staged route is what the per-kernel parity tests exercise)
+    if not d["single_net"]:
+        staged = pipeline.render_rays_forward(cfg, net_c, net_f, rb, dev(skts), dev(cyls), S, Ni, extras=True, **kw)
+        for k in out:
+            assert torch.equal(out[k], staged[k]), (k, tag)
+    print(f"render seed {seed} [{precision}] {tag}: ill-conditioned rays {n_ill} (max |d| on them {worst_ill:.1e}), max |d| " + ", ".join(f"{k} {v:.1e}" for k, v in worst.items()))
