@@ -56,6 +56,51 @@ def collectives_capturable(group=None):
     return True, None
 
 
+def _rccl_group_is_up():
+    import torch.distributed as dist
+    try:
+        return bool(dist.is_available() and dist.is_initialized() and "nccl" in str(dist.get_backend()))
+    except Exception:
+        return False
+
+
+# ---- a capture beside ProcessGroupNCCL's watchdog thread (round 6) -----------------------------------------------------------------
+# The process group runs a WATCHDOG THREAD that polls every work object still on its list (`WorkNCCL::isCompleted` -> hipEventQuery,
+# every 100 ms; a finished eager collective stays listed until the next poll after it finished), and an exception on that thread is
+# std::terminate: the rank is gone with "Process group watchdog thread terminated with exception: HIP error: operation not permitted
+# when stream is capturing".  Seen in 2 of 5 runs of the GPU suite (profiles/r06_watchdog_vs_global_capture.txt).  What the runtime
+# refuses while a capture is open, measured (tools/diag/capture_event_query_rules.py, profiles/r06_capture_event_query_rules.txt):
+#   * GLOBAL-mode capture: EVERY event query of EVERY other thread (whose own mode is global -- the watchdog's), whatever stream
+#     the event belongs to;
+#   * THREAD-LOCAL capture: other threads keep their API, EXCEPT for events whose stream is part of the capture now -- also events
+#     recorded long BEFORE the capture on a side stream that has joined it since ("operation not permitted on an event last recorded
+#     in a capturing stream").  The end event of the previous eager step's all-reduce sits on exactly such a stream (the group's
+#     internal RCCL stream / the optimiser's side stream), and it is still on the watchdog's list for up to 100 ms after the step.
+# (The torch build in this image has no wait for listed work in CUDAGraph::capture_begin -- older ones spun there -- and the watchdog
+# queries without a relaxed-mode guard.)  Hence TWO measures whenever an RCCL group is up:
+#   1. the capture is thread-local whatever the caller asked for (capture_mode_beside_a_process_group): queries of unrelated events
+#      -- a pin-memory thread's, the allocator's in another thread, the watchdog's on another communicator -- stay legal;
+#   2. the watchdog's list is DRAINED before the capture begins (drain_process_group_watchdog): with the device synchronised every
+#      listed work is complete, and the next poll -- at most one period away -- retires it; works issued INSIDE a capture are never
+#      listed (ProcessGroupNCCL checks the capture status), so nothing is left for the thread to ask about.
+WATCHDOG_PERIOD_S = 0.1          # kWatchdogThreadSleepMillis
+WATCHDOG_DRAIN_S = 0.3           # three periods: a poll that was asleep when the device went idle, the loop's own run time, slack
+
+
+def capture_mode_beside_a_process_group(requested="global"):
+    """the hipStreamCaptureMode of a capture: thread-local whenever an RCCL process group is up (measure 1 above)"""
+    return "thread_local" if requested == "global" and _rccl_group_is_up() else requested
+
+
+def drain_process_group_watchdog():
+    """measure 2 above; called with nothing in flight that the caller has not synchronised.  Costs 0.3 s per CAPTURE (a run has a
+    handful: one per step variant), nothing per step."""
+    if _rccl_group_is_up():
+        import time
+        torch.cuda.synchronize()
+        time.sleep(WATCHDOG_DRAIN_S)
+
+
 def _clear_sticky_hip_error():
     """hipGetLastError() until it reports success: a failed stream capture leaves the runtime's per-thread sticky error set, and the
     library's launch checks (hipGetLastError after every launch) would blame the next kernel for it."""
@@ -110,10 +155,12 @@ class GraphedTrainStep:
         """step_fn(i) -> dict of tensors; caster: the RayCaster (its DeviceRng and embedders supply seed / offset / tau);
         optimizer: the FusedAdam of the step.  The first `eager_steps` calls run step_fn eagerly (lazy one-off initialisation
         -- kernel attributes, allocator pools, index caches -- must not fall inside a capture).
-        capture_error_mode: torch.cuda.graph's (hipStreamCaptureMode).  "global" (the default, the tested one) makes ANY thread's
-        allocation-class HIP call during the few milliseconds of a capture an error -- e.g. a DataLoader's pin-memory thread; pass
-        "thread_local" when such threads run beside the trainer (the autograd worker's launches into the capturing stream are
-        captured in either mode).
+        capture_error_mode: torch.cuda.graph's (hipStreamCaptureMode).  "global" (the default) makes ANY thread's
+        allocation-class or query-class HIP call during the few milliseconds of a capture an error -- e.g. a DataLoader's pin-memory
+        thread; pass "thread_local" when such threads run beside the trainer (the autograd worker's launches into the capturing
+        stream are captured in either mode).  With an RCCL process group up the capture is ALWAYS thread-local, whatever is asked
+        for here, and the group's watchdog thread is given time to retire the eager collectives it still lists (see the
+        text above capture_mode_beside_a_process_group).
         warm_each_key: every new (due groups, key) variant runs eagerly once before it is captured (see the module text)."""
         self.capture_error_mode = capture_error_mode
         self.warm_each_key = bool(warm_each_key)       # False: capture a new variant at first sight (the caller vouches for warm caches)
@@ -171,6 +218,7 @@ class GraphedTrainStep:
         torch.autograd.graph.increment_version([p for g in opt.param_groups for p in g["params"]])
         g = torch.cuda.CUDAGraph()
         self.block.fills = 0
+        drain_process_group_watchdog()         # (no-op without an RCCL process group)
         if self.pool is None:
             self.pool = torch.cuda.graph_pool_handle()      # ONE pool for every graph of this stepper (they never run concurrently);
         # Python's cycle collector must not run INSIDE the capture: it would free whatever cyclic garbage earlier iterations left
@@ -182,7 +230,7 @@ class GraphedTrainStep:
         gc_was_on = gc.isenabled()
         gc.disable()
         dev = self.block.buf.device
-        ctx = torch.cuda.graph(g, pool=self.pool, capture_error_mode=self.capture_error_mode)
+        ctx = torch.cuda.graph(g, pool=self.pool, capture_error_mode=capture_mode_beside_a_process_group(self.capture_error_mode))
         entered = False
         try:
             with ops.step_block(self.block):

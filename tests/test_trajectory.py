@@ -370,19 +370,30 @@ def test_resumed_run_continues_bit_identically(graph, tmp_path):
     assert torch.equal(fused2.flat, want["flat"]) and torch.equal(fused2.exp_avg, want["m"]) and torch.equal(fused2.exp_avg_sq, want["v"])
 
 
-def _trainer_rccl_worker(port, q):
+def _trainer_rccl_worker(port, q, log_path=None):
     """one rank, RCCL, collectives forced: the Trainer's data-parallel iteration (overlap on: three early collectives per step in
     this Mixamo arrangement, the pose group's own on its cadence, split Adam) eager and through Trainer.enable_graph()"""
+    log = open(log_path, "w", buffering=1) if log_path else None
+
+    def stage(msg):
+        if log:
+            log.write(msg + "\n")
+
     try:
+        import faulthandler
         import os
+        if log:      # a hang must say where: all threads' stacks into the log, then exit (the parent reports the log)
+            faulthandler.dump_traceback_later(240, exit=True, file=log)
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ANERF_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
         import torch.distributed as dist
         torch.cuda.set_device(0)
         dev = torch.device("cuda", 0)
+        stage("init_process_group ...")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         warm = torch.zeros(8, device=dev)
         dist.all_reduce(warm)
         torch.cuda.synchronize()
+        stage("communicator up, first all-reduce done")
         ops = importlib.import_module("a-nerf_amd.ops")
         n_iter, n = 8, 64
         runs = []
@@ -406,7 +417,9 @@ def _trainer_rccl_worker(port, q):
                              cam_idxs=t(np.asarray(which, dtype=np.float32)), fgs=torch.ones(n, 1), bgs=torch.ones(n, 3))
                 loss_dict, stats = tr.train_batch(batch, i=i, global_step=500 * i)
                 trace.append(loss_dict["total_loss"].detach().clone())
+                stage(f"graph={graph} iteration {i} enqueued" + ("" if tr._gs is None else f" (captures {tr._gs.captures}, replays {tr._gs.replays})"))
             torch.cuda.synchronize()
+            stage(f"graph={graph} synchronised")
             gs = tr._gs
             runs.append(dict(trace=trace, flat=fused.flat.clone(), m=fused.exp_avg.clone(), stats=dict(fused.overlap_stats),
                              replays=0 if gs is None else gs.replays, captures=0 if gs is None else gs.captures,
@@ -414,6 +427,8 @@ def _trainer_rccl_worker(port, q):
         e, g = runs
         same = all(torch.equal(a, b) for a, b in zip(e["trace"], g["trace"])) and torch.equal(e["flat"], g["flat"]) and torch.equal(e["m"], g["m"])
         q.put({"same": bool(same), "eager_stats": e["stats"], "replays": g["replays"], "captures": g["captures"], "eager_only": g["eager_only"]})
+        stage("result sent")
+        faulthandler.cancel_dump_traceback_later()
         dist.destroy_process_group()
     except Exception:
         import traceback
@@ -422,7 +437,7 @@ def _trainer_rccl_worker(port, q):
 
 
 @pytest.mark.gpu
-def test_graphed_trainer_with_rccl_collectives_inside_the_capture():
+def test_graphed_trainer_with_rccl_collectives_inside_the_capture(tmp_path):
     """Round 6: Trainer.enable_graph() no longer steps aside when a process group is up -- the data-parallel iteration is captured
     with its collectives.  As far as ONE GPU goes: a one-rank RCCL communicator with the collectives forced (sums over one rank are
     the identity; side stream, async work handles and RCCL kernels under capture are the real thing).  Eight train_batch calls on
@@ -436,9 +451,15 @@ def test_graphed_trainer_with_rccl_collectives_inside_the_capture():
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_trainer_rccl_worker, args=(port, q))
+    log_path = str(tmp_path / "rccl_worker.log")
+    p = ctx.Process(target=_trainer_rccl_worker, args=(port, q, log_path))
     p.start()
-    r = q.get(timeout=600)
+    r = importlib.import_module("workers").await_worker(p, q, 300)
+    if r is None:
+        code = p.exitcode
+        if p.is_alive():
+            p.kill()
+        raise AssertionError(f"the RCCL worker ended without an answer (exit code {code}); its stage log and stacks:\n" + open(log_path).read()[-6000:])
     p.join(timeout=120)
     assert "error" not in r, r.get("error")
     assert r["same"] and not r["eager_only"] and r["replays"] >= 5 and r["captures"] >= 2, r
