@@ -248,17 +248,25 @@ class GraphedTrainStep:
             #      throw "Cannot register the state during capturing stage" and the half-built CUDAGraph's destructor would terminate
             #      the process ("The graph should be registered to the state") -- and (3) with the runtime's sticky error still set: the
             #      next launch of the eager fallback would report "operation failed due to a previous error during capture".
+            #  (c) capture_begin() itself raised after the stream had started capturing (torch.cuda.graph.__enter__ switches to the
+            #      capture stream first): the stream would stay in capture mode and stay current -- ended and left like (a) / (b).
             ended = False
-            if entered:
+            begun = entered
+            if not entered:
+                try:
+                    begun = bool(torch.cuda.is_current_stream_capturing())
+                except Exception:
+                    begun = True          # (an invalidated capture may make the query itself fail)
+            if begun:
                 try:
                     g.capture_end()
                     ended = True
                 except Exception:
                     pass
-                try:
-                    ctx.stream_ctx.__exit__(None, None, None)
-                except Exception:
-                    pass
+            try:
+                ctx.stream_ctx.__exit__(None, None, None)        # (a no-op error when __enter__ failed before switching streams)
+            except Exception:
+                pass
             if not ended:
                 idx = dev.index if dev.index is not None else torch.cuda.current_device()
                 try:

@@ -515,3 +515,38 @@ def test_a_failing_capture_leaves_the_stepper_usable():
     with pytest.raises(ValueError, match="boom"):        # a failure that is not the capture's propagates (from the eager call)
         gs.step(7)
     assert gs.captures == 1 and gs.replays == 2 and opt._steps[0] >= 6 and all(torch.isfinite(t) for t in (a, b, c)) and not torch.equal(b, c)
+
+
+@pytest.mark.gpu
+def test_a_capture_that_fails_inside_capture_begin_is_undone_too(monkeypatch):
+    """torch.cuda.graph.__enter__ switches to the capture stream and calls capture_begin(); if THAT raises after the stream has started
+    capturing (seen in the watchdog-race control: an error check right behind hipStreamBeginCapture), nobody would end the capture
+    or switch back.  Injected here: capture_begin does its work, then raises.  The stepper must end the capture, leave the capture
+    stream, run the iteration eagerly on the caller's stream, and capture another variant normally afterwards."""
+    graph_step = importlib.import_module("a-nerf_amd.graph_step")
+    dev = torch.device("cuda")
+    torch.manual_seed(7)
+    caster, opt, popt, st = _setup(False, 128, dev)
+    iteration = _make_iteration(caster, opt, popt, st, False)
+    gs = graph_step.GraphedTrainStep(iteration, caster, opt, eager_steps=1)
+    gs.step(1)
+    real = torch.cuda.CUDAGraph.capture_begin
+    armed = {"on": True}
+
+    def begin_then_raise(self, *a, **kw):
+        real(self, *a, **kw)
+        if armed["on"]:
+            armed["on"] = False
+            raise RuntimeError("injected: capture_begin failed after the stream began capturing")
+    monkeypatch.setattr(torch.cuda.CUDAGraph, "capture_begin", begin_then_raise)
+    before = torch.cuda.current_stream()
+    with pytest.warns(UserWarning, match="capture of variant"):
+        out = gs.step(2)
+    torch.cuda.synchronize()
+    assert torch.cuda.current_stream() == before and not torch.cuda.is_current_stream_capturing()
+    assert gs.failed_captures == 1 and list(gs.eager_only) == [(0,)] and torch.isfinite(out["loss"]) and list(opt._steps) == [2]
+    a = gs.step(3, key="other")["loss"].clone()          # another variant: eager once, then captured and replayed
+    b = gs.step(4, key="other")["loss"].clone()
+    c = gs.step(5, key="other")["loss"].clone()
+    torch.cuda.synchronize()
+    assert gs.captures == 1 and gs.replays == 2 and all(torch.isfinite(t) for t in (a, b, c))
