@@ -752,7 +752,10 @@ def scaling_model(extras, device, args=None, synth=None):
                     a = copy.copy(args)
                     a.workload, a.n_rand, a.opt_pose_step, a.graph = wl, 384, every, mode
                     # (60 steps: the skew term is p95 - median of the step period, and with 20 periods the p95 IS the maximum)
-                    a.steps, a.warmup, a.cpu_rays, a.extra, a.precision = max(60, args.steps), 3, 0, "off", "fp32"
+                    # 25 untimed steps (~60 ms): each capture is preceded by a 0.3 s pause that lets the process group's watchdog retire
+                    # the eager collectives (graph_step.drain_process_group_watchdog) -- the device idles, its clocks drop, and the first
+                    # steps after it belong to the ramp, not to the steady state a long run is in (seen as skew 103 us instead of 14-71)
+                    a.steps, a.warmup, a.cpu_rays, a.extra, a.precision = max(60, args.steps), 25, 0, "off", "fp32"
                     try:
                         r = bench_train(a, 0, 1, device, dist, synth, mixamo=wl == "train_mixamo", per_kernel=False)
                         per = r.get("period_ms") or r["step_ms"]
