@@ -151,16 +151,17 @@ class StaticBatch:
 
 
 class GraphedTrainStep:
-    def __init__(self, step_fn, caster, optimizer, eager_steps=3, enabled=True, capture_error_mode="global", warm_each_key=True):
+    def __init__(self, step_fn, caster, optimizer, eager_steps=3, enabled=True, capture_error_mode="thread_local", warm_each_key=True):
         """step_fn(i) -> dict of tensors; caster: the RayCaster (its DeviceRng and embedders supply seed / offset / tau);
         optimizer: the FusedAdam of the step.  The first `eager_steps` calls run step_fn eagerly (lazy one-off initialisation
         -- kernel attributes, allocator pools, index caches -- must not fall inside a capture).
-        capture_error_mode: torch.cuda.graph's (hipStreamCaptureMode).  "global" (the default) makes ANY thread's
-        allocation-class or query-class HIP call during the few milliseconds of a capture an error -- e.g. a DataLoader's pin-memory
-        thread; pass "thread_local" when such threads run beside the trainer (the autograd worker's launches into the capturing
-        stream are captured in either mode).  With an RCCL process group up the capture is ALWAYS thread-local, whatever is asked
-        for here, and the group's watchdog thread is given time to retire the eager collectives it still lists (see the
-        text above capture_mode_beside_a_process_group).
+        capture_error_mode: torch.cuda.graph's (hipStreamCaptureMode).  "thread_local" (the default since late round 6): only the
+        capturing thread's own allocation- / query-class HIP calls are errors during the few milliseconds of a capture; "global"
+        makes them errors in EVERY thread -- a DataLoader's pin-memory thread (run_nerf.py trains from one), a process group's
+        watchdog -- and a refused call in such a thread usually ends it.  The autograd worker's launches into the capturing stream
+        are captured in either mode.  With an RCCL process group up the capture is thread-local whatever is asked for here, and the
+        group's watchdog thread is given time to retire the eager collectives it still lists (see the text above
+        capture_mode_beside_a_process_group).
         warm_each_key: every new (due groups, key) variant runs eagerly once before it is captured (see the module text)."""
         self.capture_error_mode = capture_error_mode
         self.warm_each_key = bool(warm_each_key)       # False: capture a new variant at first sight (the caller vouches for warm caches)

@@ -72,7 +72,7 @@ class Trainer:
         return None
 
     # ---- the iteration as one hipGraph launch (opt-in) ------------------------------------------------------------------
-    def enable_graph(self, on=True, eager_steps=2, capture_error_mode="global", warm_each_key=True):
+    def enable_graph(self, on=True, eager_steps=2, capture_error_mode="thread_local", warm_each_key=True):
         """Replay the device side of train_batch -- pose layer, render, losses, backward, optimiser -- from a captured hipGraph
         (graph_step.GraphedTrainStep): one launch per iteration instead of ~45, same kernels and bit-identical results.  Needs the
         fused tail (a FusedAdam).  The loader's batch is copied into persistent device tensors before each replay; the pose
@@ -94,7 +94,7 @@ class Trainer:
         caster = self.render_kwargs_train["ray_caster"]
         self._static = graph_step.StaticBatch(self.device if self.device is not None else next(caster.parameters()).device)
         self._gs = graph_step.GraphedTrainStep(self._graph_body, caster, self._fused, eager_steps=eager_steps,
-                                               capture_error_mode=capture_error_mode,      # "thread_local": beside pin-memory threads
+                                               capture_error_mode=capture_error_mode,      # "thread_local": other threads (pin-memory, watchdogs) keep their HIP API
                                                warm_each_key=warm_each_key)
         return self
 
