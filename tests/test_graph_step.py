@@ -331,7 +331,7 @@ def _watchdog_worker(port, q, mode):
     list when a capture begins, and the capture is held open for 0.2 s before and 0.4 s AFTER the iteration has been enqueued, i.e.
     while the group's RCCL stream and the optimiser's side stream are part of the capture: six polls of the watchdog thread
     (hipEventQuery every 100 ms) fall inside it.  A thread of the test's own queries an event of an unrelated stream every
-    millisecond and counts the refusals.  mode "before_the_fix": global capture mode, no drain of the watchdog's list."""
+    millisecond (and page-locks a fresh buffer every eighth time, as a DataLoader's pin-memory thread does) and counts the refusals.  mode "before_the_fix": global capture mode, no drain of the watchdog's list."""
     try:
         import os, time, threading
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ANERF_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -345,7 +345,7 @@ def _watchdog_worker(port, q, mode):
         graph_step = importlib.import_module("a-nerf_amd.graph_step")
         chosen = graph_step.capture_mode_beside_a_process_group("global")
         if mode == "before_the_fix":
-            graph_step.capture_mode_beside_a_process_group = lambda requested="global": requested
+            graph_step.capture_mode_beside_a_process_group = lambda requested="global": "global"
             graph_step.drain_process_group_watchdog = lambda: None
         torch.manual_seed(7)
         caster, opt, popt, st = _setup(True, 128, dev)
@@ -376,6 +376,9 @@ def _watchdog_worker(port, q, mode):
                 try:
                     ev.query()
                     seen["queries"] += 1
+                    if seen["queries"] % 8 == 0:          # what a DataLoader's pin-memory thread does: a fresh page-locked buffer
+                        torch.empty(4096).pin_memory()
+                        seen["pinned"] = seen.get("pinned", 0) + 1
                 except RuntimeError as e:
                     seen["refused"] += 1
                     seen["text"] = str(e)[:200]
@@ -431,7 +434,7 @@ def test_capture_survives_the_process_group_watchdog():
     r, code = _run_watchdog_worker("fixed", 300)
     assert r is not None and "error" not in r, (r, code)
     assert r["chosen"] == "thread_local" and r["captures"] >= 2 and r["replays"] >= 2 and not r["eager_only"] and len(r["slept"]) >= 2, r
-    assert r["poller"]["refused"] == 0 and r["poller"]["queries"] > 500, r
+    assert r["poller"]["refused"] == 0 and r["poller"]["queries"] > 500 and r["poller"].get("pinned", 0) > 50, r
     c, code_c = _run_watchdog_worker("before_the_fix", 120)
     fate = (f"rank gone without an answer (exit code {code_c})" if c is None else
             "worker failed: " + c["error"].strip().splitlines()[-1][:160] if "error" in c else
